@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
+
+
+def load_golden(name):
+    """npz fixture -> dict of torch tensors (numeric arrays) / numpy (everything else)."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        a = z[k]
+        out[k] = torch.from_numpy(a) if a.dtype.kind in 'fiub' and a.ndim > 0 else a
+    return out
+
+
+def feats_of(g):
+    n = len([k for k in g if k.startswith('feat') and k[4:].isdigit()])
+    return [g['feat%d' % i] for i in range(n)]
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def has_gpu():
+    return torch.cuda.is_available()

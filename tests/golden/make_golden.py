@@ -1,0 +1,245 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE's own code.
+
+Runs only in the authoring container (needs /root/reference; never on the GPU box).  The reference
+package is imported without executing its mmcv/mmdet-dependent ``__init__`` files (stub packages with
+``__path__``) and with five tiny stand-ins for the mmcv/mmdet symbols ``models/sparsebev_transformer.py``
+imports.  The mmcv stand-ins restate mmcv-full 1.6.0 semantics
+(``MultiheadAttention`` = identity + torch.nn.MultiheadAttention, ``FFN`` = identity + Linear-ReLU-Linear);
+mmcv itself is not vendored by the reference, so parity is unpinned AT THAT BOUNDARY ONLY and the
+underlying math (torch.nn.MultiheadAttention / nn.Linear) is the oracle there.
+
+Inputs too large to commit (decoder weights, feature pyramids) are regenerated from seeds by
+``sparsebev_amd.synthetic``; each fixture stores a checksum of every regenerated tensor.
+
+    python tests/golden/make_golden.py
+"""
+import importlib
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from sparsebev_amd import synthetic as S   # noqa: E402
+
+REF = '/root/reference'
+PREFIX = 'decoder.decoder_layer.'
+
+
+def _stub(name, path=None, **attrs):
+    m = types.ModuleType(name)
+    if path:
+        m.__path__ = [path]
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+
+
+def import_reference():
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    class MultiheadAttention(BaseModule):      # mmcv 1.6.0 cnn/bricks/transformer.py semantics
+        def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0., batch_first=False):
+            super().__init__()
+            self.batch_first = batch_first
+            self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop)
+
+        def forward(self, query, attn_mask=None):
+            q = query.transpose(0, 1) if self.batch_first else query
+            out = self.attn(q, q, q, attn_mask=attn_mask)[0]
+            return query + (out.transpose(0, 1) if self.batch_first else out)
+
+    class FFN(BaseModule):
+        def __init__(self, embed_dims, feedforward_channels, ffn_drop=0.):
+            super().__init__()
+            self.layers = nn.Sequential(
+                nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)),
+                nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop))
+
+        def forward(self, x):
+            return x + self.layers(x)
+
+    class _Registry:
+        def register_module(self):
+            return lambda cls: cls
+
+    _stub('models', REF + '/models'); _stub('models.bbox', REF + '/models/bbox'); _stub('models.csrc', REF + '/models/csrc')
+    _stub('mmcv'); _stub('mmcv.runner', BaseModule=BaseModule)
+    _stub('mmcv.cnn', bias_init_with_prob=lambda p: float(-math.log((1 - p) / p)))
+    _stub('mmcv.cnn.bricks'); _stub('mmcv.cnn.bricks.transformer', MultiheadAttention=MultiheadAttention, FFN=FFN)
+    _stub('mmdet'); _stub('mmdet.models'); _stub('mmdet.models.utils'); _stub('mmdet.models.utils.builder', TRANSFORMER=_Registry())
+    tr = importlib.import_module('models.sparsebev_transformer')
+    smp = importlib.import_module('models.sparsebev_sampling')
+    wrap = importlib.import_module('models.csrc.wrapper')
+    utils = importlib.import_module('models.utils')
+    return tr, smp, wrap, utils
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def cf_from_cl(feats_cl):
+    return [f.permute(0, 4, 1, 2, 3).contiguous() for f in feats_cl]
+
+
+def edge_locs(Bp, Q, P, level_sizes, g):
+    """Coordinates covering interior points, exact 0/1, just outside (within one pixel), far outside."""
+    loc = torch.rand(Bp, Q, P, 3, generator=g)
+    loc[..., 2] = torch.randint(0, 6, (Bp, Q, P), generator=g).float() / 5
+    H0, W0 = level_sizes[0]
+    specials = [0.0, 1.0, -0.5 / (W0 - 1), 1 + 0.5 / (W0 - 1), -0.5 / (H0 - 1), 1 + 0.99 / (H0 - 1),
+                -1.0 / (W0 - 1), 1 + 1.0 / (W0 - 1), -3.0, 4.0, 0.5, 1e-7, 1 - 1e-7]
+    flat = loc.view(-1, 3)
+    for i, s in enumerate(specials):
+        flat[3 * i, 0] = s
+        flat[3 * i + 1, 1] = s
+        flat[3 * i + 2, 0] = s
+        flat[3 * i + 2, 1] = specials[(i + 5) % len(specials)]
+    return loc
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    tr, smp, wrap, utils = import_reference()
+    assert wrap.MSMV_CUDA is False
+
+    # ---- G1: msmv_sampling_pytorch (csrc/wrapper.py:14-38) ------------------------------------------------
+    for tag, pyr, C, Bp in (('L4_C8', 'tiny', 8, 8), ('L4_C64', 'tiny', 64, 4), ('L5_C8', 'tiny5', 8, 4), ('L5_C64', 'tiny5', 64, 1)):
+        g = torch.Generator().manual_seed(100 + C + len(S.PYRAMIDS[pyr][2]))
+        sizes = S.PYRAMIDS[pyr][2]
+        Q, P, L = 16, 4, len(sizes)
+        feats_cl = [torch.randn(Bp, 6, h, w, C, generator=g) for h, w in sizes]
+        loc = edge_locs(Bp, Q, P, sizes, g)
+        wts = torch.softmax(torch.randn(Bp, Q, P, L, generator=g), -1)
+        out = wrap.msmv_sampling_pytorch(cf_from_cl(feats_cl), loc, wts)
+        save('g1_msmv_' + tag, loc=loc, weights=wts, out=out, sizes=np.array(sizes),
+             **{'feat%d' % i: f for i, f in enumerate(feats_cl)})
+    # P = 7 (odd point count, exercises the generic-P path of the HIP kernel)
+    g = torch.Generator().manual_seed(7)
+    sizes = S.PYRAMIDS['tiny'][2]
+    feats_cl = [torch.randn(3, 6, h, w, 16, generator=g) for h, w in sizes]
+    loc = edge_locs(3, 9, 7, sizes, g)
+    wts = torch.softmax(torch.randn(3, 9, 7, 4, generator=g), -1)
+    out = wrap.msmv_sampling_pytorch(cf_from_cl(feats_cl), loc, wts)
+    save('g1_msmv_L4_C16_P7', loc=loc, weights=wts, out=out, sizes=np.array(sizes),
+         **{'feat%d' % i: f for i, f in enumerate(feats_cl)})
+
+    # ---- G2: sampling_4d with the DUMP taps (sparsebev_sampling.py:27-130) --------------------------------
+    for T, Q in ((1, 40), (8, 25)):
+        g = torch.Generator().manual_seed(200 + T)
+        B, G, P, C = (2 if T == 1 else 1), 4, 4, 8
+        ih, iw, sizes = S.PYRAMIDS['tiny']
+        L = len(sizes)
+        metas = S.make_img_metas(B, T, ih, iw)
+        lidar2img = torch.from_numpy(np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+        # points on a ring of 5..45 m radius around the ego, heights -3..2 m: 0-, 1- and 2-hit cases all occur
+        r = 5 + 40 * torch.rand(B, Q, T, G, P, generator=g)
+        a = 2 * math.pi * torch.rand(B, Q, T, G, P, generator=g)
+        pts = torch.stack([r * torch.cos(a), r * torch.sin(a), -3 + 5 * torch.rand(B, Q, T, G, P, generator=g)], -1)
+        sw = torch.softmax(torch.randn(B, Q, G, T, P, L, generator=g), -1)       # NOT T-expanded: pins quirk q1
+        feats = [torch.randn(B, T * 6, G * C, h, w, generator=g) for h, w in sizes]
+        feats_cf = [f.reshape(B, T, 6, G, C, *f.shape[-2:]).permute(0, 1, 3, 4, 2, 5, 6).reshape(B * T * G, C, 6, *f.shape[-2:]).contiguous()
+                    for f in feats]
+        utils.DUMP.enabled = True
+        utils.DUMP.stage_count = 0
+        out = smp.sampling_4d(pts, feats_cf, sw, lidar2img, ih, iw)
+        utils.DUMP.enabled = False
+        uvh = torch.load('%s/sample_points_cam_stage0.pth' % utils.DUMP.out_dir)
+        valid = torch.load('%s/sample_points_cam_valid_mask_stage0.pth' % utils.DUMP.out_dir)
+        nh = valid.sum(2)
+        print('  G2 T=%d hits: none %.3f one %.3f two+ %.3f' % (T, (nh == 0).float().mean(), (nh == 1).float().mean(), (nh >= 2).float().mean()))
+        save('g2_sampling4d_T%d' % T, sample_points=pts, scale_weights=sw, lidar2img=lidar2img, image_hw=np.array([ih, iw]),
+             uvh=uvh, valid=valid.to(torch.uint8), out=out, sizes=np.array(sizes),
+             **{'feat%d' % i: f for i, f in enumerate(feats)})
+
+    # ---- shared decoder config for G3..G7 -----------------------------------------------------------------
+    def build(T, L, seed):
+        cfg = dict(embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+        params = S.make_params(seed, **cfg)
+        m = tr.SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=6, num_levels=L, num_classes=10,
+                                    code_size=10, pc_range=S.PC_RANGE)
+        m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+        return m.eval(), params
+
+    def metas_for(B, T, pyr):
+        ih, iw, sizes = S.PYRAMIDS[pyr]
+        metas = S.make_img_metas(B, T, ih, iw)
+        for b, m in enumerate(metas):     # non-uniform per-camera timestamps so time_diff is not a multiple of 0.5
+            m['img_timestamp'] = [ts + 0.003 * ((i * 7 + b) % 6) for i, ts in enumerate(m['img_timestamp'])]
+        return metas, ih, iw, sizes
+
+    with torch.no_grad():
+        # ---- G3 / G4 / G5 / G6 at T=2 (small) and G4 also at T=8 ------------------------------------------
+        B, Q, T, L = 2, 36, 2, 4
+        model, params = build(T, L, seed=3)
+        layer = model.decoder.decoder_layer
+        metas, ih, iw, sizes = metas_for(B, T, 'tiny')
+        bbox, feat = S.make_queries(B, Q, seed=31)
+        feats = S.make_features(B, T, sizes, seed=32)
+        # run the reference decoder's own preamble (time_diff, lidar2img, feature regroup :60-85)
+        import copy
+        metas_run = copy.deepcopy(metas)
+        ts = np.array([m['img_timestamp'] for m in metas_run], dtype=np.float64).reshape(B, -1, 6)
+        metas_run[0]['time_diff'] = torch.from_numpy(np.mean(ts[:, :1] - ts, axis=-1).astype(np.float32))
+        metas_run[0]['lidar2img'] = torch.from_numpy(np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+        feats_cf = []
+        for f in feats:
+            Bf, TN, GC, H, W = f.shape
+            f = f.reshape(Bf, T, 6, 4, GC // 4, H, W).permute(0, 1, 3, 4, 2, 5, 6).reshape(Bf * T * 4, GC // 4, 6, H, W)
+            feats_cf.append(f.contiguous())
+        common = dict(query_bbox=bbox, query_feat=feat, time_diff=metas_run[0]['time_diff'],
+                      lidar2img=metas_run[0]['lidar2img'], image_hw=np.array([ih, iw]), sizes=np.array(sizes),
+                      cfg=np.array([B, Q, T, L]), seeds=np.array([3, 31, 32]),
+                      params_checksum=S.checksum(params), feats_checksum=S.checksum(feats))
+        g3 = layer.sampling.inner_forward(bbox, feat, feats_cf, metas_run)
+        save('g3_sampling_T2', out=g3, **common)
+        x_mix = torch.randn(B, Q, 4, T * 4, 64, generator=torch.Generator().manual_seed(33))
+        save('g4_mixing_T2', x=x_mix, out=layer.mixing.inner_forward(x_mix, feat), **common)
+        mask = torch.zeros(Q, Q, dtype=torch.bool)
+        mask[:10, 10:] = True
+        mask[10:, :4] = True
+        save('g5_selfattn_T2', out_nomask=layer.self_attn.inner_forward(bbox, feat, None),
+             out_mask=layer.self_attn.inner_forward(bbox, feat, mask), mask=mask, **common)
+        qf, cls, box = layer(bbox, feat, feats_cf, None, metas_run)
+        save('g6_layer_T2', out_feat=qf, out_cls=cls, out_bbox=box, **common)
+
+        model8, params8 = build(8, 4, seed=4)
+        x_mix = torch.randn(1, 20, 4, 32, 64, generator=torch.Generator().manual_seed(43))
+        q8 = torch.randn(1, 20, 256, generator=torch.Generator().manual_seed(44))
+        save('g4_mixing_T8', x=x_mix, query_feat=q8, out=model8.decoder.decoder_layer.mixing.inner_forward(x_mix, q8),
+             seeds=np.array([4]), params_checksum=S.checksum(params8))
+
+        # ---- G7: full 6-layer decoder through SparseBEVTransformer.forward --------------------------------
+        for tag, T, Q, pyr, L, B in (('c1', 1, 100, 'r50_704x256', 4, 1), ('c2small', 8, 100, 'tiny', 4, 1), ('L5', 2, 36, 'tiny5', 5, 2)):
+            model, params = build(T, L, seed=7)
+            metas, ih, iw, sizes = metas_for(B, T, pyr)
+            bbox, feat = S.make_queries(B, Q, seed=71)
+            feats = S.make_features(B, T, sizes, seed=72)
+            per_layer = []          # the reference layer's query_feat output at every stage (teacher forcing in tests)
+            hook = model.decoder.decoder_layer.register_forward_hook(lambda mod, inp, out: per_layer.append(out[0].clone()))
+            cls, box = model(bbox, feat, [f.clone() for f in feats], None, copy.deepcopy(metas))
+            hook.remove()
+            save('g7_decoder_' + tag, query_bbox=bbox, query_feat=feat, out_cls=cls, out_bbox=box,
+                 out_feat=torch.stack(per_layer),
+                 cfg=np.array([B, Q, T, L]), pyramid=np.array(pyr), seeds=np.array([7, 71, 72]),
+                 timestamps=np.array([m['img_timestamp'] for m in metas]),
+                 params_checksum=S.checksum(params), feats_checksum=S.checksum(feats))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,126 @@
+/*
+ * sbev_hip.h -- C ABI of libsbev_hip.so: the MI355X (gfx950) implementation of SparseBEV's
+ * adaptive spatio-temporal sampling + adaptive mixing decoder hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is plain C:
+ * raw DEVICE pointers, sizes, an explicit hipStream_t (passed as void*), an int status.
+ *   - 0 on success, a negative SBEV_E* code on failure; sbev_last_error() returns the message of the
+ *     last failure on the calling thread.  No C++ exception crosses this boundary.
+ *   - No hidden allocation and no synchronisation: outputs and workspaces are caller-allocated, all
+ *     work is enqueued on `stream` (NULL = the legacy default stream, which is what the reference's
+ *     `<<<grid, block>>>` launches use: models/csrc/msmv_sampling/msmv_sampling_forward.cu:290).
+ *   - Stateless and thread-safe for distinct streams.
+ *   - All index arithmetic is 64-bit (the reference's 32-bit offsets overflow at
+ *     B'*N*H*W*C >= 2^31: msmv_sampling_forward.cu:127).
+ * Reference interfaces replaced are cited per function as file:line inside the reference checkout.
+ */
+#ifndef SBEV_HIP_H
+#define SBEV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBEV_ABI_VERSION 1
+#define SBEV_MAX_LEVELS 5   /* c2345 and c23456 variants: models/csrc/msmv_sampling/msmv_sampling.cpp:362-369 */
+#define SBEV_MAX_POINTS 32  /* MAX_POINT: models/csrc/msmv_sampling/msmv_sampling.cpp:3,125 */
+
+typedef void* sbev_stream_t; /* hipStream_t */
+
+enum sbev_status {
+    SBEV_OK = 0,
+    SBEV_EINVAL = -1,  /* bad argument (the reference raises AT_ASSERTM -> RuntimeError: msmv_sampling.cpp:106-125) */
+    SBEV_ELAUNCH = -2, /* hipLaunch / hipGetLastError failure (the reference only printf's: msmv_sampling_forward.cu:295-298) */
+    SBEV_ENODEV = -3   /* no gfx950 device visible */
+};
+
+enum sbev_dtype { SBEV_F32 = 0, SBEV_BF16 = 1 };
+
+/* Output layouts of the sampler. */
+enum sbev_out_layout {
+    SBEV_OUT_REF = 0, /* [B', Q, C, P]  -- what _ms_deform_attn_cuda_c2345_forward returns (msmv_sampling.cpp:136) */
+    SBEV_OUT_MIX = 1  /* [B, Q, G, T*P, C] with b' = (b*T + t)*G + g, point index t*P + p -- the layout
+                         sampling_4d hands to AdaptiveMixing (models/sparsebev_sampling.py:125-128), written
+                         directly so the [B',Q,C,P] -> [B,Q,G,T*P,C] permute never touches HBM */
+};
+
+int sbev_abi_version(void);
+const char* sbev_last_error(void);
+/* Number of visible HIP devices whose arch is gfx950 (0 if none / no driver). */
+int sbev_device_count(void);
+
+/*
+ * Multi-scale multi-view bilinear sampling, forward.
+ * Replaces: _ms_deform_attn_cuda_c2345_forward / _ms_deform_attn_cuda_c23456_forward
+ *           (models/csrc/msmv_sampling/msmv_sampling.cpp:98-210, kernels msmv_sampling_forward.cu:75-267)
+ *           and their Python entry msmv_sampling() (models/csrc/wrapper.py:87-93).
+ *
+ *   out[b',q,c,p] = sum_l w[b',q,p,l] * bilinear(feat_l[b', view, :, :, c]; y*(H_l-1), x*(W_l-1))
+ *   view = round(loc.z*(N-1)); align_corners=True; a level contributes only if -1 < h_im < H_l and
+ *   -1 < w_im < W_l; each of the 4 corners is zero outside the map.
+ *
+ * feats[l]      device pointer of level l (fp32 or bf16 per feat_dtype), channel-last.  Element offset of
+ *               (b', view, h, w, c) = (b'/gdiv)*stride_bo[l] + (b'%gdiv)*stride_g + view*stride_v[l]
+ *                                     + (h*W_l + w)*stride_px + c.
+ *               The reference layout [B',N,H,W,C] is gdiv=1, stride_bo=N*H*W*C, stride_v=H*W*C, stride_px=C.
+ *               A zero-copy NHWC pyramid [B*T, N, H, W, G*C] (no regroup copy) is
+ *               gdiv=G, stride_bo=N*H*W*G*C, stride_g=C, stride_v=H*W*G*C, stride_px=G*C.
+ * hw            host int32 [L][2] = (H_l, W_l)
+ * loc           device fp32 [B',Q,P,3] = (x, y in [0,1], view/(N-1));  weights device fp32 [B',Q,P,L]
+ * out           device fp32, layout per out_layout; T and G are only read for SBEV_OUT_MIX (B' = B*T*G)
+ * Constraints: 1 <= L <= 5, 1 <= P <= 32, C % 4 == 0.
+ */
+int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                  int64_t Bp, int N, int C, int Q, int P,
+                  int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                  const float* loc, const float* weights, float* out,
+                  int out_layout, int T, int G, sbev_stream_t stream);
+
+/*
+ * Projection of 3-D sample points into all T*N cameras, camera-hit mask, first-hit view selection.
+ * Replaces: the front half of sampling_4d (models/sparsebev_sampling.py:49-114) and its DUMP taps (:82-86).
+ *
+ * BIT-EXACT contract (vs. the reference's native-PyTorch path on CPU): homogeneous coordinates are
+ * ((m0*x + m1*y) + m2*z) + m3 with separately rounded fp32 multiplies and adds (no FMA), followed by two
+ * IEEE divisions (by max(homo, eps), then by image_w / image_h);
+ * valid = homo > eps && 0 < v < 1 && 0 < u < 1; view = first valid view, 0 if none.
+ *
+ * sample_points device fp32 [B,Q,T,G*P,3] (metres);  lidar2img device fp32 [B,T*N,4,4] (image index t*N+n)
+ * loc_bp        device fp32 [B*T*G, Q, P, 3] = (u, v, view/(N-1)) -- the sampler's `loc` operand
+ * dump_uvh      optional (may be NULL) device fp32 [B,T,N,Q,G*P,3] = (u, v, max(homo,eps))   (DUMP tap)
+ * dump_valid    optional device uint8 [B,T,N,Q,G*P]                                          (DUMP tap)
+ * i_view        optional device int32 [B,T,Q,G*P]
+ */
+int sbev_project_select(const float* sample_points, const float* lidar2img,
+                        int B, int Q, int T, int N, int G, int P,
+                        float image_h, float image_w, float eps,
+                        float* loc_bp, float* dump_uvh, uint8_t* dump_valid, int32_t* i_view,
+                        sbev_stream_t stream);
+
+/*
+ * Sample-point generation and scale-weight softmax (everything in SparseBEVSampling.inner_forward between
+ * the two Linear layers and sampling_4d).
+ * Replaces: make_sample_points (models/sparsebev_sampling.py:8-24), decode_bbox (models/bbox/utils.py:63-77),
+ *           rotation_3d_in_axis v1.0.0 (models/utils.py:49-84), the velocity warp and the level softmax
+ *           (models/sparsebev_transformer.py:279-300), and the weight reorder of sampling_4d (:117-119)
+ *           INCLUDING its (b,g,t)-vs-(b,t,g) flattening quirk.
+ *
+ * query_bbox    device fp32 [B,Q,10] (cx,cy,cz in [0,1], log w,l,h, sin, cos, vx, vy)
+ * offset        device fp32 [B,Q,G*P*3]  (output of the sampling_offset Linear)
+ * scale_logits  device fp32 [B,Q,G*P*L]  (output of the scale_weights Linear, pre-softmax)
+ * time_diff     device fp32 [B,T];  pc_range host double [6] (x0,y0,z0,x1,y1,z1)
+ * sample_points device fp32 [B,Q,T,G*P,3] (out; may be NULL)
+ * weights_bp    device fp32 [B*G*T, Q, P, L] (out; may be NULL): row b' holds softmax(scale_logits)[b,q,g',p,:]
+ *               with g' = ((b' % (T*G))) / T  -- the weights the reference actually applies to sample batch b'.
+ */
+int sbev_sampling_front(const float* query_bbox, const float* offset, const float* scale_logits,
+                        const float* time_diff, const double* pc_range,
+                        int B, int Q, int T, int G, int P, int L,
+                        float* sample_points, float* weights_bp, sbev_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBEV_HIP_H */

@@ -1,0 +1,64 @@
+"""ctypes binding of libsbev_hip.so (C ABI: include/sbev_hip.h).
+
+The library is the product: if it is missing or fails to load, importing the operators raises --
+there is no PyTorch / CPU fallback anywhere in this package (the reference silently falls back to
+``F.grid_sample``, models/csrc/wrapper.py:4-11; we deliberately do not).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsbev_hip.so')
+
+_c_i64p = ctypes.POINTER(ctypes.c_int64)
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/sbev_hip.h one to one
+SIGNATURES = {
+    'sbev_abi_version': (ctypes.c_int, []),
+    'sbev_last_error': (ctypes.c_char_p, []),
+    'sbev_device_count': (ctypes.c_int, []),
+    'sbev_msmv_fwd': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,
+                                     _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_project_select': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                           _vp, _vp, _vp, _vp, _vp]),
+    'sbev_sampling_front': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SbevError(RuntimeError):
+    """A libsbev_hip.so entry point returned a negative status (message from sbev_last_error())."""
+
+
+def load():
+    """dlopen the HIP library (once) and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'sparsebev_amd: %s not found. Build it with `python -m sparsebev_amd.csrc.build` (needs hipcc, '
+            'targets gfx950). There is no CPU / PyTorch fallback for the sampling path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale: loud on purpose
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sbev_abi_version() != 1:
+        raise ImportError('sparsebev_amd: libsbev_hip.so ABI %d != 1 (stale build?)' % lib.sbev_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().sbev_last_error().decode('utf-8', 'replace')
+        raise SbevError('%s failed (%d): %s' % (what, status, msg))

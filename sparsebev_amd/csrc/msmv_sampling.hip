@@ -1,0 +1,225 @@
+// Multi-scale multi-view bilinear sampling, forward -- hand-written for gfx950 (CDNA4, wave64).
+//
+// Replaces the reference's CUDA op ms_deformable_im2col_gpu_kernel_c2345 / _c23456
+// (models/csrc/msmv_sampling/msmv_sampling_forward.cu:75-267) behind sbev_msmv_fwd (include/sbev_hip.h).
+// Written from the op's mathematical definition, not from the CUDA source: the reference maps one
+// THREAD to one (b', q, channel) and issues 4*L*P scalar 4-byte loads per thread, re-reading the
+// query's coordinates in all 64 channel threads.  Here one WAVE owns one (b', q):
+//
+//   lane = corner k (0..3) * 16 + channel quad j (0..15)
+//   one wave-wide 16-byte load = the 4 bilinear corners x 64 fp32 channels of ONE (point, level) tap
+//       = 4 x 256 B contiguous segments, i.e. every HBM/L2 request is a full 128-B line pair;
+//   the 4*L taps of a 4-point chunk are independent -> up to 20 KiB in flight per wave;
+//   each lane folds bilinear-corner weight x level weight into one coefficient and FMAs its float4;
+//   the 4 corner partials are combined once per 4-point chunk with a reduce-scatter built from
+//   v_permlane16_swap / v_permlane32_swap (no LDS, no ds_bpermute), which leaves each 16-lane row
+//   holding exactly the float4 it has to store, so the wave writes ONE fully coalesced 1-KiB row.
+//
+// Bound: HBM/L2 gather bandwidth (about 2 flop per loaded float).  Algorithmic bytes per sampled point
+// (SURVEY.md section 8d): L*4*C*sizeof(feat) + 12 + 4L + 4C  (4124 B at L=4, C=64, fp32).
+#include "sbev_common.hpp"
+
+namespace {
+
+struct MsmvArgs {
+    const void* feat[SBEV_MAX_LEVELS];
+    int H[SBEV_MAX_LEVELS];
+    int W[SBEV_MAX_LEVELS];
+    long long stride_bo[SBEV_MAX_LEVELS];
+    long long stride_v[SBEV_MAX_LEVELS];
+    long long stride_g;
+    long long stride_px;
+    const float* loc;
+    const float* w;
+    float* out;
+    long long n_waves;  // B' * Q
+    int N, C, Q, P, gdiv, T, G;
+};
+
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const unsigned short* p) {  // 4 x bf16 -> fp32 (exact)
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+
+// Reduce-scatter over the 4 corner groups (16-lane rows r = 0..3 of the wave) without LDS:
+// given one value per item i = 0..3 in every lane, returns in row r the sum over all 4 rows of item r.
+// permlane16_swap(x, y) exchanges the odd rows of x with the even rows of y, so x + y afterwards holds
+// [i0(r0+r1), i1(r0+r1), i0(r2+r3), i1(r2+r3)]; permlane32_swap(x, y) exchanges the upper half of x with
+// the lower half of y and finishes the sum.  3 swaps + 3 adds for 4 items (an all-reduce needs 8 + 8).
+__device__ __forceinline__ float pair16(float a, float b) {
+    auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float corner_reduce_scatter(float i0, float i1, float i2, float i3) {
+    const float u = pair16(i0, i1), v = pair16(i2, i3);
+    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
+template <int L, typename FT, int OUT>
+__global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * 4 + wv;  // = b' * Q + q  (wave-uniform)
+    if (wave >= a.n_waves) return;
+    const long long bp = wave / a.Q;
+    const int q = (int)(wave - bp * a.Q);
+    const int k = lane >> 4, kh = k >> 1, kw = k & 1;
+    const int j4 = (lane & 15) * 4;
+    const long long bo = bp / a.gdiv, gi = bp - bo * a.gdiv;
+    const int P = a.P, C = a.C;
+    const float* __restrict__ locq = a.loc + wave * P * 3;
+    const float* __restrict__ wq = a.w + wave * P * L;
+    const float nm1 = (float)(a.N - 1);
+
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const bool chan_ok = (c0 + j4) < C;
+        const int cj = chan_ok ? c0 + j4 : 0;
+        const FT* base[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            base[l] = reinterpret_cast<const FT*>(a.feat[l]) + bo * a.stride_bo[l] + gi * a.stride_g + cj;
+
+        for (int p0 = 0; p0 < P; p0 += 4) {
+            float4 acc[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool p_ok = (p0 + pp) < P;           // wave-uniform
+                const int p = p_ok ? p0 + pp : P - 1;
+                const float x = locq[p * 3 + 0];
+                const float y = locq[p * 3 + 1];
+                const float z = locq[p * 3 + 2] * nm1;
+                int view = (int)roundf(z);                  // reference: round(loc.z * (num_views - 1))
+                view = min(max(view, 0), a.N - 1);          // (the reference reads out of bounds here; we clamp)
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const int H = a.H[l], W = a.W[l];
+                    const float h_im = y * (float)(H - 1);  // align_corners = True
+                    const float w_im = x * (float)(W - 1);
+                    const bool lvl_ok = p_ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const float lh = h_im - hf, lw = w_im - wf;
+                    // clamp before the int conversion so NaN / huge coordinates stay addressable
+                    const int h0 = (int)fminf(fmaxf(hf, -1.f), (float)H);
+                    const int w0 = (int)fminf(fmaxf(wf, -1.f), (float)W);
+                    const int hc = h0 + kh, wc = w0 + kw;
+                    const bool inb = lvl_ok && chan_ok && hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
+                    const float cw = (kh ? lh : 1.f - lh) * (kw ? lw : 1.f - lw);
+                    const float coef = inb ? cw * wq[p * L + l] : 0.f;
+                    const int hcc = min(max(hc, 0), H - 1), wcc = min(max(wc, 0), W - 1);
+                    const long long off = view * a.stride_v[l] + ((long long)hcc * W + wcc) * a.stride_px;
+                    float4 v = load4(base[l] + off);        // always a valid address; masked by coef/inb below
+                    if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);   // corner outside the map contributes exactly 0
+                    acc[pp].x = fmaf(coef, v.x, acc[pp].x);
+                    acc[pp].y = fmaf(coef, v.y, acc[pp].y);
+                    acc[pp].z = fmaf(coef, v.z, acc[pp].z);
+                    acc[pp].w = fmaf(coef, v.w, acc[pp].w);
+                }
+            }
+            if (OUT == SBEV_OUT_REF) {
+                // out[b', q, c, p]: scatter by CHANNEL -- row k ends up with channel c0 + 4j + k of all 4 points
+                float r[4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+                    r[pp] = corner_reduce_scatter(acc[pp].x, acc[pp].y, acc[pp].z, acc[pp].w);
+                float* o = a.out + (wave * C + (c0 + j4 + k)) * P + p0;
+                if (chan_ok) {
+                    if (P == 4) {
+                        *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);   // 64 lanes -> 1 KiB row
+                    } else {
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp)
+                            if (p0 + pp < P) o[pp] = r[pp];
+                    }
+                }
+            } else {
+                // out[b, q, g, t*P + p, c] with b' = (b*T + t)*G + g: scatter by POINT -- row k ends up with
+                // the 4 channels 4j..4j+3 of point p0 + k, i.e. the wave stores 4 contiguous 256-B point rows
+                float4 s;
+                s.x = corner_reduce_scatter(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+                s.y = corner_reduce_scatter(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+                s.z = corner_reduce_scatter(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
+                s.w = corner_reduce_scatter(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
+                const long long bt = bp / a.G;
+                const int g = (int)(bp - bt * a.G);
+                const long long b = bt / a.T;
+                const int t = (int)(bt - b * a.T);
+                if (chan_ok && p0 + k < P) {
+                    float* o = a.out + ((((b * a.Q + q) * a.G + g) * a.T + t) * (long long)P + p0 + k) * C + c0 + j4;
+                    *reinterpret_cast<float4*>(o) = s;
+                }
+            }
+        }
+    }
+}
+
+template <int L, typename FT>
+int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
+    const long long blocks = (a.n_waves + 3) / 4;
+    if (blocks <= 0) return SBEV_OK;
+    if (blocks > 0x7fffffffLL) {
+        sbev::set_error("sbev_msmv_fwd: B'*Q = %lld too large for one launch", a.n_waves);
+        return SBEV_EINVAL;
+    }
+    if (out_layout == SBEV_OUT_REF)
+        hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return sbev::check_launch("sbev_msmv_fwd");
+}
+
+template <typename FT>
+int launch_t(const MsmvArgs& a, int L, int out_layout, hipStream_t s) {
+    switch (L) {
+        case 1: return launch_l<1, FT>(a, out_layout, s);
+        case 2: return launch_l<2, FT>(a, out_layout, s);
+        case 3: return launch_l<3, FT>(a, out_layout, s);
+        case 4: return launch_l<4, FT>(a, out_layout, s);
+        default: return launch_l<5, FT>(a, out_layout, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                             int64_t Bp, int N, int C, int Q, int P,
+                             int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v,
+                             int64_t stride_px, const float* loc, const float* weights, float* out,
+                             int out_layout, int T, int G, sbev_stream_t stream) {
+    SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_msmv_fwd: null descriptor array");
+    SBEV_REQUIRE(L >= 1 && L <= SBEV_MAX_LEVELS, "sbev_msmv_fwd: L=%d not in 1..%d", L, SBEV_MAX_LEVELS);
+    SBEV_REQUIRE(P >= 1 && P <= SBEV_MAX_POINTS, "sbev_msmv_fwd: num_point exceed limits (P=%d > %d)", P, SBEV_MAX_POINTS);
+    SBEV_REQUIRE(C >= 4 && C % 4 == 0, "sbev_msmv_fwd: C=%d must be a positive multiple of 4", C);
+    SBEV_REQUIRE(N >= 1 && Q >= 0 && Bp >= 0 && gdiv >= 1, "sbev_msmv_fwd: bad sizes");
+    SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16, "sbev_msmv_fwd: feat_dtype %d", feat_dtype);
+    SBEV_REQUIRE(out_layout == SBEV_OUT_REF || out_layout == SBEV_OUT_MIX, "sbev_msmv_fwd: out_layout %d", out_layout);
+    SBEV_REQUIRE(stride_px % 4 == 0 && stride_g % 4 == 0, "sbev_msmv_fwd: pixel/group strides must be multiples of 4 elements");
+    if (out_layout == SBEV_OUT_MIX)
+        SBEV_REQUIRE(T >= 1 && G >= 1 && Bp % ((int64_t)T * G) == 0, "sbev_msmv_fwd: B'=%lld is not B*T*G (T=%d, G=%d)", (long long)Bp, T, G);
+    if (Bp == 0 || Q == 0) return SBEV_OK;
+    SBEV_REQUIRE(loc && weights && out, "sbev_msmv_fwd: null loc/weights/out");
+    MsmvArgs a{};
+    for (int l = 0; l < L; ++l) {
+        SBEV_REQUIRE(feats[l] != nullptr, "sbev_msmv_fwd: feats[%d] is null", l);
+        SBEV_REQUIRE(hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_msmv_fwd: level %d has empty map", l);
+        SBEV_REQUIRE(stride_bo[l] % 4 == 0 && stride_v[l] % 4 == 0, "sbev_msmv_fwd: level %d strides must be multiples of 4 elements", l);
+        a.feat[l] = feats[l];
+        a.H[l] = hw[2 * l];
+        a.W[l] = hw[2 * l + 1];
+        a.stride_bo[l] = stride_bo[l];
+        a.stride_v[l] = stride_v[l];
+    }
+    a.stride_g = stride_g;
+    a.stride_px = stride_px;
+    a.loc = loc;
+    a.w = weights;
+    a.out = out;
+    a.n_waves = Bp * Q;
+    a.N = N; a.C = C; a.Q = Q; a.P = P; a.gdiv = gdiv; a.T = T; a.G = G;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return feat_dtype == SBEV_F32 ? launch_t<float>(a, L, out_layout, s)
+                                  : launch_t<unsigned short>(a, L, out_layout, s);
+}

@@ -1,0 +1,176 @@
+"""Python operator layer over the C ABI -- mirrors the reference's operator interface
+(models/csrc/wrapper.py:87-93 ``msmv_sampling``; models/sparsebev_sampling.py ``make_sample_points`` /
+``sampling_4d``) with the same names, argument meaning and error behaviour, but every byte of work is
+done by hand-written gfx950 kernels in libsbev_hip.so.  Tensors must live on a HIP device; there is no
+CPU path (calling these with CPU tensors raises).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+N_VIEWS = 6           # models/sparsebev_sampling.py:45
+OUT_REF, OUT_MIX = 0, 1
+_F32, _BF16 = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('sparsebev_amd ops need device tensors (no CPU fallback); got a %s tensor' % t.device)
+
+
+def _no_grad_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError('sparsebev_amd: the sampling backward (SURVEY.md section 8f rank 1) is not built yet; '
+                                  'call under torch.no_grad()')
+
+
+def _msmv_launch(feats, hw, feat_dtype, Bp, N, C, Q, P, gdiv, stride_bo, stride_g, stride_v, stride_px,
+                 loc, weights, out, out_layout, T, G):
+    L = len(feats)
+    lib = _lib.load()
+    c_feats = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
+    c_sbo = (ctypes.c_int64 * L)(*stride_bo)
+    c_sv = (ctypes.c_int64 * L)(*stride_v)
+    st = lib.sbev_msmv_fwd(c_feats, c_hw, L, feat_dtype, Bp, N, C, Q, P, gdiv, c_sbo, stride_g, c_sv, stride_px,
+                           _ptr(loc), _ptr(weights), _ptr(out), out_layout, T, G, _stream())
+    _lib.check(st, 'sbev_msmv_fwd')
+
+
+def _feat_dtype(feats):
+    dt = feats[0].dtype
+    if any(f.dtype != dt for f in feats):
+        raise RuntimeError('all feature levels must share one dtype')
+    if dt == torch.float32:
+        return _F32
+    if dt == torch.bfloat16:
+        return _BF16
+    raise RuntimeError('feature dtype must be float32 or bfloat16, got %s' % dt)
+
+
+def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_REF, T=1, G=1):
+    """Drop-in for the reference operator ``msmv_sampling`` (models/csrc/wrapper.py:87-93).
+
+    mlvl_feats: list (1..5 levels) of contiguous channel-last ``[B', N, H_l, W_l, C]`` device tensors
+    (fp32, or bf16 storage with fp32 accumulation); sampling_locations ``[B', Q, P, 3]``;
+    scale_weights ``[B', Q, P, L]``.  Returns ``[B', Q, C, P]`` fp32 (or, with ``out_layout=OUT_MIX``,
+    ``[B'/(T*G), Q, G, T*P, C]``).  Same preconditions as msmv_sampling.cpp:106-125 (contiguity, device,
+    P <= 32); violations raise RuntimeError."""
+    feats = list(mlvl_feats)
+    _need_device(sampling_locations, scale_weights, *feats)
+    _no_grad_only(sampling_locations, scale_weights, *feats)
+    if not 1 <= len(feats) <= 5:
+        raise RuntimeError('msmv_sampling supports 1..5 feature levels, got %d' % len(feats))
+    for f in feats:
+        if not f.is_contiguous():
+            raise RuntimeError('value tensor has to be contiguous')
+        if f.dim() != 5:
+            raise RuntimeError('value tensor must be [B, N, H, W, C]')
+    if not sampling_locations.is_contiguous():
+        raise RuntimeError('sampling_loc tensor has to be contiguous')
+    if not scale_weights.is_contiguous():
+        raise RuntimeError('attn_weight tensor has to be contiguous')
+    if sampling_locations.dtype != torch.float32 or scale_weights.dtype != torch.float32:
+        raise RuntimeError('sampling_loc / attn_weight must be float32')
+    Bp, N, _, _, C = feats[0].shape
+    _, Q, P, three = sampling_locations.shape
+    if three != 3 or sampling_locations.shape[0] != Bp:
+        raise RuntimeError('sampling_loc must be [B, Q, P, 3]')
+    if tuple(scale_weights.shape) != (Bp, Q, P, len(feats)):
+        raise RuntimeError('attn_weight must be [B, Q, P, %d]' % len(feats))
+    if P > 32:
+        raise RuntimeError('num_point exceed limits')
+    hw = [(f.shape[2], f.shape[3]) for f in feats]
+    sbo = [N * h * w * C for h, w in hw]
+    sv = [h * w * C for h, w in hw]
+    if out_layout == OUT_REF:
+        out = torch.empty(Bp, Q, C, P, device=feats[0].device, dtype=torch.float32)
+    else:
+        out = torch.empty(Bp // (T * G), Q, G, T * P, C, device=feats[0].device, dtype=torch.float32)
+    _msmv_launch(feats, hw, _feat_dtype(feats), Bp, N, C, Q, P, 1, sbo, 0, sv, C,
+                 sampling_locations, scale_weights, out, out_layout, T, G)
+    return out
+
+
+def msmv_sampling_nhwc(feats_nhwc, B, T, G, sampling_locations, scale_weights, out_layout=OUT_MIX):
+    """Zero-copy variant: feats_nhwc is a list of ``[B*T*N, H_l, W_l, G*C]``
+    channels-last pyramids straight from an NHWC neck; group g of sample batch b' = (b*T+t)*G+g is the
+    channel slice [g*C, (g+1)*C) -- the reference's regroup copy (models/sparsebev_transformer.py:73-85,
+    2x the feature bytes per call) never happens."""
+    feats = list(feats_nhwc)
+    _need_device(sampling_locations, scale_weights, *feats)
+    _no_grad_only(sampling_locations, scale_weights, *feats)
+    N = N_VIEWS
+    Bp, Q, P, _ = sampling_locations.shape
+    if Bp != B * T * G:
+        raise RuntimeError('sampling_loc batch %d != B*T*G = %d' % (Bp, B * T * G))
+    GC = feats[0].shape[-1]
+    C = GC // G
+    for f in feats:
+        if not f.is_contiguous() or f.dim() != 4 or f.shape[0] != B * T * N or f.shape[-1] != GC:
+            raise RuntimeError('nhwc feature level must be contiguous [B*T*6, H, W, G*C]')
+    hw = [(f.shape[1], f.shape[2]) for f in feats]
+    sbo = [N * h * w * GC for h, w in hw]
+    sv = [h * w * GC for h, w in hw]
+    if out_layout == OUT_REF:
+        out = torch.empty(Bp, Q, C, P, device=feats[0].device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, Q, G, T * P, C, device=feats[0].device, dtype=torch.float32)
+    _msmv_launch(feats, hw, _feat_dtype(feats), Bp, N, C, Q, P, G, sbo, C, sv, GC,
+                 sampling_locations.contiguous(), scale_weights.contiguous(), out, out_layout, T, G)
+    return out
+
+
+def project_select(sample_points, lidar2img, image_h, image_w, G, P, eps=1e-5, dump=False):
+    """Front half of sampling_4d (models/sparsebev_sampling.py:49-114) on device, bit-exact camera-hit
+    mask.  sample_points ``[B,Q,T,G*P,3]``, lidar2img ``[B,T*6,4,4]`` -> loc ``[B*T*G,Q,P,3]`` and, with
+    dump=True, the DUMP-tap tensors (uvh ``[B,T,6,Q,GP,3]``, valid uint8 ``[B,T,6,Q,GP]``, i_view int32
+    ``[B,T,Q,GP]``)."""
+    _need_device(sample_points, lidar2img)
+    sample_points = sample_points.contiguous().float()
+    lidar2img = lidar2img.contiguous().float()
+    B, Q, T, GP, _ = sample_points.shape
+    assert GP == G * P and lidar2img.shape[1] == T * N_VIEWS
+    dev = sample_points.device
+    loc = torch.empty(B * T * G, Q, P, 3, device=dev, dtype=torch.float32)
+    uvh = valid = iview = None
+    if dump:
+        uvh = torch.empty(B, T, N_VIEWS, Q, GP, 3, device=dev, dtype=torch.float32)
+        valid = torch.empty(B, T, N_VIEWS, Q, GP, device=dev, dtype=torch.uint8)
+        iview = torch.empty(B, T, Q, GP, device=dev, dtype=torch.int32)
+    st = _lib.load().sbev_project_select(_ptr(sample_points), _ptr(lidar2img), B, Q, T, N_VIEWS, G, P,
+                                         float(image_h), float(image_w), float(eps),
+                                         _ptr(loc), _ptr(uvh), _ptr(valid), _ptr(iview), _stream())
+    _lib.check(st, 'sbev_project_select')
+    return (loc, uvh, valid, iview) if dump else loc
+
+
+def sampling_front(query_bbox, offset, scale_logits, time_diff, pc_range, T, G, P, L,
+                   want_points=True, want_weights=True):
+    """make_sample_points + velocity warp + level softmax + weight reorder (see sbev_sampling_front in
+    include/sbev_hip.h).  Returns (sample_points [B,Q,T,G*P,3] | None, weights_bp [B*G*T,Q,P,L] | None)."""
+    _need_device(query_bbox, offset, scale_logits, time_diff)
+    B, Q = query_bbox.shape[:2]
+    dev = query_bbox.device
+    query_bbox = query_bbox.contiguous().float()
+    pts = torch.empty(B, Q, T, G * P, 3, device=dev, dtype=torch.float32) if want_points else None
+    wbp = torch.empty(B * G * T, Q, P, L, device=dev, dtype=torch.float32) if want_weights else None
+    pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    st = _lib.load().sbev_sampling_front(
+        _ptr(query_bbox), _ptr(offset.contiguous().float() if want_points else None),
+        _ptr(scale_logits.contiguous().float() if want_weights else None),
+        _ptr(time_diff.contiguous().float() if want_points else None), pc, B, Q, T, G, P, L,
+        _ptr(pts), _ptr(wbp), _stream())
+    _lib.check(st, 'sbev_sampling_front')
+    return pts, wbp

@@ -1,0 +1,79 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/sbev_hip.h
+declares (and nothing it does not), the ctypes table matches, and argument validation returns the
+documented status codes without ever touching a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from sparsebev_amd import _lib
+
+HEADER = os.path.join(ROOT, 'include', 'sbev_hip.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(sbev_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from sparsebev_amd.csrc import build
+        build.build()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    syms = declared_symbols()
+    assert 'sbev_msmv_fwd' in syms and 'sbev_project_select' in syms
+    for s in syms:
+        assert hasattr(lib, s), 'libsbev_hip.so does not export %s' % s
+    assert sorted(_lib.SIGNATURES) == syms, 'ctypes table and include/sbev_hip.h disagree'
+
+
+def test_exports_are_plain_c(lib):
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if ' T ' in l and l.split()[-1].startswith('sbev_'))
+    assert exported == declared_symbols()          # extern "C": unmangled, exactly the header's set
+
+
+def test_abi_version_and_device_query(lib):
+    assert lib.sbev_abi_version() == 1
+    assert lib.sbev_device_count() >= 0
+
+
+def test_argument_validation_without_gpu(lib):
+    L = 4
+    feats = (ctypes.c_void_p * L)(1, 1, 1, 1)
+    hw = (ctypes.c_int32 * (2 * L))(*([4, 4] * L))
+    s = (ctypes.c_int64 * L)(*([16] * L))
+    one = ctypes.c_void_p(16)
+
+    def call(L_=L, P=4, C=8, layout=0, Bp=2):
+        return lib.sbev_msmv_fwd(feats, hw, L_, 0, Bp, 6, C, 3, P, 1, s, 0, s, C, one, one, one, layout, 1, 1, None)
+
+    assert call(P=33) == -1 and b'num_point exceed limits' in lib.sbev_last_error()   # msmv_sampling.cpp:125
+    assert call(L_=6) == -1
+    assert call(C=6) == -1
+    assert call(layout=7) == -1
+    assert call(Bp=0) == 0                                                             # empty input: no launch, OK
+    assert lib.sbev_project_select(None, None, 1, 4, 1, 6, 4, 4, 1.0, 1.0, 1e-5, None, None, None, None, None) == -1
+    assert lib.sbev_project_select(None, None, 0, 4, 1, 6, 4, 4, 1.0, 1.0, 1e-5, None, None, None, None, None) == 0
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+    from sparsebev_amd import ops
+    f = [torch.zeros(1, 6, 2, 2, 4)]
+    with pytest.raises(RuntimeError, match='device tensors'):
+        ops.msmv_sampling(f, torch.zeros(1, 1, 1, 3), torch.zeros(1, 1, 1, 1))
+    # and the product package never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, 'sparsebev_amd')):
+        for fn in files:
+            if fn.endswith('.py'):
+                assert 'oracle' not in open(os.path.join(root, fn)).read().replace('c_oracle', 'oracle') or fn == 'synthetic.py' and False, fn

@@ -1,0 +1,190 @@
+"""GPU parity of the sampling path, called through the C ABI (sparsebev_amd.ops -> libsbev_hip.so):
+HIP kernels vs golden vectors made by the reference, vs the CPU oracle on seeded inputs, and -- at the
+full BASELINE config-2 size -- vs the C oracle plus size-independent properties.
+Tolerance: 1e-4 abs fp32 on sampled features (north_star); the camera-hit mask, selected view and
+projected coordinates must be bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, feats_of
+from sparsebev_amd import ops, synthetic as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = 'cuda:0'
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+@pytest.mark.parametrize('tag', ['L4_C8', 'L4_C64', 'L5_C8', 'L5_C64', 'L4_C16_P7'])
+def test_g1_msmv_vs_reference_golden(tag):
+    g = load_golden('g1_msmv_' + tag)
+    feats = [dev(f) for f in feats_of(g)]
+    out = ops.msmv_sampling(feats, dev(g['loc']), dev(g['weights']))
+    assert out.shape == g['out'].shape
+    assert (out.cpu() - g['out']).abs().max() < TOL
+    # mixing-ready layout is the same numbers, permuted (T=G=1 -> [B',Q,1,P,C])
+    mix = ops.msmv_sampling(feats, dev(g['loc']), dev(g['weights']), out_layout=ops.OUT_MIX, T=1, G=1)
+    assert torch.equal(mix[:, :, 0].permute(0, 1, 3, 2), out)
+
+
+def test_msmv_bf16_features_fp32_accumulate():
+    from oracle import sparsebev_oracle as O
+    g = load_golden('g1_msmv_L4_C64')
+    feats_bf = [f.to(torch.bfloat16) for f in feats_of(g)]
+    ref = O.msmv_sampling_kernel_semantics([f.float() for f in feats_bf], g['loc'], g['weights'])
+    out = ops.msmv_sampling([dev(f) for f in feats_bf], dev(g['loc']), dev(g['weights']))
+    assert (out.cpu() - ref).abs().max() < TOL       # bf16 is storage only: exact widening, fp32 math
+
+
+@pytest.mark.parametrize('T', [1, 8])
+def test_g2_projection_bit_exact_and_sampling4d(T):
+    from oracle import sparsebev_oracle as O
+    g = load_golden('g2_sampling4d_T%d' % T)
+    pts, sw = g['sample_points'], g['scale_weights']
+    B, Q, _, G, P, _ = pts.shape
+    ih, iw = [int(v) for v in g['image_hw']]
+    loc, uvh, valid, iview = ops.project_select(dev(pts.reshape(B, Q, T, G * P, 3)), dev(g['lidar2img']), ih, iw, G, P, dump=True)
+    assert torch.equal(valid.cpu(), g['valid'])                                                    # camera-hit mask
+    assert np.array_equal(uvh.cpu().numpy().view(np.uint32), g['uvh'].numpy().view(np.uint32))      # DUMP tap, bitwise
+    assert torch.equal(iview.cpu().long(), torch.argmax(g['valid'].permute(0, 1, 3, 4, 2), dim=-1))
+    _, taps = O.sampling_4d(pts, O.regroup_features(feats_of(g), False), sw, g['lidar2img'], ih, iw, O.msmv_sampling_gridsample)
+    assert np.array_equal(loc.cpu().numpy().view(np.uint32), taps['loc_bp'].contiguous().numpy().view(np.uint32))
+    # full sampling_4d through the HIP sampler (reference weight order incl. quirk q1 prepared on host here)
+    feats_cl = [dev(f) for f in O.regroup_features(feats_of(g), True)]
+    out = ops.msmv_sampling(feats_cl, loc, dev(taps['w_bp'].contiguous()), out_layout=ops.OUT_MIX, T=T, G=G)
+    assert (out.cpu() - g['out']).abs().max() < TOL
+
+
+def test_g3_front_project_gather_chain():
+    g = load_golden('g3_sampling_T2')
+    B, Q, T, L = [int(v) for v in g['cfg']]
+    G, P = 4, 4
+    seeds = [int(v) for v in g['seeds']]
+    params = S.make_params(seeds[0], embed_dims=256, num_frames=T, num_points=P, num_levels=L)
+    feats = S.make_features(B, T, [tuple(int(x) for x in s) for s in g['sizes']], seed=seeds[2])
+    ih, iw = [int(v) for v in g['image_hw']]
+    qf = g['query_feat']
+    off = torch.nn.functional.linear(qf, params['sampling.sampling_offset.weight'], params['sampling.sampling_offset.bias'])
+    lg = torch.nn.functional.linear(qf, params['sampling.scale_weights.weight'], params['sampling.scale_weights.bias'])
+    pts, wbp = ops.sampling_front(dev(g['query_bbox']), dev(off), dev(lg), dev(g['time_diff']), S.PC_RANGE, T, G, P, L)
+    loc = ops.project_select(pts, dev(g['lidar2img']), ih, iw, G, P)
+    # zero-copy NHWC pyramid: [B*T*6, H, W, 256]
+    nhwc = [dev(f.reshape(B * T * 6, 256, *f.shape[-2:]).permute(0, 2, 3, 1).contiguous()) for f in feats]
+    out = ops.msmv_sampling_nhwc(nhwc, B, T, G, loc, wbp)
+    assert out.shape == g['out'].shape
+    assert (out.cpu() - g['out']).abs().max() < TOL
+
+
+def test_front_kernel_vs_oracle():
+    from oracle import sparsebev_oracle as O
+    B, Q, T, G, P, L = 2, 100, 8, 4, 4, 5
+    bbox, feat = S.make_queries(B, Q, seed=5)
+    params = S.make_params(5, num_frames=T, num_levels=L)
+    td = torch.tensor([[0.0, 0.5, 1.0, 1.5, 2.1, 2.5, 3.0, 3.7], [0.0, 0.4, 1.0, 1.5, 2.0, 2.5, 3.2, 3.5]])
+    pts_ref, sw_ref = O.sampling_front(params, bbox, feat, td, S.PC_RANGE, T, P, L)
+    off = torch.nn.functional.linear(feat, params['sampling.sampling_offset.weight'], params['sampling.sampling_offset.bias'])
+    lg = torch.nn.functional.linear(feat, params['sampling.scale_weights.weight'], params['sampling.scale_weights.bias'])
+    pts, wbp = ops.sampling_front(dev(bbox), dev(off), dev(lg), dev(td), S.PC_RANGE, T, G, P, L)
+    assert (pts.cpu() - pts_ref.reshape(B, Q, T, G * P, 3)).abs().max() < 1e-4      # metres
+    w_ref = sw_ref.reshape(B, Q, G, T, P, L).permute(0, 2, 3, 1, 4, 5).reshape(B * G * T, Q, P, L)
+    assert (wbp.cpu() - w_ref).abs().max() < 1e-6
+
+
+def test_msmv_edge_cases():
+    f = [torch.randn(2, 6, 4, 5, 8, device=DEV)]
+    # empty query set and empty batch
+    assert ops.msmv_sampling(f, torch.zeros(2, 0, 4, 3, device=DEV), torch.zeros(2, 0, 4, 1, device=DEV)).shape == (2, 0, 8, 4)
+    # P at the reference's MAX_POINT
+    loc = torch.rand(2, 3, 32, 3, device=DEV)
+    loc[..., 2] = torch.randint(0, 6, (2, 3, 32), device=DEV).float() / 5
+    w = torch.rand(2, 3, 32, 1, device=DEV)
+    from oracle import sparsebev_oracle as O
+    ref = O.msmv_sampling_kernel_semantics([f[0].cpu()], loc.cpu(), w.cpu())
+    assert (ops.msmv_sampling(f, loc, w).cpu() - ref).abs().max() < TOL
+    with pytest.raises(RuntimeError, match='num_point exceed limits'):
+        ops.msmv_sampling(f, torch.rand(2, 3, 33, 3, device=DEV), torch.rand(2, 3, 33, 1, device=DEV))
+    with pytest.raises(RuntimeError, match='contiguous'):
+        ops.msmv_sampling([f[0].transpose(2, 3)], loc, w)
+    # NaN / inf / far-away coordinates: contribute exactly zero, no fault
+    bad = torch.tensor([float('nan'), float('inf'), -float('inf'), 1e30, -1e30, 0.5], device=DEV)
+    loc = torch.stack([bad, bad.flip(0), torch.full_like(bad, 0.2)], -1).reshape(1, 1, 6, 3).repeat(2, 1, 1, 1).contiguous()
+    out = ops.msmv_sampling(f, loc, torch.ones(2, 1, 6, 1, device=DEV))
+    assert torch.isfinite(out).all() and out.abs().sum() == 0
+
+
+def c2_inputs(B=1, Q=900, T=8, seed=0):
+    ih, iw, sizes = S.PYRAMIDS['r50_704x256']
+    G, P, L = 4, 4, len(sizes)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    feats = [torch.randn(B * T * G, 6, h, w, 64, generator=g, device=DEV) for h, w in sizes]
+    bbox, feat = S.make_queries(B, Q, seed=seed)
+    params = S.make_params(seed, num_frames=T, num_levels=L)
+    metas = S.make_img_metas(B, T, ih, iw)
+    l2i = torch.from_numpy(np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+    td = torch.tensor([[0.5 * t for t in range(T)]] * B)
+    off = torch.nn.functional.linear(feat, params['sampling.sampling_offset.weight'], params['sampling.sampling_offset.bias'])
+    lg = torch.nn.functional.linear(feat, params['sampling.scale_weights.weight'], params['sampling.scale_weights.bias'])
+    pts, wbp = ops.sampling_front(dev(bbox), dev(off), dev(lg), dev(td), S.PC_RANGE, T, G, P, L)
+    loc, uvh, valid, iview = ops.project_select(pts, dev(l2i), ih, iw, G, P, dump=True)
+    return feats, pts, l2i, loc, wbp, (uvh, valid, iview), (ih, iw, B, Q, T, G, P, L)
+
+
+def test_full_size_c2_vs_c_oracle_and_properties():
+    """BASELINE config 2 (r50 704x256, 900 q, T=8, bs=1): 115 200 sampled points per layer."""
+    from oracle import c_oracle
+    feats, pts, l2i, loc, wbp, (uvh, valid, iview), (ih, iw, B, Q, T, G, P, L) = c2_inputs()
+    # (1) projection + mask bit-exact against the C oracle at full size
+    uvh_r, valid_r, iview_r = c_oracle.project(pts.cpu().numpy(), l2i.numpy(), ih, iw)
+    assert np.array_equal(valid.cpu().numpy(), valid_r)
+    assert np.array_equal(iview.cpu().numpy(), iview_r)
+    assert np.array_equal(uvh.cpu().numpy().view(np.uint32), uvh_r.view(np.uint32))
+    hit = valid_r.sum(2)
+    assert 0.85 < (hit >= 1).mean() < 0.99 and (hit >= 2).mean() > 0.01      # the rig exercises 0/1/2-hit points
+    # (2) sampler vs the C oracle at full size
+    out = ops.msmv_sampling(feats, loc, wbp)
+    ref = c_oracle.msmv_fwd([f.cpu().numpy() for f in feats], loc.cpu().numpy(), wbp.cpu().numpy())
+    assert np.abs(out.cpu().numpy() - ref).max() < TOL
+    # (3) size-independent properties
+    #  linearity in the features
+    feats2 = [torch.randn_like(f) for f in feats]
+    o2 = ops.msmv_sampling(feats2, loc, wbp)
+    o12 = ops.msmv_sampling([1.5 * a - 0.5 * b for a, b in zip(feats, feats2)], loc, wbp)
+    assert (o12 - (1.5 * out - 0.5 * o2)).abs().max() < 5e-5
+    #  constant features + weights summing to one -> every fully-inside point returns the constant
+    ones = [torch.ones_like(f) for f in feats]
+    oc = ops.msmv_sampling(ones, loc, wbp)
+    inside = ((loc[..., 0] > 0) & (loc[..., 0] < 1) & (loc[..., 1] > 0) & (loc[..., 1] < 1))   # [B',Q,P]
+    assert (oc.permute(0, 1, 3, 2)[inside] - 1).abs().max() < 1e-5
+    #  layouts agree bit for bit; determinism
+    mix = ops.msmv_sampling(feats, loc, wbp, out_layout=ops.OUT_MIX, T=T, G=G)
+    ref_mix = out.reshape(B, T, G, Q, 64, P).permute(0, 3, 2, 1, 5, 4).reshape(B, Q, G, T * P, 64)
+    assert torch.equal(mix, ref_mix)
+    assert torch.equal(ops.msmv_sampling(feats, loc, wbp), out)
+
+
+def test_int64_offsets_beyond_2g_elements():
+    """The reference's int32 offsets overflow once B'*N*H*W*C >= 2^31.  Sample the
+    LAST batch entry of a 2.2e9-element level and check it against a small tensor holding just that entry."""
+    H, W, C, N = 128, 352, 64, 6
+    Bp = 128                                     # 128*6*128*352*64 = 2.21e9 elements = 8.9 GB fp32
+    try:
+        big = torch.empty(Bp, N, H, W, C, device=DEV)
+    except RuntimeError:
+        pytest.skip('not enough device memory for the 8.9 GB level')
+    g = torch.Generator(device=DEV).manual_seed(1)
+    last = torch.randn(1, N, H, W, C, generator=g, device=DEV)
+    big[-1] = last[0]
+    Q, P = 64, 4
+    loc = torch.rand(1, Q, P, 3, generator=g, device=DEV)
+    loc[..., 2] = torch.randint(0, N, (1, Q, P), generator=g, device=DEV).float() / (N - 1)
+    w = torch.rand(1, Q, P, 1, generator=g, device=DEV)
+    small = ops.msmv_sampling([last], loc, w)
+    loc_big = torch.zeros(Bp, Q, P, 3, device=DEV)
+    w_big = torch.zeros(Bp, Q, P, 1, device=DEV)
+    loc_big[-1], w_big[-1] = loc[0], w[0]
+    out = ops.msmv_sampling([big], loc_big, w_big)
+    assert torch.equal(out[-1], small[0])

@@ -138,3 +138,25 @@ def forced_layer_inputs(g):
     """(query_bbox, query_feat) the reference fed to each of its 6 layers, from the G7 fixture."""
     n = g['out_cls'].shape[0]
     return [(g['query_bbox'], g['query_feat'])] + [(g['out_bbox'][i - 1], g['out_feat'][i - 1]) for i in range(1, n)]
+
+
+# ---- the C half of the oracle (oracle/msmv_oracle.c) against the same golden vectors ----------------------
+@pytest.mark.parametrize('tag', ['L4_C8', 'L5_C64', 'L4_C16_P7'])
+def test_c_oracle_sampler(tag):
+    from oracle import c_oracle
+    g = load_golden('g1_msmv_' + tag)
+    out = c_oracle.msmv_fwd([f.numpy() for f in feats_of(g)], g['loc'].numpy(), g['weights'].numpy())
+    assert np.abs(out - g['out'].numpy()).max() < TOL
+
+
+@pytest.mark.parametrize('T', [1, 8])
+def test_c_oracle_projection_bit_exact(T):
+    from oracle import c_oracle
+    g = load_golden('g2_sampling4d_T%d' % T)
+    pts = g['sample_points']
+    B, Q, _, G, P, _ = pts.shape
+    ih, iw = [int(v) for v in g['image_hw']]
+    uvh, valid, iview = c_oracle.project(pts.reshape(B, Q, T, G * P, 3).numpy(), g['lidar2img'].numpy(), ih, iw)
+    assert np.array_equal(valid, g['valid'].numpy())
+    assert np.array_equal(uvh.view(np.uint32), g['uvh'].numpy().view(np.uint32))
+    assert np.array_equal(iview, np.argmax(g['valid'].numpy(), axis=2))

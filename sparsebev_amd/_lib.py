@@ -7,6 +7,12 @@ there is no PyTorch / CPU fallback anywhere in this package (the reference silen
 import ctypes
 import os
 
+# Load order matters: the PyTorch-ROCm wheel bundles its own libamdhip64.so.  Importing torch FIRST makes
+# the dynamic linker satisfy libsbev_hip.so's NEEDED libamdhip64.so.7 with that already-loaded runtime, so
+# our kernels and torch's streams / allocations live in ONE HIP runtime.  (Loaded the other way round the
+# process ends up with two runtimes and every launch on a torch stream fails with "no ROCm-capable device".)
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libsbev_hip.so')
 

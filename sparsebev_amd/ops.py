@@ -13,6 +13,9 @@ from . import _lib
 N_VIEWS = 6           # models/sparsebev_sampling.py:45
 OUT_REF, OUT_MIX = 0, 1
 _F32, _BF16 = 0, 1
+# bench.py sets this to a list to collect (start, end) HIP events around every sampler launch, recorded on
+# the stream the kernel is launched on; None = no instrumentation.
+PROFILE_EVENTS = None
 
 
 def _stream():
@@ -43,9 +46,16 @@ def _msmv_launch(feats, hw, feat_dtype, Bp, N, C, Q, P, gdiv, stride_bo, stride_
     c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
     c_sbo = (ctypes.c_int64 * L)(*stride_bo)
     c_sv = (ctypes.c_int64 * L)(*stride_v)
+    ev = None
+    if PROFILE_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     st = lib.sbev_msmv_fwd(c_feats, c_hw, L, feat_dtype, Bp, N, C, Q, P, gdiv, c_sbo, stride_g, c_sv, stride_px,
                            _ptr(loc), _ptr(weights), _ptr(out), out_layout, T, G, _stream())
     _lib.check(st, 'sbev_msmv_fwd')
+    if ev is not None:
+        ev[1].record()
+        PROFILE_EVENTS.append(ev)
 
 
 def _feat_dtype(feats):

@@ -1,0 +1,89 @@
+"""Multi-GPU layer: one process per GPU, samples sharded across ranks, one collective.
+
+The decoder path has no cross-sample term, so rank r of W simply owns samples
+{r, r+W, ...} -- the ``DistributedSampler(shuffle=False)`` partition the reference's loader uses
+(loaders/builder.py:26-27) -- with replicated weights and NO data-path collective.  The only exchange is the
+end-of-run metric all-reduce, the counterpart of the reference's end-of-eval result gather (val.py:132):
+``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm); ``gloo`` for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(n_gpus_requested=1, backend=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run sets them),
+    bind this process to its GPU and create the process group when WORLD_SIZE > 1.
+    Returns (rank, world_size, device)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != max(n_gpus_requested, 1) and world > 1:
+        raise RuntimeError('--gpus %d but WORLD_SIZE=%d' % (n_gpus_requested, world))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this driver
+        backend = backend or ('nccl' if use_gpu else 'gloo')
+        kw = {'device_id': device} if (use_gpu and backend == 'nccl') else {}
+        dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+class SampleShard:
+    """Which samples this rank owns, and the metric reduction at the end."""
+
+    def __init__(self, rank, world):
+        assert 0 <= rank < world
+        self.rank, self.world = rank, world
+
+    def owns(self, sample_index):
+        return sample_index % self.world == self.rank
+
+    def indices(self, n_samples):
+        """Global sample indices of this rank: r, r+W, r+2W, ... < n_samples."""
+        return list(range(self.rank, n_samples, self.world))
+
+    def _device(self):
+        if dist.is_initialized() and dist.get_backend() == 'nccl':
+            return torch.device('cuda', torch.cuda.current_device())
+        return torch.device('cpu')
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def reduce_metrics(self, elapsed_s, samples_done, checksum):
+        """(max elapsed over ranks, total samples, sum of per-rank output checksums).  Two tiny all-reduces
+        (MAX and SUM) of fp64 scalars: latency-bound, link bandwidth irrelevant."""
+        if self.world == 1:
+            return float(elapsed_s), float(samples_done), float(checksum)
+        dev = self._device()
+        t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+        s = torch.tensor([samples_done, checksum], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        return float(t[0]), float(s[0]), float(s[1])
+
+    def gather_results(self, local_results, n_samples):
+        """All ranks' per-sample results in global sample order (mirrors multi_gpu_test(gpu_collect=True),
+        val.py:132): local_results[i] belongs to global sample rank + i*world."""
+        if self.world == 1:
+            return list(local_results)[:n_samples]
+        bucket = [None] * self.world
+        dist.all_gather_object(bucket, list(local_results))
+        out = [None] * n_samples
+        for r, items in enumerate(bucket):
+            for i, item in enumerate(items):
+                gi = r + i * self.world
+                if gi < n_samples:
+                    out[gi] = item
+        return out
+
+    def shutdown(self):
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()

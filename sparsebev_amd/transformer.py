@@ -1,0 +1,329 @@
+"""Drop-in ``SparseBEVTransformer`` for ``SparseBEVHead`` -- MI355X-native decoder hot path.
+
+Interface parity with the reference:
+  * same registry name and constructor kwargs as ``models/sparsebev_transformer.py:16-26``
+    (``dict(type='SparseBEVTransformer', embed_dims, num_frames, num_points, num_layers, num_levels,
+    num_classes, code_size, pc_range)``; ``init_cfg`` must be None);
+  * same ``forward(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas) -> (cls_scores, bbox_preds)``
+    (``:32-38``), same ``init_weights()`` (``:28-30,146-153,206-208,265-268,348-349``);
+  * identical ``state_dict`` keys (48 tensors under ``decoder.decoder_layer.``), so reference checkpoints
+    load with ``strict=True``.
+The module tree below exists only to own parameters under those names; the arithmetic is done by the HIP
+kernels in libsbev_hip.so through ``sparsebev_amd.ops`` / ``sparsebev_amd.dense``.  Differences on purpose:
+inputs are never mutated (the reference overwrites ``mlvl_feats[lvl]`` and ``img_metas[0]``, ``:65,70,85``),
+and the 2x-feature-bytes regroup copy (``:73-85``) is replaced by one NCHW->NHWC relayout (or nothing at
+all when the neck already produces channels-last features).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dense, ops
+from .utils import DUMP
+
+try:  # optional: register with mmdet's registry when the OpenMMLab stack is present
+    from mmcv.runner import BaseModule as _Base
+    from mmdet.models.utils.builder import TRANSFORMER as _REGISTRY
+except Exception:  # noqa: BLE001  (mmcv / mmdet are absent in the build image)
+    _REGISTRY = None
+
+    class _Base(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+N_VIEWS, N_GROUPS, N_HEADS, OUT_POINTS, FFN_CHANNELS = 6, 4, 8, 128, 512
+
+
+def _register(cls):
+    if _REGISTRY is not None:
+        try:
+            return _REGISTRY.register_module()(cls)
+        except KeyError:        # the reference's own class is already registered under this name
+            return cls
+    return cls
+
+
+class _AttentionParams(nn.Module):
+    """Parameter holder with mmcv-1.6.0 ``MultiheadAttention`` key names: ``attn.in_proj_weight`` etc."""
+
+    def __init__(self, embed_dims, num_heads):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, dropout=0.0)
+
+
+class _FFNParams(nn.Module):
+    """mmcv-1.6.0 ``FFN`` key names: ``layers.0.0`` (Linear D->F) and ``layers.1`` (Linear F->D)."""
+
+    def __init__(self, embed_dims, feedforward_channels):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(0.1)),
+            nn.Linear(feedforward_channels, embed_dims), nn.Dropout(0.1))
+
+
+class SparseBEVSelfAttention(_Base):
+    """Scale-adaptive self attention, models/sparsebev_transformer.py:196-248."""
+
+    def __init__(self, embed_dims=256, num_heads=8, dropout=0.1, pc_range=(), init_cfg=None):
+        super().__init__(init_cfg)
+        self.pc_range = list(pc_range)
+        self.num_heads = num_heads
+        self.attention = _AttentionParams(embed_dims, num_heads)
+        self.gen_tau = nn.Linear(embed_dims, num_heads)
+
+    @torch.no_grad()
+    def init_weights(self):
+        nn.init.zeros_(self.gen_tau.weight)
+        nn.init.uniform_(self.gen_tau.bias, 0.0, 2.0)
+
+    def forward(self, query_bbox, query_feat, pre_attn_mask=None):
+        a = self.attention.attn
+        out = dense.scale_adaptive_self_attention(
+            query_bbox, query_feat, self.pc_range, self.num_heads,
+            a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+            self.gen_tau.weight, self.gen_tau.bias, pre_attn_mask)
+        return out
+
+
+class SparseBEVSampling(_Base):
+    """Adaptive spatio-temporal sampling, models/sparsebev_transformer.py:251-317."""
+
+    def __init__(self, embed_dims=256, num_frames=4, num_groups=4, num_points=8, num_levels=4, pc_range=(), init_cfg=None):
+        super().__init__(init_cfg)
+        self.num_frames, self.num_points, self.num_groups, self.num_levels = num_frames, num_points, num_groups, num_levels
+        self.pc_range = list(pc_range)
+        self.sampling_offset = nn.Linear(embed_dims, num_groups * num_points * 3)
+        self.scale_weights = nn.Linear(embed_dims, num_groups * num_points * num_levels)
+
+    @torch.no_grad()
+    def init_weights(self):
+        nn.init.zeros_(self.sampling_offset.weight)
+        nn.init.uniform_(self.sampling_offset.bias, -0.5, 0.5)
+
+    def forward(self, query_bbox, query_feat, feats, ctx):
+        """feats: FeaturePyramid (channels-last, resident); ctx: DecoderContext.  -> [B,Q,G,T*P,C]"""
+        T, G, P, L = self.num_frames, self.num_groups, self.num_points, self.num_levels
+        # one fused Linear for both generators: [B,Q,256] x [256, G*P*3 + G*P*L]
+        both = dense.linear(query_feat, ctx.cat_weight(self.sampling_offset, self.scale_weights),
+                            ctx.cat_bias(self.sampling_offset, self.scale_weights))
+        n_off = G * P * 3
+        offset, logits = both[..., :n_off].contiguous(), both[..., n_off:].contiguous()
+        pts, w_bp = ops.sampling_front(query_bbox, offset, logits, ctx.time_diff, self.pc_range, T, G, P, L)
+        if DUMP.enabled:
+            loc, uvh, valid, _ = ops.project_select(pts, ctx.lidar2img, ctx.image_h, ctx.image_w, G, P, dump=True)
+            DUMP.save('sample_points_cam', uvh)
+            DUMP.save('sample_points_cam_valid_mask', valid.float())
+        else:
+            loc = ops.project_select(pts, ctx.lidar2img, ctx.image_h, ctx.image_w, G, P)
+        return feats.sample(loc, w_bp, T, G)
+
+
+class AdaptiveMixing(nn.Module):
+    """Adaptive channel + point mixing, models/sparsebev_transformer.py:320-387."""
+
+    def __init__(self, in_dim, in_points, n_groups=1, query_dim=None, out_dim=None, out_points=None):
+        super().__init__()
+        out_dim = out_dim if out_dim is not None else in_dim
+        out_points = out_points if out_points is not None else in_points
+        query_dim = query_dim if query_dim is not None else in_dim
+        self.query_dim, self.in_dim, self.in_points, self.n_groups = query_dim, in_dim, in_points, n_groups
+        self.out_dim, self.out_points = out_dim, out_points
+        self.eff_in_dim, self.eff_out_dim = in_dim // n_groups, out_dim // n_groups
+        self.m_parameters = self.eff_in_dim * self.eff_out_dim
+        self.s_parameters = self.in_points * self.out_points
+        self.total_parameters = self.m_parameters + self.s_parameters
+        self.parameter_generator = nn.Linear(self.query_dim, self.n_groups * self.total_parameters)
+        self.out_proj = nn.Linear(self.eff_out_dim * self.out_points * self.n_groups, self.query_dim)
+
+    @torch.no_grad()
+    def init_weights(self):
+        nn.init.zeros_(self.parameter_generator.weight)
+
+    def forward(self, x, query):
+        return dense.adaptive_mixing(x, query, self.parameter_generator.weight, self.parameter_generator.bias,
+                                     self.out_proj.weight, self.out_proj.bias, self.out_points)
+
+
+class SparseBEVTransformerDecoderLayer(_Base):
+    """models/sparsebev_transformer.py:104-193."""
+
+    def __init__(self, embed_dims, num_frames=8, num_points=4, num_levels=4, num_classes=10, code_size=10,
+                 num_cls_fcs=2, num_reg_fcs=2, pc_range=(), init_cfg=None):
+        super().__init__(init_cfg)
+        self.embed_dims, self.num_classes, self.code_size, self.pc_range = embed_dims, num_classes, code_size, list(pc_range)
+        D = embed_dims
+        self.position_encoder = nn.Sequential(nn.Linear(3, D), nn.LayerNorm(D), nn.ReLU(inplace=True),
+                                              nn.Linear(D, D), nn.LayerNorm(D), nn.ReLU(inplace=True))
+        self.self_attn = SparseBEVSelfAttention(D, num_heads=N_HEADS, dropout=0.1, pc_range=pc_range)
+        self.sampling = SparseBEVSampling(D, num_frames=num_frames, num_groups=N_GROUPS, num_points=num_points,
+                                          num_levels=num_levels, pc_range=pc_range)
+        self.mixing = AdaptiveMixing(in_dim=D, in_points=num_points * num_frames, n_groups=N_GROUPS, out_points=OUT_POINTS)
+        self.ffn = _FFNParams(D, FFN_CHANNELS)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(D), nn.LayerNorm(D), nn.LayerNorm(D)
+        cls = []
+        for _ in range(num_cls_fcs):
+            cls += [nn.Linear(D, D), nn.LayerNorm(D), nn.ReLU(inplace=True)]
+        cls.append(nn.Linear(D, num_classes))
+        self.cls_branch = nn.Sequential(*cls)
+        reg = []
+        for _ in range(num_reg_fcs):
+            reg += [nn.Linear(D, D), nn.ReLU(inplace=True)]
+        reg.append(nn.Linear(D, code_size))
+        self.reg_branch = nn.Sequential(*reg)
+
+    @torch.no_grad()
+    def init_weights(self):
+        self.self_attn.init_weights()
+        self.sampling.init_weights()
+        self.mixing.init_weights()
+        nn.init.constant_(self.cls_branch[-1].bias, float(-math.log((1 - 0.01) / 0.01)))   # bias_init_with_prob(0.01)
+
+    def forward(self, query_bbox, query_feat, feats, attn_mask, ctx):
+        pe = self.position_encoder
+        pos = dense.linear_ln_relu(query_bbox[..., :3].contiguous(), pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)
+        pos = dense.linear_ln_relu(pos, pe[3].weight, pe[3].bias, pe[4].weight, pe[4].bias)
+        x = query_feat + pos
+        x = dense.layer_norm(self.self_attn(query_bbox, x, attn_mask), self.norm1.weight, self.norm1.bias)
+        sampled = self.sampling(query_bbox, x, feats, ctx)
+        x = dense.layer_norm(self.mixing(sampled, x), self.norm2.weight, self.norm2.bias)
+        f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]
+        h = dense.linear(x, f0.weight, f0.bias, relu=True)
+        x = dense.layer_norm(dense.linear(h, f1.weight, f1.bias, residual=x), self.norm3.weight, self.norm3.bias)
+        cb, rb = self.cls_branch, self.reg_branch
+        c = dense.linear_ln_relu(x, cb[0].weight, cb[0].bias, cb[1].weight, cb[1].bias)
+        c = dense.linear_ln_relu(c, cb[3].weight, cb[3].bias, cb[4].weight, cb[4].bias)
+        cls_score = dense.linear(c, cb[6].weight, cb[6].bias)
+        r = dense.linear(x, rb[0].weight, rb[0].bias, relu=True)
+        r = dense.linear(r, rb[2].weight, rb[2].bias, relu=True)
+        reg = dense.linear(r, rb[4].weight, rb[4].bias)
+        bbox_pred = dense.refine_bbox(query_bbox, reg, ctx.vel_div)
+        if DUMP.enabled:
+            DUMP.save('query_bbox', ops_decode(query_bbox, self.pc_range))
+            DUMP.save('bbox_pred', ops_decode(bbox_pred, self.pc_range))
+            DUMP.save('cls_score', torch.sigmoid(cls_score))
+        return x, cls_score, bbox_pred
+
+
+def ops_decode(bbox, pc_range):
+    """decode_bbox (models/bbox/utils.py:63-77) for the DUMP taps only (debug path)."""
+    lo = bbox.new_tensor(pc_range[:3])
+    span = bbox.new_tensor([pc_range[3] - pc_range[0], pc_range[4] - pc_range[1], pc_range[5] - pc_range[2]])
+    return torch.cat([bbox[..., :3] * span + lo, bbox[..., 3:6].exp(), torch.atan2(bbox[..., 6:7], bbox[..., 7:8]),
+                      bbox[..., 8:10]], dim=-1)
+
+
+class FeaturePyramid:
+    """Channels-last, device-resident view of the FPN output for the sampler.
+
+    Built from the reference layout ``list[L] of [B, T*N, G*C, H, W]`` (models/sparsebev.py:126-131).  If a
+    level is already channels-last in memory (``permute(0,1,3,4,2)`` contiguous) it is used in place;
+    otherwise ONE relayout to ``[B*T*N, H, W, G*C]`` is made.  Group g is addressed as the channel slice
+    [g*C, (g+1)*C) inside the kernel, so the reference's per-group regroup copy never exists."""
+
+    def __init__(self, mlvl_feats):
+        self.levels = []
+        self.copied = 0
+        f0 = mlvl_feats[0]
+        self.B, TN, self.GC = f0.shape[0], f0.shape[1], f0.shape[2]
+        self.T = TN // N_VIEWS
+        for f in mlvl_feats:
+            if not f.is_cuda:
+                raise RuntimeError('SparseBEVTransformer (sparsebev_amd) needs device features; there is no CPU path')
+            nhwc = f.permute(0, 1, 3, 4, 2)
+            if not nhwc.is_contiguous():
+                nhwc = dense.to_channels_last(f)
+                self.copied += 1
+            self.levels.append(nhwc.reshape(self.B * TN, f.shape[3], f.shape[4], self.GC))
+
+    def sample(self, loc, w_bp, T, G):
+        return ops.msmv_sampling_nhwc(self.levels, self.B, T, G, loc, w_bp, out_layout=ops.OUT_MIX)
+
+
+class DecoderContext:
+    """Per-call constants: time_diff, lidar2img, image size (models/sparsebev_transformer.py:60-70,276)."""
+
+    def __init__(self, img_metas, B, device):
+        ts = np.array([m['img_timestamp'] for m in img_metas], dtype=np.float64).reshape(B, -1, N_VIEWS)
+        td = np.mean(ts[:, :1, :] - ts, axis=-1).astype(np.float32)                # [B,T]; float64 mean then fp32
+        l2i = np.asarray([m['lidar2img'] for m in img_metas]).astype(np.float32)   # [B,T*N,4,4]
+        self.time_diff = torch.from_numpy(td).to(device)
+        self.lidar2img = torch.from_numpy(l2i).to(device)
+        self.image_h, self.image_w = img_metas[0]['img_shape'][0][:2]
+        # velocity divisor of :179-183: time_diff[:,1] with values < 1e-5 replaced by 1 (only when T > 1)
+        if td.shape[1] > 1:
+            d = td[:, 1].copy()
+            d[d < 1e-5] = 1.0
+            self.vel_div = torch.from_numpy(d).to(device)
+        else:
+            self.vel_div = None
+        self._cat = {}
+
+    def cat_weight(self, a, b):
+        key = ('w', id(a), id(b), a.weight._version, b.weight._version)
+        if key not in self._cat:
+            self._cat[key] = torch.cat([a.weight, b.weight], 0).contiguous()
+        return self._cat[key]
+
+    def cat_bias(self, a, b):
+        key = ('b', id(a), id(b), a.bias._version, b.bias._version)
+        if key not in self._cat:
+            self._cat[key] = torch.cat([a.bias, b.bias], 0).contiguous()
+        return self._cat[key]
+
+
+class SparseBEVTransformerDecoder(_Base):
+    """models/sparsebev_transformer.py:41-101 (one shared layer applied num_layers times)."""
+
+    def __init__(self, embed_dims, num_frames=8, num_points=4, num_layers=6, num_levels=4, num_classes=10,
+                 code_size=10, pc_range=(), init_cfg=None):
+        super().__init__(init_cfg)
+        self.num_layers, self.pc_range = num_layers, list(pc_range)
+        self.decoder_layer = SparseBEVTransformerDecoderLayer(embed_dims, num_frames, num_points, num_levels,
+                                                              num_classes, code_size, pc_range=pc_range)
+
+    @torch.no_grad()
+    def init_weights(self):
+        self.decoder_layer.init_weights()
+
+    def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
+        B = query_bbox.shape[0]
+        ctx = DecoderContext(img_metas, B, query_bbox.device)
+        feats = mlvl_feats if isinstance(mlvl_feats, FeaturePyramid) else FeaturePyramid(mlvl_feats)
+        query_bbox = query_bbox.float().contiguous()
+        query_feat = query_feat.float().contiguous()
+        cls_scores, bbox_preds = [], []
+        for i in range(self.num_layers):
+            DUMP.stage_count = i
+            query_feat, cls_score, bbox_pred = self.decoder_layer(query_bbox, query_feat, feats, attn_mask, ctx)
+            query_bbox = bbox_pred.detach()
+            cls_scores.append(cls_score)
+            bbox_preds.append(bbox_pred)
+        return torch.stack(cls_scores), torch.stack(bbox_preds)
+
+
+@_register
+class SparseBEVTransformer(_Base):
+    """models/sparsebev_transformer.py:16-38."""
+
+    def __init__(self, embed_dims, num_frames=8, num_points=4, num_layers=6, num_levels=4, num_classes=10,
+                 code_size=10, pc_range=[], init_cfg=None):
+        assert init_cfg is None, 'To prevent abnormal initialization behavior, init_cfg is not allowed to be set'
+        super().__init__(init_cfg=init_cfg)
+        self.embed_dims = embed_dims
+        self.pc_range = pc_range
+        self.decoder = SparseBEVTransformerDecoder(embed_dims, num_frames, num_points, num_layers, num_levels,
+                                                   num_classes, code_size, pc_range=pc_range)
+
+    @torch.no_grad()
+    def init_weights(self):
+        self.decoder.init_weights()
+
+    def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError('sparsebev_amd implements the inference forward of the decoder; the backward '
+                                      '(SURVEY.md section 8f) is not built yet -- call in eval() under torch.no_grad()')
+        with torch.no_grad():
+            cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas)
+            return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)

@@ -1,0 +1,36 @@
+"""Module-level switches the reference exposes next to the hot path (models/utils.py:309-325)."""
+import os
+import tempfile
+
+import torch
+
+
+class DumpConfig:
+    """The ``DUMP`` debug taps (models/utils.py:309-317).  When ``enabled`` the decoder writes, per stage,
+    ``sample_points_cam_stage{i}.pth`` ([B,T,N,Q,GP,3] = u, v, max(homo,eps)),
+    ``sample_points_cam_valid_mask_stage{i}.pth`` ([B,T,N,Q,GP] float 0/1), ``sasa_tau_stage{i}.pth``,
+    ``query_bbox_stage{i}.pth``, ``bbox_pred_stage{i}.pth`` and ``cls_score_stage{i}.pth`` into ``out_dir``
+    -- the files viz_sample_points.py:83-105 reads."""
+
+    def __init__(self):
+        self.enabled = False
+        self.out_dir = tempfile.mkdtemp()
+        self.stage_count = 0
+        self.frame_count = 0
+
+    def save(self, name, tensor):
+        torch.save(tensor.detach().cpu(), os.path.join(self.out_dir, '%s_stage%d.pth' % (name, self.stage_count)))
+
+
+DUMP = DumpConfig()
+
+
+class Version:
+    """Checkpoint convention switch (models/utils.py:320-325).  Only 'v1.0.0' (the default, and the only
+    convention any shipped config uses) is implemented by the HIP kernels."""
+
+    def __init__(self):
+        self.name = 'v1.0.0'
+
+
+VERSION = Version()

@@ -1,0 +1,89 @@
+"""GPU parity of the drop-in SparseBEVTransformer (sparsebev_amd.transformer) against golden vectors
+recorded from the reference decoder, teacher-forced per layer (1e-4) and free-running (sanity bound)."""
+import copy
+
+import pytest
+import torch
+
+from conftest import load_golden
+from sparsebev_amd import synthetic as S
+from sparsebev_amd.transformer import SparseBEVTransformer, FeaturePyramid, DecoderContext
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = 'cuda:0'
+PREFIX = 'decoder.decoder_layer.'
+
+
+def build(T, L, seed):
+    params = S.make_params(seed, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=6, num_levels=L, num_classes=10,
+                             code_size=10, pc_range=S.PC_RANGE)
+    missing = m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)   # identical key set
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize('tag', ['c1', 'c2small', 'L5'])
+def test_g7_decoder_teacher_forced_and_free_running(tag):
+    g = load_golden('g7_decoder_' + tag)
+    B, Q, T, L = [int(v) for v in g['cfg']]
+    seeds = [int(v) for v in g['seeds']]
+    ih, iw, sizes = S.PYRAMIDS[str(g['pyramid'])]
+    model = build(T, L, seeds[0])
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=seeds[2])]
+    metas = S.make_img_metas(B, T, ih, iw)
+    for b, m in enumerate(metas):
+        m['img_timestamp'] = [float(v) for v in g['timestamps'][b]]
+    # free-running, through the public forward (the SparseBEVHead call site, sparsebev_head.py:77-83)
+    metas_in = copy.deepcopy(metas)
+    cls, box = model(g['query_bbox'].to(DEV), g['query_feat'].to(DEV), list(feats), None, metas_in)
+    assert cls.shape == g['out_cls'].shape and box.shape == g['out_bbox'].shape
+    assert (cls[0].cpu() - g['out_cls'][0]).abs().max() < TOL
+    assert (box[0].cpu() - g['out_bbox'][0]).abs().max() < TOL
+    assert (cls.cpu() - g['out_cls']).abs().max() < 0.2           # rounding noise grows ~5x per random-init layer
+    assert 'time_diff' not in metas_in[0] and not torch.is_tensor(metas_in[0]['lidar2img'])   # inputs not mutated
+    # teacher-forced: each layer from the reference's own inputs
+    layer = model.decoder.decoder_layer
+    pyr, ctx = FeaturePyramid(feats), DecoderContext(metas, B, torch.device(DEV))
+    n = g['out_cls'].shape[0]
+    ins = [(g['query_bbox'], g['query_feat'])] + [(g['out_bbox'][i - 1], g['out_feat'][i - 1]) for i in range(1, n)]
+    with torch.no_grad():
+        for i, (qb, qf) in enumerate(ins):
+            x, c, bb = layer(qb.to(DEV), qf.to(DEV), pyr, None, ctx)
+            assert (x.cpu() - g['out_feat'][i]).abs().max() < TOL, i
+            assert (c.cpu() - g['out_cls'][i]).abs().max() < TOL, i
+            assert (bb.cpu() - g['out_bbox'][i]).abs().max() < TOL, i
+
+
+def test_g5_self_attention_with_dn_mask():
+    g = load_golden('g5_selfattn_T2')
+    model = build(2, 4, int(g['seeds'][0]))
+    sa = model.decoder.decoder_layer.self_attn
+    with torch.no_grad():
+        a = sa(g['query_bbox'].to(DEV), g['query_feat'].to(DEV), None)
+        b = sa(g['query_bbox'].to(DEV), g['query_feat'].to(DEV), g['mask'].bool().to(DEV))
+    assert (a.cpu() - g['out_nomask']).abs().max() < TOL
+    assert (b.cpu() - g['out_mask']).abs().max() < TOL
+
+
+@pytest.mark.parametrize('name,T', [('g4_mixing_T2', 2), ('g4_mixing_T8', 8)])
+def test_g4_adaptive_mixing(name, T):
+    g = load_golden(name)
+    model = build(T, 4, int(g['seeds'][0]))
+    with torch.no_grad():
+        out = model.decoder.decoder_layer.mixing(g['x'].to(DEV), g['query_feat'].to(DEV))
+    assert (out.cpu() - g['out']).abs().max() < TOL
+
+
+def test_state_dict_keys_match_reference():
+    m = SparseBEVTransformer(256, num_frames=8, pc_range=S.PC_RANGE)
+    keys = sorted(m.state_dict())
+    want = sorted(PREFIX + k for k in S.param_shapes())
+    assert keys == want and len(keys) == 48
+    m.init_weights()
+    sd = m.state_dict()
+    assert sd[PREFIX + 'mixing.parameter_generator.weight'].abs().sum() == 0
+    assert sd[PREFIX + 'sampling.sampling_offset.weight'].abs().sum() == 0
+    assert sd[PREFIX + 'self_attn.gen_tau.weight'].abs().sum() == 0
+    assert abs(float(sd[PREFIX + 'cls_branch.6.bias'][0]) + 4.59512) < 1e-4

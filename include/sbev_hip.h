@@ -120,6 +120,49 @@ int sbev_sampling_front(const float* query_bbox, const float* offset, const floa
                         int B, int Q, int T, int G, int P, int L,
                         float* sample_points, float* weights_bp, sbev_stream_t stream);
 
+/*
+ * nn.Linear on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate).
+ *   Y[m,n] = act( sum_k X[m,k] * W[n,k] + bias[n] ) + residual[m,n]
+ * Replaces: every torch.nn.Linear / F.linear of the decoder layer (models/sparsebev_transformer.py:116-153,
+ *           203,262-263,343-344,358,378; mmcv MultiheadAttention in/out projections and FFN, :7,125,202).
+ * X [M,ldx], W [N,ldw] (both K-contiguous, 16-byte aligned, ld % 4 == 0), bias [N] or NULL,
+ * residual [M,ldy] or NULL (added AFTER the activation, the `identity + out` form of mmcv FFN / MHA),
+ * relu != 0 applies max(.,0) before the residual.
+ */
+int sbev_linear_f32(const float* X, const float* W, const float* bias, const float* residual, float* Y,
+                    int64_t M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldy, int relu,
+                    sbev_stream_t stream);
+
+/*
+ * Split-K variant for long reductions with a small output (AdaptiveMixing.out_proj: K = 32768, N = 256,
+ * models/sparsebev_transformer.py:344,378), with the whole epilogue of that call site fused into the slab
+ * reduction: + bias, optional ReLU, + residual (`query + out`, :379), optional LayerNorm(N) (norm2, :171).
+ * workspace: device buffer of sbev_linear_splitk_workspace(M, N, splits) bytes.  N % 4 == 0, N <= 1024.
+ */
+int64_t sbev_linear_splitk_workspace(int64_t M, int N, int splits);
+int sbev_linear_splitk_f32(const float* X, const float* W, const float* bias, const float* residual,
+                           const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                           int64_t M, int N, int K, int64_t ldx, int64_t ldw, int relu,
+                           int splits, float* workspace, sbev_stream_t stream);
+
+/* Row LayerNorm (+ optional ReLU) of X [M,N], N % 4 == 0, N <= 1024.
+ * Replaces: nn.LayerNorm(embed_dims) (+ nn.ReLU) at models/sparsebev_transformer.py:117-121,127-129,132-136,169-172. */
+int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps, float* Y,
+                        int64_t M, int N, int relu, sbev_stream_t stream);
+
+/*
+ * Adaptive mixing core: per (query, group)  y = relu(LN_[Pout,C]( S @ relu(LN_[Pin,C]( x @ M )) )).
+ * Replaces: the two dynamic matmuls + F.layer_norm + ReLU of AdaptiveMixing.inner_forward
+ *           (models/sparsebev_transformer.py:362-374).  The parameter generator (:358) and the out-projection
+ *           (:377-379) around it are sbev_linear_f32 / sbev_linear_splitk_f32.
+ * x       device fp32 [BQ, G, Pin, C]          (= the sampler's SBEV_OUT_MIX output)
+ * params  device fp32 [BQ, G, C*C + Pout*Pin]  (per (q,g): M[C_in,C_out] then S[Pout,Pin]; the generator's output)
+ * y       device fp32 [BQ, G, Pout, C]         (flattened [g][o][c] it is the out-projection's input row)
+ * Built for C = 64, Pout = 128 (hard-coded in the reference: sparsebev_transformer.py:124); Pin % 4 == 0, Pin <= 120.
+ */
+int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
+                             int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,16 @@ SIGNATURES = {
     'sbev_sampling_front': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double),
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            _vp, _vp, _vp]),
+    'sbev_linear_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_linear_splitk_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sbev_linear_splitk_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp,
+                                              ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'sbev_layer_norm_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
+                                           ctypes.c_int, _vp]),
+    'sbev_adaptive_mixing_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_float, _vp]),
 }
 
 _lib = None

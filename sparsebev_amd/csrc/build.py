@@ -15,6 +15,8 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno
 UNITS = {
     'capi_common.hip': [],
     'msmv_sampling.hip': [],
+    'gemm.hip': [],
+    'mixing.hip': [],
     # bit-exact projection: no FMA contraction anywhere in this file
     'project.hip': ['-ffp-contract=off'],
 }

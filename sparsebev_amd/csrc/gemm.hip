@@ -1,0 +1,362 @@
+// fp32 "Linear" GEMM on the gfx950 matrix cores:  Y[M,N] = act(X[M,K] . W[N,K]^T + bias) (+ residual)
+//
+// Used for every nn.Linear of the decoder layer (models/sparsebev_transformer.py:116-153,203,262-263,
+// 343-344 and the mmcv MultiheadAttention / FFN projections); the two that matter are the adaptive-mixing
+// parameter generator [B*Q,256]x[256,32768] and its out-projection [B*Q,32768]x[32768,256] (15.1 GFLOP
+// each per layer-sample at config 2).
+//
+// Exact-fp32 path: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise an fmaf chain, so parity with the
+// reference's fp32 math holds to rounding-order noise).  Peak 157 TF (=the f32 vector peak), reached with
+// one wave per SIMD; both operands are K-contiguous ("NT" GEMM), which is exactly the nn.Linear layout.
+//
+// Tile: 128x128x32 per 256-thread workgroup, 2x2 waves, each wave 2x2 MFMA tiles of 32x32 (64 accumulator
+// VGPRs).  Global -> registers (16-B loads, issued one K-step ahead) -> LDS (double buffered, ONE barrier per
+// K-step) -> ds_read_b64 fragments (two k values per read feed two consecutive MFMAs).  LDS rows are padded
+// to 36 floats: keeps ds_write_b128 16-B aligned and leaves a 2-way conflict on the b64 reads (32 reads per
+// 64 MFMAs of 64 cycles each: invisible).  Split-K (grid.z) writes fp32 partial slabs for the K=32768
+// out-projection; sbev_splitk_reduce_* combines them in the next kernel's prologue (a launch boundary is
+// cheaper than an in-launch cross-XCD hand-off at this size, cdna_hip_programming.md section 5).
+#include "sbev_common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32, LDT = 36;  // LDT: padded LDS row stride (floats)
+// tile = (64*WM) x (64*WN): 2x2 waves, each WM x WN MFMA tiles of 32x32.  <2,2> = 128x128 for the big GEMMs,
+// <1,1> = 64x64 for the many small [B*Q,256]x[256,256..768] linears, which otherwise launch < 32 workgroups.
+
+struct GemmArgs {
+    const float* X;      // [M, ldx]
+    const float* W;      // [N, ldw]
+    const float* bias;   // [N] or null
+    const float* res;    // [M, ldy] or null
+    float* Y;            // [M, ldy]   (split-K: [splits, M, N] slabs, ldy = N)
+    long long M;
+    int N, K;            // K = full reduction length
+    long long ldx, ldw, ldy;
+    int k_per_split;     // multiple of BK
+    int relu;
+};
+
+// XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (MI355X_MICROARCH.md), so give
+// each XCD a contiguous run of tiles -> neighbouring tiles (which share a W panel) hit the same L2.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned id, unsigned n) {
+    const unsigned q = n / 8, r = n % 8, x = id % 8, s = id / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+template <bool SPLIT, int WM, int WN, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDT];
+    float* As = lds;                   // [2][BM][LDT]
+    float* Bs = lds + 2 * BM * LDT;    // [2][BN][LDT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const unsigned tiles_n = (a.N + BN - 1) / BN;
+    const unsigned tiles_m = (unsigned)((a.M + BM - 1) / BM);
+    // tile order: N fastest inside an XCD chunk so concurrently running tiles share the X panel and walk W
+    const unsigned t = xcd_swizzle(blockIdx.x, tiles_m * tiles_n);
+    const unsigned tm = t / tiles_n, tn = t % tiles_n;
+    const long long m0 = (long long)tm * BM;
+    const int n0 = tn * BN;
+    const int kbeg = SPLIT ? blockIdx.z * a.k_per_split : 0;
+    const int kend = SPLIT ? min(a.K, kbeg + a.k_per_split) : a.K;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    // staging map: thread -> (row = tid/8 + 32*i, 4 floats at col = (tid%8)*4)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    constexpr int PA = BM / 32, PB = BN / 32;
+    const float* xp[PA];
+    const float* wp[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        long long r = m0 + srow + 32 * i;
+        r = r < a.M ? r : a.M - 1;                      // clamp: rows past M are computed and never stored
+        xp[i] = a.X + r * a.ldx + scol;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        int c = n0 + srow + 32 * i;
+        c = c < a.N ? c : a.N - 1;
+        wp[i] = a.W + (long long)c * a.ldw + scol;
+    }
+    float4 ra[PA], rb[PB];
+    auto gload = [&](int kt) {
+        const int k = kbeg + kt * BK;
+        auto ld = [&](const float* p) {
+            // RAGGED is a separate instantiation on purpose: a run-time "vector or element-wise" choice makes
+            // hipcc branch around every load and wait vmcnt(0) each time (cdna_hip_programming.md, .s trap (c)).
+            if (!RAGGED) return *reinterpret_cast<const float4*>(p + k);
+            float v[4];                                  // K % 32 != 0: zero-fill element-wise
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (k + scol + e) < kend ? p[k + e] : 0.f;
+            return make_float4(v[0], v[1], v[2], v[3]);
+        };
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ra[i] = ld(xp[i]);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = ld(wp[i]);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(&As[(buf * BM + srow + 32 * i) * LDT + scol]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(&Bs[(buf * BN + srow + 32 * i) * LDT + scol]) = rb[i];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;   // fragment row / k-half
+    if (nk > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);                 // in flight under this step's 64 MFMAs
+        const float* Ab = As + (buf * BM + wr * 32 * WM + fr) * LDT + 2 * fh;
+        const float* Bb = Bs + (buf * BN + wc * 32 * WN + fr) * LDT + 2 * fh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float2 fa[WM], fb[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) fa[i] = *reinterpret_cast<const float2*>(Ab + i * 32 * LDT + kk * 4);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) fb[j] = *reinterpret_cast<const float2*>(Bb + j * 32 * LDT + kk * 4);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);               // the other buffer: nobody reads it during this step
+        __syncthreads();
+    }
+
+    // epilogue: accumulators -> LDS (the staging buffers are free after the last barrier) -> row-major float4
+    // pass, so bias / residual reads and the Y stores are 512-B contiguous per row instead of 128-B column
+    // fragments.  C/D layout of the 32x32 MFMA: column j = lane & 31, row i = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+    constexpr int LDC = BN + 4;
+    static_assert(BM * LDC <= 2 * (BM + BN) * LDT, "C tile must fit in the staging LDS");
+    float* Cs = lds;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = wr * 32 * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                Cs[r * LDC + wc * 32 * WN + j * 32 + fr] = acc[i][j][e];
+            }
+    __syncthreads();
+    float* Y = SPLIT ? a.Y + (long long)blockIdx.z * a.M * a.ldy : a.Y;
+    constexpr int TPR = BN / 4;                 // threads per row (float4 each)
+    constexpr int RPP = 256 / TPR;              // rows per pass
+    const int er = tid / TPR, ec = (tid % TPR) * 4;
+    const int n = n0 + ec;
+    const bool vec = (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) && (n + 3 < a.N) &&
+                     (SPLIT || !a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!SPLIT && a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (n + e) < a.N ? a.bias[n + e] : 0.f;
+    }
+#pragma unroll 4
+    for (int it = 0; it < BM / RPP; ++it) {
+        const int r = er + it * RPP;
+        const long long m = m0 + r;
+        if (m >= a.M) break;
+        const float4 c4 = *reinterpret_cast<const float4*>(&Cs[r * LDC + ec]);
+        float v[4] = {c4.x, c4.y, c4.z, c4.w};
+        if (!SPLIT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += bv[e];
+                if (a.relu) v[e] = fmaxf(v[e], 0.f);
+            }
+        }
+        float* yp = Y + m * a.ldy + n;
+        if (vec) {
+            if (!SPLIT && a.res) {
+                const float4 r4 = *reinterpret_cast<const float4*>(a.res + m * a.ldy + n);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < a.N) {
+                    if (!SPLIT && a.res) v[e] += a.res[m * a.ldy + n + e];
+                    yp[e] = v[e];
+                }
+        }
+    }
+}
+
+struct ReduceArgs {
+    const float* slabs;  // [splits, M, N]
+    const float* bias;   // [N] or null
+    const float* res;    // [M, N] or null
+    const float* ln_w;   // [N] or null -> no LayerNorm
+    const float* ln_b;
+    float* Y;            // [M, N]
+    long long M;
+    int N, splits, relu;
+    float eps;
+};
+
+// one wave per output row (N <= 1024, N % 4 == 0): sum the split-K slabs, + bias, (+ residual), optional
+// LayerNorm over the row (two-pass in registers), optional ReLU.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    constexpr int MAXV = 4;                              // float4 chunks per lane: N <= 64*4*4 = 1024
+    float4 v[MAXV];
+    const int nvec = a.N / 4;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int i4 = lane + 64 * c;
+        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < nvec) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < a.splits; ++z) {
+                const float4 p = *reinterpret_cast<const float4*>(a.slabs + ((long long)z * a.M + row) * a.N + i4 * 4);
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + i4 * 4);
+                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            }
+            if (a.relu && !a.ln_w) {
+                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+            }
+            if (a.res) {
+                const float4 r = *reinterpret_cast<const float4*>(a.res + row * a.N + i4 * 4);
+                acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+            }
+            v[c] = acc;
+            s += (acc.x + acc.y) + (acc.z + acc.w);
+        }
+    }
+    if (a.ln_w) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)a.N;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c)
+            if (lane + 64 * c < nvec) {
+                const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q / (float)a.N + a.eps);
+#pragma unroll
+        for (int c = 0; c < MAXV; ++c) {
+            const int i4 = lane + 64 * c;
+            if (i4 < nvec) {
+                const float4 g = *reinterpret_cast<const float4*>(a.ln_w + i4 * 4);
+                const float4 b = *reinterpret_cast<const float4*>(a.ln_b + i4 * 4);
+                float4 o;
+                o.x = (v[c].x - mean) * rstd * g.x + b.x;
+                o.y = (v[c].y - mean) * rstd * g.y + b.y;
+                o.z = (v[c].z - mean) * rstd * g.z + b.z;
+                o.w = (v[c].w - mean) * rstd * g.w + b.w;
+                if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                v[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int i4 = lane + 64 * c;
+        if (i4 < nvec) *reinterpret_cast<float4*>(a.Y + row * a.N + i4 * 4) = v[c];
+    }
+}
+
+}  // namespace
+
+extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias, const float* residual, float* Y,
+                               int64_t M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldy, int relu,
+                               sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 1 && K >= 1, "sbev_linear_f32: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && W && Y, "sbev_linear_f32: null pointer");
+    SBEV_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && ldx >= K && ldw >= K && ldy >= N, "sbev_linear_f32: leading dimensions (ldx, ldw multiples of 4)");
+    SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0, "sbev_linear_f32: X and W must be 16-byte aligned");
+    GemmArgs a{X, W, bias, residual, Y, M, N, K, ldx, ldw, ldy, K, relu};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long big = ((M + 127) / 128) * ((N + 127) / 128);
+    SBEV_REQUIRE(big <= 0x3fffffffLL, "sbev_linear_f32: too many tiles");
+    const long long small = ((M + 63) / 64) * ((N + 63) / 64);
+    if (K % BK != 0) {  // slow path (never taken by the decoder: its K are 256 / 512 / 32768)
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, true>), dim3((unsigned)small), dim3(256), 0, s, a);
+    } else if (big >= 256) {   // enough 128x128 tiles to fill the 256 CUs
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 2, 2, false>), dim3((unsigned)big), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, false>), dim3((unsigned)small), dim3(256), 0, s, a);
+    }
+    return sbev::check_launch("sbev_linear_f32");
+}
+
+extern "C" int64_t sbev_linear_splitk_workspace(int64_t M, int N, int splits) {
+    return (int64_t)sizeof(float) * M * N * (splits > 0 ? splits : 0);
+}
+
+extern "C" int sbev_linear_splitk_f32(const float* X, const float* W, const float* bias, const float* residual,
+                                      const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                      int64_t M, int N, int K, int64_t ldx, int64_t ldw, int relu,
+                                      int splits, float* workspace, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024 && K >= 1, "sbev_linear_splitk_f32: need N %% 4 == 0, N <= 1024 (N=%d)", N);
+    SBEV_REQUIRE(splits >= 1 && splits <= 1024, "sbev_linear_splitk_f32: splits=%d", splits);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && W && Y && workspace, "sbev_linear_splitk_f32: null pointer");
+    SBEV_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && ldx >= K && ldw >= K, "sbev_linear_splitk_f32: leading dimensions");
+    SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)W | (uintptr_t)workspace) & 15) == 0, "sbev_linear_splitk_f32: 16-byte alignment");
+    SBEV_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), "sbev_linear_splitk_f32: ln_w and ln_b go together");
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    const int used = (K + kps - 1) / kps;
+    GemmArgs a{X, W, nullptr, nullptr, workspace, M, N, K, ldx, ldw, (long long)N, kps, 0};
+    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (K % BK != 0)
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, true>), dim3((unsigned)tiles, 1, (unsigned)used), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, false>), dim3((unsigned)tiles, 1, (unsigned)used), dim3(256), 0, s, a);
+    int st = sbev::check_launch("sbev_linear_splitk_f32 (gemm)");
+    if (st != SBEV_OK) return st;
+    ReduceArgs r{workspace, bias, residual, ln_w, ln_b, Y, M, N, used, relu, ln_eps};
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, r);
+    return sbev::check_launch("sbev_linear_splitk_f32 (reduce)");
+}
+
+// Row-wise LayerNorm (+ optional ReLU) of [M, N] (N % 4 == 0, N <= 1024): the split-K reducer with one slab.
+extern "C" int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps, float* Y,
+                                   int64_t M, int N, int relu, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024, "sbev_layer_norm_f32: need N %% 4 == 0, N <= 1024 (N=%d)", N);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && Y && ln_w && ln_b, "sbev_layer_norm_f32: null pointer");
+    ReduceArgs r{X, nullptr, nullptr, ln_w, ln_b, Y, M, N, 1, relu, eps};
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), r);
+    return sbev::check_launch("sbev_layer_norm_f32");
+}

@@ -1,0 +1,212 @@
+// Adaptive mixing core (gfx950): per (query, group) the two dynamic matmuls with their LayerNorm + ReLU.
+//
+// Replaces the middle of AdaptiveMixing.inner_forward (models/sparsebev_transformer.py:362-374):
+//     y = relu(layer_norm_[Pin,C]( x[Pin,C] @ M[C,C] ))          adaptive channel mixing
+//     y = relu(layer_norm_[Pout,C]( S[Pout,Pin] @ y[Pin,C] ))    adaptive point mixing
+// M and S are the per-query dynamic weights produced by the parameter-generator Linear (sbev_linear_f32).
+//
+// One 256-thread workgroup per (b*Q + q, g).  x, M, S are staged once into LDS with 16-byte coalesced loads
+// (40 KiB at C=64, Pin=32, Pout=128), both matmuls run on v_mfma_f32_16x16x4_f32 (exact fp32), wave w owns the
+// 16-channel column slab w of both outputs, the LayerNorm statistics are two-pass (mean, then centred
+// variance) block reductions, the intermediate never leaves LDS, and the [Pout,C] result is transposed through
+// LDS so the workgroup writes its 32 KiB output as one contiguous run of 16-byte stores.
+// Bound: HBM (72 KiB moved per ~3k MFMA cycles of work).
+#include "sbev_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MixArgs {
+    const float* x;       // [BQ, G, Pin, C]
+    const float* params;  // [BQ, G, C*C + Pout*Pin]   (M = [C_in, C_out] first, then S = [Pout, Pin])
+    float* y;             // [BQ, G, Pout, C]
+    long long n_items;    // BQ * G
+    int Pin;
+    float eps;
+};
+
+constexpr int C = 64, POUT = 128;
+constexpr int LDA = C + 4;    // A-operand rows (x): 16-B aligned rows, <= 2-way bank conflict on fragment reads
+constexpr int LDB = C + 16;   // B-operand rows (M, y1): row stride = 16 banks -> conflict-free fragment reads
+constexpr int LDY = C + 4;    // output transpose buffer
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum of one float per thread (4 waves); `red` is 4 floats of LDS; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* red, int wave, int lane) {
+    v = wave_sum(v);
+    __syncthreads();                      // protect `red` from the previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int RT>   // RT = ceil(Pin / 16) row tiles of the first matmul (1..8)
+__global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Pin = a.Pin;
+    const int lds_s = Pin + 4;                                  // S row stride
+    float* red = smem;                                          // [4] block-reduction scratch (never aliased)
+    float* Xs = smem + 4;                                       // [RT*16][LDA]
+    float* Ms = Xs + RT * 16 * LDA;                             // [C][LDB]
+    float* Ss = Ms + C * LDB;                                   // [POUT][lds_s]
+    float* Y1 = Ss + POUT * lds_s;                              // [RT*16][LDB]
+    float* Yo = smem + 4;                                       // [POUT][LDY], aliases Xs/Ms/Ss/Y1 after matmul 2
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long item = blockIdx.x;
+    const float* xg = a.x + item * Pin * C;
+    const float* pg = a.params + item * (C * C + POUT * Pin);
+    const float* sg = pg + C * C;
+
+    // ---- stage x, M, S (coalesced float4) --------------------------------------------------------------
+    for (int i = tid; i < RT * 16 * (C / 4); i += 256) {
+        const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < Pin) v = *reinterpret_cast<const float4*>(xg + r * C + c4);
+        *reinterpret_cast<float4*>(&Xs[r * LDA + c4]) = v;      // rows >= Pin are zero padding
+    }
+    for (int i = tid; i < C * (C / 4); i += 256) {
+        const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
+        *reinterpret_cast<float4*>(&Ms[r * LDB + c4]) = *reinterpret_cast<const float4*>(pg + r * C + c4);
+    }
+    for (int i = tid; i < POUT * Pin / 4; i += 256) {
+        const int r = (i * 4) / Pin, c4 = (i * 4) % Pin;
+        *reinterpret_cast<float4*>(&Ss[r * lds_s + c4]) = *reinterpret_cast<const float4*>(sg + i * 4);
+    }
+    __syncthreads();
+
+    const int fi = lane & 15, fk = lane >> 4;                   // fragment row/col index, k sub-index
+    const int cw = wave * 16;                                   // this wave's channel slab
+
+    // ---- matmul 1: y1[Pin, 64] = x[Pin, 64] @ M[64, 64]; wave w -> columns [16w, 16w+16) ----------------
+    f32x4 acc1[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < C; k0 += 4) {
+        const float b = Ms[(k0 + fk) * LDB + cw + fi];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float av = Xs[(r * 16 + fi) * LDA + k0 + fk];
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc1[r], 0, 0, 0);
+        }
+    }
+    // C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg
+    // ---- LayerNorm over all Pin*64 elements (no affine, biased variance), ReLU --------------------------
+    const float n1 = (float)(Pin * C);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += (r * 16 + fk * 4 + e) < Pin ? acc1[r][e] : 0.f;
+    const float mean1 = block_sum(s, red, wave, lane) / n1;
+    float qv = 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = acc1[r][e] - mean1;
+            qv += (r * 16 + fk * 4 + e) < Pin ? d * d : 0.f;
+        }
+    const float rstd1 = rsqrtf(block_sum(qv, red, wave, lane) / n1 + a.eps);
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            Y1[(r * 16 + fk * 4 + e) * LDB + cw + fi] = fmaxf((acc1[r][e] - mean1) * rstd1, 0.f);
+    __syncthreads();
+
+    // ---- matmul 2: y2[128, 64] = S[128, Pin] @ y1[Pin, 64]; wave w -> columns [16w, 16w+16), 8 row tiles -
+    f32x4 acc2[POUT / 16];
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Pin; k0 += 4) {
+        const float b = Y1[(k0 + fk) * LDB + cw + fi];
+#pragma unroll
+        for (int r = 0; r < POUT / 16; ++r) {
+            const float av = Ss[(r * 16 + fi) * lds_s + k0 + fk];
+            acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc2[r], 0, 0, 0);
+        }
+    }
+    // ---- LayerNorm over 128*64 elements, ReLU ------------------------------------------------------------
+    const float n2 = (float)(POUT * C);
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc2[r][e];
+    const float mean2 = block_sum(s, red, wave, lane) / n2;     // (its barriers also fence the Ss/Y1 reads above)
+    qv = 0.f;
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = acc2[r][e] - mean2;
+            qv += d * d;
+        }
+    const float rstd2 = rsqrtf(block_sum(qv, red, wave, lane) / n2 + a.eps);
+    // ---- transpose through LDS, then one contiguous 32 KiB store ------------------------------------------
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            Yo[(r * 16 + fk * 4 + e) * LDY + cw + fi] = fmaxf((acc2[r][e] - mean2) * rstd2, 0.f);
+    __syncthreads();
+    float* yg = a.y + item * POUT * C;
+#pragma unroll
+    for (int i = tid; i < POUT * (C / 4); i += 256) {
+        const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
+        *reinterpret_cast<float4*>(yg + r * C + c4) = *reinterpret_cast<const float4*>(&Yo[r * LDY + c4]);
+    }
+}
+
+template <int RT>
+int launch_mix(const MixArgs& a, hipStream_t s) {
+    const int Pin = a.Pin;
+    size_t floats = (size_t)RT * 16 * LDA + C * LDB + POUT * (Pin + 4) + (size_t)RT * 16 * LDB;
+    const size_t out_floats = (size_t)POUT * LDY;
+    if (floats < out_floats) floats = out_floats;
+    const size_t bytes = (floats + 4) * sizeof(float);
+    auto k = adaptive_mixing_kernel<RT>;
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            sbev::set_error("sbev_adaptive_mixing_f32: cannot reserve %zu B of LDS: %s", bytes, hipGetErrorString(e));
+            return SBEV_ELAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(256), bytes, s, a);
+    return sbev::check_launch("sbev_adaptive_mixing_f32");
+}
+
+}  // namespace
+
+extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
+                                        int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
+                                        sbev_stream_t stream) {
+    SBEV_REQUIRE(BQ >= 0 && G >= 1, "sbev_adaptive_mixing_f32: bad sizes");
+    SBEV_REQUIRE(Cg == C && Pout == POUT, "sbev_adaptive_mixing_f32: built for C=64 channels per group and 128 out points (got %d, %d)", Cg, Pout);
+    SBEV_REQUIRE(Pin >= 4 && Pin % 4 == 0 && Pin <= 120, "sbev_adaptive_mixing_f32: in_points=%d must be a multiple of 4 in 4..120 (LDS budget)", Pin);
+    if (BQ == 0) return SBEV_OK;
+    SBEV_REQUIRE(x && params && y, "sbev_adaptive_mixing_f32: null pointer");
+    SBEV_REQUIRE(BQ * G <= 0x7fffffffLL, "sbev_adaptive_mixing_f32: too many items");
+    MixArgs a{x, params, y, BQ * G, Pin, eps};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch ((Pin + 15) / 16) {
+        case 1: return launch_mix<1>(a, s);
+        case 2: return launch_mix<2>(a, s);
+        case 3: return launch_mix<3>(a, s);
+        case 4: return launch_mix<4>(a, s);
+        case 5: return launch_mix<5>(a, s);
+        case 6: return launch_mix<6>(a, s);
+        case 7: return launch_mix<7>(a, s);
+        default: return launch_mix<8>(a, s);
+    }
+}

@@ -7,19 +7,31 @@ no CPU path in the product.
 """
 import math
 
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
+from . import _lib
+
 # op -> implementation currently used on the device
 NATIVE = {
-    'linear': 'aten',
-    'layer_norm': 'aten',
-    'linear_ln_relu': 'aten',
+    'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
+    'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',
+    'linear_ln_relu': 'hip (Linear(3->D) of the position encoder: aten)',
     'self_attention': 'aten',
-    'adaptive_mixing': 'aten',
+    'adaptive_mixing': 'hip: gemm (generator) + adaptive_mixing_kernel (v_mfma_f32_16x16x4_f32) + split-K gemm (out-proj, fused residual + LayerNorm)',
     'refine_bbox': 'aten',
     'to_channels_last': 'aten',
 }
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _dev(*ts):
@@ -28,23 +40,77 @@ def _dev(*ts):
             raise RuntimeError('sparsebev_amd.dense needs device tensors (no CPU fallback)')
 
 
-def linear(x, w, b, relu=False, residual=None):
+def _ws(nbytes, device):
+    """Reusable split-K workspace (one per device; grown on demand, stream-ordered reuse)."""
+    key = str(device)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+_WORKSPACES = {}
+SPLITK_MIN_K = 2048          # reductions at least this long with few output tiles go split-K
+
+
+def _splits_for(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if K < SPLITK_MIN_K or tiles >= 128 or N % 4 or N > 1024:
+        return 1
+    return max(1, min(K // 512, (512 + tiles - 1) // tiles))
+
+
+def linear(x, w, b, relu=False, residual=None, ln=None, ln_relu=False):
+    """y = act(x @ w.T + b) (+ residual), optionally followed by LayerNorm(ln=(gamma, beta)) (+ ReLU): the
+    fp32 MFMA GEMM of csrc/gemm.hip (split-K with the fused epilogue when the reduction is long)."""
     _dev(x, w)
-    y = F.linear(x, w, b)
-    if relu:
-        y = torch.relu(y)
-    if residual is not None:
-        y = y + residual
+    K, N = x.shape[-1], w.shape[0]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if K % 4 != 0:                                   # only the 3-wide position-encoder input; see position_encode()
+        raise RuntimeError('sbev linear needs K %% 4 == 0 (got K=%d)' % K)
+    w = w.contiguous()
+    res2 = residual.reshape(-1, N).contiguous() if residual is not None else None
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    splits = _splits_for(M, N, K)
+    if splits > 1 or (ln is not None and N % 4 == 0 and N <= 1024 and K >= 1024):
+        wsb = lib.sbev_linear_splitk_workspace(M, N, splits)
+        ws = _ws(wsb, x.device)
+        st = lib.sbev_linear_splitk_f32(_p(x2), _p(w), _p(b), _p(res2), _p(ln[0] if ln else None), _p(ln[1] if ln else None),
+                                        1e-5, _p(y), M, N, K, K, K, int(relu or (ln_relu and ln is None)), splits, _p(ws), _stream())
+        _lib.check(st, 'sbev_linear_splitk_f32')
+        if ln is not None and ln_relu:
+            raise RuntimeError('ln_relu with split-K: use layer_norm(relu=True) separately')
+        return y.reshape(*lead, N)
+    st = lib.sbev_linear_f32(_p(x2), _p(w), _p(b), _p(res2), _p(y), M, N, K, K, K, N, int(relu), _stream())
+    _lib.check(st, 'sbev_linear_f32')
+    y = y.reshape(*lead, N)
+    if ln is not None:
+        y = layer_norm(y, ln[0], ln[1], relu=ln_relu)
     return y
 
 
-def layer_norm(x, w, b, eps=1e-5):
-    _dev(x)
-    return F.layer_norm(x, [x.shape[-1]], w, b, eps)
+def layer_norm(x, w, b, eps=1e-5, relu=False):
+    _dev(x, w, b)
+    N = x.shape[-1]
+    x2 = x.reshape(-1, N)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    st = _lib.load().sbev_layer_norm_f32(_p(x2), _p(w), _p(b), eps, _p(y), x2.shape[0], N, int(relu), _stream())
+    _lib.check(st, 'sbev_layer_norm_f32')
+    return y.reshape(x.shape)
 
 
 def linear_ln_relu(x, w, b, lnw, lnb):
-    return torch.relu(layer_norm(linear(x, w, b), lnw, lnb))
+    if x.shape[-1] % 4 != 0:          # Linear(3 -> D) of the position encoder: 3 FMAs per output, not a GEMM
+        return torch.relu(F.layer_norm(F.linear(x, w, b), [w.shape[0]], lnw, lnb))
+    return linear(x, w, b, ln=(lnw, lnb), ln_relu=True)
 
 
 def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b, out_w, out_b, tau_w, tau_b, pre_attn_mask=None):
@@ -67,16 +133,21 @@ def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b
     return x + F.linear(o, out_w, out_b)
 
 
-def adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points):
-    """models/sparsebev_transformer.py:351-381.  x [B,Q,G,Pin,C], query [B,Q,D] -> [B,Q,D]."""
+def adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points, ln=None):
+    """models/sparsebev_transformer.py:351-381.  x [B,Q,G,Pin,C], query [B,Q,D] -> [B,Q,D]
+    (= LayerNorm(query + out_proj(mix)) when ln=(gamma, beta) is given: the norm2 of the decoder layer, fused).
+
+    Three launches: parameter-generator GEMM -> per-(query, group) mixing kernel -> split-K out-projection whose
+    slab reducer also applies bias, the `query +` residual and the LayerNorm."""
     _dev(x, query)
     B, Q, G, Pin, C = x.shape
-    gen = F.linear(query, pg_w, pg_b).reshape(B * Q, G, -1)
-    M = gen[..., : C * C].reshape(B * Q, G, C, C)
-    S = gen[..., C * C:].reshape(B * Q, G, out_points, Pin)
-    y = torch.relu(F.layer_norm(torch.matmul(x.reshape(B * Q, G, Pin, C), M), [Pin, C]))
-    y = torch.relu(F.layer_norm(torch.matmul(S, y), [out_points, C]))
-    return query + F.linear(y.reshape(B, Q, -1), op_w, op_b)
+    D = query.shape[-1]
+    x = x.contiguous()
+    params = linear(query, pg_w, pg_b)                                     # [B,Q,G*(C*C+Pout*Pin)]
+    mixed = torch.empty(B, Q, G * out_points * C, device=x.device, dtype=torch.float32)
+    st = _lib.load().sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), B * Q, G, Pin, C, out_points, 1e-5, _stream())
+    _lib.check(st, 'sbev_adaptive_mixing_f32')
+    return linear(mixed, op_w, op_b, residual=query, ln=ln)
 
 
 def refine_bbox(query_bbox, reg, vel_div):

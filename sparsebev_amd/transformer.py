@@ -141,9 +141,9 @@ class AdaptiveMixing(nn.Module):
     def init_weights(self):
         nn.init.zeros_(self.parameter_generator.weight)
 
-    def forward(self, x, query):
+    def forward(self, x, query, ln=None):
         return dense.adaptive_mixing(x, query, self.parameter_generator.weight, self.parameter_generator.bias,
-                                     self.out_proj.weight, self.out_proj.bias, self.out_points)
+                                     self.out_proj.weight, self.out_proj.bias, self.out_points, ln=ln)
 
 
 class SparseBEVTransformerDecoderLayer(_Base):
@@ -187,7 +187,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
         x = query_feat + pos
         x = dense.layer_norm(self.self_attn(query_bbox, x, attn_mask), self.norm1.weight, self.norm1.bias)
         sampled = self.sampling(query_bbox, x, feats, ctx)
-        x = dense.layer_norm(self.mixing(sampled, x), self.norm2.weight, self.norm2.bias)
+        x = self.mixing(sampled, x, ln=(self.norm2.weight, self.norm2.bias))       # norm2 fused into the out-proj reducer
         f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]
         h = dense.linear(x, f0.weight, f0.bias, relu=True)
         x = dense.layer_norm(dense.linear(h, f1.weight, f1.bias, residual=x), self.norm3.weight, self.norm3.bias)

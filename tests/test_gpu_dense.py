@@ -1,0 +1,88 @@
+"""GPU parity of the dense kernels (csrc/gemm.hip ...) against fp64 math on the CPU."""
+import pytest
+import torch
+
+from sparsebev_amd import dense
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def ref_linear(x, w, b, relu=False, res=None, ln=None):
+    y = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+    if relu:
+        y = y.clamp(min=0)
+    if res is not None:
+        y = y + res.double()
+    if ln is not None:
+        y = torch.nn.functional.layer_norm(y, [y.shape[-1]], ln[0].double(), ln[1].double())
+    return y
+
+
+@pytest.mark.parametrize('M,N,K', [(900, 32768, 256), (900, 256, 256), (900, 768, 256), (900, 112, 256), (900, 512, 256),
+                                   (900, 256, 512), (900, 10, 256), (37, 72, 100), (1, 8, 4), (3600, 256, 256), (129, 130, 36)])
+@pytest.mark.parametrize('relu,use_res', [(False, False), (True, True)])
+def test_linear_shapes(M, N, K, relu, use_res):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if use_res else None
+    y = dense.linear(x.to(DEV), w.to(DEV), b.to(DEV), relu=relu, residual=res.to(DEV) if use_res else None)
+    ref = ref_linear(x, w, b, relu, res)
+    assert y.shape == (M, N)
+    assert (y.cpu().double() - ref).abs().max() < 2e-5
+
+
+def test_out_proj_splitk_fused_epilogue():
+    # AdaptiveMixing.out_proj: K = 32768, N = 256, + query residual, + LayerNorm (norm2)
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 900, 256, 32768
+    x = torch.randn(M, K, generator=g).clamp(min=0)
+    w = (2 * torch.rand(N, K, generator=g) - 1) / K ** 0.5
+    b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    lw, lb = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    y = dense.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=res.to(DEV), ln=(lw.to(DEV), lb.to(DEV)))
+    ref = ref_linear(x, w, b, False, res, (lw, lb))
+    assert (y.cpu().double() - ref).abs().max() < 2e-5
+    y2 = dense.linear(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert (y2.cpu().double() - ref_linear(x, w, b)).abs().max() < 2e-5
+
+
+def test_layer_norm_and_relu():
+    g = torch.Generator().manual_seed(1)
+    x = 3 * torch.randn(2, 450, 256, generator=g) + 1
+    lw, lb = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    y = dense.layer_norm(x.to(DEV), lw.to(DEV), lb.to(DEV))
+    ref = torch.nn.functional.layer_norm(x.double(), [256], lw.double(), lb.double())
+    assert (y.cpu().double() - ref).abs().max() < 1e-5
+    y = dense.layer_norm(x.to(DEV), lw.to(DEV), lb.to(DEV), relu=True)
+    assert (y.cpu().double() - ref.clamp(min=0)).abs().max() < 1e-5
+
+
+def test_linear_rejects_cpu_and_misaligned():
+    with pytest.raises(RuntimeError):
+        dense.linear(torch.zeros(4, 8), torch.zeros(4, 8), None)
+    with pytest.raises(RuntimeError):
+        dense.linear(torch.zeros(4, 3, device=DEV), torch.zeros(4, 3, device=DEV), None)
+
+
+@pytest.mark.parametrize('Pin', [4, 8, 32, 60])
+def test_adaptive_mixing_core_vs_fp64(Pin):
+    import ctypes
+    from sparsebev_amd import _lib
+    g = torch.Generator().manual_seed(Pin)
+    BQ, G, C, Pout = 37, 4, 64, 128
+    x = torch.randn(BQ, G, Pin, C, generator=g)
+    prm = torch.randn(BQ, G, C * C + Pout * Pin, generator=g) * 0.3
+    M = prm[..., : C * C].reshape(BQ, G, C, C).double()
+    S = prm[..., C * C:].reshape(BQ, G, Pout, Pin).double()
+    y = torch.relu(torch.nn.functional.layer_norm(x.double() @ M, [Pin, C]))
+    ref = torch.relu(torch.nn.functional.layer_norm(S @ y, [Pout, C]))
+    out = torch.empty(BQ, G, Pout, C, device=DEV)
+    xd, pd = x.to(DEV), prm.to(DEV)
+    st = _lib.load().sbev_adaptive_mixing_f32(ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(pd.data_ptr()),
+                                              ctypes.c_void_p(out.data_ptr()), BQ, G, Pin, C, Pout, 1e-5,
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    assert (out.cpu().double() - ref).abs().max() < 2e-5

@@ -163,6 +163,49 @@ int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, fl
 int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
                              int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
 
+/*
+ * Scale-adaptive self attention core (flash-style; the [B,H,Q,Q] bias is never materialised).
+ * Replaces: SparseBEVSelfAttention.inner_forward's distance/tau mask construction
+ *           (models/sparsebev_transformer.py:215-227,236-248) and the softmax(QK^T/sqrt(d) + mask)V core of
+ *           the mmcv/torch MultiheadAttention it calls (:228).
+ * qkvt    device fp32 [B,Q,ld]: columns [0,HD*H) = q, [HD*H,2HD*H) = k, [2HD*H,3HD*H) = v (the packed in_proj
+ *         output), [3HD*H, 3HD*H+H) = tau (gen_tau output; one GEMM with the 8 tau rows appended to in_proj)
+ * centers device fp32 [B,Q,2]: decoded box centres in metres (sbev_box_centers)
+ * mask    optional device uint8 [Q,Q], 1 = masked (-inf), the query-denoising mask (:224-225); NULL at inference
+ * out     device fp32 [B,Q,H*HD] (input of the out-projection)
+ * Built for head_dim = 32.
+ */
+int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* centers, const uint8_t* mask, float* out,
+                  int B, int Q, int H, int head_dim, sbev_stream_t stream);
+
+/* centers[i] = query_bbox[i, 0:2] * (range_max - range_min) + range_min  (decode_bbox, models/bbox/utils.py:63-71) */
+int sbev_box_centers(const float* query_bbox, const double* pc_range, float* centers, int64_t BQ, sbev_stream_t stream);
+
+/*
+ * Box refinement of one decoder layer.
+ * Replaces: refine_bbox (models/sparsebev_transformer.py:155-160) with inverse_sigmoid (models/utils.py:87-102)
+ *           and the velocity / time_diff division (:179-183).
+ * out[:, 0:3] = sigmoid(reg[:, 0:3] + logit(clamp(query_bbox[:, 0:3]))), out[:, 3:] = reg[:, 3:],
+ * out[:, 8:] /= vel_div[b] when vel_div != NULL (vel_div[b] = time_diff[b,1], values < 1e-5 replaced by 1).
+ */
+int sbev_refine_bbox(const float* query_bbox, const float* reg, const float* vel_div, float* out,
+                     int B, int Q, int code_size, sbev_stream_t stream);
+
+/*
+ * Batched NCHW -> NHWC relayout of one pyramid level: in [n_images, channels, hw] -> out [n_images, hw, channels].
+ * Replaces: the permute + contiguous feature regroup of the decoder (models/sparsebev_transformer.py:73-85); the
+ *           per-group split of that regroup is not needed (sbev_msmv_fwd addresses group g as a channel slice).
+ */
+int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int channels, int hw, sbev_stream_t stream);
+
+/*
+ * y = relu(LayerNorm(x[:, 0:3] @ w^T + b)): the first half of the position encoder
+ * (nn.Linear(3, D), nn.LayerNorm(D), nn.ReLU: models/sparsebev_transformer.py:116-119).  x [M, ldx], w [N,3].
+ */
+int sbev_linear3_ln_relu_f32(const float* x, int64_t ldx, const float* w, const float* b,
+                             const float* ln_w, const float* ln_b, float eps, float* y,
+                             int64_t M, int N, sbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

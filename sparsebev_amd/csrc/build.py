@@ -17,6 +17,8 @@ UNITS = {
     'msmv_sampling.hip': [],
     'gemm.hip': [],
     'mixing.hip': [],
+    'attention.hip': [],
+    'layout.hip': [],
     # bit-exact projection: no FMA contraction anywhere in this file
     'project.hip': ['-ffp-contract=off'],
 }

@@ -1,0 +1,158 @@
+// Feature relayout NCHW -> NHWC (gfx950) and the position encoder's first layer.
+//
+// sbev_nchw_to_nhwc: the FPN hands the decoder [B*T*N, G*C, H, W] maps (models/sparsebev.py:126-131); the
+// sampler wants a pixel's channels contiguous.  The reference does this (and a per-group split) with
+// permute + contiguous on every call (models/sparsebev_transformer.py:73-85).  Here it is one batched tiled
+// transpose -- 64 channels x 64 pixels per workgroup through LDS, 16-byte global accesses on both sides --
+// and it is skipped entirely when the neck already emits channels-last memory.  Pure HBM traffic: 2 x bytes.
+#include "sbev_common.hpp"
+
+namespace {
+
+struct TrArgs {
+    const float* in;   // [N, R, S]   (R = channels, S = H*W pixels)
+    float* out;        // [N, S, R]
+    int R, S;
+};
+
+constexpr int TS = 64, TLD = 65;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(const TrArgs a) {
+    __shared__ float tile[TS * TLD];                    // tile[pixel][channel]
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
+    const long long img = blockIdx.z;
+    const float* in = a.in + img * a.R * a.S;
+    float* out = a.out + img * a.R * a.S;
+    if (VEC) {   // S % 4 == 0 and R % 4 == 0
+        // read: thread -> (channel = tid/16 + 16*i, 4 pixels at (tid%16)*4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + (tid >> 4) + 16 * i, s = s0 + (tid & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.R && s < a.S) v = *reinterpret_cast<const float4*>(in + (long long)r * a.S + s);
+            const int lr = (tid >> 4) + 16 * i, ls = (tid & 15) * 4;
+            tile[(ls + 0) * TLD + lr] = v.x;
+            tile[(ls + 1) * TLD + lr] = v.y;
+            tile[(ls + 2) * TLD + lr] = v.z;
+            tile[(ls + 3) * TLD + lr] = v.w;
+        }
+        __syncthreads();
+        // write: thread -> (pixel = tid/16 + 16*i, 4 channels at (tid%16)*4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ls = (tid >> 4) + 16 * i, lr = (tid & 15) * 4;
+            const int s = s0 + ls, r = r0 + lr;
+            if (s < a.S && r < a.R) {
+                const float4 v = make_float4(tile[ls * TLD + lr], tile[ls * TLD + lr + 1], tile[ls * TLD + lr + 2], tile[ls * TLD + lr + 3]);
+                *reinterpret_cast<float4*>(out + (long long)s * a.R + r) = v;
+            }
+        }
+    } else {
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int lr = i / TS, ls = i % TS;
+            const int r = r0 + lr, s = s0 + ls;
+            tile[ls * TLD + lr] = (r < a.R && s < a.S) ? in[(long long)r * a.S + s] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int ls = i / TS, lr = i % TS;
+            const int r = r0 + lr, s = s0 + ls;
+            if (r < a.R && s < a.S) out[(long long)s * a.R + r] = tile[ls * TLD + lr];
+        }
+    }
+}
+
+struct PosArgs {
+    const float* x;     // [M, ldx] (first 3 columns used)
+    const float* w;     // [N, 3]
+    const float* b;     // [N]
+    const float* ln_w;  // [N]
+    const float* ln_b;
+    float* y;           // [M, N]
+    long long M;
+    int N, ldx;
+    float eps;
+};
+
+// Linear(3 -> N) + LayerNorm(N) + ReLU, one wave per row (N <= 1024, N % 4 == 0): 3 FMAs per output are not
+// a GEMM.  (position_encoder[0..2], models/sparsebev_transformer.py:116-119)
+__global__ __launch_bounds__(256) void linear3_ln_relu_kernel(const PosArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const float x0 = a.x[row * a.ldx], x1 = a.x[row * a.ldx + 1], x2 = a.x[row * a.ldx + 2];
+    constexpr int MAXV = 4;
+    float v[MAXV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int n0 = (lane + 64 * c) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.f;
+            if (n0 + e < a.N) {
+                const float* w = a.w + (long long)(n0 + e) * 3;
+                t = ((x0 * w[0] + x1 * w[1]) + x2 * w[2]) + a.b[n0 + e];
+                s += t;
+            }
+            v[c][e] = t;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)a.N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((lane + 64 * c) * 4 + e < a.N) {
+                const float d = v[c][e] - mean;
+                q += d * d;
+            }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)a.N + a.eps);
+#pragma unroll
+    for (int c = 0; c < MAXV; ++c) {
+        const int n0 = (lane + 64 * c) * 4;
+        if (n0 < a.N) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[c][e] - mean) * rstd * a.ln_w[n0 + e] + a.ln_b[n0 + e], 0.f);
+            *reinterpret_cast<float4*>(a.y + row * a.N + n0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int channels, int hw,
+                                     sbev_stream_t stream) {
+    SBEV_REQUIRE(n_images >= 0 && channels >= 1 && hw >= 1, "sbev_nchw_to_nhwc_f32: bad sizes");
+    if (n_images == 0) return SBEV_OK;
+    SBEV_REQUIRE(in && out && in != out, "sbev_nchw_to_nhwc_f32: null or aliased pointers");
+    SBEV_REQUIRE(n_images <= 65535, "sbev_nchw_to_nhwc_f32: at most 65535 images per call");
+    TrArgs a{in, out, channels, hw};
+    dim3 grid((hw + TS - 1) / TS, (channels + TS - 1) / TS, (unsigned)n_images);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = (hw % 4 == 0) && (channels % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(transpose_tiles_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(transpose_tiles_kernel<false>, grid, dim3(256), 0, s, a);
+    return sbev::check_launch("sbev_nchw_to_nhwc_f32");
+}
+
+extern "C" int sbev_linear3_ln_relu_f32(const float* x, int64_t ldx, const float* w, const float* b,
+                                        const float* ln_w, const float* ln_b, float eps, float* y,
+                                        int64_t M, int N, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024 && ldx >= 3, "sbev_linear3_ln_relu_f32: need N %% 4 == 0, N <= 1024, ldx >= 3");
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(x && w && b && ln_w && ln_b && y, "sbev_linear3_ln_relu_f32: null pointer");
+    PosArgs a{x, w, b, ln_w, ln_b, y, M, N, (int)ldx, eps};
+    hipLaunchKernelGGL(linear3_ln_relu_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_linear3_ln_relu_f32");
+}

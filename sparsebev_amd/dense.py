@@ -18,11 +18,11 @@ from . import _lib
 NATIVE = {
     'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
     'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',
-    'linear_ln_relu': 'hip (Linear(3->D) of the position encoder: aten)',
-    'self_attention': 'aten',
+    'linear_ln_relu': 'hip: gemm + LayerNorm/ReLU reducer; Linear(3->D): linear3_ln_relu_kernel',
+    'self_attention': 'hip: centers + gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
     'adaptive_mixing': 'hip: gemm (generator) + adaptive_mixing_kernel (v_mfma_f32_16x16x4_f32) + split-K gemm (out-proj, fused residual + LayerNorm)',
-    'refine_bbox': 'aten',
-    'to_channels_last': 'aten',
+    'refine_bbox': 'hip: refine_kernel',
+    'to_channels_last': 'hip: transpose_tiles_kernel',
 }
 
 
@@ -108,29 +108,64 @@ def layer_norm(x, w, b, eps=1e-5, relu=False):
 
 
 def linear_ln_relu(x, w, b, lnw, lnb):
-    if x.shape[-1] % 4 != 0:          # Linear(3 -> D) of the position encoder: 3 FMAs per output, not a GEMM
-        return torch.relu(F.layer_norm(F.linear(x, w, b), [w.shape[0]], lnw, lnb))
+    """relu(LayerNorm(x @ w.T + b)).  K == 3 (position encoder, input = the first 3 columns of query_bbox) has
+    its own kernel: 3 FMAs per output are not a GEMM."""
+    if w.shape[1] == 3:
+        _dev(x, w)
+        N = w.shape[0]
+        ldx = x.shape[-1]
+        x2 = x.reshape(-1, ldx)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+        st = _lib.load().sbev_linear3_ln_relu_f32(_p(x2), ldx, _p(w.contiguous()), _p(b), _p(lnw), _p(lnb), 1e-5, _p(y),
+                                                  x2.shape[0], N, _stream())
+        _lib.check(st, 'sbev_linear3_ln_relu_f32')
+        return y.reshape(*x.shape[:-1], N)
     return linear(x, w, b, ln=(lnw, lnb), ln_relu=True)
 
 
-def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b, out_w, out_b, tau_w, tau_b, pre_attn_mask=None):
-    """models/sparsebev_transformer.py:210-228,236-248 + mmcv MultiheadAttention(batch_first) = x + MHA(x)."""
+_CAT_CACHE = {}
+
+
+def _cat_rows(*tensors):
+    """torch.cat(tensors, 0), cached until any source is modified in place (parameters are static at inference)."""
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    hit = _CAT_CACHE.get(key)
+    if hit is None:
+        if len(_CAT_CACHE) > 64:
+            _CAT_CACHE.clear()
+        hit = torch.cat([t.detach() for t in tensors], 0).contiguous()
+        _CAT_CACHE[key] = hit
+    return hit
+
+
+def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b, out_w, out_b, tau_w, tau_b,
+                                  pre_attn_mask=None, ln=None):
+    """models/sparsebev_transformer.py:210-228,236-248 + mmcv MultiheadAttention(batch_first) = x + MHA(x),
+    optionally followed by LayerNorm (ln = norm1 of the decoder layer).
+
+    Launches: box centres -> ONE in-projection GEMM (q | k | v | tau, N = 3D + H) -> flash-style attention with
+    the distance bias computed on the fly -> out-projection GEMM with the residual (and LayerNorm) fused."""
     _dev(query_bbox, x)
     B, Q, D = x.shape
     hd = D // num_heads
-    cx = query_bbox[..., 0] * (pc_range[3] - pc_range[0]) + pc_range[0]
-    cy = query_bbox[..., 1] * (pc_range[4] - pc_range[1]) + pc_range[1]
-    xy = torch.stack([cx, cy], -1)
-    dist = -torch.norm(xy[:, :, None, :] - xy[:, None, :, :], dim=-1)
-    tau = F.linear(x, tau_w, tau_b)
-    bias = dist[:, None] * tau.permute(0, 2, 1)[..., None]
+    lib = _lib.load()
+    query_bbox = query_bbox.contiguous()
+    centers = torch.empty(B, Q, 2, device=x.device, dtype=torch.float32)
+    pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    _lib.check(lib.sbev_box_centers(_p(query_bbox), pc, _p(centers), B * Q, _stream()), 'sbev_box_centers')
+    pad = (-num_heads) % 4                                   # keep the packed row stride a multiple of 4 floats
+    w_all = _cat_rows(in_w, tau_w, *( [tau_w.new_zeros(pad, D)] if pad else [] ))
+    b_all = _cat_rows(in_b, tau_b, *( [tau_b.new_zeros(pad)] if pad else [] ))
+    qkvt = linear(x, w_all, b_all)                           # [B,Q,3D+H(+pad)]
+    mask = None
     if pre_attn_mask is not None:
-        bias = bias.masked_fill(pre_attn_mask[None, None], float('-inf'))
-    qkv = F.linear(x, in_w, in_b)
-    q, k, v = (t.reshape(B, Q, num_heads, hd).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
-    att = torch.softmax(torch.matmul(q / math.sqrt(hd), k.transpose(-1, -2)) + bias, dim=-1)
-    o = torch.matmul(att, v).permute(0, 2, 1, 3).reshape(B, Q, D)
-    return x + F.linear(o, out_w, out_b)
+        mask = pre_attn_mask.to(device=x.device, dtype=torch.uint8).contiguous()
+    att = torch.empty(B, Q, D, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sbev_sasa_f32(_p(qkvt), qkvt.shape[-1], _p(centers), _p(mask), _p(att), B, Q, num_heads, hd, _stream()),
+               'sbev_sasa_f32')
+    return linear(att, out_w, out_b, residual=x, ln=ln)
 
 
 def adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points, ln=None):
@@ -154,16 +189,21 @@ def refine_bbox(query_bbox, reg, vel_div):
     """refine_bbox + velocity / time_diff (models/sparsebev_transformer.py:155-160,179-183; inverse_sigmoid
     models/utils.py:87-102)."""
     _dev(query_bbox, reg)
-    p = query_bbox[..., 0:3].clamp(0, 1)
-    logit = torch.log(p.clamp(min=1e-5) / (1 - p).clamp(min=1e-5))
-    xyz = torch.sigmoid(reg[..., 0:3] + logit)
-    vel = reg[..., 8:]
-    if vel_div is not None:
-        vel = vel / vel_div[:, None, None]
-    return torch.cat([xyz, reg[..., 3:8], vel], dim=-1)
+    B, Q, code = reg.shape
+    out = torch.empty_like(reg)
+    st = _lib.load().sbev_refine_bbox(_p(query_bbox.contiguous()), _p(reg.contiguous()), _p(vel_div), _p(out), B, Q, code, _stream())
+    _lib.check(st, 'sbev_refine_bbox')
+    return out
 
 
 def to_channels_last(f):
-    """[B,TN,GC,H,W] -> contiguous [B,TN,H,W,GC]."""
+    """[B,TN,GC,H,W] -> contiguous [B,TN,H,W,GC] (one tiled-transpose launch per level)."""
     _dev(f)
-    return f.permute(0, 1, 3, 4, 2).contiguous()
+    if f.dtype != torch.float32:
+        return f.permute(0, 1, 3, 4, 2).contiguous()        # bf16 pyramids: expected to arrive channels-last already
+    B, TN, GC, H, W = f.shape
+    f = f.contiguous()
+    out = torch.empty(B, TN, H, W, GC, device=f.device, dtype=f.dtype)
+    st = _lib.load().sbev_nchw_to_nhwc_f32(_p(f), _p(out), B * TN, GC, H * W, _stream())
+    _lib.check(st, 'sbev_nchw_to_nhwc_f32')
+    return out

@@ -78,13 +78,15 @@ class SparseBEVSelfAttention(_Base):
         nn.init.zeros_(self.gen_tau.weight)
         nn.init.uniform_(self.gen_tau.bias, 0.0, 2.0)
 
-    def forward(self, query_bbox, query_feat, pre_attn_mask=None):
+    def forward(self, query_bbox, query_feat, pre_attn_mask=None, ln=None):
         a = self.attention.attn
-        out = dense.scale_adaptive_self_attention(
+        if DUMP.enabled:     # sasa_tau tap (models/sparsebev_transformer.py:218-219); debug path only
+            DUMP.save('sasa_tau', dense.linear(query_feat, dense._cat_rows(self.gen_tau.weight, self.gen_tau.weight.new_zeros(4, query_feat.shape[-1])),
+                                               dense._cat_rows(self.gen_tau.bias, self.gen_tau.bias.new_zeros(4)))[..., :self.num_heads])
+        return dense.scale_adaptive_self_attention(
             query_bbox, query_feat, self.pc_range, self.num_heads,
             a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-            self.gen_tau.weight, self.gen_tau.bias, pre_attn_mask)
-        return out
+            self.gen_tau.weight, self.gen_tau.bias, pre_attn_mask, ln=ln)
 
 
 class SparseBEVSampling(_Base):
@@ -182,10 +184,10 @@ class SparseBEVTransformerDecoderLayer(_Base):
 
     def forward(self, query_bbox, query_feat, feats, attn_mask, ctx):
         pe = self.position_encoder
-        pos = dense.linear_ln_relu(query_bbox[..., :3].contiguous(), pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)
+        pos = dense.linear_ln_relu(query_bbox, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)   # reads columns 0:3
         pos = dense.linear_ln_relu(pos, pe[3].weight, pe[3].bias, pe[4].weight, pe[4].bias)
         x = query_feat + pos
-        x = dense.layer_norm(self.self_attn(query_bbox, x, attn_mask), self.norm1.weight, self.norm1.bias)
+        x = self.self_attn(query_bbox, x, attn_mask, ln=(self.norm1.weight, self.norm1.bias))
         sampled = self.sampling(query_bbox, x, feats, ctx)
         x = self.mixing(sampled, x, ln=(self.norm2.weight, self.norm2.bias))       # norm2 fused into the out-proj reducer
         f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]

@@ -86,3 +86,56 @@ def test_adaptive_mixing_core_vs_fp64(Pin):
                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert st == 0
     assert (out.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(3, 256, 8, 22), (2, 256, 10, 25), (5, 64, 64, 176), (1, 100, 7, 9)])
+def test_nchw_to_nhwc(shape):
+    n, c, h, w = shape
+    x = torch.randn(1, n, c, h, w, device=DEV)
+    y = dense.to_channels_last(x)
+    assert y.shape == (1, n, h, w, c)
+    assert torch.equal(y, x.permute(0, 1, 3, 4, 2).contiguous())
+
+
+def test_position_encoder_first_layer():
+    g = torch.Generator().manual_seed(3)
+    bbox = torch.rand(2, 450, 10, generator=g)
+    w, b = torch.randn(256, 3, generator=g), torch.randn(256, generator=g)
+    lw, lb = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    y = dense.linear_ln_relu(bbox.to(DEV), w.to(DEV), b.to(DEV), lw.to(DEV), lb.to(DEV))
+    ref = torch.relu(torch.nn.functional.layer_norm(bbox[..., :3].double() @ w.double().t() + b.double(), [256], lw.double(), lb.double()))
+    assert (y.cpu().double() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('Q,use_mask', [(900, False), (100, True), (37, True)])
+def test_sasa_core_vs_fp64(Q, use_mask):
+    import math
+    from sparsebev_amd import synthetic as S
+    g = torch.Generator().manual_seed(Q)
+    B, H, D = 2, 8, 256
+    x = torch.randn(B, Q, D, generator=g)
+    bbox = torch.rand(B, Q, 10, generator=g)
+    in_w, in_b = torch.randn(3 * D, D, generator=g) / 16, 0.1 * torch.randn(3 * D, generator=g)
+    out_w, out_b = torch.randn(D, D, generator=g) / 16, 0.1 * torch.randn(D, generator=g)
+    tau_w, tau_b = 0.02 * torch.randn(H, D, generator=g), 2 * torch.rand(H, generator=g)
+    mask = None
+    if use_mask:
+        mask = torch.rand(Q, Q, generator=g) < 0.3
+        mask.fill_diagonal_(False)
+    d = lambda t: t.to(DEV) if t is not None else None
+    y = dense.scale_adaptive_self_attention(d(bbox), d(x), S.PC_RANGE, H, d(in_w), d(in_b), d(out_w), d(out_b), d(tau_w), d(tau_b), d(mask))
+    # fp64 reference
+    xd = x.double()
+    cx = bbox[..., 0].double() * 102.4 - 51.2
+    cy = bbox[..., 1].double() * 102.4 - 51.2
+    xy = torch.stack([cx, cy], -1)
+    dist = -(xy[:, :, None] - xy[:, None]).norm(dim=-1)
+    tau = xd @ tau_w.double().t() + tau_b.double()
+    bias = dist[:, None] * tau.permute(0, 2, 1)[..., None]
+    if mask is not None:
+        bias = bias.masked_fill(mask[None, None], float('-inf'))
+    qkv = xd @ in_w.double().t() + in_b.double()
+    q, k, v = (t.reshape(B, Q, H, 32).permute(0, 2, 1, 3) for t in qkv.chunk(3, -1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32) + bias, -1) @ v
+    ref = xd + att.permute(0, 2, 1, 3).reshape(B, Q, D) @ out_w.double().t() + out_b.double()
+    assert (y.cpu().double() - ref).abs().max() < 2e-5

@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from sparsebev_amd import ops, synthetic as S                      # noqa: E402
+from sparsebev_amd import runtime, synthetic as S                  # noqa: E402
 from sparsebev_amd.parallel import SampleShard, init_distributed   # noqa: E402
 from sparsebev_amd.transformer import SparseBEVTransformer         # noqa: E402
 
@@ -121,7 +121,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ops.PROFILE_EVENTS = []                      # (start, end) HIP events around every sampler launch
+    runtime.profile_sampler(True)                # HIP events around every sampler launch, on its stream
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -131,14 +131,14 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     elapsed = time.perf_counter() - t0
-    events, ops.PROFILE_EVENTS = ops.PROFILE_EVENTS, None
+    kernel_ms = sorted(runtime.read_sampler_ms())
+    runtime.profile_sampler(False)
     checksum = float(cls.double().abs().sum().item() + box.double().abs().sum().item())
 
     # the one collective: metric all-reduce (MAX of elapsed, SUM of samples / checksum) over RCCL
     elapsed_max, samples, checksum_sum = shard.reduce_metrics(elapsed, args.steps * B, checksum)
 
     if rank == 0:
-        kernel_ms = sorted(s.elapsed_time(e) for s, e in events)
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         npts = B * T * 4 * Q * 4                                   # B' * Q * P sampled points per launch
         sf = 2 if fdtype == torch.bfloat16 else 4

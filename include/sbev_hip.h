@@ -108,14 +108,16 @@ int sbev_project_select(const float* sample_points, const float* lidar2img,
  *           INCLUDING its (b,g,t)-vs-(b,t,g) flattening quirk.
  *
  * query_bbox    device fp32 [B,Q,10] (cx,cy,cz in [0,1], log w,l,h, sin, cos, vx, vy)
- * offset        device fp32 [B,Q,G*P*3]  (output of the sampling_offset Linear)
- * scale_logits  device fp32 [B,Q,G*P*L]  (output of the scale_weights Linear, pre-softmax)
+ * offset        device fp32 [B*Q, ld_offset]: first G*P*3 columns = output of the sampling_offset Linear
+ * scale_logits  device fp32 [B*Q, ld_logits]: first G*P*L columns = output of the scale_weights Linear (pre-softmax)
+ *               (row strides let both live in ONE packed GEMM output: the two Linears are fused into N = G*P*(3+L))
  * time_diff     device fp32 [B,T];  pc_range host double [6] (x0,y0,z0,x1,y1,z1)
  * sample_points device fp32 [B,Q,T,G*P,3] (out; may be NULL)
  * weights_bp    device fp32 [B*G*T, Q, P, L] (out; may be NULL): row b' holds softmax(scale_logits)[b,q,g',p,:]
  *               with g' = ((b' % (T*G))) / T  -- the weights the reference actually applies to sample batch b'.
  */
-int sbev_sampling_front(const float* query_bbox, const float* offset, const float* scale_logits,
+int sbev_sampling_front(const float* query_bbox, const float* offset, int64_t ld_offset,
+                        const float* scale_logits, int64_t ld_logits,
                         const float* time_diff, const double* pc_range,
                         int B, int Q, int T, int G, int P, int L,
                         float* sample_points, float* weights_bp, sbev_stream_t stream);
@@ -145,10 +147,11 @@ int sbev_linear_splitk_f32(const float* X, const float* W, const float* bias, co
                            int64_t M, int N, int K, int64_t ldx, int64_t ldw, int relu,
                            int splits, float* workspace, sbev_stream_t stream);
 
-/* Row LayerNorm (+ optional ReLU) of X [M,N], N % 4 == 0, N <= 1024.
+/* Row LayerNorm (+ optional ReLU) (+ optional add_after [M,N], e.g. query_feat + position encoding, :167) of X [M,N],
+ * N % 4 == 0, N <= 1024.
  * Replaces: nn.LayerNorm(embed_dims) (+ nn.ReLU) at models/sparsebev_transformer.py:117-121,127-129,132-136,169-172. */
-int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps, float* Y,
-                        int64_t M, int N, int relu, sbev_stream_t stream);
+int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps,
+                        const float* add_after, float* Y, int64_t M, int N, int relu, sbev_stream_t stream);
 
 /*
  * Adaptive mixing core: per (query, group)  y = relu(LN_[Pout,C]( S @ relu(LN_[Pin,C]( x @ M )) )).
@@ -205,6 +208,57 @@ int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int cha
 int sbev_linear3_ln_relu_f32(const float* x, int64_t ldx, const float* w, const float* b,
                              const float* ln_w, const float* ln_b, float eps, float* y,
                              int64_t M, int N, sbev_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Whole-decoder runtime: ONE call enqueues every kernel of every layer (28 launches per layer) on `stream`.
+ * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward
+ *           (models/sparsebev_transformer.py:56-101,162-193) at inference.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct sbev_decoder_config {
+    int32_t B, Q, T, N, G, P, L;        /* batch, queries, frames, views (6), groups (4), points, levels */
+    int32_t D, H, ffn;                  /* embed dims (256), heads (8), FFN hidden (512) */
+    int32_t num_classes, code_size, num_layers, out_points;
+    int32_t attn_in_rows;               /* rows of attn_in_w: 3*D + H rounded up to a multiple of 4 */
+    int32_t feat_dtype;                 /* enum sbev_dtype of the pyramid */
+    int32_t hw[SBEV_MAX_LEVELS][2];     /* (H_l, W_l) */
+    float image_h, image_w, eps_homo;   /* img_shape and the 1e-5 of sampling_4d */
+    double pc_range[6];
+} sbev_decoder_config;
+
+/* Device pointers of the shared decoder layer's parameters (reference state-dict names in comments, prefix
+ * decoder.decoder_layer.).  Linear weights are [out, in] row-major exactly as nn.Linear stores them. */
+typedef struct sbev_decoder_weights {
+    const float *pe0_w, *pe0_b, *pe1_g, *pe1_b, *pe3_w, *pe3_b, *pe4_g, *pe4_b;  /* position_encoder.{0,1,3,4} */
+    const float *attn_in_w, *attn_in_b;   /* rows: self_attn.attention.attn.in_proj_{weight,bias}, then self_attn.gen_tau.*, then zero padding */
+    const float *attn_out_w, *attn_out_b; /* self_attn.attention.attn.out_proj.* */
+    const float *samp_w, *samp_b;         /* rows: sampling.sampling_offset.*, then sampling.scale_weights.* */
+    const float *pg_w, *pg_b, *op_w, *op_b;                       /* mixing.parameter_generator.*, mixing.out_proj.* */
+    const float *ffn0_w, *ffn0_b, *ffn1_w, *ffn1_b;               /* ffn.layers.0.0.*, ffn.layers.1.* */
+    const float *norm1_g, *norm1_b, *norm2_g, *norm2_b, *norm3_g, *norm3_b;
+    const float *cls0_w, *cls0_b, *cls1_g, *cls1_b, *cls3_w, *cls3_b, *cls4_g, *cls4_b, *cls6_w, *cls6_b;  /* cls_branch.* */
+    const float *reg0_w, *reg0_b, *reg2_w, *reg2_b, *reg4_w, *reg4_b;                                        /* reg_branch.* */
+} sbev_decoder_weights;
+
+/* Bytes of scratch sbev_decoder_forward needs for this config (-1 on an invalid config). */
+int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg);
+
+/*
+ * feats_nhwc  host array [L] of device pointers, level l = [B*T*N, H_l, W_l, D] channels-last (fp32 / bf16)
+ * query_bbox  [B,Q,10], query_feat [B,Q,D], time_diff [B,T], lidar2img [B,T*N,4,4], vel_div [B] (or NULL if T == 1),
+ * attn_mask   optional uint8 [Q,Q] (query denoising), NULL at inference
+ * cls_out     [num_layers,B,Q,num_classes], bbox_out [num_layers,B,Q,code_size]  (NOT nan_to_num'ed)
+ * workspace   256-byte aligned device scratch of >= sbev_decoder_workspace_bytes(cfg) bytes
+ */
+int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights,
+                         const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
+                         const float* time_diff, const float* lidar2img, const float* vel_div,
+                         const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                         void* workspace, int64_t workspace_bytes, sbev_stream_t stream);
+
+/* Bracket every sbev_msmv_fwd launch with HIP events on its stream (enable != 0), and read back + clear the
+ * elapsed times in ms (blocks until those launches finished).  Measurement aid for bench.py's roofline figure. */
+int sbev_profile_sampler(int enable);
+int sbev_profile_sampler_read(float* ms, int max_n);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ SIGNATURES = {
     'sbev_project_select': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                            _vp, _vp, _vp, _vp, _vp]),
-    'sbev_sampling_front': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double),
+    'sbev_sampling_front': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double),
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            _vp, _vp, _vp]),
     'sbev_linear_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
@@ -41,7 +41,7 @@ SIGNATURES = {
     'sbev_linear_splitk_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp,
                                               ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, _vp, _vp]),
-    'sbev_layer_norm_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
+    'sbev_layer_norm_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_int64, ctypes.c_int,
                                            ctypes.c_int, _vp]),
     'sbev_adaptive_mixing_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_float, _vp]),
@@ -52,6 +52,11 @@ SIGNATURES = {
     'sbev_nchw_to_nhwc_f32': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_linear3_ln_relu_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp,
                                                 ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_decoder_workspace_bytes': (ctypes.c_int64, [_vp]),
+    'sbev_decoder_forward': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _vp, ctypes.c_int64, _vp]),
+    'sbev_profile_sampler': (ctypes.c_int, [ctypes.c_int]),
+    'sbev_profile_sampler_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
 }
 
 _lib = None

@@ -19,6 +19,7 @@ UNITS = {
     'mixing.hip': [],
     'attention.hip': [],
     'layout.hip': [],
+    'decoder.hip': [],
     # bit-exact projection: no FMA contraction anywhere in this file
     'project.hip': ['-ffp-contract=off'],
 }

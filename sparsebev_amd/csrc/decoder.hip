@@ -1,0 +1,211 @@
+// Host-side decoder runtime (C++): enqueues the whole 6-layer SparseBEV decoder forward -- every kernel of
+// every layer -- on one HIP stream from ONE C-ABI call, so no interpreter sits between launches.
+//
+// Replaces the Python control flow of SparseBEVTransformerDecoder.forward / SparseBEVTransformerDecoderLayer.
+// forward (models/sparsebev_transformer.py:56-101,162-193) for inference.  All buffers come from a caller-
+// provided workspace (size: sbev_decoder_workspace_bytes); nothing is allocated, nothing synchronises.
+// The launch sequence is static for a given config, which also makes it capturable into a hipGraph by the
+// caller (the stream may be in capture mode: no call in here is capture-illegal).
+#include "sbev_common.hpp"
+
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    float* take(size_t n_floats) {
+        float* r = reinterpret_cast<float*>(base + off);
+        off += (n_floats * sizeof(float) + 255) / 256 * 256;
+        return r;
+    }
+};
+
+struct Buffers {
+    float *t0, *t1, *x, *x1, *x2, *x3, *centers, *qkvt, *att, *so, *pts, *wbp, *loc, *sampled, *params, *mixed, *slabs,
+        *h, *c0, *c1, *r0, *r1, *reg, *bbox;
+    size_t bytes;
+};
+
+int out_proj_splits(long long M, int N, int K) {
+    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    long long s = (512 + tiles - 1) / tiles;
+    if (s > K / 512) s = K / 512;
+    return (int)(s < 1 ? 1 : s);
+}
+
+Buffers carve(const sbev_decoder_config& c, void* ws) {
+    Carver k(ws);
+    const size_t BQ = (size_t)c.B * c.Q, D = c.D;
+    const int Cg = c.D / c.G, Pin = c.T * c.P;
+    const size_t pgN = (size_t)c.G * (Cg * Cg + Pin * c.out_points);
+    const size_t mixN = (size_t)c.G * c.out_points * Cg;
+    Buffers b{};
+    b.t0 = k.take(BQ * D); b.t1 = k.take(BQ * D);
+    b.x = k.take(BQ * D); b.x1 = k.take(BQ * D); b.x2 = k.take(BQ * D); b.x3 = k.take(BQ * D);
+    b.centers = k.take(BQ * 2);
+    b.qkvt = k.take(BQ * (size_t)c.attn_in_rows);
+    b.att = k.take(BQ * D);
+    b.so = k.take(BQ * (size_t)(c.G * c.P * (3 + c.L)));
+    b.pts = k.take(BQ * c.T * c.G * c.P * 3);
+    b.wbp = k.take(BQ * c.T * c.G * c.P * c.L);
+    b.loc = k.take(BQ * c.T * c.G * c.P * 3);
+    b.sampled = k.take(BQ * c.G * Pin * Cg);
+    b.params = k.take(BQ * pgN);
+    b.mixed = k.take(BQ * mixN);
+    b.slabs = k.take((size_t)out_proj_splits(BQ, c.D, (int)mixN) * BQ * D);
+    b.h = k.take(BQ * c.ffn);
+    b.c0 = k.take(BQ * D); b.c1 = k.take(BQ * D); b.r0 = k.take(BQ * D); b.r1 = k.take(BQ * D);
+    b.reg = k.take(BQ * c.code_size);
+    b.bbox = k.take(BQ * 10);
+    b.bytes = k.off;
+    return b;
+}
+
+int validate(const sbev_decoder_config* c) {
+    SBEV_REQUIRE(c != nullptr, "sbev_decoder: null config");
+    SBEV_REQUIRE(c->B >= 1 && c->Q >= 1 && c->T >= 1 && c->N >= 1 && c->G >= 1 && c->P >= 1, "sbev_decoder: bad sizes");
+    SBEV_REQUIRE(c->L >= 1 && c->L <= SBEV_MAX_LEVELS, "sbev_decoder: num_levels %d", c->L);
+    SBEV_REQUIRE(c->D % (4 * c->G) == 0 && c->D % c->H == 0 && c->D / c->H == 32, "sbev_decoder: embed_dims %d / heads %d (head_dim must be 32)", c->D, c->H);
+    SBEV_REQUIRE(c->D / c->G == 64 && c->out_points == 128, "sbev_decoder: built for 64 channels per group and 128 out points");
+    SBEV_REQUIRE(c->attn_in_rows >= 3 * c->D + c->H && c->attn_in_rows % 4 == 0, "sbev_decoder: attn_in_rows %d", c->attn_in_rows);
+    SBEV_REQUIRE(c->code_size >= 10 && c->num_layers >= 1 && c->num_classes >= 1 && c->ffn % 4 == 0, "sbev_decoder: head sizes");
+    return SBEV_OK;
+}
+
+#define TRY(expr)                 \
+    do {                          \
+        int st__ = (expr);        \
+        if (st__ != SBEV_OK) return st__; \
+    } while (0)
+
+}  // namespace
+
+extern "C" int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg) {
+    if (validate(cfg) != SBEV_OK) return -1;
+    return (int64_t)carve(*cfg, nullptr).bytes;
+}
+
+extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_decoder_weights* w,
+                                    const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
+                                    const float* time_diff, const float* lidar2img, const float* vel_div,
+                                    const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                                    void* workspace, int64_t workspace_bytes, sbev_stream_t stream) {
+    TRY(validate(cfg));
+    const sbev_decoder_config& c = *cfg;
+    SBEV_REQUIRE(w && feats_nhwc && query_bbox && query_feat && time_diff && lidar2img && cls_out && bbox_out && workspace,
+                 "sbev_decoder_forward: null pointer");
+    SBEV_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sbev_decoder_forward: workspace must be 256-byte aligned");
+    const Buffers b = carve(c, workspace);
+    SBEV_REQUIRE((int64_t)b.bytes <= workspace_bytes, "sbev_decoder_forward: workspace too small (%lld < %zu)", (long long)workspace_bytes, b.bytes);
+
+    const int64_t BQ = (int64_t)c.B * c.Q;
+    const int D = c.D, Cg = c.D / c.G, Pin = c.T * c.P;
+    const int pgN = c.G * (Cg * Cg + Pin * c.out_points);
+    const int mixN = c.G * c.out_points * Cg;
+    const int soN = c.G * c.P * (3 + c.L);
+    const int splits = out_proj_splits(BQ, D, mixN);
+    const float eps = 1e-5f;
+
+    // feature pyramid descriptors: zero-copy NHWC, group g = channel slice [g*Cg, (g+1)*Cg)
+    int32_t hw[2 * SBEV_MAX_LEVELS];
+    int64_t sbo[SBEV_MAX_LEVELS], sv[SBEV_MAX_LEVELS];
+    for (int l = 0; l < c.L; ++l) {
+        hw[2 * l] = c.hw[l][0];
+        hw[2 * l + 1] = c.hw[l][1];
+        sv[l] = (int64_t)c.hw[l][0] * c.hw[l][1] * D;
+        sbo[l] = sv[l] * c.N;
+    }
+
+    const float* bbox = query_bbox;
+    const float* feat = query_feat;
+    for (int layer = 0; layer < c.num_layers; ++layer) {
+        float* cls_l = cls_out + (int64_t)layer * BQ * c.num_classes;
+        float* box_l = bbox_out + (int64_t)layer * BQ * c.code_size;
+        // position encoder -> x = feat + pos                                   (sparsebev_transformer.py:166-167)
+        TRY(sbev_linear3_ln_relu_f32(bbox, 10, w->pe0_w, w->pe0_b, w->pe1_g, w->pe1_b, eps, b.t0, BQ, D, stream));
+        TRY(sbev_linear_f32(b.t0, w->pe3_w, w->pe3_b, nullptr, b.t1, BQ, D, D, D, D, D, 0, stream));
+        TRY(sbev_layer_norm_f32(b.t1, w->pe4_g, w->pe4_b, eps, feat, b.x, BQ, D, 1, stream));
+        // scale-adaptive self attention + norm1                                (:169)
+        TRY(sbev_box_centers(bbox, c.pc_range, b.centers, BQ, stream));
+        TRY(sbev_linear_f32(b.x, w->attn_in_w, w->attn_in_b, nullptr, b.qkvt, BQ, c.attn_in_rows, D, D, D, c.attn_in_rows, 0, stream));
+        TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, b.centers, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
+        TRY(sbev_linear_f32(b.att, w->attn_out_w, w->attn_out_b, b.x, b.t1, BQ, D, D, D, D, D, 0, stream));
+        TRY(sbev_layer_norm_f32(b.t1, w->norm1_g, w->norm1_b, eps, nullptr, b.x1, BQ, D, 0, stream));
+        // adaptive spatio-temporal sampling                                     (:170)
+        TRY(sbev_linear_f32(b.x1, w->samp_w, w->samp_b, nullptr, b.so, BQ, soN, D, D, D, soN, 0, stream));
+        TRY(sbev_sampling_front(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, c.pc_range,
+                                c.B, c.Q, c.T, c.G, c.P, c.L, b.pts, b.wbp, stream));
+        TRY(sbev_project_select(b.pts, lidar2img, c.B, c.Q, c.T, c.N, c.G, c.P, c.image_h, c.image_w, c.eps_homo,
+                                b.loc, nullptr, nullptr, nullptr, stream));
+        TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                          c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
+        // adaptive mixing + norm2                                               (:171)
+        TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
+        TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
+        TRY(sbev_linear_splitk_f32(b.mixed, w->op_w, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN, mixN,
+                                   0, splits, b.slabs, stream));
+        // FFN + norm3                                                           (:172)
+        TRY(sbev_linear_f32(b.x2, w->ffn0_w, w->ffn0_b, nullptr, b.h, BQ, c.ffn, D, D, D, c.ffn, 1, stream));
+        TRY(sbev_linear_f32(b.h, w->ffn1_w, w->ffn1_b, b.x2, b.t1, BQ, D, c.ffn, c.ffn, c.ffn, D, 0, stream));
+        TRY(sbev_layer_norm_f32(b.t1, w->norm3_g, w->norm3_b, eps, nullptr, b.x3, BQ, D, 0, stream));
+        // classification / regression branches, box refinement                  (:174-183)
+        TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, stream));
+        TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, stream));
+        TRY(sbev_linear_f32(b.c1, w->cls3_w, w->cls3_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, stream));
+        TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, stream));
+        TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, stream));
+        TRY(sbev_linear_f32(b.x3, w->reg0_w, w->reg0_b, nullptr, b.r0, BQ, D, D, D, D, D, 1, stream));
+        TRY(sbev_linear_f32(b.r0, w->reg2_w, w->reg2_b, nullptr, b.r1, BQ, D, D, D, D, D, 1, stream));
+        TRY(sbev_linear_f32(b.r1, w->reg4_w, w->reg4_b, nullptr, b.reg, BQ, c.code_size, D, D, D, c.code_size, 0, stream));
+        TRY(sbev_refine_bbox(bbox, b.reg, c.T > 1 ? vel_div : nullptr, box_l, c.B, c.Q, c.code_size, stream));
+        // next layer: query_bbox = bbox_pred.detach() (:93), query_feat = this layer's output
+        bbox = box_l;
+        // x3 is read by the next layer only as `feat` in its third launch and rewritten only by its norm3: no copy
+        feat = b.x3;
+    }
+    return SBEV_OK;
+}
+
+// ---- sampler launch timing (HIP events on the launch stream), used by bench.py for the roofline figure ------
+namespace sbev {
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+
+bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return false;
+    if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) return false;
+    (void)hipEventRecord(*e0, s);
+    return true;
+}
+void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    (void)hipEventRecord(e1, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_events.emplace_back(e0, e1);
+}
+}  // namespace sbev
+
+extern "C" int sbev_profile_sampler(int enable) {
+    std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
+    sbev::g_prof_on = enable != 0;
+    return SBEV_OK;
+}
+
+extern "C" int sbev_profile_sampler_read(float* ms, int max_n) {
+    std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
+    int n = 0;
+    for (auto& ev : sbev::g_prof_events) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess && ms && n < max_n)
+            ms[n++] = t;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    sbev::g_prof_events.clear();
+    return n;
+}

@@ -215,6 +215,7 @@ struct ReduceArgs {
     const float* res;    // [M, N] or null
     const float* ln_w;   // [N] or null -> no LayerNorm
     const float* ln_b;
+    const float* post;   // [M, N] or null: added after LayerNorm / ReLU  (x = query_feat + pos-encoding form)
     float* Y;            // [M, N]
     long long M;
     int N, splits, relu;
@@ -289,7 +290,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) 
 #pragma unroll
     for (int c = 0; c < MAXV; ++c) {
         const int i4 = lane + 64 * c;
-        if (i4 < nvec) *reinterpret_cast<float4*>(a.Y + row * a.N + i4 * 4) = v[c];
+        if (i4 < nvec) {
+            if (a.post) {
+                const float4 r = *reinterpret_cast<const float4*>(a.post + row * a.N + i4 * 4);
+                v[c].x += r.x; v[c].y += r.y; v[c].z += r.z; v[c].w += r.w;
+            }
+            *reinterpret_cast<float4*>(a.Y + row * a.N + i4 * 4) = v[c];
+        }
     }
 }
 
@@ -345,18 +352,18 @@ extern "C" int sbev_linear_splitk_f32(const float* X, const float* W, const floa
         hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, false>), dim3((unsigned)tiles, 1, (unsigned)used), dim3(256), 0, s, a);
     int st = sbev::check_launch("sbev_linear_splitk_f32 (gemm)");
     if (st != SBEV_OK) return st;
-    ReduceArgs r{workspace, bias, residual, ln_w, ln_b, Y, M, N, used, relu, ln_eps};
+    ReduceArgs r{workspace, bias, residual, ln_w, ln_b, nullptr, Y, M, N, used, relu, ln_eps};
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, r);
     return sbev::check_launch("sbev_linear_splitk_f32 (reduce)");
 }
 
 // Row-wise LayerNorm (+ optional ReLU) of [M, N] (N % 4 == 0, N <= 1024): the split-K reducer with one slab.
-extern "C" int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps, float* Y,
-                                   int64_t M, int N, int relu, sbev_stream_t stream) {
+extern "C" int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps,
+                                   const float* add_after, float* Y, int64_t M, int N, int relu, sbev_stream_t stream) {
     SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024, "sbev_layer_norm_f32: need N %% 4 == 0, N <= 1024 (N=%d)", N);
     if (M == 0) return SBEV_OK;
     SBEV_REQUIRE(X && Y && ln_w && ln_b, "sbev_layer_norm_f32: null pointer");
-    ReduceArgs r{X, nullptr, nullptr, ln_w, ln_b, Y, M, N, 1, relu, eps};
+    ReduceArgs r{X, nullptr, nullptr, ln_w, ln_b, add_after, Y, M, N, 1, relu, eps};
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), r);
     return sbev::check_launch("sbev_layer_norm_f32");
 }

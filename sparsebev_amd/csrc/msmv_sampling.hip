@@ -164,10 +164,13 @@ int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
         sbev::set_error("sbev_msmv_fwd: B'*Q = %lld too large for one launch", a.n_waves);
         return SBEV_EINVAL;
     }
+    hipEvent_t e0, e1;
+    const bool prof = sbev::profile_begin(s, &e0, &e1);
     if (out_layout == SBEV_OUT_REF)
         hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (prof) sbev::profile_end(s, e0, e1);
     return sbev::check_launch("sbev_msmv_fwd");
 }
 

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void project_select_kernel(const ProjArgs a) {
 
 struct FrontArgs {
     const float* bbox;      // [B,Q,10]
-    const float* offset;    // [B,Q,GP*3]
-    const float* logits;    // [B,Q,GP*L]
+    const float* offset;    // [B*Q, ld_off]   (first GP*3 columns)
+    const float* logits;    // [B*Q, ld_logit] (first GP*L columns)
+    long long ld_off, ld_logit;
     const float* time_diff; // [B,T]
     float* pts;             // [B,Q,T,GP,3] or null
     float* w_bp;            // [B*G*T,Q,P,L] or null
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void sampling_front_kernel(const FrontArgs a) 
         const float cz = bb[2] * a.pc_span[2] + a.pc_lo[2];
         const float yaw = atan2f(bb[6], bb[7]);
         const float cs = cosf(yaw), sn = sinf(yaw);
-        const float* of = a.offset + bq * GP * 3 + gp * 3;
+        const float* of = a.offset + bq * a.ld_off + gp * 3;
         const float dx = expf(bb[3]) * of[0], dy = expf(bb[4]) * of[1], dz = expf(bb[5]) * of[2];
         // rotation about z, v1.0.0 convention: x' = x cos - y sin ; y' = x sin + y cos
         const float px = cx + (dx * cs + dy * (-sn));
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void sampling_front_kernel(const FrontArgs a) 
     }
     if (a.w_bp) {
         const int g = gp / a.P, p = gp - g * a.P;
-        const float* lg = a.logits + bq * GP * a.L + gp * a.L;
+        const float* lg = a.logits + bq * a.ld_logit + gp * a.L;
         float mx = lg[0];
         for (int l = 1; l < a.L; ++l) mx = fmaxf(mx, lg[l]);
         float e[SBEV_MAX_LEVELS];
@@ -154,7 +155,8 @@ extern "C" int sbev_project_select(const float* sample_points, const float* lida
     return sbev::check_launch("sbev_project_select");
 }
 
-extern "C" int sbev_sampling_front(const float* query_bbox, const float* offset, const float* scale_logits,
+extern "C" int sbev_sampling_front(const float* query_bbox, const float* offset, int64_t ld_offset,
+                                   const float* scale_logits, int64_t ld_logits,
                                    const float* time_diff, const double* pc_range,
                                    int B, int Q, int T, int G, int P, int L,
                                    float* sample_points, float* weights_bp, sbev_stream_t stream) {
@@ -164,8 +166,11 @@ extern "C" int sbev_sampling_front(const float* query_bbox, const float* offset,
     SBEV_REQUIRE(query_bbox && pc_range, "sbev_sampling_front: null pointer");
     SBEV_REQUIRE(!sample_points || (offset && time_diff), "sbev_sampling_front: sample_points needs offset and time_diff");
     SBEV_REQUIRE(!weights_bp || scale_logits, "sbev_sampling_front: weights_bp needs scale_logits");
+    SBEV_REQUIRE((!sample_points || ld_offset >= (int64_t)G * P * 3) && (!weights_bp || ld_logits >= (int64_t)G * P * L),
+                 "sbev_sampling_front: row strides smaller than the rows");
     FrontArgs a{};
     a.bbox = query_bbox; a.offset = offset; a.logits = scale_logits; a.time_diff = time_diff;
+    a.ld_off = ld_offset; a.ld_logit = ld_logits;
     a.pts = sample_points; a.w_bp = weights_bp;
     for (int i = 0; i < 3; ++i) {
         a.pc_lo[i] = (float)pc_range[i];                          // python float -> fp32 scalar, as torch does

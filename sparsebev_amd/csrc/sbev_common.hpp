@@ -30,4 +30,8 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
+bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
+void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+
 }  // namespace sbev

@@ -95,14 +95,16 @@ def linear(x, w, b, relu=False, residual=None, ln=None, ln_relu=False):
     return y
 
 
-def layer_norm(x, w, b, eps=1e-5, relu=False):
+def layer_norm(x, w, b, eps=1e-5, relu=False, add_after=None):
+    """relu?(LayerNorm(x)) (+ add_after)"""
     _dev(x, w, b)
     N = x.shape[-1]
     x2 = x.reshape(-1, N)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     y = torch.empty_like(x2)
-    st = _lib.load().sbev_layer_norm_f32(_p(x2), _p(w), _p(b), eps, _p(y), x2.shape[0], N, int(relu), _stream())
+    aa = add_after.reshape(-1, N).contiguous() if add_after is not None else None
+    st = _lib.load().sbev_layer_norm_f32(_p(x2), _p(w), _p(b), eps, _p(aa), _p(y), x2.shape[0], N, int(relu), _stream())
     _lib.check(st, 'sbev_layer_norm_f32')
     return y.reshape(x.shape)
 
@@ -129,15 +131,18 @@ _CAT_CACHE = {}
 
 
 def _cat_rows(*tensors):
-    """torch.cat(tensors, 0), cached until any source is modified in place (parameters are static at inference)."""
-    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    """torch.cat(tensors, 0), cached until any source is modified in place (parameters are static at inference).
+    The entry keeps its source tensors alive and is matched by object identity, so a recycled device address can
+    never alias a stale entry."""
+    key = tuple(id(t) for t in tensors)
     hit = _CAT_CACHE.get(key)
-    if hit is None:
-        if len(_CAT_CACHE) > 64:
-            _CAT_CACHE.clear()
-        hit = torch.cat([t.detach() for t in tensors], 0).contiguous()
-        _CAT_CACHE[key] = hit
-    return hit
+    if hit is not None and all(a is b and a._version == v for a, b, v in zip(hit[0], tensors, hit[1])):
+        return hit[2]
+    if len(_CAT_CACHE) > 64:
+        _CAT_CACHE.clear()
+    out = torch.cat([t.detach() for t in tensors], 0).contiguous()
+    _CAT_CACHE[key] = (tensors, tuple(t._version for t in tensors), out)
+    return out
 
 
 def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b, out_w, out_b, tau_w, tau_b,
@@ -155,9 +160,10 @@ def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b
     centers = torch.empty(B, Q, 2, device=x.device, dtype=torch.float32)
     pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
     _lib.check(lib.sbev_box_centers(_p(query_bbox), pc, _p(centers), B * Q, _stream()), 'sbev_box_centers')
-    pad = (-num_heads) % 4                                   # keep the packed row stride a multiple of 4 floats
-    w_all = _cat_rows(in_w, tau_w, *( [tau_w.new_zeros(pad, D)] if pad else [] ))
-    b_all = _cat_rows(in_b, tau_b, *( [tau_b.new_zeros(pad)] if pad else [] ))
+    if (3 * D + num_heads) % 4 != 0:
+        raise RuntimeError('3*embed_dims + num_heads must be a multiple of 4')
+    w_all = _cat_rows(in_w, tau_w)
+    b_all = _cat_rows(in_b, tau_b)
     qkvt = linear(x, w_all, b_all)                           # [B,Q,3D+H(+pad)]
     mask = None
     if pre_attn_mask is not None:

@@ -13,9 +13,6 @@ from . import _lib
 N_VIEWS = 6           # models/sparsebev_sampling.py:45
 OUT_REF, OUT_MIX = 0, 1
 _F32, _BF16 = 0, 1
-# bench.py sets this to a list to collect (start, end) HIP events around every sampler launch, recorded on
-# the stream the kernel is launched on; None = no instrumentation.
-PROFILE_EVENTS = None
 
 
 def _stream():
@@ -46,16 +43,9 @@ def _msmv_launch(feats, hw, feat_dtype, Bp, N, C, Q, P, gdiv, stride_bo, stride_
     c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
     c_sbo = (ctypes.c_int64 * L)(*stride_bo)
     c_sv = (ctypes.c_int64 * L)(*stride_v)
-    ev = None
-    if PROFILE_EVENTS is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     st = lib.sbev_msmv_fwd(c_feats, c_hw, L, feat_dtype, Bp, N, C, Q, P, gdiv, c_sbo, stride_g, c_sv, stride_px,
                            _ptr(loc), _ptr(weights), _ptr(out), out_layout, T, G, _stream())
     _lib.check(st, 'sbev_msmv_fwd')
-    if ev is not None:
-        ev[1].record()
-        PROFILE_EVENTS.append(ev)
 
 
 def _feat_dtype(feats):
@@ -169,18 +159,28 @@ def project_select(sample_points, lidar2img, image_h, image_w, G, P, eps=1e-5, d
 def sampling_front(query_bbox, offset, scale_logits, time_diff, pc_range, T, G, P, L,
                    want_points=True, want_weights=True):
     """make_sample_points + velocity warp + level softmax + weight reorder (see sbev_sampling_front in
-    include/sbev_hip.h).  Returns (sample_points [B,Q,T,G*P,3] | None, weights_bp [B*G*T,Q,P,L] | None)."""
+    include/sbev_hip.h).  offset [B,Q,>=G*P*3] and scale_logits [B,Q,>=G*P*L] may be column slices of one packed
+    GEMM output (only their last-dim stride must be 1).
+    Returns (sample_points [B,Q,T,G*P,3] | None, weights_bp [B*G*T,Q,P,L] | None)."""
     _need_device(query_bbox, offset, scale_logits, time_diff)
     B, Q = query_bbox.shape[:2]
     dev = query_bbox.device
     query_bbox = query_bbox.contiguous().float()
+
+    def rows(t):
+        if t is None:
+            return None, 0
+        if t.stride(-1) != 1 or t.stride(0) != Q * t.stride(1):
+            t = t.contiguous()
+        return t, t.stride(1)
+
+    offset, ld_off = rows(offset if want_points else None)
+    scale_logits, ld_lg = rows(scale_logits if want_weights else None)
+    td = time_diff.contiguous().float() if want_points else None
     pts = torch.empty(B, Q, T, G * P, 3, device=dev, dtype=torch.float32) if want_points else None
     wbp = torch.empty(B * G * T, Q, P, L, device=dev, dtype=torch.float32) if want_weights else None
     pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
-    st = _lib.load().sbev_sampling_front(
-        _ptr(query_bbox), _ptr(offset.contiguous().float() if want_points else None),
-        _ptr(scale_logits.contiguous().float() if want_weights else None),
-        _ptr(time_diff.contiguous().float() if want_points else None), pc, B, Q, T, G, P, L,
-        _ptr(pts), _ptr(wbp), _stream())
+    st = _lib.load().sbev_sampling_front(_ptr(query_bbox), _ptr(offset), ld_off, _ptr(scale_logits), ld_lg, _ptr(td), pc,
+                                         B, Q, T, G, P, L, _ptr(pts), _ptr(wbp), _stream())
     _lib.check(st, 'sbev_sampling_front')
     return pts, wbp

@@ -1,0 +1,144 @@
+"""Python face of the C++ decoder runtime (csrc/decoder.hip): one ctypes call enqueues the whole 6-layer
+forward.  Mirrors include/sbev_hip.h's sbev_decoder_config / sbev_decoder_weights field for field."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+MAX_LEVELS = 5
+_f = ctypes.c_void_p
+
+
+class DecoderConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('B', 'Q', 'T', 'N', 'G', 'P', 'L', 'D', 'H', 'ffn', 'num_classes',
+                                              'code_size', 'num_layers', 'out_points', 'attn_in_rows', 'feat_dtype')] + \
+               [('hw', (ctypes.c_int32 * 2) * MAX_LEVELS), ('image_h', ctypes.c_float), ('image_w', ctypes.c_float),
+                ('eps_homo', ctypes.c_float), ('pc_range', ctypes.c_double * 6)]
+
+
+_WEIGHT_FIELDS = ['pe0_w', 'pe0_b', 'pe1_g', 'pe1_b', 'pe3_w', 'pe3_b', 'pe4_g', 'pe4_b',
+                  'attn_in_w', 'attn_in_b', 'attn_out_w', 'attn_out_b', 'samp_w', 'samp_b',
+                  'pg_w', 'pg_b', 'op_w', 'op_b', 'ffn0_w', 'ffn0_b', 'ffn1_w', 'ffn1_b',
+                  'norm1_g', 'norm1_b', 'norm2_g', 'norm2_b', 'norm3_g', 'norm3_b',
+                  'cls0_w', 'cls0_b', 'cls1_g', 'cls1_b', 'cls3_w', 'cls3_b', 'cls4_g', 'cls4_b', 'cls6_w', 'cls6_b',
+                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b']
+
+
+class DecoderWeights(ctypes.Structure):
+    _fields_ = [(n, _f) for n in _WEIGHT_FIELDS]
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class DecoderRuntime:
+    """Binds a SparseBEVTransformerDecoder's parameters (by pointer) to the C++ runtime and owns the workspace.
+    Re-binds automatically when a parameter is replaced or modified in place (``_version`` / ``data_ptr`` change)."""
+
+    def __init__(self, decoder):
+        self.decoder = decoder
+        self._sig = None
+        self._keep = None          # tensors whose storage the weight struct points into
+        self._weights = None
+        self._ws = None
+        self._ws_key = None
+
+    # -- weights -----------------------------------------------------------------------------------------
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.decoder.parameters())
+
+    def _bind(self):
+        layer = self.decoder.decoder_layer
+        for p in layer.parameters():
+            if not p.is_cuda or p.dtype != torch.float32:
+                raise RuntimeError('sparsebev_amd runtime needs fp32 parameters on the device (call .to("cuda"))')
+        pe, sa, smp, mix = layer.position_encoder, layer.self_attn, layer.sampling, layer.mixing
+        att = sa.attention.attn
+        D, H = layer.embed_dims, sa.num_heads
+        pad = (-(3 * D + H)) % 4
+        with torch.no_grad():
+            attn_in_w = torch.cat([att.in_proj_weight, sa.gen_tau.weight] + ([att.in_proj_weight.new_zeros(pad, D)] if pad else []), 0).contiguous()
+            attn_in_b = torch.cat([att.in_proj_bias, sa.gen_tau.bias] + ([att.in_proj_bias.new_zeros(pad)] if pad else []), 0).contiguous()
+            samp_w = torch.cat([smp.sampling_offset.weight, smp.scale_weights.weight], 0).contiguous()
+            samp_b = torch.cat([smp.sampling_offset.bias, smp.scale_weights.bias], 0).contiguous()
+        cb, rb, ffn = layer.cls_branch, layer.reg_branch, layer.ffn.layers
+        t = dict(
+            pe0_w=pe[0].weight, pe0_b=pe[0].bias, pe1_g=pe[1].weight, pe1_b=pe[1].bias,
+            pe3_w=pe[3].weight, pe3_b=pe[3].bias, pe4_g=pe[4].weight, pe4_b=pe[4].bias,
+            attn_in_w=attn_in_w, attn_in_b=attn_in_b, attn_out_w=att.out_proj.weight, attn_out_b=att.out_proj.bias,
+            samp_w=samp_w, samp_b=samp_b,
+            pg_w=mix.parameter_generator.weight, pg_b=mix.parameter_generator.bias,
+            op_w=mix.out_proj.weight, op_b=mix.out_proj.bias,
+            ffn0_w=ffn[0][0].weight, ffn0_b=ffn[0][0].bias, ffn1_w=ffn[1].weight, ffn1_b=ffn[1].bias,
+            norm1_g=layer.norm1.weight, norm1_b=layer.norm1.bias, norm2_g=layer.norm2.weight, norm2_b=layer.norm2.bias,
+            norm3_g=layer.norm3.weight, norm3_b=layer.norm3.bias,
+            cls0_w=cb[0].weight, cls0_b=cb[0].bias, cls1_g=cb[1].weight, cls1_b=cb[1].bias,
+            cls3_w=cb[3].weight, cls3_b=cb[3].bias, cls4_g=cb[4].weight, cls4_b=cb[4].bias,
+            cls6_w=cb[6].weight, cls6_b=cb[6].bias,
+            reg0_w=rb[0].weight, reg0_b=rb[0].bias, reg2_w=rb[2].weight, reg2_b=rb[2].bias,
+            reg4_w=rb[4].weight, reg4_b=rb[4].bias)
+        keep = {k: v.detach().contiguous() for k, v in t.items()}
+        w = DecoderWeights()
+        for k in _WEIGHT_FIELDS:
+            setattr(w, k, keep[k].data_ptr())
+        self._keep, self._weights = keep, w
+        self._attn_in_rows = attn_in_w.shape[0]
+
+    # -- forward -----------------------------------------------------------------------------------------
+    def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
+        """pyramid: transformer.FeaturePyramid; ctx: transformer.DecoderContext.  Returns (cls, bbox) stacked over
+        layers (not nan_to_num'ed)."""
+        sig = self._signature()
+        if sig != self._sig:
+            self._bind()
+            self._sig = sig
+        dec, layer = self.decoder, self.decoder.decoder_layer
+        smp = layer.sampling
+        B, Q, D = query_feat.shape
+        dev = query_feat.device
+        cfg = DecoderConfig()
+        cfg.B, cfg.Q, cfg.T, cfg.N, cfg.G, cfg.P, cfg.L = B, Q, smp.num_frames, 6, smp.num_groups, smp.num_points, smp.num_levels
+        cfg.D, cfg.H, cfg.ffn = D, layer.self_attn.num_heads, layer.ffn.layers[0][0].weight.shape[0]
+        cfg.num_classes, cfg.code_size, cfg.num_layers = layer.num_classes, layer.code_size, dec.num_layers
+        cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
+        cfg.feat_dtype = 1 if pyramid.levels[0].dtype == torch.bfloat16 else 0
+        if len(pyramid.levels) != cfg.L or pyramid.T != cfg.T or pyramid.B != B:
+            raise RuntimeError('feature pyramid (L=%d, T=%d, B=%d) does not match the decoder config (L=%d, T=%d, B=%d)'
+                               % (len(pyramid.levels), pyramid.T, pyramid.B, cfg.L, cfg.T, B))
+        for l, f in enumerate(pyramid.levels):
+            cfg.hw[l][0], cfg.hw[l][1] = f.shape[1], f.shape[2]
+        cfg.image_h, cfg.image_w, cfg.eps_homo = float(ctx.image_h), float(ctx.image_w), 1e-5
+        for i, v in enumerate(dec.pc_range):
+            cfg.pc_range[i] = float(v)
+        lib = _lib.load()
+        need = lib.sbev_decoder_workspace_bytes(ctypes.byref(cfg))
+        if need < 0:
+            raise _lib.SbevError('sbev_decoder_workspace_bytes: ' + lib.sbev_last_error().decode())
+        key = (str(dev), need)
+        if self._ws is None or self._ws_key != key:
+            self._ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+            self._ws_key = key
+        ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
+        cls = torch.empty(cfg.num_layers, B, Q, cfg.num_classes, device=dev, dtype=torch.float32)
+        box = torch.empty(cfg.num_layers, B, Q, cfg.code_size, device=dev, dtype=torch.float32)
+        feats = (ctypes.c_void_p * cfg.L)(*[f.data_ptr() for f in pyramid.levels])
+        mask = attn_mask.to(device=dev, dtype=torch.uint8).contiguous() if attn_mask is not None else None
+        qb, qf = query_bbox.contiguous(), query_feat.contiguous()
+        st = lib.sbev_decoder_forward(ctypes.byref(cfg), ctypes.byref(self._weights), feats, _ptr(qb), _ptr(qf),
+                                      _ptr(ctx.time_diff), _ptr(ctx.lidar2img), _ptr(ctx.vel_div), _ptr(mask),
+                                      _ptr(cls), _ptr(box), ctypes.c_void_p(ws_ptr), need,
+                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(st, 'sbev_decoder_forward')
+        return cls, box
+
+
+def profile_sampler(enable):
+    _lib.load().sbev_profile_sampler(1 if enable else 0)
+
+
+def read_sampler_ms(max_n=4096):
+    buf = (ctypes.c_float * max_n)()
+    n = _lib.load().sbev_profile_sampler_read(buf, max_n)
+    return [buf[i] for i in range(n)]

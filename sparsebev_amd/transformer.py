@@ -81,8 +81,9 @@ class SparseBEVSelfAttention(_Base):
     def forward(self, query_bbox, query_feat, pre_attn_mask=None, ln=None):
         a = self.attention.attn
         if DUMP.enabled:     # sasa_tau tap (models/sparsebev_transformer.py:218-219); debug path only
-            DUMP.save('sasa_tau', dense.linear(query_feat, dense._cat_rows(self.gen_tau.weight, self.gen_tau.weight.new_zeros(4, query_feat.shape[-1])),
-                                               dense._cat_rows(self.gen_tau.bias, self.gen_tau.bias.new_zeros(4)))[..., :self.num_heads])
+            w4 = torch.cat([self.gen_tau.weight, self.gen_tau.weight.new_zeros((-self.num_heads) % 4, query_feat.shape[-1])], 0)
+            b4 = torch.cat([self.gen_tau.bias, self.gen_tau.bias.new_zeros((-self.num_heads) % 4)], 0)
+            DUMP.save('sasa_tau', dense.linear(query_feat, w4, b4)[..., :self.num_heads])
         return dense.scale_adaptive_self_attention(
             query_bbox, query_feat, self.pc_range, self.num_heads,
             a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
@@ -108,10 +109,10 @@ class SparseBEVSampling(_Base):
         """feats: FeaturePyramid (channels-last, resident); ctx: DecoderContext.  -> [B,Q,G,T*P,C]"""
         T, G, P, L = self.num_frames, self.num_groups, self.num_points, self.num_levels
         # one fused Linear for both generators: [B,Q,256] x [256, G*P*3 + G*P*L]
-        both = dense.linear(query_feat, ctx.cat_weight(self.sampling_offset, self.scale_weights),
-                            ctx.cat_bias(self.sampling_offset, self.scale_weights))
+        both = dense.linear(query_feat, dense._cat_rows(self.sampling_offset.weight, self.scale_weights.weight),
+                            dense._cat_rows(self.sampling_offset.bias, self.scale_weights.bias))
         n_off = G * P * 3
-        offset, logits = both[..., :n_off].contiguous(), both[..., n_off:].contiguous()
+        offset, logits = both[..., :n_off], both[..., n_off:]       # column slices of the packed rows (no copy)
         pts, w_bp = ops.sampling_front(query_bbox, offset, logits, ctx.time_diff, self.pc_range, T, G, P, L)
         if DUMP.enabled:
             loc, uvh, valid, _ = ops.project_select(pts, ctx.lidar2img, ctx.image_h, ctx.image_w, G, P, dump=True)
@@ -185,8 +186,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
     def forward(self, query_bbox, query_feat, feats, attn_mask, ctx):
         pe = self.position_encoder
         pos = dense.linear_ln_relu(query_bbox, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)   # reads columns 0:3
-        pos = dense.linear_ln_relu(pos, pe[3].weight, pe[3].bias, pe[4].weight, pe[4].bias)
-        x = query_feat + pos
+        x = dense.layer_norm(dense.linear(pos, pe[3].weight, pe[3].bias), pe[4].weight, pe[4].bias, relu=True, add_after=query_feat)
         x = self.self_attn(query_bbox, x, attn_mask, ln=(self.norm1.weight, self.norm1.bias))
         sampled = self.sampling(query_bbox, x, feats, ctx)
         x = self.mixing(sampled, x, ln=(self.norm2.weight, self.norm2.bias))       # norm2 fused into the out-proj reducer
@@ -260,19 +260,6 @@ class DecoderContext:
             self.vel_div = torch.from_numpy(d).to(device)
         else:
             self.vel_div = None
-        self._cat = {}
-
-    def cat_weight(self, a, b):
-        key = ('w', id(a), id(b), a.weight._version, b.weight._version)
-        if key not in self._cat:
-            self._cat[key] = torch.cat([a.weight, b.weight], 0).contiguous()
-        return self._cat[key]
-
-    def cat_bias(self, a, b):
-        key = ('b', id(a), id(b), a.bias._version, b.bias._version)
-        if key not in self._cat:
-            self._cat[key] = torch.cat([a.bias, b.bias], 0).contiguous()
-        return self._cat[key]
 
 
 class SparseBEVTransformerDecoder(_Base):
@@ -282,6 +269,7 @@ class SparseBEVTransformerDecoder(_Base):
                  code_size=10, pc_range=(), init_cfg=None):
         super().__init__(init_cfg)
         self.num_layers, self.pc_range = num_layers, list(pc_range)
+        self._runtime = None
         self.decoder_layer = SparseBEVTransformerDecoderLayer(embed_dims, num_frames, num_points, num_levels,
                                                               num_classes, code_size, pc_range=pc_range)
 
@@ -289,12 +277,19 @@ class SparseBEVTransformerDecoder(_Base):
     def init_weights(self):
         self.decoder_layer.init_weights()
 
-    def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
+    def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=False):
+        """Default: the C++ runtime enqueues all layers from one call (csrc/decoder.hip).  ``layerwise=True`` (and
+        the DUMP debug taps) run the same kernels one Python call at a time -- the path the per-op tests use."""
         B = query_bbox.shape[0]
         ctx = DecoderContext(img_metas, B, query_bbox.device)
         feats = mlvl_feats if isinstance(mlvl_feats, FeaturePyramid) else FeaturePyramid(mlvl_feats)
         query_bbox = query_bbox.float().contiguous()
         query_feat = query_feat.float().contiguous()
+        if not (layerwise or DUMP.enabled):
+            if self._runtime is None:
+                from .runtime import DecoderRuntime
+                self._runtime = DecoderRuntime(self)
+            return self._runtime.forward(query_bbox, query_feat, feats, ctx, attn_mask)
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):
             DUMP.stage_count = i
@@ -322,10 +317,10 @@ class SparseBEVTransformer(_Base):
     def init_weights(self):
         self.decoder.init_weights()
 
-    def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
+    def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=False):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise NotImplementedError('sparsebev_amd implements the inference forward of the decoder; the backward '
                                       '(SURVEY.md section 8f) is not built yet -- call in eval() under torch.no_grad()')
         with torch.no_grad():
-            cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas)
+            cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=layerwise)
             return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)

@@ -43,6 +43,9 @@ def test_g7_decoder_teacher_forced_and_free_running(tag):
     assert (box[0].cpu() - g['out_bbox'][0]).abs().max() < TOL
     assert (cls.cpu() - g['out_cls']).abs().max() < 0.2           # rounding noise grows ~5x per random-init layer
     assert 'time_diff' not in metas_in[0] and not torch.is_tensor(metas_in[0]['lidar2img'])   # inputs not mutated
+    # the C++ runtime (one call, all layers) and the layer-by-layer Python path launch the same kernels
+    cls_lw, box_lw = model(g['query_bbox'].to(DEV), g['query_feat'].to(DEV), list(feats), None, copy.deepcopy(metas), layerwise=True)
+    assert torch.equal(cls, cls_lw) and torch.equal(box, box_lw)
     # teacher-forced: each layer from the reference's own inputs
     layer = model.decoder.decoder_layer
     pyr, ctx = FeaturePyramid(feats), DecoderContext(metas, B, torch.device(DEV))

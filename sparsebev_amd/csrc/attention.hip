@@ -8,7 +8,7 @@
 // c = decoded (x, y) box centres in metres.  The in-projection (with gen_tau's 8 rows appended: one GEMM,
 // N = 3D + H) runs before this kernel and the out-projection + residual + norm1 after it (sbev_linear_f32).
 //
-// One workgroup = NW waves x 16 query rows of one (batch, head).  K/V tiles of 64 keys are staged in LDS
+// One workgroup = 2 row groups x 16 query rows of one (batch, head), x 2 key halves.  K/V tiles of 64 keys are staged in LDS
 // (16-B coalesced loads: a key's 32-float head slice is one 128-B line), S = QK^T and O += PV run on
 // v_mfma_f32_16x16x4_f32 (exact fp32), the distance bias is recomputed from the centres on the fly, the
 // softmax is the online (running max / running sum) form, and P goes from the MFMA C layout to the A layout
@@ -21,7 +21,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 32;        // head dim (embed 256 / 8 heads)
 constexpr int KT = 64;        // keys per tile
-constexpr int NW = 2;         // waves per workgroup -> 32 query rows
+constexpr int NQ = 2;         // query row groups (16 rows each) per workgroup
+constexpr int KS = 2;         // key splits per workgroup: wave (ks, qg) walks key tiles ks, ks+KS, ... of row group qg
+constexpr int NWAVES = NQ * KS;
 constexpr int LDK = HD + 4;   // K tile row stride (B operand of QK^T is read along d: rows = keys)
 constexpr int LDV = HD + 16;  // V tile row stride (B operand of PV is read along keys: stride = 16 banks)
 constexpr int LDP = KT + 4;   // P patch row stride
@@ -46,22 +48,27 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * NW) void sasa_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
-    __shared__ __attribute__((aligned(16))) float Vs[KT * LDV];
-    __shared__ __attribute__((aligned(16))) float Cs[KT * 2];
-    __shared__ __attribute__((aligned(16))) float Ps[NW * 16 * LDP];
+// With Q = 900 and 8 heads there are only 232 (head, 32-row) work items -- fewer than CUs -- so the workgroup
+// also splits the KEYS: 4 waves = 2 row groups x 2 key halves, one wave per SIMD, each with its own running
+// (max, sum, O) that are merged through LDS at the end (the flash-decoding combine).
+template <bool MASK>
+__global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ks[KS * KT * LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[KS * KT * LDV];
+    __shared__ __attribute__((aligned(16))) float Cs[KS * KT * 2];
+    __shared__ __attribute__((aligned(16))) float Ps[NWAVES * 16 * LDP];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave % NQ, ks = wave / NQ;
     const int fi = lane & 15, fk = lane >> 4;
-    const int qtiles = (a.Q + 16 * NW - 1) / (16 * NW);
+    const int qtiles = (a.Q + 16 * NQ - 1) / (16 * NQ);
     const int qt = blockIdx.x % qtiles;
     const int h = (blockIdx.x / qtiles) % a.H;
     const int b = blockIdx.x / (qtiles * a.H);
     const int D = a.H * HD;
     const float* base = a.qkvt + (long long)b * a.Q * a.ld;
-    const int q0 = qt * 16 * NW + wave * 16;                 // this wave's first query row
+    const int q0 = qt * 16 * NQ + qg * 16;                   // this wave's first query row
 
     // Q fragments (A operand: row = fi, k = 4s + fk), pre-scaled like torch's MHA (q * head_dim^-0.5)
     float qf[HD / 4];
@@ -86,95 +93,164 @@ __global__ __launch_bounds__(64 * NW) void sasa_kernel(const AttnArgs a) {
     o_acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o_acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float* Pw = Ps + wave * 16 * LDP;
+    const float* Kw = Ks + ks * KT * LDK;
+    const float* Vw = Vs + ks * KT * LDV;
+    const float* Cw = Cs + ks * KT * 2;
 
-    for (int k0 = 0; k0 < a.Q; k0 += KT) {
-        __syncthreads();                                       // previous tile fully consumed
-        for (int i = tid; i < KT * (HD / 4); i += 64 * NW) {   // 8 x float4 per key
+    // K/V staging: the workgroup fetches KS tiles (KS*64 keys) per iteration; thread -> SLOTS x (key row, float4
+    // column) of K and of V, plus one key centre for tid < KS*KT.  Tiles are fetched into registers one iteration
+    // AHEAD (issue-early / write-late), so their L2 latency hides under this iteration's MFMAs and softmax.
+    constexpr int SLOTS = KS * KT * (HD / 4) / (64 * NWAVES);
+    float4 rk[SLOTS], rv[SLOTS];
+    float2 rc = make_float2(0.f, 0.f);
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int i = tid + j * 64 * NWAVES;
             const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             const int kj = min(k0 + r, a.Q - 1);
             const float* row = base + (long long)kj * a.ld + h * HD + c4;
-            *reinterpret_cast<float4*>(&Ks[r * LDK + c4]) = *reinterpret_cast<const float4*>(row + D);
-            *reinterpret_cast<float4*>(&Vs[r * LDV + c4]) = *reinterpret_cast<const float4*>(row + 2 * D);
+            rk[j] = *reinterpret_cast<const float4*>(row + D);
+            rv[j] = *reinterpret_cast<const float4*>(row + 2 * D);
         }
-        for (int i = tid; i < KT; i += 64 * NW) {
-            const int kj = min(k0 + i, a.Q - 1);
-            Cs[2 * i] = a.centers[((long long)b * a.Q + kj) * 2];
-            Cs[2 * i + 1] = a.centers[((long long)b * a.Q + kj) * 2 + 1];
+        if (tid < KS * KT) {
+            const int kj = min(k0 + tid, a.Q - 1);
+            rc = *reinterpret_cast<const float2*>(a.centers + ((long long)b * a.Q + kj) * 2);
         }
-        __syncthreads();
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int i = tid + j * 64 * NWAVES;
+            const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;      // r in [0, KS*KT): tile r / KT, row r % KT
+            *reinterpret_cast<float4*>(&Ks[r * LDK + c4]) = rk[j];
+            *reinterpret_cast<float4*>(&Vs[r * LDV + c4]) = rv[j];
+        }
+        if (tid < KS * KT) { Cs[2 * tid] = rc.x; Cs[2 * tid + 1] = rc.y; }
+    };
+    fetch(0);
+    stash();
+    __syncthreads();
 
-        // S = (Q/sqrt(d)) K^T : 4 key sub-tiles of 16
-        f32x4 s_acc[KT / 16];
-#pragma unroll
-        for (int c = 0; c < KT / 16; ++c) {
-            s_acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < HD / 4; ++s)
-                s_acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], Ks[(c * 16 + fi) * LDK + 4 * s + fk], s_acc[c], 0, 0, 0);
-        }
-        // + distance bias, masks; tile row max.  C layout: column (key) = fi, row (query) = fk*4 + e
-        float tmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int c = 0; c < KT / 16; ++c) {
-            const int kj = k0 + c * 16 + fi;
-            const float kx = Cs[2 * (c * 16 + fi)], ky = Cs[2 * (c * 16 + fi) + 1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dx = cx[e] - kx, dy = cy[e] - ky;
-                float v = s_acc[c][e] + (-sqrtf(dx * dx + dy * dy)) * tau[e];
-                const int qi = q0 + fk * 4 + e;
-                bool dead = kj >= a.Q;
-                if (a.mask && !dead && qi < a.Q) dead = a.mask[(long long)qi * a.Q + kj] != 0;
-                v = dead ? -INFINITY : v;
-                s_acc[c][e] = v;
-                tmax[e] = fmaxf(tmax[e], v);
-            }
-        }
-        float alpha[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float m_new = fmaxf(m_run[e], row16_max(tmax[e]));
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;       // fully masked so far: keep everything 0
-            alpha[e] = __expf(m_run[e] - m_use);                        // exp(-inf) = 0 on the first tile
-            m_run[e] = m_new;
-            float psum = 0.f;
+    for (int k0 = 0; k0 < a.Q; k0 += KS * KT) {
+        const bool more = k0 + KS * KT < a.Q;
+        if (more) fetch(k0 + KS * KT);                         // in flight during this iteration's compute
+        const int kbase = k0 + ks * KT;                        // this wave's key tile
+        if (kbase < a.Q) {
+            // S = (Q/sqrt(d)) K^T : 4 key sub-tiles of 16
+            f32x4 s_acc[KT / 16];
 #pragma unroll
             for (int c = 0; c < KT / 16; ++c) {
-                const float p = __expf(s_acc[c][e] - m_use);
-                s_acc[c][e] = p;
-                psum += p;
+                s_acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < HD / 4; ++s)
+                    s_acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], Kw[(c * 16 + fi) * LDK + 4 * s + fk], s_acc[c], 0, 0, 0);
             }
-            l_run[e] = l_run[e] * alpha[e] + row16_sum(psum);
+            // + distance bias, masks; tile row max.  C layout: column (key) = fi, row (query) = fk*4 + e
+            float tmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int c = 0; c < KT / 16; ++c) {
+                const int kj = kbase + c * 16 + fi;
+                const float kx = Cw[2 * (c * 16 + fi)], ky = Cw[2 * (c * 16 + fi) + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dx = cx[e] - kx, dy = cy[e] - ky;
+                    // v_sqrt_f32 (1 ulp): |d(dist*tau)| <= ~2e-5 on logits that are O(10), far inside the budget
+                    float v = s_acc[c][e] - __builtin_amdgcn_sqrtf(dx * dx + dy * dy) * tau[e];
+                    bool dead = kj >= a.Q;
+                    if (MASK) {
+                        const int qi = min(q0 + fk * 4 + e, a.Q - 1);
+                        dead = dead || a.mask[(long long)qi * a.Q + min(kj, a.Q - 1)] != 0;
+                    }
+                    v = dead ? -INFINITY : v;
+                    s_acc[c][e] = v;
+                    tmax[e] = fmaxf(tmax[e], v);
+                }
+            }
+            float alpha[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float m_new = fmaxf(m_run[e], row16_max(tmax[e]));
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;   // fully masked so far: keep everything 0
+                alpha[e] = __expf(m_run[e] - m_use);                    // exp(-inf) = 0 on the first tile
+                m_run[e] = m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int c = 0; c < KT / 16; ++c) {
+                    const float p = __expf(s_acc[c][e] - m_use);
+                    s_acc[c][e] = p;
+                    psum += p;
+                }
+                l_run[e] = l_run[e] * alpha[e] + row16_sum(psum);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o_acc[t][e] *= alpha[e];
+            // P: C layout -> LDS -> A layout (row = fi, k = key)
+#pragma unroll
+            for (int c = 0; c < KT / 16; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Pw[(fk * 4 + e) * LDP + c * 16 + fi] = s_acc[c][e];
+            // the patch is private to this wave and a wave's DS operations execute in issue order, so the reads
+            // below see the writes above without a workgroup barrier; only keep the compiler from reordering them
+            __builtin_amdgcn_wave_barrier();
+            // O += P V : 2 column tiles of 16 dims, K = 64 keys
+#pragma unroll
+            for (int s = 0; s < KT / 4; ++s) {
+                const float pa = Pw[fi * LDP + 4 * s + fk];
+                o_acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vw[(4 * s + fk) * LDV + fi], o_acc[0], 0, 0, 0);
+                o_acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vw[(4 * s + fk) * LDV + 16 + fi], o_acc[1], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o_acc[t][e] *= alpha[e];
-        // P: C layout -> LDS -> A layout (row = fi, k = key)
-#pragma unroll
-        for (int c = 0; c < KT / 16; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Pw[(fk * 4 + e) * LDP + c * 16 + fi] = s_acc[c][e];
-        // the patch is private to this wave and a wave's DS operations execute in issue order, so the reads
-        // below see the writes above without a workgroup barrier; only keep the compiler from reordering them
-        __builtin_amdgcn_wave_barrier();
-        // O += P V : 2 column tiles of 16 dims, K = 64 keys
-#pragma unroll
-        for (int s = 0; s < KT / 4; ++s) {
-            const float pa = Pw[fi * LDP + 4 * s + fk];
-            o_acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vs[(4 * s + fk) * LDV + fi], o_acc[0], 0, 0, 0);
-            o_acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vs[(4 * s + fk) * LDV + 16 + fi], o_acc[1], 0, 0, 0);
+        __syncthreads();                                       // every wave is done with these K/V/centre tiles
+        if (more) {
+            stash();
+            __syncthreads();
         }
     }
-    // normalise and store: C layout column = dim (fi), row = query (fk*4 + e)
+    // merge the KS key-split partials of each row group (flash-decoding combine) through LDS, then normalise.
+    // Ks is free now: slot layout [ks][qg][12 values][64 lanes]
+    float* mg = Ks;
+    if (ks > 0) {
+        float* d = mg + ((ks - 1) * NQ + qg) * 12 * 64;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int qi = q0 + fk * 4 + e;
-        if (qi < a.Q) {
-            const float inv = 1.f / l_run[e];
-            float* o = a.out + ((long long)b * a.Q + qi) * D + h * HD;
-            o[fi] = o_acc[0][e] * inv;
-            o[16 + fi] = o_acc[1][e] * inv;
+        for (int e = 0; e < 4; ++e) {
+            d[(0 + e) * 64 + lane] = m_run[e];
+            d[(4 + e) * 64 + lane] = o_acc[0][e];
+            d[(8 + e) * 64 + lane] = o_acc[1][e];
+        }
+    }
+    float* lg = Vs;                                            // l_run partials, same indexing with 4 values
+    if (ks > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lg[(((ks - 1) * NQ + qg) * 4 + e) * 64 + lane] = l_run[e];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float m = m_run[e], l = l_run[e], o0 = o_acc[0][e], o1 = o_acc[1][e];
+#pragma unroll
+            for (int z = 1; z < KS; ++z) {
+                const float* d = mg + ((z - 1) * NQ + qg) * 12 * 64;
+                const float m2 = d[(0 + e) * 64 + lane];
+                const float l2 = lg[(((z - 1) * NQ + qg) * 4 + e) * 64 + lane];
+                const float mn = fmaxf(m, m2);
+                const float mu = mn == -INFINITY ? 0.f : mn;
+                const float f1 = __expf(m - mu), f2 = __expf(m2 - mu);
+                o0 = o0 * f1 + d[(4 + e) * 64 + lane] * f2;
+                o1 = o1 * f1 + d[(8 + e) * 64 + lane] * f2;
+                l = l * f1 + l2 * f2;
+                m = mn;
+            }
+            const int qi = q0 + fk * 4 + e;
+            if (qi < a.Q) {
+                const float inv = 1.f / l;
+                float* o = a.out + ((long long)b * a.Q + qi) * D + h * HD;
+                o[fi] = o0 * inv;                               // C layout: column = dim (fi), row = query
+                o[16 + fi] = o1 * inv;
+            }
         }
     }
 }
@@ -231,9 +307,13 @@ extern "C" int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* centers
     SBEV_REQUIRE(qkvt && centers && out, "sbev_sasa_f32: null pointer");
     SBEV_REQUIRE((((uintptr_t)qkvt) & 15) == 0, "sbev_sasa_f32: qkvt must be 16-byte aligned");
     AttnArgs a{qkvt, centers, mask, out, B, Q, H, (int)ld, 1.0f / sqrtf((float)HD)};
-    const long long blocks = (long long)B * H * ((Q + 16 * NW - 1) / (16 * NW));
+    const long long blocks = (long long)B * H * ((Q + 16 * NQ - 1) / (16 * NQ));
     SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_sasa_f32: too many blocks");
-    hipLaunchKernelGGL(sasa_kernel, dim3((unsigned)blocks), dim3(64 * NW), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (mask)
+        hipLaunchKernelGGL(sasa_kernel<true>, dim3((unsigned)blocks), dim3(64 * NWAVES), 0, s, a);
+    else
+        hipLaunchKernelGGL(sasa_kernel<false>, dim3((unsigned)blocks), dim3(64 * NWAVES), 0, s, a);
     return sbev::check_launch("sbev_sasa_f32");
 }
 

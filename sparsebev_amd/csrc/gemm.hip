@@ -58,9 +58,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
     const int wr = wave >> 1, wc = wave & 1;
     const unsigned tiles_n = (a.N + BN - 1) / BN;
     const unsigned tiles_m = (unsigned)((a.M + BM - 1) / BM);
-    // tile order: N fastest inside an XCD chunk so concurrently running tiles share the X panel and walk W
+    // tile order inside an XCD's contiguous chunk: walk the SHORTER tile dimension fastest, so the panel of the
+    // longer operand (W for the parameter generator: 33.5 MB) is fetched once per XCD and re-used from its L2 by
+    // the few tiles of the other dimension, instead of every XCD streaming the whole of it.
     const unsigned t = xcd_swizzle(blockIdx.x, tiles_m * tiles_n);
-    const unsigned tm = t / tiles_n, tn = t % tiles_n;
+    const bool m_fast = tiles_n >= tiles_m;
+    const unsigned tm = m_fast ? t % tiles_m : t / tiles_n;
+    const unsigned tn = m_fast ? t / tiles_m : t % tiles_n;
     const long long m0 = (long long)tm * BM;
     const int n0 = tn * BN;
     const int kbeg = SPLIT ? blockIdx.z * a.k_per_split : 0;
@@ -209,6 +213,81 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
     }
 }
 
+// ---- latency-oriented variant for the many small linears ([B*Q,256] x [256,256..776], 0.1-0.35 GFLOP) -------
+// With 128x128 or 64x64 tiles these launch only 16-60 workgroups whose waves each grind through the whole K:
+// ~10 us for 118 MFLOP.  Here a workgroup owns one 32x32 output tile and its 4 waves SPLIT K four ways; every
+// wave pulls its A / B fragments straight from global memory (L2-resident operands, each element used once per
+// wave, so LDS staging would only add a barrier), runs K/4/2 MFMAs, and the four partial tiles are combined
+// through 16 KiB of LDS into a float4 row-major epilogue.  232 workgroups / 928 waves for [900,256]x[256,256].
+template <int KC>   // KC = K / 4 / 8: float4 k-blocks per wave (8 for K = 256, 16 for K = 512)
+__global__ __launch_bounds__(256) void gemm_nt_f32_small_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned tiles_n = (a.N + 31) / 32;
+    const unsigned tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const long long m0 = (long long)tm * 32;
+    const int n0 = tn * 32;
+    long long ra = m0 + fr;
+    ra = ra < a.M ? ra : a.M - 1;
+    int rb = n0 + fr;
+    rb = rb < a.N ? rb : a.N - 1;
+    const float* xp = a.X + ra * a.ldx + wave * (KC * 8) + 4 * fh;
+    const float* wp = a.W + (long long)rb * a.ldw + wave * (KC * 8) + 4 * fh;
+    float4 fa[KC], fb[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {       // all loads in flight before the first MFMA
+        fa[i] = *reinterpret_cast<const float4*>(xp + i * 8);
+        fb[i] = *reinterpret_cast<const float4*>(wp + i * 8);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // lanes with fh = 0 / 1 hold k = 8i + {0..3} / 8i + {4..7}: any k <-> (step, half) bijection is a valid MFMA order
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[i].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // thread -> row r = tid / 8, columns c..c+3 = (tid % 8) * 4;  C/D layout: row = (e&3) + 8*(e>>2) + 4*fh, col = lane&31
+    const int r = tid >> 3, c = (tid & 7) * 4;
+    const int e = (r & 3) + 4 * (r >> 3), h = (r >> 2) & 1;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(&red[(w * 16 + e) * 64 + h * 32 + c]);
+        v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    }
+    const long long m = m0 + r;
+    const int n = n0 + c;
+    if (m >= a.M || n >= a.N) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (a.bias && n + q < a.N) v[q] += a.bias[n + q];
+        if (a.relu) v[q] = fmaxf(v[q], 0.f);
+    }
+    float* yp = a.Y + m * a.ldy + n;
+    const bool vec = (a.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.Y) & 15) == 0) && (n + 3 < a.N) &&
+                     (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0);
+    if (vec) {
+        if (a.res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(a.res + m * a.ldy + n);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n + q < a.N) yp[q] = v[q] + (a.res ? a.res[m * a.ldy + n + q] : 0.f);
+    }
+}
+
 struct ReduceArgs {
     const float* slabs;  // [splits, M, N]
     const float* bias;   // [N] or null
@@ -319,6 +398,12 @@ extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, true>), dim3((unsigned)small), dim3(256), 0, s, a);
     } else if (big >= 256) {   // enough 128x128 tiles to fill the 256 CUs
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 2, 2, false>), dim3((unsigned)big), dim3(256), 0, s, a);
+    } else if (K == 256 || K == 512) {   // the decoder's small linears: 32x32 tiles, K split over the 4 waves
+        const long long t32 = ((M + 31) / 32) * ((N + 31) / 32);
+        if (K == 256)
+            hipLaunchKernelGGL((gemm_nt_f32_small_kernel<8>), dim3((unsigned)t32), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((gemm_nt_f32_small_kernel<16>), dim3((unsigned)t32), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, false>), dim3((unsigned)small), dim3(256), 0, s, a);
     }

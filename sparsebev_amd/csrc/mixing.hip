@@ -46,17 +46,17 @@ __device__ __forceinline__ float block_sum(float v, float* red, int wave, int la
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int RT>   // RT = ceil(Pin / 16) row tiles of the first matmul (1..8)
+template <int RT, bool WIDE>   // RT = ceil(Pin / 16) row tiles of matmul 1; WIDE: Pin % 16 == 0 (b128 A reads in matmul 2)
 __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
     const int lds_s = Pin + 4;                                  // S row stride
     float* red = smem;                                          // [4] block-reduction scratch (never aliased)
-    float* Xs = smem + 4;                                       // [RT*16][LDA]
-    float* Ms = Xs + RT * 16 * LDA;                             // [C][LDB]
+    float* Xs = smem + 4;                                       // [RT*16][LDA]  (dead after matmul 1)
+    float* Y1 = smem + 4;                                       // [RT*16][LDB]  aliases Xs: written after LayerNorm 1
+    float* Ms = Y1 + RT * 16 * LDB;                             // [C][LDB]
     float* Ss = Ms + C * LDB;                                   // [POUT][lds_s]
-    float* Y1 = Ss + POUT * lds_s;                              // [RT*16][LDB]
-    float* Yo = smem + 4;                                       // [POUT][LDY], aliases Xs/Ms/Ss/Y1 after matmul 2
+    float* Yo = smem + 4;                                       // [POUT][LDY], aliases everything after matmul 2
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,13 +89,20 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     f32x4 acc1[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < C; k0 += 4) {
-        const float b = Ms[(k0 + fk) * LDB + cw + fi];
+    // K is walked in blocks of 16: lane group fk owns k = 16*blk + 4*fk + j (j = 0..3), so an A fragment is ONE
+    // 16-byte LDS read per 4 MFMAs (any k <-> (step, lane group) bijection is a valid order for A and B together)
+#pragma unroll
+    for (int blk = 0; blk < C / 16; ++blk) {
+        float bq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = Ms[(16 * blk + 4 * fk + j) * LDB + cw + fi];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            const float av = Xs[(r * 16 + fi) * LDA + k0 + fk];
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc1[r], 0, 0, 0);
+            const float4 a4 = *reinterpret_cast<const float4*>(&Xs[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bq[0], acc1[r], 0, 0, 0);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bq[1], acc1[r], 0, 0, 0);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bq[2], acc1[r], 0, 0, 0);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bq[3], acc1[r], 0, 0, 0);
         }
     }
     // C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg
@@ -127,12 +134,28 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     f32x4 acc2[POUT / 16];
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < Pin; k0 += 4) {
-        const float b = Y1[(k0 + fk) * LDB + cw + fi];
+    if (WIDE) {
+        for (int blk = 0; blk < Pin / 16; ++blk) {
+            float bq[4];
 #pragma unroll
-        for (int r = 0; r < POUT / 16; ++r) {
-            const float av = Ss[(r * 16 + fi) * lds_s + k0 + fk];
-            acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc2[r], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) bq[j] = Y1[(16 * blk + 4 * fk + j) * LDB + cw + fi];
+#pragma unroll
+            for (int r = 0; r < POUT / 16; ++r) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&Ss[(r * 16 + fi) * lds_s + 16 * blk + 4 * fk]);
+                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bq[0], acc2[r], 0, 0, 0);
+                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bq[1], acc2[r], 0, 0, 0);
+                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bq[2], acc2[r], 0, 0, 0);
+                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bq[3], acc2[r], 0, 0, 0);
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < Pin; k0 += 4) {
+            const float b = Y1[(k0 + fk) * LDB + cw + fi];
+#pragma unroll
+            for (int r = 0; r < POUT / 16; ++r) {
+                const float av = Ss[(r * 16 + fi) * lds_s + k0 + fk];
+                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc2[r], 0, 0, 0);
+            }
         }
     }
     // ---- LayerNorm over 128*64 elements, ReLU ------------------------------------------------------------
@@ -167,14 +190,14 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     }
 }
 
-template <int RT>
-int launch_mix(const MixArgs& a, hipStream_t s) {
+template <int RT, bool WIDE>
+int launch_mix_w(const MixArgs& a, hipStream_t s) {
     const int Pin = a.Pin;
-    size_t floats = (size_t)RT * 16 * LDA + C * LDB + POUT * (Pin + 4) + (size_t)RT * 16 * LDB;
+    size_t floats = (size_t)RT * 16 * LDB + C * LDB + POUT * (Pin + 4);
     const size_t out_floats = (size_t)POUT * LDY;
     if (floats < out_floats) floats = out_floats;
     const size_t bytes = (floats + 4) * sizeof(float);
-    auto k = adaptive_mixing_kernel<RT>;
+    auto k = adaptive_mixing_kernel<RT, WIDE>;
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) {
@@ -184,6 +207,11 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(256), bytes, s, a);
     return sbev::check_launch("sbev_adaptive_mixing_f32");
+}
+
+template <int RT>
+int launch_mix(const MixArgs& a, hipStream_t s) {
+    return a.Pin % 16 == 0 ? launch_mix_w<RT, true>(a, s) : launch_mix_w<RT, false>(a, s);
 }
 
 }  // namespace

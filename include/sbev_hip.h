@@ -37,6 +37,7 @@ enum sbev_status {
 };
 
 enum sbev_dtype { SBEV_F32 = 0, SBEV_BF16 = 1 };
+enum sbev_gemm_mode { SBEV_GEMM_F32 = 0 /* exact: f32-input MFMA */, SBEV_GEMM_BF16X3 = 1 /* opt-in 3 x bf16 split */ };
 
 /* Output layouts of the sampler. */
 enum sbev_out_layout {
@@ -209,6 +210,27 @@ int sbev_linear3_ln_relu_f32(const float* x, int64_t ldx, const float* w, const 
                              const float* ln_w, const float* ln_b, float eps, float* y,
                              int64_t M, int N, sbev_stream_t stream);
 
+/* Split-K slab reducer: Y = LayerNorm?( relu?( sum_z slabs[z] + bias ) + residual ), slabs [splits, M, N]. */
+int sbev_splitk_reduce_f32(const float* slabs, int splits, const float* bias, const float* residual,
+                           const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                           int64_t M, int N, int relu, sbev_stream_t stream);
+
+/*
+ * Opt-in "3 x bf16" Linear for the two large GEMMs of AdaptiveMixing (models/sparsebev_transformer.py:358,378):
+ * both fp32 operands are split into bf16 (hi, lo) pairs and Y = Xhi.Whi + Xhi.Wlo + Xlo.Whi is accumulated in
+ * fp32 on v_mfma_f32_32x32x16_bf16.  fp32-class accuracy (about 2^-16 relative per product; 1.2e-5 max abs error on
+ * the reference's AdaptiveMixing fixture), ~3-5x the speed of the exact-fp32 MFMA path; NOT bit-equal to fp32 math,
+ * hence never the default.  sbev_split_bf16x3_weights converts W [N,K] fp32 once into W2 [N, K/8, 2, 8] bf16
+ * (same byte count); K % 32 == 0.
+ */
+int sbev_split_bf16x3_weights(const float* W, uint16_t* W2, int64_t N, int K, sbev_stream_t stream);
+int sbev_linear_bf16x3(const float* X, const uint16_t* W2, const float* bias, const float* residual, float* Y,
+                       int64_t M, int N, int K, int64_t ldx, int64_t ldy, int relu, sbev_stream_t stream);
+int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* bias, const float* residual,
+                              const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                              int64_t M, int N, int K, int64_t ldx, int relu, int splits, float* workspace,
+                              sbev_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Whole-decoder runtime: ONE call enqueues every kernel of every layer (28 launches per layer) on `stream`.
  * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward
@@ -222,6 +244,7 @@ typedef struct sbev_decoder_config {
     int32_t feat_dtype;                 /* enum sbev_dtype of the pyramid */
     int32_t hw[SBEV_MAX_LEVELS][2];     /* (H_l, W_l) */
     float image_h, image_w, eps_homo;   /* img_shape and the 1e-5 of sampling_4d */
+    int32_t gemm_mode;                  /* enum sbev_gemm_mode for the two large mixing GEMMs (0 = exact fp32) */
     double pc_range[6];
 } sbev_decoder_config;
 
@@ -233,6 +256,7 @@ typedef struct sbev_decoder_weights {
     const float *attn_out_w, *attn_out_b; /* self_attn.attention.attn.out_proj.* */
     const float *samp_w, *samp_b;         /* rows: sampling.sampling_offset.*, then sampling.scale_weights.* */
     const float *pg_w, *pg_b, *op_w, *op_b;                       /* mixing.parameter_generator.*, mixing.out_proj.* */
+    const uint16_t *pg_w2, *op_w2;                                /* their sbev_split_bf16x3_weights images (gemm_mode 1; else NULL) */
     const float *ffn0_w, *ffn0_b, *ffn1_w, *ffn1_b;               /* ffn.layers.0.0.*, ffn.layers.1.* */
     const float *norm1_g, *norm1_b, *norm2_g, *norm2_b, *norm3_g, *norm3_b;
     const float *cls0_w, *cls0_b, *cls1_g, *cls1_b, *cls3_w, *cls3_b, *cls4_g, *cls4_b, *cls6_w, *cls6_b;  /* cls_branch.* */

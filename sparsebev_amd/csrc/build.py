@@ -16,6 +16,7 @@ UNITS = {
     'capi_common.hip': [],
     'msmv_sampling.hip': [],
     'gemm.hip': [],
+    'gemm_bf16x3.hip': [],
     'mixing.hip': [],
     'attention.hip': [],
     'layout.hip': [],

@@ -73,6 +73,7 @@ int validate(const sbev_decoder_config* c) {
     SBEV_REQUIRE(c->D / c->G == 64 && c->out_points == 128, "sbev_decoder: built for 64 channels per group and 128 out points");
     SBEV_REQUIRE(c->attn_in_rows >= 3 * c->D + c->H && c->attn_in_rows % 4 == 0, "sbev_decoder: attn_in_rows %d", c->attn_in_rows);
     SBEV_REQUIRE(c->code_size >= 10 && c->num_layers >= 1 && c->num_classes >= 1 && c->ffn % 4 == 0, "sbev_decoder: head sizes");
+    SBEV_REQUIRE(c->gemm_mode == SBEV_GEMM_F32 || c->gemm_mode == SBEV_GEMM_BF16X3, "sbev_decoder: gemm_mode %d", c->gemm_mode);
     return SBEV_OK;
 }
 
@@ -99,6 +100,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     SBEV_REQUIRE(w && feats_nhwc && query_bbox && query_feat && time_diff && lidar2img && cls_out && bbox_out && workspace,
                  "sbev_decoder_forward: null pointer");
     SBEV_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sbev_decoder_forward: workspace must be 256-byte aligned");
+    SBEV_REQUIRE(cfg->gemm_mode != SBEV_GEMM_BF16X3 || (w->pg_w2 && w->op_w2), "sbev_decoder_forward: gemm_mode bf16x3 needs pg_w2 / op_w2");
     const Buffers b = carve(c, workspace);
     SBEV_REQUIRE((int64_t)b.bytes <= workspace_bytes, "sbev_decoder_forward: workspace too small (%lld < %zu)", (long long)workspace_bytes, b.bytes);
 
@@ -144,10 +146,17 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
                           c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
         // adaptive mixing + norm2                                               (:171)
-        TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
+        if (c.gemm_mode == SBEV_GEMM_BF16X3)
+            TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, stream));
+        else
+            TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
         TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
-        TRY(sbev_linear_splitk_f32(b.mixed, w->op_w, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN, mixN,
-                                   0, splits, b.slabs, stream));
+        if (c.gemm_mode == SBEV_GEMM_BF16X3)
+            TRY(sbev_linear_splitk_bf16x3(b.mixed, w->op_w2, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
+                                          0, splits, b.slabs, stream));
+        else
+            TRY(sbev_linear_splitk_f32(b.mixed, w->op_w, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN, mixN,
+                                       0, splits, b.slabs, stream));
         // FFN + norm3                                                           (:172)
         TRY(sbev_linear_f32(b.x2, w->ffn0_w, w->ffn0_b, nullptr, b.h, BQ, c.ffn, D, D, D, c.ffn, 1, stream));
         TRY(sbev_linear_f32(b.h, w->ffn1_w, w->ffn1_b, b.x2, b.t1, BQ, D, c.ffn, c.ffn, c.ffn, D, 0, stream));

@@ -442,6 +442,18 @@ extern "C" int sbev_linear_splitk_f32(const float* X, const float* W, const floa
     return sbev::check_launch("sbev_linear_splitk_f32 (reduce)");
 }
 
+// The split-K slab reducer on its own (shared with the bf16x3 GEMM): Y = LN?( relu?(sum_z slabs[z] + bias) + residual )
+extern "C" int sbev_splitk_reduce_f32(const float* slabs, int splits, const float* bias, const float* residual,
+                                      const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                      int64_t M, int N, int relu, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024 && splits >= 1, "sbev_splitk_reduce_f32: need N %% 4 == 0, N <= 1024");
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(slabs && Y && ((ln_w == nullptr) == (ln_b == nullptr)), "sbev_splitk_reduce_f32: null pointer");
+    ReduceArgs r{slabs, bias, residual, ln_w, ln_b, nullptr, Y, M, N, splits, relu, ln_eps};
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), r);
+    return sbev::check_launch("sbev_splitk_reduce_f32");
+}
+
 // Row-wise LayerNorm (+ optional ReLU) of [M, N] (N % 4 == 0, N <= 1024): the split-K reducer with one slab.
 extern "C" int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, float eps,
                                    const float* add_after, float* Y, int64_t M, int N, int relu, sbev_stream_t stream) {

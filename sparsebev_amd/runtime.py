@@ -7,6 +7,7 @@ import torch
 from . import _lib
 
 MAX_LEVELS = 5
+GEMM_F32, GEMM_BF16X3 = 0, 1      # sbev_gemm_mode
 _f = ctypes.c_void_p
 
 
@@ -14,12 +15,12 @@ class DecoderConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('B', 'Q', 'T', 'N', 'G', 'P', 'L', 'D', 'H', 'ffn', 'num_classes',
                                               'code_size', 'num_layers', 'out_points', 'attn_in_rows', 'feat_dtype')] + \
                [('hw', (ctypes.c_int32 * 2) * MAX_LEVELS), ('image_h', ctypes.c_float), ('image_w', ctypes.c_float),
-                ('eps_homo', ctypes.c_float), ('pc_range', ctypes.c_double * 6)]
+                ('eps_homo', ctypes.c_float), ('gemm_mode', ctypes.c_int32), ('pc_range', ctypes.c_double * 6)]
 
 
 _WEIGHT_FIELDS = ['pe0_w', 'pe0_b', 'pe1_g', 'pe1_b', 'pe3_w', 'pe3_b', 'pe4_g', 'pe4_b',
                   'attn_in_w', 'attn_in_b', 'attn_out_w', 'attn_out_b', 'samp_w', 'samp_b',
-                  'pg_w', 'pg_b', 'op_w', 'op_b', 'ffn0_w', 'ffn0_b', 'ffn1_w', 'ffn1_b',
+                  'pg_w', 'pg_b', 'op_w', 'op_b', 'pg_w2', 'op_w2', 'ffn0_w', 'ffn0_b', 'ffn1_w', 'ffn1_b',
                   'norm1_g', 'norm1_b', 'norm2_g', 'norm2_b', 'norm3_g', 'norm3_b',
                   'cls0_w', 'cls0_b', 'cls1_g', 'cls1_b', 'cls3_w', 'cls3_b', 'cls4_g', 'cls4_b', 'cls6_w', 'cls6_b',
                   'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b']
@@ -37,8 +38,9 @@ class DecoderRuntime:
     """Binds a SparseBEVTransformerDecoder's parameters (by pointer) to the C++ runtime and owns the workspace.
     Re-binds automatically when a parameter is replaced or modified in place (``_version`` / ``data_ptr`` change)."""
 
-    def __init__(self, decoder):
+    def __init__(self, decoder, gemm_mode=0):
         self.decoder = decoder
+        self.gemm_mode = gemm_mode
         self._sig = None
         self._keep = None          # tensors whose storage the weight struct points into
         self._weights = None
@@ -80,9 +82,18 @@ class DecoderRuntime:
             reg0_w=rb[0].weight, reg0_b=rb[0].bias, reg2_w=rb[2].weight, reg2_b=rb[2].bias,
             reg4_w=rb[4].weight, reg4_b=rb[4].bias)
         keep = {k: v.detach().contiguous() for k, v in t.items()}
+        if self.gemm_mode == GEMM_BF16X3:      # one-off (hi, lo) bf16 images of the two big weight matrices
+            lib = _lib.load()
+            for name in ('pg_w', 'op_w'):
+                src = keep[name]
+                img = torch.empty(src.shape[0], src.shape[1] * 2, device=src.device, dtype=torch.int16)
+                _lib.check(lib.sbev_split_bf16x3_weights(_ptr(src), _ptr(img), src.shape[0], src.shape[1],
+                                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                           'sbev_split_bf16x3_weights')
+                keep[name + '2'] = img
         w = DecoderWeights()
         for k in _WEIGHT_FIELDS:
-            setattr(w, k, keep[k].data_ptr())
+            setattr(w, k, keep[k].data_ptr() if k in keep else None)
         self._keep, self._weights = keep, w
         self._attn_in_rows = attn_in_w.shape[0]
 
@@ -104,6 +115,7 @@ class DecoderRuntime:
         cfg.num_classes, cfg.code_size, cfg.num_layers = layer.num_classes, layer.code_size, dec.num_layers
         cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
         cfg.feat_dtype = 1 if pyramid.levels[0].dtype == torch.bfloat16 else 0
+        cfg.gemm_mode = self.gemm_mode
         if len(pyramid.levels) != cfg.L or pyramid.T != cfg.T or pyramid.B != B:
             raise RuntimeError('feature pyramid (L=%d, T=%d, B=%d) does not match the decoder config (L=%d, T=%d, B=%d)'
                                % (len(pyramid.levels), pyramid.T, pyramid.B, cfg.L, cfg.T, B))

@@ -1,0 +1,77 @@
+"""CPU-side checks of the host logic around the C ABI (no GPU needed): module/state-dict compatibility with the
+reference, per-call context (time_diff, lidar2img, velocity divisor), sharding helpers, loud failure modes."""
+import numpy as np
+import pytest
+import torch
+
+from sparsebev_amd import synthetic as S
+from sparsebev_amd.transformer import SparseBEVTransformer, DecoderContext, FeaturePyramid
+
+PREFIX = 'decoder.decoder_layer.'
+
+
+def test_state_dict_keys_match_reference():
+    m = SparseBEVTransformer(256, num_frames=8, pc_range=S.PC_RANGE)
+    keys = sorted(m.state_dict())
+    want = sorted(PREFIX + k for k in S.param_shapes())
+    assert keys == want and len(keys) == 48
+    m.init_weights()
+    sd = m.state_dict()
+    assert sd[PREFIX + 'mixing.parameter_generator.weight'].abs().sum() == 0
+    assert sd[PREFIX + 'sampling.sampling_offset.weight'].abs().sum() == 0
+    assert sd[PREFIX + 'self_attn.gen_tau.weight'].abs().sum() == 0
+    assert abs(float(sd[PREFIX + 'cls_branch.6.bias'][0]) + 4.59512) < 1e-4
+
+
+def test_decoder_context_matches_oracle_prologue():
+    from oracle import sparsebev_oracle as O
+    B, T = 2, 8
+    metas = S.make_img_metas(B, T, 256, 704)
+    for b, m in enumerate(metas):
+        m['img_timestamp'] = [ts + 0.003 * ((i * 7 + b) % 6) for i, ts in enumerate(m['img_timestamp'])]
+    ctx = DecoderContext(metas, B, torch.device('cpu'))
+    td = O.time_diff_from_metas(metas, B)
+    assert torch.equal(ctx.time_diff, td)                                  # float64 mean -> fp32, bit for bit
+    assert ctx.lidar2img.shape == (B, T * 6, 4, 4) and ctx.lidar2img.dtype == torch.float32
+    assert (ctx.image_h, ctx.image_w) == (256, 704)
+    exp = td[:, 1].clone()
+    exp[exp < 1e-5] = 1.0
+    assert torch.equal(ctx.vel_div, exp)
+    assert 'time_diff' not in metas[0]                                     # the reference mutates img_metas[0]; we do not
+    # T == 1: no velocity division (models/sparsebev_transformer.py:180)
+    assert DecoderContext(S.make_img_metas(1, 1, 256, 704), 1, torch.device('cpu')).vel_div is None
+
+
+def test_zero_time_diff_is_replaced_by_one():
+    metas = S.make_img_metas(1, 2, 256, 704, frame_dt=0.0)                 # both frames share a timestamp
+    ctx = DecoderContext(metas, 1, torch.device('cpu'))
+    assert float(ctx.vel_div[0]) == 1.0
+
+
+def test_product_refuses_cpu_features_and_training():
+    m = SparseBEVTransformer(256, num_frames=1, pc_range=S.PC_RANGE).eval()
+    feats = S.make_features(1, 1, S.PYRAMIDS['tiny'][2])
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        FeaturePyramid(feats)
+    bbox, feat = S.make_queries(1, 4)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(bbox, feat, feats, None, S.make_img_metas(1, 1, 256, 704))
+    with pytest.raises(AssertionError):
+        SparseBEVTransformer(256, init_cfg=dict(type='Xavier'))            # same guard as the reference (:19-20)
+
+
+def test_synthetic_rig_hit_statistics():
+    """The bench rig must exercise 0-, 1- and 2-hit points in realistic proportions."""
+    from oracle import sparsebev_oracle as O
+    B, Q, T = 1, 400, 8
+    ih, iw, _ = S.PYRAMIDS['r50_704x256']
+    metas = S.make_img_metas(B, T, ih, iw)
+    bbox, feat = S.make_queries(B, Q)
+    prm = S.make_params(0)
+    pts, _ = O.sampling_front(prm, bbox, feat, O.time_diff_from_metas(metas, B), S.PC_RANGE, T, 4, 4)
+    l2i = torch.from_numpy(np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+    _, valid = O.project_points(pts.reshape(B, Q, T, 16, 3), l2i, ih, iw)
+    hits = valid.sum(2)
+    assert 0.85 < (hits >= 1).float().mean() < 0.99
+    assert 0.01 < (hits >= 2).float().mean() < 0.15

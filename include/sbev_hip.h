@@ -80,6 +80,21 @@ int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_d
                   int out_layout, int T, int G, sbev_stream_t stream);
 
 /*
+ * Multi-scale multi-view bilinear sampling, backward (fp32 features).
+ * Replaces: _ms_deform_attn_cuda_c2345_backward / _c23456_backward (models/csrc/msmv_sampling/msmv_sampling.cpp:212-360,
+ *           kernels msmv_sampling_backward.cu:29-361) = MSMVSamplingC2345.backward (models/csrc/wrapper.py:51-61).
+ * Same feature addressing as sbev_msmv_fwd.  grad_feats[l] (fp32, same layout as feats[l]) is ACCUMULATED into with
+ * float atomics -- the caller zero-fills it (the reference's host code does `zeros_like`, :244-249).
+ * grad_out [B',Q,C,P]; grad_loc [B',Q,P,3] (x, y scaled by (W_l-1), (H_l-1) like :102-104; the view component is
+ * written as 0) and grad_weights [B',Q,P,L] are fully overwritten, without atomics.
+ */
+int sbev_msmv_bwd(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
+                  int64_t Bp, int N, int C, int Q, int P,
+                  int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                  const float* loc, const float* weights, const float* grad_out,
+                  float* grad_loc, float* grad_weights, sbev_stream_t stream);
+
+/*
  * Projection of 3-D sample points into all T*N cameras, camera-hit mask, first-hit view selection.
  * Replaces: the front half of sampling_4d (models/sparsebev_sampling.py:49-114) and its DUMP taps (:82-86).
  *

@@ -110,6 +110,52 @@ def msmv_sampling_kernel_semantics(feats_cl, loc, weights):
     return acc.permute(0, 1, 3, 2).contiguous()
 
 
+def msmv_sampling_backward(feats_cl, loc, weights, grad_out):
+    """Backward of A1 -- restatement of models/csrc/msmv_sampling/msmv_sampling_backward.cu:29-224.
+
+    feats_cl list of [B',N,H,W,C]; loc [B',Q,P,3]; weights [B',Q,P,L]; grad_out [B',Q,C,P].
+    Returns (grad_feats list like feats_cl, grad_loc [B',Q,P,3] with a ZERO view component -- the CUDA op never
+    writes it (:102-104) and the reference pipeline feeds a non-differentiable argmax there --, grad_weights)."""
+    Bp, N, _, _, C = feats_cl[0].shape
+    Q, P = loc.shape[1:3]
+    g = grad_out.permute(0, 1, 3, 2)                                  # [B',Q,P,C]
+    x, y = loc[..., 0], loc[..., 1]
+    z = loc[..., 2] * (N - 1)
+    view = torch.where(z >= 0, torch.floor(z + 0.5), torch.ceil(z - 0.5)).long().clamp(0, N - 1)
+    b_ix = torch.arange(Bp)[:, None, None].expand(Bp, Q, P)
+    grad_loc = torch.zeros_like(loc)
+    grad_w = torch.zeros_like(weights)
+    grad_feats = []
+    for l, f in enumerate(feats_cl):
+        H, W = f.shape[2:4]
+        h_im, w_im = y * (H - 1), x * (W - 1)
+        ok = (h_im > -1) & (w_im > -1) & (h_im < H) & (w_im < W)
+        h0f, w0f = torch.floor(h_im), torch.floor(w_im)
+        lh, lw = h_im - h0f, w_im - w0f
+        hh, hw = 1 - lh, 1 - lw
+        h0, w0 = h0f.long(), w0f.long()
+        gf = torch.zeros_like(f)
+        wl = weights[..., l]
+        vals = []
+        for dh, dw, cw in ((0, 0, hh * hw), (0, 1, hh * lw), (1, 0, lh * hw), (1, 1, lh * lw)):
+            hc, wc = h0 + dh, w0 + dw
+            inb = ok & (hc >= 0) & (hc <= H - 1) & (wc >= 0) & (wc <= W - 1)
+            hcc, wcc = hc.clamp(0, H - 1), wc.clamp(0, W - 1)
+            v = torch.where(inb[..., None], f[b_ix, view, hcc, wcc], torch.zeros(1))
+            vals.append(v)
+            contrib = torch.where(inb, cw * wl, torch.zeros_like(cw))[..., None] * g
+            gf.index_put_((b_ix, view, hcc, wcc), contrib, accumulate=True)
+        v1, v2, v3, v4 = vals
+        val = (hh * hw)[..., None] * v1 + (hh * lw)[..., None] * v2 + (lh * hw)[..., None] * v3 + (lh * lw)[..., None] * v4
+        grad_w[..., l] = (g * val).sum(-1)
+        gww = hh[..., None] * (v2 - v1) + lh[..., None] * (v4 - v3)        # d val / d w_im
+        ghw = hw[..., None] * (v3 - v1) + lw[..., None] * (v4 - v2)        # d val / d h_im
+        grad_loc[..., 0] += (W - 1) * wl * (g * gww).sum(-1)
+        grad_loc[..., 1] += (H - 1) * wl * (g * ghw).sum(-1)
+        grad_feats.append(gf)
+    return grad_feats, grad_loc, grad_w
+
+
 def regroup_features(mlvl_feats, channel_last):
     """models/sparsebev_transformer.py:73-85: [B,T*N,G*C,H,W] -> [B*T*G,N,H,W,C] or [B*T*G,C,N,H,W]."""
     out = []

@@ -64,6 +64,10 @@ SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp]),
     'sbev_linear_splitk_bf16x3': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'sbev_msmv_bwd': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _c_i32p, ctypes.c_int,
+                                     ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,
+                                     _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -79,9 +83,14 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            'sparsebev_amd: %s not found. Build it with `python -m sparsebev_amd.csrc.build` (needs hipcc, '
-            'targets gfx950). There is no CPU / PyTorch fallback for the sampling path.' % LIB_PATH)
+        # not a fallback: the only alternative to a prebuilt library is building the same HIP sources now
+        try:
+            from .csrc import build as _build
+            _build.build()
+        except Exception as e:      # noqa: BLE001
+            raise ImportError(
+                'sparsebev_amd: %s not found and building it failed (%s). Build it with `python -m sparsebev_amd.csrc.build` '
+                '(needs hipcc, targets gfx950). There is no CPU / PyTorch fallback for this path.' % (LIB_PATH, e))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale: loud on purpose

@@ -15,6 +15,8 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno
 UNITS = {
     'capi_common.hip': [],
     'msmv_sampling.hip': [],
+    # hardware float atomics (global_atomic_add_f32) for the grad_value scatter instead of a CAS loop
+    'msmv_sampling_bwd.hip': ['-munsafe-fp-atomics'],
     'gemm.hip': [],
     'gemm_bf16x3.hip': [],
     'mixing.hip': [],

@@ -1,0 +1,163 @@
+// Multi-scale multi-view bilinear sampling, BACKWARD (gfx950).  SURVEY.md section 8f rank 1.
+//
+// Replaces ms_deformable_col2im_gpu_kernel_gm_c2345 / _c23456 (models/csrc/msmv_sampling/msmv_sampling_backward.cu:
+// 108-361, helper :29-105) behind sbev_msmv_bwd.  The reference maps one thread to one (b', q, channel, point) and
+// issues, per tap, 4 atomics into grad_value PLUS 3 same-address atomics (grad_attn_weight, grad_sampling_loc x/y)
+// on which all 64 channel threads of a point collide.  Here one WAVE owns one (b', q), as in the forward:
+//   * grad_sampling_loc and grad_attn_weight are reduced across the wave's 64 lanes in registers and written
+//     with plain stores -- the wave is their only writer, so they need NO atomics at all;
+//   * only grad_value is scattered with atomics (different queries do hit the same pixels): lane = corner k x
+//     channel j, the 4 channels of a lane are j, j+16, j+32, j+48, so each global_atomic_add_f32 instruction
+//     covers four 64-byte runs (one per corner) instead of 64 scattered dwords.
+// grad wrt the view coordinate is zero by definition (the reference never writes it, :102-104).
+#include "sbev_common.hpp"
+
+namespace {
+
+struct BwdArgs {
+    const float* feat[SBEV_MAX_LEVELS];
+    float* gfeat[SBEV_MAX_LEVELS];
+    int H[SBEV_MAX_LEVELS];
+    int W[SBEV_MAX_LEVELS];
+    long long stride_bo[SBEV_MAX_LEVELS];
+    long long stride_v[SBEV_MAX_LEVELS];
+    long long stride_g, stride_px;
+    const float* loc;
+    const float* w;
+    const float* gout;     // [B',Q,C,P]
+    float* gloc;           // [B',Q,P,3]
+    float* gw;             // [B',Q,P,L]
+    long long n_waves;
+    int N, C, Q, P, gdiv;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void msmv_bwd_kernel(const BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    if (wave >= a.n_waves) return;
+    const long long bp = wave / a.Q;
+    const int k = lane >> 4, kh = k >> 1, kw = k & 1, j = lane & 15;
+    const long long bo = bp / a.gdiv, gi = bp - bo * a.gdiv;
+    const int P = a.P, C = a.C;
+    const float* __restrict__ locq = a.loc + wave * P * 3;
+    const float* __restrict__ wq = a.w + wave * P * L;
+    const float* __restrict__ gq = a.gout + wave * C * P;
+    const float nm1 = (float)(a.N - 1);
+
+    for (int p = 0; p < P; ++p) {
+        const float x = locq[p * 3 + 0], y = locq[p * 3 + 1];
+        int view = (int)roundf(locq[p * 3 + 2] * nm1);
+        view = min(max(view, 0), a.N - 1);
+        float gx = 0.f, gy = 0.f, gwl[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) gwl[l] = 0.f;
+        for (int c0 = 0; c0 < C; c0 += 64) {
+            float g[4];
+            bool cok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + j + 16 * i;
+                cok[i] = c < C;
+                g[i] = cok[i] ? gq[c * P + p] : 0.f;
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int H = a.H[l], W = a.W[l];
+                const float h_im = y * (float)(H - 1), w_im = x * (float)(W - 1);
+                const bool lvl_ok = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                if (!lvl_ok) continue;                                   // wave-uniform
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const float lh = h_im - hf, lw = w_im - wf;
+                const int hc = (int)hf + kh, wc = (int)wf + kw;
+                const bool inb = hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
+                const float ch = kh ? lh : 1.f - lh, cwid = kw ? lw : 1.f - lw;
+                const float cw = ch * cwid;
+                const float wl = wq[p * L + l];
+                const long long off = bo * a.stride_bo[l] + gi * a.stride_g + view * a.stride_v[l] +
+                                      ((long long)min(max(hc, 0), H - 1) * W + min(max(wc, 0), W - 1)) * a.stride_px;
+                const float* f = a.feat[l] + off;
+                float* gf = a.gfeat[l] + off;
+                float dot = 0.f;                                         // sum_i g_i * v_i  (this corner, this lane)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + j + 16 * i;
+                    if (inb && cok[i]) {
+                        dot += g[i] * f[c];
+                        atomicAdd(gf + c, cw * wl * g[i]);               // global_atomic_add_f32 (-munsafe-fp-atomics)
+                    }
+                }
+                gwl[l] += cw * dot;                                      // d/d weight_l = sum_c g_c * bilinear_c
+                // d bilinear / d w_im = hh (v2 - v1) + lh (v4 - v3);  d / d h_im = hw (v3 - v1) + lw (v4 - v2)
+                gx += (kw ? 1.f : -1.f) * ch * dot * wl * (float)(W - 1);
+                gy += (kh ? 1.f : -1.f) * cwid * dot * wl * (float)(H - 1);
+            }
+        }
+        gx = wave_sum(gx);
+        gy = wave_sum(gy);
+#pragma unroll
+        for (int l = 0; l < L; ++l) gwl[l] = wave_sum(gwl[l]);
+        if (lane == 0) {
+            float* o = a.gloc + (wave * P + p) * 3;
+            o[0] = gx; o[1] = gy; o[2] = 0.f;
+            float* ow = a.gw + (wave * P + p) * L;
+#pragma unroll
+            for (int l = 0; l < L; ++l) ow[l] = gwl[l];
+        }
+    }
+}
+
+template <int L>
+int launch_bwd(const BwdArgs& a, hipStream_t s) {
+    const long long blocks = (a.n_waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) {
+        sbev::set_error("sbev_msmv_bwd: B'*Q too large");
+        return SBEV_EINVAL;
+    }
+    hipLaunchKernelGGL(msmv_bwd_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return sbev::check_launch("sbev_msmv_bwd");
+}
+
+}  // namespace
+
+extern "C" int sbev_msmv_bwd(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
+                             int64_t Bp, int N, int C, int Q, int P,
+                             int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                             const float* loc, const float* weights, const float* grad_out,
+                             float* grad_loc, float* grad_weights, sbev_stream_t stream) {
+    SBEV_REQUIRE(feats && grad_feats && hw && stride_bo && stride_v, "sbev_msmv_bwd: null descriptor array");
+    SBEV_REQUIRE(L >= 1 && L <= SBEV_MAX_LEVELS, "sbev_msmv_bwd: L=%d", L);
+    SBEV_REQUIRE(P >= 1 && P <= SBEV_MAX_POINTS, "sbev_msmv_bwd: num_point exceed limits (P=%d)", P);
+    SBEV_REQUIRE(C >= 1 && N >= 1 && Q >= 0 && Bp >= 0 && gdiv >= 1, "sbev_msmv_bwd: bad sizes");
+    if (Bp == 0 || Q == 0) return SBEV_OK;
+    SBEV_REQUIRE(loc && weights && grad_out && grad_loc && grad_weights, "sbev_msmv_bwd: null pointer");
+    BwdArgs a{};
+    for (int l = 0; l < L; ++l) {
+        SBEV_REQUIRE(feats[l] && grad_feats[l], "sbev_msmv_bwd: level %d pointer is null", l);
+        a.feat[l] = static_cast<const float*>(feats[l]);
+        a.gfeat[l] = static_cast<float*>(grad_feats[l]);
+        a.H[l] = hw[2 * l];
+        a.W[l] = hw[2 * l + 1];
+        a.stride_bo[l] = stride_bo[l];
+        a.stride_v[l] = stride_v[l];
+    }
+    a.stride_g = stride_g; a.stride_px = stride_px;
+    a.loc = loc; a.w = weights; a.gout = grad_out; a.gloc = grad_loc; a.gw = grad_weights;
+    a.n_waves = Bp * Q;
+    a.N = N; a.C = C; a.Q = Q; a.P = P; a.gdiv = gdiv;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (L) {
+        case 1: return launch_bwd<1>(a, s);
+        case 2: return launch_bwd<2>(a, s);
+        case 3: return launch_bwd<3>(a, s);
+        case 4: return launch_bwd<4>(a, s);
+        default: return launch_bwd<5>(a, s);
+    }
+}

@@ -59,6 +59,55 @@ def _feat_dtype(feats):
     raise RuntimeError('feature dtype must be float32 or bfloat16, got %s' % dt)
 
 
+def _msmv_forward(feats, sampling_locations, scale_weights, out_layout, T, G):
+    Bp, N, _, _, C = feats[0].shape
+    _, Q, P, _ = sampling_locations.shape
+    hw = [(f.shape[2], f.shape[3]) for f in feats]
+    sbo = [N * h * w * C for h, w in hw]
+    sv = [h * w * C for h, w in hw]
+    if out_layout == OUT_REF:
+        out = torch.empty(Bp, Q, C, P, device=feats[0].device, dtype=torch.float32)
+    else:
+        out = torch.empty(Bp // (T * G), Q, G, T * P, C, device=feats[0].device, dtype=torch.float32)
+    _msmv_launch(feats, hw, _feat_dtype(feats), Bp, N, C, Q, P, 1, sbo, 0, sv, C,
+                 sampling_locations, scale_weights, out, out_layout, T, G)
+    return out
+
+
+class MSMVSampling(torch.autograd.Function):
+    """Autograd wrapper, the counterpart of MSMVSamplingC2345 / C23456 (models/csrc/wrapper.py:41-84): forward and
+    backward are both HIP kernels (sbev_msmv_fwd / sbev_msmv_bwd); fp32 features, reference layout."""
+
+    @staticmethod
+    def forward(ctx, sampling_locations, scale_weights, *feats):
+        ctx.save_for_backward(sampling_locations, scale_weights, *feats)
+        return _msmv_forward(list(feats), sampling_locations, scale_weights, OUT_REF, 1, 1)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        loc, weights, *feats = ctx.saved_tensors
+        if feats[0].dtype != torch.float32:
+            raise NotImplementedError('msmv_sampling backward needs fp32 features')
+        grad_output = grad_output.contiguous().float()
+        L = len(feats)
+        Bp, N, _, _, C = feats[0].shape
+        _, Q, P, _ = loc.shape
+        gfeats = [torch.zeros_like(f) for f in feats]              # the op accumulates with atomics
+        gloc = torch.empty_like(loc)
+        gw = torch.empty_like(weights)
+        hw = [(f.shape[2], f.shape[3]) for f in feats]
+        lib = _lib.load()
+        c_feats = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+        c_gfeats = (ctypes.c_void_p * L)(*[f.data_ptr() for f in gfeats])
+        c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
+        c_sbo = (ctypes.c_int64 * L)(*[N * h * w * C for h, w in hw])
+        c_sv = (ctypes.c_int64 * L)(*[h * w * C for h, w in hw])
+        st = lib.sbev_msmv_bwd(c_feats, c_gfeats, c_hw, L, Bp, N, C, Q, P, 1, c_sbo, 0, c_sv, C,
+                               _ptr(loc), _ptr(weights), _ptr(grad_output), _ptr(gloc), _ptr(gw), _stream())
+        _lib.check(st, 'sbev_msmv_bwd')
+        return (gloc, gw, *gfeats)
+
+
 def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_REF, T=1, G=1):
     """Drop-in for the reference operator ``msmv_sampling`` (models/csrc/wrapper.py:87-93).
 
@@ -66,10 +115,10 @@ def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_
     (fp32, or bf16 storage with fp32 accumulation); sampling_locations ``[B', Q, P, 3]``;
     scale_weights ``[B', Q, P, L]``.  Returns ``[B', Q, C, P]`` fp32 (or, with ``out_layout=OUT_MIX``,
     ``[B'/(T*G), Q, G, T*P, C]``).  Same preconditions as msmv_sampling.cpp:106-125 (contiguity, device,
-    P <= 32); violations raise RuntimeError."""
+    P <= 32); violations raise RuntimeError.  Differentiable (reference layout, fp32 features) like the
+    reference's autograd Functions."""
     feats = list(mlvl_feats)
     _need_device(sampling_locations, scale_weights, *feats)
-    _no_grad_only(sampling_locations, scale_weights, *feats)
     if not 1 <= len(feats) <= 5:
         raise RuntimeError('msmv_sampling supports 1..5 feature levels, got %d' % len(feats))
     for f in feats:
@@ -83,7 +132,7 @@ def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_
         raise RuntimeError('attn_weight tensor has to be contiguous')
     if sampling_locations.dtype != torch.float32 or scale_weights.dtype != torch.float32:
         raise RuntimeError('sampling_loc / attn_weight must be float32')
-    Bp, N, _, _, C = feats[0].shape
+    Bp = feats[0].shape[0]
     _, Q, P, three = sampling_locations.shape
     if three != 3 or sampling_locations.shape[0] != Bp:
         raise RuntimeError('sampling_loc must be [B, Q, P, 3]')
@@ -91,16 +140,12 @@ def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_
         raise RuntimeError('attn_weight must be [B, Q, P, %d]' % len(feats))
     if P > 32:
         raise RuntimeError('num_point exceed limits')
-    hw = [(f.shape[2], f.shape[3]) for f in feats]
-    sbo = [N * h * w * C for h, w in hw]
-    sv = [h * w * C for h, w in hw]
-    if out_layout == OUT_REF:
-        out = torch.empty(Bp, Q, C, P, device=feats[0].device, dtype=torch.float32)
-    else:
-        out = torch.empty(Bp // (T * G), Q, G, T * P, C, device=feats[0].device, dtype=torch.float32)
-    _msmv_launch(feats, hw, _feat_dtype(feats), Bp, N, C, Q, P, 1, sbo, 0, sv, C,
-                 sampling_locations, scale_weights, out, out_layout, T, G)
-    return out
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (sampling_locations, scale_weights, *feats))
+    if needs_grad:
+        if out_layout != OUT_REF:
+            raise NotImplementedError('autograd is wired for the reference output layout only')
+        return MSMVSampling.apply(sampling_locations, scale_weights, *feats)
+    return _msmv_forward(feats, sampling_locations, scale_weights, out_layout, T, G)
 
 
 def msmv_sampling_nhwc(feats_nhwc, B, T, G, sampling_locations, scale_weights, out_layout=OUT_MIX):

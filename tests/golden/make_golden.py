@@ -139,6 +139,26 @@ def main():
     save('g1_msmv_L4_C16_P7', loc=loc, weights=wts, out=out, sizes=np.array(sizes),
          **{'feat%d' % i: f for i, f in enumerate(feats_cl)})
 
+    # ---- G8: backward of msmv_sampling_pytorch by autograd (the reference's training path without the CUDA op) ----
+    for tag, pyr, C, Bp in (('L4_C8', 'tiny', 8, 3), ('L5_C64', 'tiny5', 64, 1)):
+        g = torch.Generator().manual_seed(800 + C)
+        sizes = S.PYRAMIDS[pyr][2]
+        Q, P, L = 12, 4, len(sizes)
+        feats_cl = [torch.randn(Bp, 6, h, w, C, generator=g) for h, w in sizes]
+        loc = torch.rand(Bp, Q, P, 3, generator=g) * 1.2 - 0.1          # interior + a border band on every side
+        loc[..., 2] = torch.randint(0, 6, (Bp, Q, P), generator=g).float() / 5
+        wts = torch.softmax(torch.randn(Bp, Q, P, L, generator=g), -1)
+        gout = torch.randn(Bp, Q, C, P, generator=g)
+        feats_cf = [f.clone().requires_grad_(True) for f in cf_from_cl(feats_cl)]
+        loc_g, wts_g = loc.clone().requires_grad_(True), wts.clone().requires_grad_(True)
+        with torch.enable_grad():
+            out = wrap.msmv_sampling_pytorch(feats_cf, loc_g, wts_g)
+            out.backward(gout)
+        save('g8_msmv_bwd_' + tag, loc=loc, weights=wts, grad_out=gout, sizes=np.array(sizes),
+             grad_loc_xy=loc_g.grad[..., :2], grad_weights=wts_g.grad,
+             **{'feat%d' % i: f for i, f in enumerate(feats_cl)},
+             **{'grad_feat%d' % i: f.grad.permute(0, 2, 3, 4, 1).contiguous() for i, f in enumerate(feats_cf)})
+
     # ---- G2: sampling_4d with the DUMP taps (sparsebev_sampling.py:27-130) --------------------------------
     for T, Q in ((1, 40), (8, 25)):
         g = torch.Generator().manual_seed(200 + T)

@@ -188,3 +188,35 @@ def test_int64_offsets_beyond_2g_elements():
     loc_big[-1], w_big[-1] = loc[0], w[0]
     out = ops.msmv_sampling([big], loc_big, w_big)
     assert torch.equal(out[-1], small[0])
+
+
+@pytest.mark.parametrize('tag', ['L4_C8', 'L5_C64'])
+def test_g8_msmv_backward_vs_reference_autograd(tag):
+    """grads of the HIP op vs the reference's native-PyTorch sampler differentiated by autograd."""
+    g = load_golden('g8_msmv_bwd_' + tag)
+    feats = [dev(f).requires_grad_(True) for f in feats_of(g)]
+    loc, w = dev(g['loc']).requires_grad_(True), dev(g['weights']).requires_grad_(True)
+    out = ops.msmv_sampling(feats, loc, w)
+    out.backward(dev(g['grad_out']))
+    for i, f in enumerate(feats):
+        assert (f.grad.cpu() - g['grad_feat%d' % i]).abs().max() < TOL
+    assert (w.grad.cpu() - g['grad_weights']).abs().max() < TOL
+    scale = max(1.0, g['grad_loc_xy'].abs().max().item())
+    assert (loc.grad.cpu()[..., :2] - g['grad_loc_xy']).abs().max() < TOL * scale
+    assert loc.grad[..., 2].abs().max() == 0            # like the reference op: no gradient for the view index
+
+
+def test_msmv_backward_full_size_vs_oracle_sample():
+    """Config-2-sized backward (115 200 points): spot-check against the torch oracle on one sample batch entry."""
+    from oracle import sparsebev_oracle as O
+    feats, pts, l2i, loc, wbp, _, (ih, iw, B, Q, T, G, P, L) = c2_inputs()
+    gout = torch.randn(loc.shape[0], Q, 64, P, device=DEV)
+    fl = [f.clone().requires_grad_(True) for f in feats]
+    lc, ww = loc.clone().requires_grad_(True), wbp.clone().requires_grad_(True)
+    ops.msmv_sampling(fl, lc, ww).backward(gout)
+    b = 5
+    gf, gl, gw = O.msmv_sampling_backward([f[b:b + 1].cpu() for f in feats], loc[b:b + 1].cpu(), wbp[b:b + 1].cpu(), gout[b:b + 1].cpu())
+    assert (ww.grad[b:b + 1].cpu() - gw).abs().max() < 5e-4
+    assert (lc.grad[b:b + 1].cpu() - gl).abs().max() < 5e-4 * max(1.0, gl.abs().max().item())
+    for a, r in zip(fl, gf):
+        assert (a.grad[b:b + 1].cpu() - r).abs().max() < 5e-4

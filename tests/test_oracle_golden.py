@@ -160,3 +160,16 @@ def test_c_oracle_projection_bit_exact(T):
     assert np.array_equal(valid, g['valid'].numpy())
     assert np.array_equal(uvh.view(np.uint32), g['uvh'].numpy().view(np.uint32))
     assert np.array_equal(iview, np.argmax(g['valid'].numpy(), axis=2))
+
+
+@pytest.mark.parametrize('tag', ['L4_C8', 'L5_C64'])
+def test_g8_sampler_backward_restatement(tag):
+    g = load_golden('g8_msmv_bwd_' + tag)
+    feats = feats_of(g)
+    gf, gl, gw = O.msmv_sampling_backward(feats, g['loc'], g['weights'], g['grad_out'])
+    for i, f in enumerate(gf):
+        assert (f - g['grad_feat%d' % i]).abs().max() < TOL
+    assert (gw - g['grad_weights']).abs().max() < TOL
+    scale = max(1.0, g['grad_loc_xy'].abs().max().item())
+    assert (gl[..., :2] - g['grad_loc_xy']).abs().max() < TOL * scale
+    assert gl[..., 2].abs().max() == 0

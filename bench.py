@@ -118,6 +118,7 @@ def main():
     ap.add_argument('--nhwc', action='store_true', help='features already channels-last in HBM (zero-copy input)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
+    ap.add_argument('--overlap', action='store_true', help='two-stream fork/join of independent sub-chains in the runtime (default off: +1 %)')
     ap.add_argument('--gemm', default='f32', choices=['f32', 'bf16x3'],
                     help='f32 = exact f32-input MFMA (default); bf16x3 = opt-in 3 x bf16 split of the two big mixing GEMMs')
     args = ap.parse_args()
@@ -130,6 +131,7 @@ def main():
 
     model = build_model(T, L, device)
     model.decoder.gemm_mode = 1 if args.gemm == 'bf16x3' else 0
+    model.decoder.overlap = args.overlap
     shard = SampleShard(rank, world)
     # per-rank synthetic inputs (seed = rank), generated on the device and left resident
     feats = S.make_features(B, T, sizes, seed=rank, device=device, dtype=fdtype)

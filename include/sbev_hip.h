@@ -260,6 +260,9 @@ typedef struct sbev_decoder_config {
     int32_t hw[SBEV_MAX_LEVELS][2];     /* (H_l, W_l) */
     float image_h, image_w, eps_homo;   /* img_shape and the 1e-5 of sampling_4d */
     int32_t gemm_mode;                  /* enum sbev_gemm_mode for the two large mixing GEMMs (0 = exact fp32) */
+    int32_t overlap;                    /* != 0: run the parameter-generator GEMM and the classification branch on an
+                                           internal second stream (created once per process) beside the sampling chain /
+                                           regression branch, joined back into `stream` with events */
     double pc_range[6];
 } sbev_decoder_config;
 

@@ -77,6 +77,31 @@ int validate(const sbev_decoder_config* c) {
     return SBEV_OK;
 }
 
+// Second stream + events for the two independent sub-chains of a layer (created once per process, lazily):
+//   * the parameter-generator GEMM (MFMA-bound) only needs x1, so it runs beside the sampling chain
+//     (Linear -> sample points -> projection -> gather: memory/latency-bound);
+//   * the classification branch only feeds the output, so it runs beside the regression branch / next layer.
+struct Aux {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    bool ok = false;
+};
+Aux& aux() {
+    static Aux a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        bool ok = hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess;
+        for (auto& e : a.ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        a.ok = ok;
+    });
+    return a;
+}
+inline int hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return SBEV_OK;
+    sbev::set_error("%s: %s", what, hipGetErrorString(e));
+    return SBEV_ELAUNCH;
+}
+
 #define TRY(expr)                 \
     do {                          \
         int st__ = (expr);        \
@@ -122,6 +147,14 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         sbo[l] = sv[l] * c.N;
     }
 
+    hipStream_t s_main = reinterpret_cast<hipStream_t>(stream);
+    Aux& ax = aux();
+    const bool fork = c.overlap != 0 && ax.ok;
+    sbev_stream_t s_aux = fork ? reinterpret_cast<sbev_stream_t>(ax.stream) : stream;
+    int evi = 0;
+    auto next_ev = [&]() { return ax.ev[(evi++) & 7]; };
+    hipEvent_t ev_cls = nullptr;
+
     const float* bbox = query_bbox;
     const float* feat = query_feat;
     for (int layer = 0; layer < c.num_layers; ++layer) {
@@ -137,6 +170,21 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, b.centers, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
         TRY(sbev_linear_f32(b.att, w->attn_out_w, w->attn_out_b, b.x, b.t1, BQ, D, D, D, D, D, 0, stream));
         TRY(sbev_layer_norm_f32(b.t1, w->norm1_g, w->norm1_b, eps, nullptr, b.x1, BQ, D, 0, stream));
+        // fork: parameter generator (needs only x1) on the aux stream, beside the sampling chain
+        hipEvent_t ev_pg = nullptr;
+        if (fork) {
+            hipEvent_t e = next_ev();
+            TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
+            TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
+        }
+        if (c.gemm_mode == SBEV_GEMM_BF16X3)
+            TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, s_aux));
+        else
+            TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, s_aux));
+        if (fork) {
+            ev_pg = next_ev();
+            TRY(hip_ok(hipEventRecord(ev_pg, ax.stream), "hipEventRecord"));
+        }
         // adaptive spatio-temporal sampling                                     (:170)
         TRY(sbev_linear_f32(b.x1, w->samp_w, w->samp_b, nullptr, b.so, BQ, soN, D, D, D, soN, 0, stream));
         TRY(sbev_sampling_front(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, c.pc_range,
@@ -145,11 +193,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                                 b.loc, nullptr, nullptr, nullptr, stream));
         TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
                           c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
-        // adaptive mixing + norm2                                               (:171)
-        if (c.gemm_mode == SBEV_GEMM_BF16X3)
-            TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, stream));
-        else
-            TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
+        // adaptive mixing + norm2 (join: the generator's output is needed now)  (:171)
+        if (fork) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_pg, 0), "hipStreamWaitEvent"));
         TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
         if (c.gemm_mode == SBEV_GEMM_BF16X3)
             TRY(sbev_linear_splitk_bf16x3(b.mixed, w->op_w2, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
@@ -157,16 +202,27 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         else
             TRY(sbev_linear_splitk_f32(b.mixed, w->op_w, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN, mixN,
                                        0, splits, b.slabs, stream));
+        // (the previous layer's classification branch still reads x3 on the aux stream: join before x3 is rewritten)
+        if (fork && ev_cls) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_cls, 0), "hipStreamWaitEvent"));
         // FFN + norm3                                                           (:172)
         TRY(sbev_linear_f32(b.x2, w->ffn0_w, w->ffn0_b, nullptr, b.h, BQ, c.ffn, D, D, D, c.ffn, 1, stream));
         TRY(sbev_linear_f32(b.h, w->ffn1_w, w->ffn1_b, b.x2, b.t1, BQ, D, c.ffn, c.ffn, c.ffn, D, 0, stream));
         TRY(sbev_layer_norm_f32(b.t1, w->norm3_g, w->norm3_b, eps, nullptr, b.x3, BQ, D, 0, stream));
-        // classification / regression branches, box refinement                  (:174-183)
-        TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, stream));
-        TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, stream));
-        TRY(sbev_linear_f32(b.c1, w->cls3_w, w->cls3_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, stream));
-        TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, stream));
-        TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, stream));
+        // classification branch (output only) on the aux stream; regression branch + box refinement on the main one (:174-183)
+        if (fork) {
+            hipEvent_t e = next_ev();
+            TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
+            TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
+        }
+        TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
+        TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
+        TRY(sbev_linear_f32(b.c1, w->cls3_w, w->cls3_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
+        TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
+        TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, s_aux));
+        if (fork) {
+            ev_cls = next_ev();
+            TRY(hip_ok(hipEventRecord(ev_cls, ax.stream), "hipEventRecord"));
+        }
         TRY(sbev_linear_f32(b.x3, w->reg0_w, w->reg0_b, nullptr, b.r0, BQ, D, D, D, D, D, 1, stream));
         TRY(sbev_linear_f32(b.r0, w->reg2_w, w->reg2_b, nullptr, b.r1, BQ, D, D, D, D, D, 1, stream));
         TRY(sbev_linear_f32(b.r1, w->reg4_w, w->reg4_b, nullptr, b.reg, BQ, c.code_size, D, D, D, c.code_size, 0, stream));
@@ -176,6 +232,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // x3 is read by the next layer only as `feat` in its third launch and rewritten only by its norm3: no copy
         feat = b.x3;
     }
+    if (fork && ev_cls) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_cls, 0), "hipStreamWaitEvent"));   // final join
     return SBEV_OK;
 }
 

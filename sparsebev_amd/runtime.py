@@ -15,7 +15,8 @@ class DecoderConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('B', 'Q', 'T', 'N', 'G', 'P', 'L', 'D', 'H', 'ffn', 'num_classes',
                                               'code_size', 'num_layers', 'out_points', 'attn_in_rows', 'feat_dtype')] + \
                [('hw', (ctypes.c_int32 * 2) * MAX_LEVELS), ('image_h', ctypes.c_float), ('image_w', ctypes.c_float),
-                ('eps_homo', ctypes.c_float), ('gemm_mode', ctypes.c_int32), ('pc_range', ctypes.c_double * 6)]
+                ('eps_homo', ctypes.c_float), ('gemm_mode', ctypes.c_int32), ('overlap', ctypes.c_int32),
+                ('pc_range', ctypes.c_double * 6)]
 
 
 _WEIGHT_FIELDS = ['pe0_w', 'pe0_b', 'pe1_g', 'pe1_b', 'pe3_w', 'pe3_b', 'pe4_g', 'pe4_b',
@@ -38,9 +39,10 @@ class DecoderRuntime:
     """Binds a SparseBEVTransformerDecoder's parameters (by pointer) to the C++ runtime and owns the workspace.
     Re-binds automatically when a parameter is replaced or modified in place (``_version`` / ``data_ptr`` change)."""
 
-    def __init__(self, decoder, gemm_mode=0):
+    def __init__(self, decoder, gemm_mode=0, overlap=False):
         self.decoder = decoder
         self.gemm_mode = gemm_mode
+        self.overlap = overlap
         self._sig = None
         self._keep = None          # tensors whose storage the weight struct points into
         self._weights = None
@@ -116,6 +118,7 @@ class DecoderRuntime:
         cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
         cfg.feat_dtype = 1 if pyramid.levels[0].dtype == torch.bfloat16 else 0
         cfg.gemm_mode = self.gemm_mode
+        cfg.overlap = 1 if self.overlap else 0
         if len(pyramid.levels) != cfg.L or pyramid.T != cfg.T or pyramid.B != B:
             raise RuntimeError('feature pyramid (L=%d, T=%d, B=%d) does not match the decoder config (L=%d, T=%d, B=%d)'
                                % (len(pyramid.levels), pyramid.T, pyramid.B, cfg.L, cfg.T, B))

@@ -270,6 +270,8 @@ class SparseBEVTransformerDecoder(_Base):
         super().__init__(init_cfg)
         self.num_layers, self.pc_range = num_layers, list(pc_range)
         self._runtime = None
+        self.overlap = False        # opt-in two-stream fork/join in the C++ runtime (generator GEMM || sampling chain): measured
+                                    # +1 % samples/s at c2 -- the kernels time-share the CUs -- and it doubles the sampler's wall time
         self.gemm_mode = 0          # 0 = exact fp32 MFMA (default); 1 = opt-in 3 x bf16 split for the two big mixing GEMMs
         self.decoder_layer = SparseBEVTransformerDecoderLayer(embed_dims, num_frames, num_points, num_levels,
                                                               num_classes, code_size, pc_range=pc_range)
@@ -287,9 +289,9 @@ class SparseBEVTransformerDecoder(_Base):
         query_bbox = query_bbox.float().contiguous()
         query_feat = query_feat.float().contiguous()
         if not (layerwise or DUMP.enabled):
-            if self._runtime is None or self._runtime.gemm_mode != self.gemm_mode:
+            if self._runtime is None or self._runtime.gemm_mode != self.gemm_mode or self._runtime.overlap != self.overlap:
                 from .runtime import DecoderRuntime
-                self._runtime = DecoderRuntime(self, self.gemm_mode)
+                self._runtime = DecoderRuntime(self, self.gemm_mode, self.overlap)
             return self._runtime.forward(query_bbox, query_feat, feats, ctx, attn_mask)
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):

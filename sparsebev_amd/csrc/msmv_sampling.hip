@@ -9,7 +9,9 @@
 //   lane = corner k (0..3) * 16 + channel quad j (0..15)
 //   one wave-wide 16-byte load = the 4 bilinear corners x 64 fp32 channels of ONE (point, level) tap
 //       = 4 x 256 B contiguous segments, i.e. every HBM/L2 request is a full 128-B line pair;
-//   the 4*L taps of a 4-point chunk are independent -> up to 20 KiB in flight per wave;
+//   the chunk's coordinates and level weights arrive in ONE coalesced load and are broadcast with v_readlane
+//   (scalar registers), so the 4*L taps of a 4-point chunk are independent back-to-back loads -> up to 20 KiB in
+//   flight per wave;
 //   each lane folds bilinear-corner weight x level weight into one coefficient and FMAs its float4;
 //   the 4 corner partials are combined once per 4-point chunk with a reduce-scatter built from
 //   v_permlane16_swap / v_permlane32_swap (no LDS, no ds_bpermute), which leaves each 16-lane row
@@ -58,6 +60,11 @@ __device__ __forceinline__ float corner_reduce_scatter(float i0, float i1, float
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// v_readlane_b32 of a float (the builtin is typed int: pass the bits, not the value)
+__device__ __forceinline__ float bcast(float v, int src_lane) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src_lane));
+}
+
 template <int L, typename FT, int OUT>
 __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
     const int lane = threadIdx.x & 63;
@@ -83,20 +90,32 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
             base[l] = reinterpret_cast<const FT*>(a.feat[l]) + bo * a.stride_bo[l] + gi * a.stride_g + cj;
 
         for (int p0 = 0; p0 < P; p0 += 4) {
-            float4 acc[4];
+            // ONE coalesced request for this chunk's 12 coordinates (lanes 0..11) and 4*L level weights (lanes
+            // 16..16+4L), then v_readlane broadcasts into scalar registers.  Nothing else is loaded between here and
+            // the feature taps, so the compiler can issue all 4*L tap loads back to back.  (Loading a weight inside
+            // the tap made hipcc guard it with the in-bounds branch and wait vmcnt(0) -- draining every earlier tap.)
+            const int npts = min(4, P - p0);
+            float lv = 0.f;
+            if (lane < npts * 3) lv = locq[p0 * 3 + lane];
+            if (lane >= 16 && lane < 16 + npts * L) lv = wq[p0 * L + (lane - 16)];
+            // phase 1: geometry of all 4*L taps (32-bit element offsets inside this sample-batch slab, coefficient,
+            // in-bounds bit); phase 2: issue ALL tap loads; phase 3: consume.  Written as three unrolled passes so the
+            // scheduler keeps 4*L x 16 B per lane in flight instead of interleaving a few loads with their waits.
+            int toff[4][L];
+            float tcoef[4][L];
+            unsigned inb_bits = 0;
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool p_ok = (p0 + pp) < P;           // wave-uniform
-                const int p = p_ok ? p0 + pp : P - 1;
-                const float x = locq[p * 3 + 0];
-                const float y = locq[p * 3 + 1];
-                const float z = locq[p * 3 + 2] * nm1;
+                const bool p_ok = pp < npts;               // wave-uniform
+                const float x = bcast(lv, pp * 3 + 0);
+                const float y = bcast(lv, pp * 3 + 1);
+                const float z = bcast(lv, pp * 3 + 2) * nm1;
                 int view = (int)roundf(z);                  // reference: round(loc.z * (num_views - 1))
                 view = min(max(view, 0), a.N - 1);          // (the reference reads out of bounds here; we clamp)
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
                     const int H = a.H[l], W = a.W[l];
+                    const float wl = bcast(lv, 16 + pp * L + l);
                     const float h_im = y * (float)(H - 1);  // align_corners = True
                     const float w_im = x * (float)(W - 1);
                     const bool lvl_ok = p_ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
@@ -108,11 +127,28 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
                     const int hc = h0 + kh, wc = w0 + kw;
                     const bool inb = lvl_ok && chan_ok && hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
                     const float cw = (kh ? lh : 1.f - lh) * (kw ? lw : 1.f - lw);
-                    const float coef = inb ? cw * wq[p * L + l] : 0.f;
+                    tcoef[pp][l] = inb ? cw * wl : 0.f;
+                    inb_bits |= (inb ? 1u : 0u) << (pp * L + l);
                     const int hcc = min(max(hc, 0), H - 1), wcc = min(max(wc, 0), W - 1);
-                    const long long off = view * a.stride_v[l] + ((long long)hcc * W + wcc) * a.stride_px;
-                    float4 v = load4(base[l] + off);        // always a valid address; masked by coef/inb below
-                    if (!inb) v = make_float4(0.f, 0.f, 0.f, 0.f);   // corner outside the map contributes exactly 0
+                    toff[pp][l] = (int)(view * a.stride_v[l] + ((long long)hcc * W + wcc) * a.stride_px);   // < 2^31: one slab
+                }
+            }
+            float4 tv[4][L];
+            __builtin_amdgcn_sched_barrier(0);     // pin the phases: hipcc otherwise re-interleaves loads, waits and math
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int l = 0; l < L; ++l) tv[pp][l] = load4(base[l] + toff[pp][l]);   // always a valid address
+            __builtin_amdgcn_sched_barrier(0);
+            float4 acc[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    float4 v = tv[pp][l];
+                    if (!((inb_bits >> (pp * L + l)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // outside the map: exactly 0
+                    const float coef = tcoef[pp][l];
                     acc[pp].x = fmaf(coef, v.x, acc[pp].x);
                     acc[pp].y = fmaf(coef, v.y, acc[pp].y);
                     acc[pp].z = fmaf(coef, v.z, acc[pp].z);

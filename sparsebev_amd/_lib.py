@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsbev_hip.so')
+LIB_PATH = os.environ.get('SBEV_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsbev_hip.so')   # override: A/B builds
 
 _c_i64p = ctypes.POINTER(ctypes.c_int64)
 _c_i32p = ctypes.POINTER(ctypes.c_int32)

@@ -2,7 +2,7 @@
 """bench.py -- decoder hot-path throughput on MI355X (BASELINE.json metric: samples/sec, 6-cam T=8 900q
 r50 704x256; plus the sampling kernel's HBM roofline fraction and a CPU native-PyTorch baseline).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -112,13 +112,14 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--nhwc', action='store_true', help='features already channels-last in HBM (zero-copy input)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--online', action='store_true', help='streaming mode: per step only ONE new frame (6 images) is relayouted into the per-frame feature ring (cache.FrameFeatureCache); the other T-1 frames stay resident')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
-    ap.add_argument('--overlap', action='store_true', help='two-stream fork/join of independent sub-chains in the runtime (default off: +1 %)')
+    ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
     ap.add_argument('--gemm', default='f32', choices=['f32', 'bf16x3'],
                     help='f32 = exact f32-input MFMA (default); bf16x3 = opt-in 3 x bf16 split of the two big mixing GEMMs')
     args = ap.parse_args()
@@ -141,8 +142,21 @@ def main():
     bbox, qfeat = bbox.to(device), qfeat.to(device)
     metas = S.make_img_metas(B, T, ih, iw)
 
-    def step():
-        return model(bbox, qfeat, list(feats), None, copy.deepcopy(metas))
+    if args.online:
+        from sparsebev_amd.cache import FrameFeatureCache
+        ring = FrameFeatureCache(T, n_slots=T)
+        per_frame = [[f[:, t * 6:(t + 1) * 6].contiguous() for f in feats] for t in range(T)]
+        for fr in reversed(per_frame):
+            ring.push(fr)
+        tick = [0]
+
+        def step():
+            ring.push(per_frame[tick[0] % T])         # the new frame's 6 images (NCHW, as the neck emits them)
+            tick[0] += 1
+            return model(bbox, qfeat, ring.pyramid(), None, copy.deepcopy(metas))
+    else:
+        def step():
+            return model(bbox, qfeat, list(feats), None, copy.deepcopy(metas))
 
     for _ in range(args.warmup):
         step()
@@ -196,7 +210,7 @@ def main():
             'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + (' (mixing GEMMs: 3xbf16 split, f32 accumulate)' if args.gemm == 'bf16x3' else ''),
             'data': 'synthetic',
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
-                                   '%s feature input' % (args.config, pyr, Q, T, B, 'NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)'),
+                                   '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
                        'checksum': checksum_sum},
             'roofline': {'kernel': 'msmv_fwd_kernel (adaptive sampling gather)', 'bound': 'hbm',

@@ -26,6 +26,7 @@ extern "C" {
 #define SBEV_ABI_VERSION 1
 #define SBEV_MAX_LEVELS 5   /* c2345 and c23456 variants: models/csrc/msmv_sampling/msmv_sampling.cpp:362-369 */
 #define SBEV_MAX_POINTS 32  /* MAX_POINT: models/csrc/msmv_sampling/msmv_sampling.cpp:3,125 */
+#define SBEV_MAX_FRAMES 16  /* frames per sample in the online feature ring (the reference evicts its cache at 16: models/sparsebev.py:286-292) */
 
 typedef void* sbev_stream_t; /* hipStream_t */
 
@@ -78,6 +79,22 @@ int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_d
                   int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
                   const float* loc, const float* weights, float* out,
                   int out_layout, int T, int G, sbev_stream_t stream);
+
+/*
+ * sbev_msmv_fwd over an ONLINE FRAME RING (streaming inference).
+ * Replaces: the per-call `torch.cat` of cached per-frame features (models/sparsebev.py:297-303) plus the decoder's
+ *           regroup copy (models/sparsebev_transformer.py:73-85): features of every frame stay where they were
+ *           written -- level l is ONE resident NHWC buffer [B, n_slots, N, H_l, W_l, G*C] -- and logical frame t
+ *           (0 = current, T-1 = oldest) of sample batch b' = (b*T + t)*G + g is read from slot frame_slots[t].
+ *           Per step only the newest frame's 6 images are relayouted into the slot of the evicted frame.
+ * Same arguments as sbev_msmv_fwd except: stride_slot[l] = elements between consecutive slots (N*H_l*W_l*G*C);
+ * gdiv must equal G; frame_slots = host int32 [T], values in [0, n_slots); 1 <= T <= SBEV_MAX_FRAMES.
+ */
+int sbev_msmv_fwd_ring(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                       int64_t Bp, int N, int C, int Q, int P,
+                       int gdiv, const int64_t* stride_slot, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                       const float* loc, const float* weights, float* out,
+                       int out_layout, int T, int G, const int32_t* frame_slots, int n_slots, sbev_stream_t stream);
 
 /*
  * Multi-scale multi-view bilinear sampling, backward (fp32 features).
@@ -260,6 +277,8 @@ typedef struct sbev_decoder_config {
     int32_t hw[SBEV_MAX_LEVELS][2];     /* (H_l, W_l) */
     float image_h, image_w, eps_homo;   /* img_shape and the 1e-5 of sampling_4d */
     int32_t gemm_mode;                  /* enum sbev_gemm_mode for the two large mixing GEMMs (0 = exact fp32) */
+    int32_t n_slots;                    /* 0: feats_nhwc[l] = [B*T*N, H, W, D] (dense); > 0: online frame ring [B, n_slots, N, H, W, D] */
+    int32_t frame_slots[SBEV_MAX_FRAMES]; /* ring only: physical slot of logical frame t (see sbev_msmv_fwd_ring) */
     int32_t overlap;                    /* != 0: run the parameter-generator GEMM and the classification branch on an
                                            internal second stream (created once per process) beside the sampling chain /
                                            regression branch, joined back into `stream` with events */

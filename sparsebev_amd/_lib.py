@@ -68,6 +68,10 @@ SIGNATURES = {
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sbev_msmv_fwd_ring': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,
+                                          _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int, _vp]),
 }
 
 _lib = None

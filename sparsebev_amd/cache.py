@@ -1,0 +1,71 @@
+"""Online (streaming) per-frame feature ring -- SURVEY.md section 8f rank 2.
+
+The reference's published FPS is measured in online mode: features of past frames are cached per frame and only
+the 6 new images go through the backbone (models/sparsebev.py:255-321) -- but every step it still ``torch.cat``s
+all T cached frames (:297-303) and the decoder then regroup-copies them again (models/sparsebev_transformer.py:
+73-85).  Here each level is ONE resident channels-last buffer ``[B, n_slots, 6, H, W, C]``; a new frame is
+relayouted (NCHW -> NHWC, one launch per level) straight into the slot of the evicted frame and the sampler reads
+logical frame t through a slot table (``sbev_msmv_fwd_ring``), so nothing older than the newest frame is ever moved.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+N_VIEWS = 6
+
+
+class FrameFeatureCache:
+    def __init__(self, num_frames, n_slots=None):
+        self.T = num_frames
+        self.n_slots = n_slots or num_frames
+        if not self.T <= self.n_slots <= 16:
+            raise ValueError('need num_frames <= n_slots <= 16 (the reference evicts its cache at 16 frames)')
+        self.buffers = None            # list[L] of [B, n_slots, 6, H, W, C]
+        self.order = []                # physical slots, newest first
+        self.B = None
+
+    def _alloc(self, frame_feats):
+        f0 = frame_feats[0]
+        self.B = f0.shape[0]
+        self.buffers = [torch.empty(self.B, self.n_slots, N_VIEWS, f.shape[3], f.shape[4], f.shape[2], device=f.device, dtype=torch.float32)
+                        for f in frame_feats]
+
+    def push(self, frame_feats):
+        """frame_feats: list[L] of [B, 6, C, H_l, W_l] fp32 device tensors = the neck's output for the 6 NEW images."""
+        if self.buffers is None:
+            self._alloc(frame_feats)
+        slot = len(self.order) if len(self.order) < self.n_slots else self.order.pop()      # free slot, else evict the oldest
+        lib = _lib.load()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for f, buf in zip(frame_feats, self.buffers):
+            if not f.is_cuda or f.dtype != torch.float32 or f.shape[0] != self.B or f.shape[1] != N_VIEWS:
+                raise RuntimeError('frame features must be fp32 device tensors [B, 6, C, H, W]')
+            f = f.contiguous()
+            C, H, W = f.shape[2:]
+            for b in range(self.B):
+                st = lib.sbev_nchw_to_nhwc_f32(ctypes.c_void_p(f[b].data_ptr()), ctypes.c_void_p(buf[b, slot].data_ptr()),
+                                               N_VIEWS, C, H * W, stream)
+                _lib.check(st, 'sbev_nchw_to_nhwc_f32')
+        self.order.insert(0, slot)
+        del self.order[self.n_slots:]
+
+    def pyramid(self):
+        """View of the newest T frames for the decoder (drop-in for transformer.FeaturePyramid)."""
+        if len(self.order) < self.T:
+            raise RuntimeError('only %d of %d frames cached' % (len(self.order), self.T))
+        return RingPyramid(self)
+
+
+class RingPyramid:
+    def __init__(self, cache):
+        self.B, self.T = cache.B, cache.T
+        self.n_slots = cache.n_slots
+        self.frame_slots = list(cache.order[:cache.T])
+        self.levels = [b.reshape(cache.B * cache.n_slots * N_VIEWS, b.shape[3], b.shape[4], b.shape[5]) for b in cache.buffers]
+        self.GC = cache.buffers[0].shape[-1]
+        self.copied = 0
+
+    def sample(self, loc, w_bp, T, G):
+        return ops.msmv_sampling_ring(self.levels, self.B, T, G, self.frame_slots, self.n_slots, loc, w_bp)

@@ -149,7 +149,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
 
     hipStream_t s_main = reinterpret_cast<hipStream_t>(stream);
     Aux& ax = aux();
-    const bool fork = c.overlap != 0 && ax.ok;
+    const bool fork = c.overlap != 0 && ax.ok;        // classification branch on the aux stream
+    const bool fork_pg = c.overlap == 1 && ax.ok;     // + parameter-generator GEMM beside the sampling chain
     sbev_stream_t s_aux = fork ? reinterpret_cast<sbev_stream_t>(ax.stream) : stream;
     int evi = 0;
     auto next_ev = [&]() { return ax.ev[(evi++) & 7]; };
@@ -172,16 +173,16 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         TRY(sbev_layer_norm_f32(b.t1, w->norm1_g, w->norm1_b, eps, nullptr, b.x1, BQ, D, 0, stream));
         // fork: parameter generator (needs only x1) on the aux stream, beside the sampling chain
         hipEvent_t ev_pg = nullptr;
-        if (fork) {
+        if (fork_pg) {
             hipEvent_t e = next_ev();
             TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
             TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
         }
         if (c.gemm_mode == SBEV_GEMM_BF16X3)
-            TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, s_aux));
+            TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, fork_pg ? s_aux : stream));
         else
-            TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, s_aux));
-        if (fork) {
+            TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, fork_pg ? s_aux : stream));
+        if (fork_pg) {
             ev_pg = next_ev();
             TRY(hip_ok(hipEventRecord(ev_pg, ax.stream), "hipEventRecord"));
         }
@@ -191,10 +192,14 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                                 c.B, c.Q, c.T, c.G, c.P, c.L, b.pts, b.wbp, stream));
         TRY(sbev_project_select(b.pts, lidar2img, c.B, c.Q, c.T, c.N, c.G, c.P, c.image_h, c.image_w, c.eps_homo,
                                 b.loc, nullptr, nullptr, nullptr, stream));
-        TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
-                          c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
+        if (c.n_slots > 0)
+            TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                                   c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, c.frame_slots, c.n_slots, stream));
+        else
+            TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                              c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
         // adaptive mixing + norm2 (join: the generator's output is needed now)  (:171)
-        if (fork) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_pg, 0), "hipStreamWaitEvent"));
+        if (fork_pg) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_pg, 0), "hipStreamWaitEvent"));
         TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
         if (c.gemm_mode == SBEV_GEMM_BF16X3)
             TRY(sbev_linear_splitk_bf16x3(b.mixed, w->op_w2, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,

@@ -36,6 +36,9 @@ struct MsmvArgs {
     float* out;
     long long n_waves;  // B' * Q
     int N, C, Q, P, gdiv, T, G;
+    // online frame ring (sbev_msmv_fwd_ring): logical frame t of a sample lives in physical slot slots[t] of n_slots
+    int ring_T, n_slots;
+    int slots[SBEV_MAX_FRAMES];
 };
 
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -75,7 +78,12 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
     const int q = (int)(wave - bp * a.Q);
     const int k = lane >> 4, kh = k >> 1, kw = k & 1;
     const int j4 = (lane & 15) * 4;
-    const long long bo = bp / a.gdiv, gi = bp - bo * a.gdiv;
+    long long bo = bp / a.gdiv;
+    const long long gi = bp - bo * a.gdiv;
+    if (a.ring_T) {                                          // (b, t) -> (b, slot[t]) in the per-frame feature ring
+        const long long b = bo / a.ring_T;
+        bo = b * a.n_slots + a.slots[(int)(bo - b * a.ring_T)];
+    }
     const int P = a.P, C = a.C;
     const float* __restrict__ locq = a.loc + wave * P * 3;
     const float* __restrict__ wq = a.w + wave * P * L;
@@ -223,11 +231,11 @@ int launch_t(const MsmvArgs& a, int L, int out_layout, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
-                             int64_t Bp, int N, int C, int Q, int P,
-                             int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v,
-                             int64_t stride_px, const float* loc, const float* weights, float* out,
-                             int out_layout, int T, int G, sbev_stream_t stream) {
+static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                         int64_t Bp, int N, int C, int Q, int P,
+                         int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v,
+                         int64_t stride_px, const float* loc, const float* weights, float* out,
+                         int out_layout, int T, int G, const int32_t* frame_slots, int n_slots, sbev_stream_t stream) {
     SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_msmv_fwd: null descriptor array");
     SBEV_REQUIRE(L >= 1 && L <= SBEV_MAX_LEVELS, "sbev_msmv_fwd: L=%d not in 1..%d", L, SBEV_MAX_LEVELS);
     SBEV_REQUIRE(P >= 1 && P <= SBEV_MAX_POINTS, "sbev_msmv_fwd: num_point exceed limits (P=%d > %d)", P, SBEV_MAX_POINTS);
@@ -258,7 +266,37 @@ extern "C" int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L,
     a.out = out;
     a.n_waves = Bp * Q;
     a.N = N; a.C = C; a.Q = Q; a.P = P; a.gdiv = gdiv; a.T = T; a.G = G;
+    if (frame_slots) {
+        SBEV_REQUIRE(T >= 1 && T <= SBEV_MAX_FRAMES && n_slots >= T && gdiv == G && Bp % ((int64_t)T * G) == 0,
+                     "sbev_msmv_fwd_ring: need 1 <= T <= %d, n_slots >= T, gdiv == G, B' = B*T*G", SBEV_MAX_FRAMES);
+        a.ring_T = T;
+        a.n_slots = n_slots;
+        for (int t = 0; t < T; ++t) {
+            SBEV_REQUIRE(frame_slots[t] >= 0 && frame_slots[t] < n_slots, "sbev_msmv_fwd_ring: frame_slots[%d] = %d out of range", t, frame_slots[t]);
+            a.slots[t] = frame_slots[t];
+        }
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return feat_dtype == SBEV_F32 ? launch_t<float>(a, L, out_layout, s)
                                   : launch_t<unsigned short>(a, L, out_layout, s);
+}
+
+extern "C" int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                             int64_t Bp, int N, int C, int Q, int P,
+                             int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v,
+                             int64_t stride_px, const float* loc, const float* weights, float* out,
+                             int out_layout, int T, int G, sbev_stream_t stream) {
+    return msmv_fwd_impl(feats, hw, L, feat_dtype, Bp, N, C, Q, P, gdiv, stride_bo, stride_g, stride_v, stride_px, loc, weights,
+                         out, out_layout, T, G, nullptr, 0, stream);
+}
+
+extern "C" int sbev_msmv_fwd_ring(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                  int64_t Bp, int N, int C, int Q, int P,
+                                  int gdiv, const int64_t* stride_slot, int64_t stride_g, const int64_t* stride_v,
+                                  int64_t stride_px, const float* loc, const float* weights, float* out,
+                                  int out_layout, int T, int G, const int32_t* frame_slots, int n_slots,
+                                  sbev_stream_t stream) {
+    SBEV_REQUIRE(frame_slots != nullptr, "sbev_msmv_fwd_ring: frame_slots is null");
+    return msmv_fwd_impl(feats, hw, L, feat_dtype, Bp, N, C, Q, P, gdiv, stride_slot, stride_g, stride_v, stride_px, loc, weights,
+                         out, out_layout, T, G, frame_slots, n_slots, stream);
 }

@@ -1,20 +1,16 @@
 """Dense half of the decoder layer (linears, LayerNorms, scale-adaptive self attention, adaptive mixing,
 box refinement, NCHW->NHWC relayout) on the device.
 
-``NATIVE`` records which of these are hand-written gfx950 kernels in libsbev_hip.so and which still run as
-stock PyTorch-ROCm device ops (rocBLAS / ATen).  Every function here requires device tensors -- there is
-no CPU path in the product.
+Every op here is a hand-written gfx950 kernel in libsbev_hip.so (``NATIVE`` names the kernel behind each);
+nothing runs through rocBLAS / ATen, and every function requires device tensors -- there is no CPU path.
 """
-import math
-
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
-# op -> implementation currently used on the device
+# op -> kernel(s) it launches
 NATIVE = {
     'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
     'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',

@@ -177,6 +177,39 @@ def msmv_sampling_nhwc(feats_nhwc, B, T, G, sampling_locations, scale_weights, o
     return out
 
 
+def msmv_sampling_ring(levels, B, T, G, frame_slots, n_slots, sampling_locations, scale_weights, out_layout=OUT_MIX):
+    """Sampler over the online frame ring (cache.FrameFeatureCache): levels[l] = [B*n_slots*6, H, W, G*C]; logical frame
+    t of a sample is read from physical slot frame_slots[t] (sbev_msmv_fwd_ring)."""
+    feats = list(levels)
+    _need_device(sampling_locations, scale_weights, *feats)
+    _no_grad_only(sampling_locations, scale_weights, *feats)
+    N = N_VIEWS
+    Bp, Q, P, _ = sampling_locations.shape
+    if Bp != B * T * G:
+        raise RuntimeError('sampling_loc batch %d != B*T*G = %d' % (Bp, B * T * G))
+    GC = feats[0].shape[-1]
+    C = GC // G
+    L = len(feats)
+    hw = [(f.shape[1], f.shape[2]) for f in feats]
+    sslot = [N * h * w * GC for h, w in hw]
+    sv = [h * w * GC for h, w in hw]
+    if out_layout == OUT_REF:
+        out = torch.empty(Bp, Q, C, P, device=feats[0].device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, Q, G, T * P, C, device=feats[0].device, dtype=torch.float32)
+    lib = _lib.load()
+    c_feats = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
+    c_ss = (ctypes.c_int64 * L)(*sslot)
+    c_sv = (ctypes.c_int64 * L)(*sv)
+    c_slots = (ctypes.c_int32 * T)(*[int(s) for s in frame_slots])
+    st = lib.sbev_msmv_fwd_ring(c_feats, c_hw, L, _feat_dtype(feats), Bp, N, C, Q, P, G, c_ss, C, c_sv, GC,
+                                _ptr(sampling_locations.contiguous()), _ptr(scale_weights.contiguous()), _ptr(out),
+                                out_layout, T, G, c_slots, n_slots, _stream())
+    _lib.check(st, 'sbev_msmv_fwd_ring')
+    return out
+
+
 def project_select(sample_points, lidar2img, image_h, image_w, G, P, eps=1e-5, dump=False):
     """Front half of sampling_4d (models/sparsebev_sampling.py:49-114) on device, bit-exact camera-hit
     mask.  sample_points ``[B,Q,T,G*P,3]``, lidar2img ``[B,T*6,4,4]`` -> loc ``[B*T*G,Q,P,3]`` and, with

@@ -15,7 +15,8 @@ class DecoderConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('B', 'Q', 'T', 'N', 'G', 'P', 'L', 'D', 'H', 'ffn', 'num_classes',
                                               'code_size', 'num_layers', 'out_points', 'attn_in_rows', 'feat_dtype')] + \
                [('hw', (ctypes.c_int32 * 2) * MAX_LEVELS), ('image_h', ctypes.c_float), ('image_w', ctypes.c_float),
-                ('eps_homo', ctypes.c_float), ('gemm_mode', ctypes.c_int32), ('overlap', ctypes.c_int32),
+                ('eps_homo', ctypes.c_float), ('gemm_mode', ctypes.c_int32), ('n_slots', ctypes.c_int32),
+                ('frame_slots', ctypes.c_int32 * 16), ('overlap', ctypes.c_int32),
                 ('pc_range', ctypes.c_double * 6)]
 
 
@@ -118,7 +119,12 @@ class DecoderRuntime:
         cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
         cfg.feat_dtype = 1 if pyramid.levels[0].dtype == torch.bfloat16 else 0
         cfg.gemm_mode = self.gemm_mode
-        cfg.overlap = 1 if self.overlap else 0
+        slots = getattr(pyramid, 'frame_slots', None)
+        if slots is not None:
+            cfg.n_slots = pyramid.n_slots
+            for t, sl in enumerate(slots):
+                cfg.frame_slots[t] = int(sl)
+        cfg.overlap = int(self.overlap)
         if len(pyramid.levels) != cfg.L or pyramid.T != cfg.T or pyramid.B != B:
             raise RuntimeError('feature pyramid (L=%d, T=%d, B=%d) does not match the decoder config (L=%d, T=%d, B=%d)'
                                % (len(pyramid.levels), pyramid.T, pyramid.B, cfg.L, cfg.T, B))

@@ -285,7 +285,7 @@ class SparseBEVTransformerDecoder(_Base):
         the DUMP debug taps) run the same kernels one Python call at a time -- the path the per-op tests use."""
         B = query_bbox.shape[0]
         ctx = DecoderContext(img_metas, B, query_bbox.device)
-        feats = mlvl_feats if isinstance(mlvl_feats, FeaturePyramid) else FeaturePyramid(mlvl_feats)
+        feats = mlvl_feats if hasattr(mlvl_feats, 'levels') else FeaturePyramid(mlvl_feats)   # FeaturePyramid / cache.RingPyramid pass through
         query_bbox = query_bbox.float().contiguous()
         query_feat = query_feat.float().contiguous()
         if not (layerwise or DUMP.enabled):

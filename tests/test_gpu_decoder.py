@@ -142,3 +142,30 @@ def test_dump_taps_match_reference_recording(tmp_path):
     # the dump path (layer-by-layer) and the runtime path give the same numbers
     cls_rt, box_rt = model(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
     assert torch.equal(cls, cls_rt) and torch.equal(box, box_rt)
+
+
+def test_online_frame_ring_equals_dense_features():
+    """pushing frames one at a time into the per-frame ring (only the new frame is relayouted) gives
+    bit-identical decoder output to handing the whole [B, T*6, C, H, W] stack over, also after evictions wrapped
+    the ring."""
+    from sparsebev_amd.cache import FrameFeatureCache
+    B, Q, T, L = 2, 36, 4, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 31)
+    bbox, feat = S.make_queries(B, Q, seed=32)
+    metas = S.make_img_metas(B, T, ih, iw)
+    g = torch.Generator(device=DEV).manual_seed(33)
+    frames = [[torch.randn(B, 6, 256, h, w, generator=g, device=DEV) for h, w in sizes] for _ in range(T + 3)]   # oldest first
+    cache = FrameFeatureCache(T, n_slots=T + 1)
+    for i, fr in enumerate(frames):
+        cache.push(fr)
+        if i + 1 < T:
+            continue
+        newest_first = frames[i::-1][:T]
+        dense = [torch.cat([f[l] for f in newest_first], dim=1) for l in range(L)]           # [B, T*6, C, H, W], t = 0 newest
+        a = model(bbox.to(DEV), feat.to(DEV), dense, None, copy.deepcopy(metas))
+        r = model(bbox.to(DEV), feat.to(DEV), cache.pyramid(), None, copy.deepcopy(metas))
+        assert torch.equal(a[0], r[0]) and torch.equal(a[1], r[1]), i
+        lw = model(bbox.to(DEV), feat.to(DEV), cache.pyramid(), None, copy.deepcopy(metas), layerwise=True)
+        assert torch.equal(a[0], lw[0])
+    assert sorted(cache.order) == list(range(T + 1))                                          # every slot in use, no growth

@@ -9,10 +9,10 @@
 //   lane = corner k (0..3) * 16 + channel quad j (0..15)
 //   one wave-wide 16-byte load = the 4 bilinear corners x 64 fp32 channels of ONE (point, level) tap
 //       = 4 x 256 B contiguous segments, i.e. every HBM/L2 request is a full 128-B line pair;
-//   the chunk's coordinates and level weights arrive in ONE coalesced load and are broadcast with v_readlane
-//   (scalar registers), so the 4*L taps of a 4-point chunk are independent back-to-back loads -> up to 20 KiB in
-//   flight per wave;
-//   each lane folds bilinear-corner weight x level weight into one coefficient and FMAs its float4;
+//   the chunk's coordinates and level weights arrive in ONE coalesced load; the tap geometry is computed once per
+//   wave with lanes = (tap, corner) pairs and handed to the gathering lanes with ds_bpermute, so the 4*L taps of a
+//   4-point chunk are independent back-to-back loads -> up to 20 KiB in flight per wave, ~15 VALU ops per tap;
+//   each lane FMAs its float4 with one coefficient = bilinear-corner weight x level weight;
 //   the 4 corner partials are combined once per 4-point chunk with a reduce-scatter built from
 //   v_permlane16_swap / v_permlane32_swap (no LDS, no ds_bpermute), which leaves each 16-lane row
 //   holding exactly the float4 it has to store, so the wave writes ONE fully coalesced 1-KiB row.
@@ -63,11 +63,6 @@ __device__ __forceinline__ float corner_reduce_scatter(float i0, float i1, float
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-// v_readlane_b32 of a float (the builtin is typed int: pass the bits, not the value)
-__device__ __forceinline__ float bcast(float v, int src_lane) {
-    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), src_lane));
-}
-
 template <int L, typename FT, int OUT>
 __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
     const int lane = threadIdx.x & 63;
@@ -76,7 +71,7 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
     if (wave >= a.n_waves) return;
     const long long bp = wave / a.Q;
     const int q = (int)(wave - bp * a.Q);
-    const int k = lane >> 4, kh = k >> 1, kw = k & 1;
+    const int k = lane >> 4;
     const int j4 = (lane & 15) * 4;
     long long bo = bp / a.gdiv;
     const long long gi = bp - bo * a.gdiv;
@@ -99,54 +94,72 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
 
         for (int p0 = 0; p0 < P; p0 += 4) {
             // ONE coalesced request for this chunk's 12 coordinates (lanes 0..11) and 4*L level weights (lanes
-            // 16..16+4L), then v_readlane broadcasts into scalar registers.  Nothing else is loaded between here and
-            // the feature taps, so the compiler can issue all 4*L tap loads back to back.  (Loading a weight inside
-            // the tap made hipcc guard it with the in-bounds branch and wait vmcnt(0) -- draining every earlier tap.)
+            // 16..16+4L).  Nothing else is loaded between here and the feature taps, so all 4*L tap loads can be issued
+            // back to back.  (Loading a weight inside the tap made hipcc guard it with the in-bounds branch and wait
+            // vmcnt(0) -- draining every earlier tap: 99 us instead of 64.)
             const int npts = min(4, P - p0);
             float lv = 0.f;
             if (lane < npts * 3) lv = locq[p0 * 3 + lane];
             if (lane >= 16 && lane < 16 + npts * L) lv = wq[p0 * L + (lane - 16)];
-            // phase 1: geometry of all 4*L taps (32-bit element offsets inside this sample-batch slab, coefficient,
-            // in-bounds bit); phase 2: issue ALL tap loads; phase 3: consume.  Written as three unrolled passes so the
-            // scheduler keeps 4*L x 16 B per lane in flight instead of interleaving a few loads with their waits.
-            int toff[4][L];
-            float tcoef[4][L];
-            unsigned inb_bits = 0;
+            // Phase 1 -- tap geometry, computed ONCE per wave with the lanes as (tap, corner) pairs instead of
+            // redundantly in all 64 lanes (gfx9 has no scalar float ALU, so "wave-uniform" math costs full VALU rate;
+            // the first version spent ~1500 VALU instructions per query there and was VALU-, not memory-bound):
+            // setup lane s handles tap s/4 = (point, level) and corner s%4 and produces one coefficient
+            // (corner weight x level weight, 0 outside the map) and one 32-bit element offset (bit 31 = "outside").
+            // 4*L*4 = 64 pairs for L = 4: exactly one pass; L = 5 takes a second pass for taps 16..19.
+            constexpr int NPASS = (4 * L * 4 + 63) / 64;
+            float s_coef[NPASS];
+            int s_off[NPASS];
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const bool p_ok = pp < npts;               // wave-uniform
-                const float x = bcast(lv, pp * 3 + 0);
-                const float y = bcast(lv, pp * 3 + 1);
-                const float z = bcast(lv, pp * 3 + 2) * nm1;
-                int view = (int)roundf(z);                  // reference: round(loc.z * (num_views - 1))
-                view = min(max(view, 0), a.N - 1);          // (the reference reads out of bounds here; we clamp)
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int t = ps * 16 + (lane >> 2);          // tap index = pp * L + l
+                const int sc = lane & 3, skh = sc >> 1, skw = sc & 1;
+                const int pp = t / L, l = t - pp * L;         // L is a compile-time constant
+                const bool t_ok = t < 4 * L && pp < npts;
+                const int ppc = min(pp, 3);
+                const float x = __shfl(lv, ppc * 3 + 0), y = __shfl(lv, ppc * 3 + 1), z = __shfl(lv, ppc * 3 + 2);
+                const float wl = __shfl(lv, 16 + min(t, 4 * L - 1));
+                int H = a.H[0], W = a.W[0], sv = (int)a.stride_v[0];
+#pragma unroll
+                for (int i = 1; i < L; ++i)
+                    if (l == i) { H = a.H[i]; W = a.W[i]; sv = (int)a.stride_v[i]; }
+                int view = (int)roundf(z * nm1);              // reference: round(loc.z * (num_views - 1))
+                view = min(max(view, 0), a.N - 1);            // (the reference reads out of bounds here; we clamp)
+                const float h_im = y * (float)(H - 1);        // align_corners = True
+                const float w_im = x * (float)(W - 1);
+                const bool lvl_ok = t_ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const float lh = h_im - hf, lw = w_im - wf;
+                // clamp before the int conversion so NaN / huge coordinates stay addressable
+                const int hc = (int)fminf(fmaxf(hf, -1.f), (float)H) + skh;
+                const int wc = (int)fminf(fmaxf(wf, -1.f), (float)W) + skw;
+                const bool inb = lvl_ok && hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
+                const float cw = (skh ? lh : 1.f - lh) * (skw ? lw : 1.f - lw);
+                s_coef[ps] = inb ? cw * wl : 0.f;
+                const int hcc = min(max(hc, 0), H - 1), wcc = min(max(wc, 0), W - 1);
+                const int off = view * sv + (hcc * W + wcc) * (int)a.stride_px;      // < 2^31: inside one sample-batch slab
+                s_off[ps] = inb ? off : (off | (int)0x80000000);
+            }
+            // Phase 2 -- every lane (corner k, channel quad j) fetches the (coef, offset) of ITS corner of tap t with two
+            // ds_bpermute (the LDS crossbar: this is the "stage the query's coordinates once" step, without an LDS round
+            // trip through memory), and ALL 4*L tap loads are issued back to back; phase 3 consumes them.
+            float tcoef[4][L];
+            int toff[4][L];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const int H = a.H[l], W = a.W[l];
-                    const float wl = bcast(lv, 16 + pp * L + l);
-                    const float h_im = y * (float)(H - 1);  // align_corners = True
-                    const float w_im = x * (float)(W - 1);
-                    const bool lvl_ok = p_ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                    const float hf = floorf(h_im), wf = floorf(w_im);
-                    const float lh = h_im - hf, lw = w_im - wf;
-                    // clamp before the int conversion so NaN / huge coordinates stay addressable
-                    const int h0 = (int)fminf(fmaxf(hf, -1.f), (float)H);
-                    const int w0 = (int)fminf(fmaxf(wf, -1.f), (float)W);
-                    const int hc = h0 + kh, wc = w0 + kw;
-                    const bool inb = lvl_ok && chan_ok && hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
-                    const float cw = (kh ? lh : 1.f - lh) * (kw ? lw : 1.f - lw);
-                    tcoef[pp][l] = inb ? cw * wl : 0.f;
-                    inb_bits |= (inb ? 1u : 0u) << (pp * L + l);
-                    const int hcc = min(max(hc, 0), H - 1), wcc = min(max(wc, 0), W - 1);
-                    toff[pp][l] = (int)(view * a.stride_v[l] + ((long long)hcc * W + wcc) * a.stride_px);   // < 2^31: one slab
+                    const int t = pp * L + l;
+                    const int src = ((t & 15) * 4 + k) * 4;   // byte address of setup lane (t%16)*4 + k
+                    tcoef[pp][l] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(s_coef[t / 16])));
+                    toff[pp][l] = __builtin_amdgcn_ds_bpermute(src, s_off[t / 16]);
                 }
-            }
             float4 tv[4][L];
             __builtin_amdgcn_sched_barrier(0);     // pin the phases: hipcc otherwise re-interleaves loads, waits and math
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-                for (int l = 0; l < L; ++l) tv[pp][l] = load4(base[l] + toff[pp][l]);   // always a valid address
+                for (int l = 0; l < L; ++l) tv[pp][l] = load4(base[l] + (toff[pp][l] & 0x7fffffff));   // always a valid address
             __builtin_amdgcn_sched_barrier(0);
             float4 acc[4];
 #pragma unroll
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
                     float4 v = tv[pp][l];
-                    if (!((inb_bits >> (pp * L + l)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // outside the map: exactly 0
+                    if (toff[pp][l] < 0 || !chan_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);   // outside the map: exactly 0
                     const float coef = tcoef[pp][l];
                     acc[pp].x = fmaf(coef, v.x, acc[pp].x);
                     acc[pp].y = fmaf(coef, v.y, acc[pp].y);

@@ -18,11 +18,12 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HD = 32;        // head dim (embed 256 / 8 heads)
 constexpr int KT = 64;        // keys per tile
 constexpr int NQ = 2;         // query row groups (16 rows each) per workgroup
-constexpr int KS = 2;         // key splits per workgroup: wave (ks, qg) walks key tiles ks, ks+KS, ... of row group qg
+constexpr int KS = 4;         // key splits per workgroup: wave (ks, qg) walks key tiles ks, ks+KS, ... of row group qg
 constexpr int NWAVES = NQ * KS;
 constexpr int LDK = HD + 4;   // K tile row stride (B operand of QK^T is read along d: rows = keys)
 constexpr int LDV = HD + 16;  // V tile row stride (B operand of PV is read along keys: stride = 16 banks)
@@ -37,19 +38,27 @@ struct AttnArgs {
     float scale;                // 1/sqrt(HD)
 };
 
-__device__ __forceinline__ float row16_max(float v) {   // reduce over the 16 lanes that share (lane >> 4)
-#pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+// All-reduce over the 16 lanes that share (lane >> 4), on the VALU's DPP path (no LDS round trips -- with one or
+// two waves per SIMD every ds_bpermute latency would be exposed): row_mirror pairs i <-> 15-i, row_half_mirror pairs
+// i <-> 7-i inside each half, then the two quad permutes; after the four steps every lane holds the full result.
+#define SBEV_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, 0xf, 0xf, true))
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, SBEV_DPP(v, 0x140));   // row_mirror
+    v = fmaxf(v, SBEV_DPP(v, 0x141));   // row_half_mirror
+    v = fmaxf(v, SBEV_DPP(v, 0x4e));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, SBEV_DPP(v, 0xb1));    // quad_perm [1,0,3,2]
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    v += SBEV_DPP(v, 0x140);
+    v += SBEV_DPP(v, 0x141);
+    v += SBEV_DPP(v, 0x4e);
+    v += SBEV_DPP(v, 0xb1);
     return v;
 }
 
 // With Q = 900 and 8 heads there are only 232 (head, 32-row) work items -- fewer than CUs -- so the workgroup
-// also splits the KEYS: 4 waves = 2 row groups x 2 key halves, one wave per SIMD, each with its own running
+// also splits the KEYS: 8 waves = 2 row groups x 4 key quarters (two waves per SIMD), each with its own running
 // (max, sum, O) that are merged through LDS at the end (the flash-decoding combine).
 template <bool MASK>
 __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
@@ -101,8 +110,10 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
     // column) of K and of V, plus one key centre for tid < KS*KT.  Tiles are fetched into registers one iteration
     // AHEAD (issue-early / write-late), so their L2 latency hides under this iteration's MFMAs and softmax.
     constexpr int SLOTS = KS * KT * (HD / 4) / (64 * NWAVES);
-    float4 rk[SLOTS], rv[SLOTS];
-    float2 rc = make_float2(0.f, 0.f);
+    // clang vector types, NOT HIP's struct float4: arrays of the struct type captured by the lambdas below are not
+    // promoted to registers (hipcc parked rk in LDS and rv in scratch, and waited for every load right after issuing it)
+    f32x4 rk[SLOTS], rv[SLOTS];
+    f32x2 rc = {0.f, 0.f};
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
@@ -110,21 +121,21 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;
             const int kj = min(k0 + r, a.Q - 1);
             const float* row = base + (long long)kj * a.ld + h * HD + c4;
-            rk[j] = *reinterpret_cast<const float4*>(row + D);
-            rv[j] = *reinterpret_cast<const float4*>(row + 2 * D);
+            rk[j] = *reinterpret_cast<const f32x4*>(row + D);
+            rv[j] = *reinterpret_cast<const f32x4*>(row + 2 * D);
         }
-        if (tid < KS * KT) {
-            const int kj = min(k0 + tid, a.Q - 1);
-            rc = *reinterpret_cast<const float2*>(a.centers + ((long long)b * a.Q + kj) * 2);
-        }
+        // unconditional on purpose (threads >= KS*KT re-read a valid centre and drop it): a guarded load makes hipcc
+        // wait vmcnt(0) right here, which would drain the K/V prefetch it was issued with
+        const int kj = min(k0 + (tid % (KS * KT)), a.Q - 1);
+        rc = *reinterpret_cast<const f32x2*>(a.centers + ((long long)b * a.Q + kj) * 2);
     };
     auto stash = [&]() {
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
             const int i = tid + j * 64 * NWAVES;
             const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;      // r in [0, KS*KT): tile r / KT, row r % KT
-            *reinterpret_cast<float4*>(&Ks[r * LDK + c4]) = rk[j];
-            *reinterpret_cast<float4*>(&Vs[r * LDV + c4]) = rv[j];
+            *reinterpret_cast<f32x4*>(&Ks[r * LDK + c4]) = rk[j];
+            *reinterpret_cast<f32x4*>(&Vs[r * LDV + c4]) = rv[j];
         }
         if (tid < KS * KT) { Cs[2 * tid] = rc.x; Cs[2 * tid + 1] = rc.y; }
     };
@@ -134,7 +145,9 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
 
     for (int k0 = 0; k0 < a.Q; k0 += KS * KT) {
         const bool more = k0 + KS * KT < a.Q;
-        if (more) fetch(k0 + KS * KT);                         // in flight during this iteration's compute
+        // in flight during this iteration's compute.  Unconditional (the last iteration re-fetches tile 0 and drops
+        // it): under `if (more)` hipcc copies the loaded registers at the join and waits for them right here.
+        fetch(more ? k0 + KS * KT : 0);
         const int kbase = k0 + ks * KT;                        // this wave's key tile
         if (kbase < a.Q) {
             // S = (Q/sqrt(d)) K^T : 4 key sub-tiles of 16

@@ -337,8 +337,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) 
         }
     }
     if (a.ln_w) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        s = sbev::wave_sum_dpp(s);
         const float mean = s / (float)a.N;
         float q = 0.f;
 #pragma unroll
@@ -347,8 +346,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) 
                 const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
                 q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+        q = sbev::wave_sum_dpp(q);
         const float rstd = rsqrtf(q / (float)a.N + a.eps);
 #pragma unroll
         for (int c = 0; c < MAXV; ++c) {

@@ -31,11 +31,7 @@ constexpr int LDA = C + 4;    // A-operand rows (x): 16-B aligned rows, <= 2-way
 constexpr int LDB = C + 16;   // B-operand rows (M, y1): row stride = 16 banks -> conflict-free fragment reads
 constexpr int LDY = C + 4;    // output transpose buffer
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return sbev::wave_sum_dpp(v); }
 
 // block-wide sum of one float per thread (4 waves); `red` is 4 floats of LDS; result broadcast to all threads
 __device__ __forceinline__ float block_sum(float v, float* red, int wave, int lane) {

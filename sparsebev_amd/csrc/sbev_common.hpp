@@ -34,4 +34,23 @@ constexpr int kWave = 64;  // CDNA wavefront
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
 void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 
+// Sum over the 64 lanes of a wave without LDS traffic (ds_bpermute-based __shfl_xor costs an LDS round trip per
+// step, which is pure exposed latency when only a few waves share a SIMD): 4 DPP steps reduce each 16-lane row
+// (row_mirror, row_half_mirror, two quad permutes), then the 4 row sums are combined with v_readlane.
+// Every lane receives the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define SBEV_DPP_F(x, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), ctrl, 0xf, 0xf, true))
+    v += SBEV_DPP_F(v, 0x140);
+    v += SBEV_DPP_F(v, 0x141);
+    v += SBEV_DPP_F(v, 0x4e);
+    v += SBEV_DPP_F(v, 0xb1);
+#undef SBEV_DPP_F
+    const int b = (int)__float_as_uint(v);
+    const float r0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 0));
+    const float r1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 32));
+    const float r3 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 }  // namespace sbev

@@ -169,3 +169,46 @@ def test_online_frame_ring_equals_dense_features():
         lw = model(bbox.to(DEV), feat.to(DEV), cache.pyramid(), None, copy.deepcopy(metas), layerwise=True)
         assert torch.equal(a[0], lw[0])
     assert sorted(cache.order) == list(range(T + 1))                                          # every slot in use, no growth
+
+
+@pytest.mark.parametrize('B,Q,T,pyr', [(1, 900, 8, 'tiny'), (2, 400, 8, 'tiny'), (1, 100, 1, 'tiny5')])
+def test_one_layer_at_benchmark_query_counts_vs_oracle(B, Q, T, pyr):
+    """The BASELINE configs' query counts (900 = 7 x 128 + 4 rows, 2 x 400, 100) and frame counts through every
+    kernel of one decoder layer, against the CPU oracle on the same seeded inputs (1e-4)."""
+    from oracle import sparsebev_oracle as O
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    L = len(sizes)
+    model = build(T, L, 41)
+    model.decoder.num_layers = 1
+    params = S.make_params(41, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    bbox, feat = S.make_queries(B, Q, seed=42)
+    feats = S.make_features(B, T, sizes, seed=43)
+    metas = S.make_img_metas(B, T, ih, iw)
+    cls, box = model(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
+    cls_r, box_r, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1,
+                                sampler=O.msmv_sampling_kernel_semantics)
+    assert (cls[0].cpu() - cls_r[0]).abs().max() < TOL
+    assert (box[0].cpu() - box_r[0]).abs().max() < TOL
+
+
+def test_dn_attention_mask_through_runtime():
+    """Query-denoising attention mask (models/sparsebev_transformer.py:224-225) through the C++ runtime."""
+    from oracle import sparsebev_oracle as O
+    B, Q, T, L = 1, 64, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 51)
+    model.decoder.num_layers = 1
+    params = S.make_params(51, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    bbox, feat = S.make_queries(B, Q, seed=52)
+    feats = S.make_features(B, T, sizes, seed=53)
+    metas = S.make_img_metas(B, T, ih, iw)
+    mask = torch.zeros(Q, Q, dtype=torch.bool)
+    mask[:20, 20:] = True            # DN groups cannot see the matching part ...
+    mask[20:, :20] = True            # ... and vice versa
+    cls, box = model(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], mask.to(DEV), copy.deepcopy(metas))
+    cls_r, box_r, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1,
+                                sampler=O.msmv_sampling_kernel_semantics, pre_attn_mask=mask)
+    assert (cls[0].cpu() - cls_r[0]).abs().max() < TOL
+    assert (box[0].cpu() - box_r[0]).abs().max() < TOL
+    cls_n, _ = model(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
+    assert (cls_n - cls).abs().max() > 1e-3

@@ -187,6 +187,18 @@ int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, fl
                         const float* add_after, float* Y, int64_t M, int N, int relu, sbev_stream_t stream);
 
 /*
+ * sbev_sampling_front + sbev_project_select fused into one launch (what the decoder runtime uses): the intermediate
+ * [B,Q,T,G*P,3] sample-point tensor never exists.  Same arithmetic in the same no-FMA translation unit, so loc_bp and
+ * weights_bp are bit-identical to the two-call path (tested).  No DUMP outputs: use the two calls for the debug taps.
+ */
+int sbev_sample_and_project(const float* query_bbox, const float* offset, int64_t ld_offset,
+                            const float* scale_logits, int64_t ld_logits,
+                            const float* time_diff, const float* lidar2img, const double* pc_range,
+                            int B, int Q, int T, int N, int G, int P, int L,
+                            float image_h, float image_w, float eps,
+                            float* loc_bp, float* weights_bp, sbev_stream_t stream);
+
+/*
  * Adaptive mixing core: per (query, group)  y = relu(LN_[Pout,C]( S @ relu(LN_[Pin,C]( x @ M )) )).
  * Replaces: the two dynamic matmuls + F.layer_norm + ReLU of AdaptiveMixing.inner_forward
  *           (models/sparsebev_transformer.py:362-374).  The parameter generator (:358) and the out-projection
@@ -206,16 +218,14 @@ int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
  *           the mmcv/torch MultiheadAttention it calls (:228).
  * qkvt    device fp32 [B,Q,ld]: columns [0,HD*H) = q, [HD*H,2HD*H) = k, [2HD*H,3HD*H) = v (the packed in_proj
  *         output), [3HD*H, 3HD*H+H) = tau (gen_tau output; one GEMM with the 8 tau rows appended to in_proj)
- * centers device fp32 [B,Q,2]: decoded box centres in metres (sbev_box_centers)
+ * query_bbox device fp32 [B,Q,10]; the box centres in metres, c = bbox[:, 0:2] * (range_max - range_min) + range_min
+ *         (decode_bbox, models/bbox/utils.py:63-71), are formed inside the kernel from pc_range (host double [6])
  * mask    optional device uint8 [Q,Q], 1 = masked (-inf), the query-denoising mask (:224-225); NULL at inference
  * out     device fp32 [B,Q,H*HD] (input of the out-projection)
  * Built for head_dim = 32.
  */
-int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* centers, const uint8_t* mask, float* out,
-                  int B, int Q, int H, int head_dim, sbev_stream_t stream);
-
-/* centers[i] = query_bbox[i, 0:2] * (range_max - range_min) + range_min  (decode_bbox, models/bbox/utils.py:63-71) */
-int sbev_box_centers(const float* query_bbox, const double* pc_range, float* centers, int64_t BQ, sbev_stream_t stream);
+int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                  const uint8_t* mask, float* out, int B, int Q, int H, int head_dim, sbev_stream_t stream);
 
 /*
  * Box refinement of one decoder layer.
@@ -264,7 +274,7 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
                               sbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Whole-decoder runtime: ONE call enqueues every kernel of every layer (28 launches per layer) on `stream`.
+ * Whole-decoder runtime: ONE call enqueues every kernel of every layer (26 launches per layer) on `stream`.
  * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward
  *           (models/sparsebev_transformer.py:56-101,162-193) at inference.
  * ---------------------------------------------------------------------------------------------------------- */

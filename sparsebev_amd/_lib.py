@@ -45,9 +45,8 @@ SIGNATURES = {
                                            ctypes.c_int, _vp]),
     'sbev_adaptive_mixing_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_float, _vp]),
-    'sbev_sasa_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                     ctypes.c_int, _vp]),
-    'sbev_box_centers': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _vp, ctypes.c_int64, _vp]),
+    'sbev_sasa_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double), _vp, _vp,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_refine_bbox': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_nchw_to_nhwc_f32': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_linear3_ln_relu_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp,
@@ -72,6 +71,10 @@ SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,
                                           _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i32p, ctypes.c_int, _vp]),
+    'sbev_sample_and_project': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp,
+                                               ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -31,7 +31,8 @@ constexpr int LDP = KT + 4;   // P patch row stride
 
 struct AttnArgs {
     const float* qkvt;          // [B, Q, ld]: q | k | v | tau
-    const float* centers;       // [B, Q, 2] metres
+    const float* bbox;          // [B, Q, 10]: columns 0, 1 = normalised centre -> metres via lo/span (decode_bbox)
+    float lo[2], span[2];
     const unsigned char* mask;  // [Q, Q] (1 = masked) or null
     float* out;                 // [B, Q, H*HD]
     int B, Q, H, ld;
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int qi = min(q0 + fk * 4 + e, a.Q - 1);
-        cx[e] = a.centers[((long long)b * a.Q + qi) * 2 + 0];
-        cy[e] = a.centers[((long long)b * a.Q + qi) * 2 + 1];
+        cx[e] = a.bbox[((long long)b * a.Q + qi) * 10 + 0] * a.span[0] + a.lo[0];
+        cy[e] = a.bbox[((long long)b * a.Q + qi) * 10 + 1] * a.span[1] + a.lo[1];
         tau[e] = base[(long long)qi * a.ld + 3 * D + h];
     }
     float m_run[4], l_run[4];
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
         // unconditional on purpose (threads >= KS*KT re-read a valid centre and drop it): a guarded load makes hipcc
         // wait vmcnt(0) right here, which would drain the K/V prefetch it was issued with
         const int kj = min(k0 + (tid % (KS * KT)), a.Q - 1);
-        rc = *reinterpret_cast<const f32x2*>(a.centers + ((long long)b * a.Q + kj) * 2);
+        rc = *reinterpret_cast<const f32x2*>(a.bbox + ((long long)b * a.Q + kj) * 10);
     };
     auto stash = [&]() {
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             *reinterpret_cast<f32x4*>(&Ks[r * LDK + c4]) = rk[j];
             *reinterpret_cast<f32x4*>(&Vs[r * LDV + c4]) = rv[j];
         }
-        if (tid < KS * KT) { Cs[2 * tid] = rc.x; Cs[2 * tid + 1] = rc.y; }
+        if (tid < KS * KT) { Cs[2 * tid] = rc.x * a.span[0] + a.lo[0]; Cs[2 * tid + 1] = rc.y * a.span[1] + a.lo[1]; }
     };
     fetch(0);
     stash();
@@ -273,19 +274,9 @@ struct MiscArgs {
     const float* reg;       // [BQ,code]
     const float* vel_div;   // [B] or null
     float* out;             // [BQ,code]
-    float* centers;         // [BQ,2]
-    float lo[3], span[3];
     long long BQ;
     int Q, code;
 };
-
-// box centres in metres for the distance bias (decode_bbox xy, models/bbox/utils.py:63-71)
-__global__ void centers_kernel(const MiscArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.BQ) return;
-    a.centers[2 * i] = a.bbox[i * 10] * a.span[0] + a.lo[0];
-    a.centers[2 * i + 1] = a.bbox[i * 10 + 1] * a.span[1] + a.lo[1];
-}
 
 // refine_bbox + velocity / time_diff (models/sparsebev_transformer.py:155-160,179-183; inverse_sigmoid
 // models/utils.py:87-102)
@@ -311,15 +302,21 @@ __global__ void refine_kernel(const MiscArgs a) {
 
 }  // namespace
 
-extern "C" int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* centers, const uint8_t* mask, float* out,
-                             int B, int Q, int H, int head_dim, sbev_stream_t stream) {
+extern "C" int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                             const uint8_t* mask, float* out, int B, int Q, int H, int head_dim, sbev_stream_t stream) {
     SBEV_REQUIRE(B >= 0 && Q >= 0 && H >= 1, "sbev_sasa_f32: bad sizes");
     SBEV_REQUIRE(head_dim == HD, "sbev_sasa_f32: built for head_dim 32 (got %d)", head_dim);
     SBEV_REQUIRE(ld >= 3 * H * HD + H && ld % 4 == 0, "sbev_sasa_f32: row stride %lld must be >= 3*H*32 + H and a multiple of 4", (long long)ld);
     if (B == 0 || Q == 0) return SBEV_OK;
-    SBEV_REQUIRE(qkvt && centers && out, "sbev_sasa_f32: null pointer");
-    SBEV_REQUIRE((((uintptr_t)qkvt) & 15) == 0, "sbev_sasa_f32: qkvt must be 16-byte aligned");
-    AttnArgs a{qkvt, centers, mask, out, B, Q, H, (int)ld, 1.0f / sqrtf((float)HD)};
+    SBEV_REQUIRE(qkvt && query_bbox && pc_range && out, "sbev_sasa_f32: null pointer");
+    SBEV_REQUIRE((((uintptr_t)qkvt) & 15) == 0 && (((uintptr_t)query_bbox) & 7) == 0, "sbev_sasa_f32: qkvt must be 16-byte, query_bbox 8-byte aligned");
+    AttnArgs a{};
+    a.qkvt = qkvt; a.bbox = query_bbox; a.mask = mask; a.out = out;
+    a.B = B; a.Q = Q; a.H = H; a.ld = (int)ld; a.scale = 1.0f / sqrtf((float)HD);
+    for (int i = 0; i < 2; ++i) {           // decode_bbox: python-float scalars cast to fp32 (models/bbox/utils.py:69-70)
+        a.lo[i] = (float)pc_range[i];
+        a.span[i] = (float)(pc_range[3 + i] - pc_range[i]);
+    }
     const long long blocks = (long long)B * H * ((Q + 16 * NQ - 1) / (16 * NQ));
     SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_sasa_f32: too many blocks");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -328,20 +325,6 @@ extern "C" int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* centers
     else
         hipLaunchKernelGGL(sasa_kernel<false>, dim3((unsigned)blocks), dim3(64 * NWAVES), 0, s, a);
     return sbev::check_launch("sbev_sasa_f32");
-}
-
-extern "C" int sbev_box_centers(const float* query_bbox, const double* pc_range, float* centers, int64_t BQ,
-                                sbev_stream_t stream) {
-    if (BQ <= 0) return SBEV_OK;
-    SBEV_REQUIRE(query_bbox && pc_range && centers, "sbev_box_centers: null pointer");
-    MiscArgs a{};
-    a.bbox = query_bbox; a.centers = centers; a.BQ = BQ;
-    for (int i = 0; i < 3; ++i) {
-        a.lo[i] = (float)pc_range[i];
-        a.span[i] = (float)(pc_range[3 + i] - pc_range[i]);
-    }
-    hipLaunchKernelGGL(centers_kernel, dim3((unsigned)((BQ + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-    return sbev::check_launch("sbev_box_centers");
 }
 
 extern "C" int sbev_refine_bbox(const float* query_bbox, const float* reg, const float* vel_div, float* out,

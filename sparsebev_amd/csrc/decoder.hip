@@ -25,7 +25,7 @@ struct Carver {
 };
 
 struct Buffers {
-    float *t0, *t1, *x, *x1, *x2, *x3, *centers, *qkvt, *att, *so, *pts, *wbp, *loc, *sampled, *params, *mixed, *slabs,
+    float *t0, *t1, *x, *x1, *x2, *x3, *qkvt, *att, *so, *wbp, *loc, *sampled, *params, *mixed, *slabs,
         *h, *c0, *c1, *r0, *r1, *reg, *bbox;
     size_t bytes;
 };
@@ -46,11 +46,9 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     Buffers b{};
     b.t0 = k.take(BQ * D); b.t1 = k.take(BQ * D);
     b.x = k.take(BQ * D); b.x1 = k.take(BQ * D); b.x2 = k.take(BQ * D); b.x3 = k.take(BQ * D);
-    b.centers = k.take(BQ * 2);
     b.qkvt = k.take(BQ * (size_t)c.attn_in_rows);
     b.att = k.take(BQ * D);
     b.so = k.take(BQ * (size_t)(c.G * c.P * (3 + c.L)));
-    b.pts = k.take(BQ * c.T * c.G * c.P * 3);
     b.wbp = k.take(BQ * c.T * c.G * c.P * c.L);
     b.loc = k.take(BQ * c.T * c.G * c.P * 3);
     b.sampled = k.take(BQ * c.G * Pin * Cg);
@@ -166,9 +164,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         TRY(sbev_linear_f32(b.t0, w->pe3_w, w->pe3_b, nullptr, b.t1, BQ, D, D, D, D, D, 0, stream));
         TRY(sbev_layer_norm_f32(b.t1, w->pe4_g, w->pe4_b, eps, feat, b.x, BQ, D, 1, stream));
         // scale-adaptive self attention + norm1                                (:169)
-        TRY(sbev_box_centers(bbox, c.pc_range, b.centers, BQ, stream));
         TRY(sbev_linear_f32(b.x, w->attn_in_w, w->attn_in_b, nullptr, b.qkvt, BQ, c.attn_in_rows, D, D, D, c.attn_in_rows, 0, stream));
-        TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, b.centers, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
+        TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
         TRY(sbev_linear_f32(b.att, w->attn_out_w, w->attn_out_b, b.x, b.t1, BQ, D, D, D, D, D, 0, stream));
         TRY(sbev_layer_norm_f32(b.t1, w->norm1_g, w->norm1_b, eps, nullptr, b.x1, BQ, D, 0, stream));
         // fork: parameter generator (needs only x1) on the aux stream, beside the sampling chain
@@ -188,10 +185,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         }
         // adaptive spatio-temporal sampling                                     (:170)
         TRY(sbev_linear_f32(b.x1, w->samp_w, w->samp_b, nullptr, b.so, BQ, soN, D, D, D, soN, 0, stream));
-        TRY(sbev_sampling_front(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, c.pc_range,
-                                c.B, c.Q, c.T, c.G, c.P, c.L, b.pts, b.wbp, stream));
-        TRY(sbev_project_select(b.pts, lidar2img, c.B, c.Q, c.T, c.N, c.G, c.P, c.image_h, c.image_w, c.eps_homo,
-                                b.loc, nullptr, nullptr, nullptr, stream));
+        TRY(sbev_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
+                                    c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
         if (c.n_slots > 0)
             TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
                                    c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, c.frame_slots, c.n_slots, stream));

@@ -15,7 +15,7 @@ NATIVE = {
     'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
     'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',
     'linear_ln_relu': 'hip: gemm + LayerNorm/ReLU reducer; Linear(3->D): linear3_ln_relu_kernel',
-    'self_attention': 'hip: centers + gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
+    'self_attention': 'hip: gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
     'adaptive_mixing': 'hip: gemm (generator) + adaptive_mixing_kernel (v_mfma_f32_16x16x4_f32) + split-K gemm (out-proj, fused residual + LayerNorm)',
     'refine_bbox': 'hip: refine_kernel',
     'to_channels_last': 'hip: transpose_tiles_kernel',
@@ -146,16 +146,14 @@ def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b
     """models/sparsebev_transformer.py:210-228,236-248 + mmcv MultiheadAttention(batch_first) = x + MHA(x),
     optionally followed by LayerNorm (ln = norm1 of the decoder layer).
 
-    Launches: box centres -> ONE in-projection GEMM (q | k | v | tau, N = 3D + H) -> flash-style attention with
-    the distance bias computed on the fly -> out-projection GEMM with the residual (and LayerNorm) fused."""
+    Launches: ONE in-projection GEMM (q | k | v | tau, N = 3D + H) -> flash-style attention with the distance bias
+    computed on the fly from the boxes -> out-projection GEMM with the residual (and LayerNorm) fused."""
     _dev(query_bbox, x)
     B, Q, D = x.shape
     hd = D // num_heads
     lib = _lib.load()
     query_bbox = query_bbox.contiguous()
-    centers = torch.empty(B, Q, 2, device=x.device, dtype=torch.float32)
     pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
-    _lib.check(lib.sbev_box_centers(_p(query_bbox), pc, _p(centers), B * Q, _stream()), 'sbev_box_centers')
     if (3 * D + num_heads) % 4 != 0:
         raise RuntimeError('3*embed_dims + num_heads must be a multiple of 4')
     w_all = _cat_rows(in_w, tau_w)
@@ -165,7 +163,7 @@ def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b
     if pre_attn_mask is not None:
         mask = pre_attn_mask.to(device=x.device, dtype=torch.uint8).contiguous()
     att = torch.empty(B, Q, D, device=x.device, dtype=torch.float32)
-    _lib.check(lib.sbev_sasa_f32(_p(qkvt), qkvt.shape[-1], _p(centers), _p(mask), _p(att), B, Q, num_heads, hd, _stream()),
+    _lib.check(lib.sbev_sasa_f32(_p(qkvt), qkvt.shape[-1], _p(query_bbox), pc, _p(mask), _p(att), B, Q, num_heads, hd, _stream()),
                'sbev_sasa_f32')
     return linear(att, out_w, out_b, residual=x, ln=ln)
 

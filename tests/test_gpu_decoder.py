@@ -212,3 +212,24 @@ def test_dn_attention_mask_through_runtime():
     assert (box[0].cpu() - box_r[0]).abs().max() < TOL
     cls_n, _ = model(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
     assert (cls_n - cls).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize('P,T,L,pyr', [(8, 2, 5, 'tiny5'), (2, 4, 4, 'tiny'), (8, 15, 4, 'tiny')])
+def test_other_point_and_frame_counts_vs_oracle(P, T, L, pyr):
+    """num_points / num_frames other than the r50 defaults: the reference's eva02 config uses P = 8, T = 15
+    (configs/vit_eva02_1600x640_trainval_future.py:54-58), i.e. 120 in-points for adaptive mixing."""
+    from oracle import sparsebev_oracle as O
+    B, Q = 1, 36
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    params = S.make_params(61, embed_dims=256, num_frames=T, num_points=P, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=P, num_layers=1, num_levels=L, pc_range=S.PC_RANGE)
+    m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    bbox, feat = S.make_queries(B, Q, seed=62)
+    feats = S.make_features(B, T, sizes, seed=63)
+    metas = S.make_img_metas(B, T, ih, iw)
+    cls, box = m(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
+    cls_r, box_r, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1, num_points=P,
+                                sampler=O.msmv_sampling_kernel_semantics)
+    assert (cls[0].cpu() - cls_r[0]).abs().max() < TOL
+    assert (box[0].cpu() - box_r[0]).abs().max() < TOL

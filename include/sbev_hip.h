@@ -169,6 +169,17 @@ int sbev_linear_f32(const float* X, const float* W, const float* bias, const flo
                     sbev_stream_t stream);
 
 /*
+ * Up to 3 independent small Linear layers (K = 256 or 512, same K) in ONE launch, e.g. the classification and the
+ * regression branch of a decoder layer (models/sparsebev_transformer.py:174-175), which both consume the layer output.
+ * Each problem has exactly the semantics of sbev_linear_f32.
+ */
+typedef struct sbev_linear_problem {
+    const float* X; const float* W; const float* bias; const float* residual; float* Y;
+    int64_t M; int32_t N, K; int64_t ldx, ldw, ldy; int32_t relu;
+} sbev_linear_problem;
+int sbev_linear_group_f32(const sbev_linear_problem* probs, int n, sbev_stream_t stream);
+
+/*
  * Split-K variant for long reductions with a small output (AdaptiveMixing.out_proj: K = 32768, N = 256,
  * models/sparsebev_transformer.py:344,378), with the whole epilogue of that call site fused into the slab
  * reduction: + bias, optional ReLU, + residual (`query + out`, :379), optional LayerNorm(N) (norm2, :171).

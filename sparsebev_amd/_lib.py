@@ -75,6 +75,7 @@ SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
 }
 
 _lib = None

@@ -214,18 +214,38 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
             TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
         }
-        TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
-        TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
-        TRY(sbev_linear_f32(b.c1, w->cls3_w, w->cls3_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
-        TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
-        TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, s_aux));
-        if (fork) {
-            ev_cls = next_ev();
-            TRY(hip_ok(hipEventRecord(ev_cls, ax.stream), "hipEventRecord"));
+        // the two branches are independent chains of small linears: each level of them shares one grouped launch
+        // (with `fork` the classification branch goes to the aux stream instead)
+        auto prob = [&](const float* X, const float* W, const float* bias, float* Y, int N, int relu) {
+            return sbev_linear_problem{X, W, bias, nullptr, Y, BQ, N, D, D, D, N, relu};
+        };
+        // only while sbev_linear_f32 would pick the same small-tile kernel for each of them (keeps the results identical
+        // to the op-by-op path); large batches have enough tiles per linear anyway
+        const bool grouped = !fork && (D == 256 || D == 512) && ((BQ + 127) / 128) * ((D + 127) / 128) < 256;
+        if (grouped) {
+            const sbev_linear_problem g1[2] = {prob(b.x3, w->cls0_w, w->cls0_b, b.c0, D, 0), prob(b.x3, w->reg0_w, w->reg0_b, b.r0, D, 1)};
+            TRY(sbev_linear_group_f32(g1, 2, stream));
+            TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, stream));
+            const sbev_linear_problem g2[2] = {prob(b.c1, w->cls3_w, w->cls3_b, b.c0, D, 0), prob(b.r0, w->reg2_w, w->reg2_b, b.r1, D, 1)};
+            TRY(sbev_linear_group_f32(g2, 2, stream));
+            TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, stream));
+            const sbev_linear_problem g3[2] = {prob(b.c1, w->cls6_w, w->cls6_b, cls_l, c.num_classes, 0),
+                                               prob(b.r1, w->reg4_w, w->reg4_b, b.reg, c.code_size, 0)};
+            TRY(sbev_linear_group_f32(g3, 2, stream));
+        } else {   // s_aux == stream unless forked
+            TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
+            TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
+            TRY(sbev_linear_f32(b.c1, w->cls3_w, w->cls3_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
+            TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
+            TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, s_aux));
+            if (fork) {
+                ev_cls = next_ev();
+                TRY(hip_ok(hipEventRecord(ev_cls, ax.stream), "hipEventRecord"));
+            }
+            TRY(sbev_linear_f32(b.x3, w->reg0_w, w->reg0_b, nullptr, b.r0, BQ, D, D, D, D, D, 1, stream));
+            TRY(sbev_linear_f32(b.r0, w->reg2_w, w->reg2_b, nullptr, b.r1, BQ, D, D, D, D, D, 1, stream));
+            TRY(sbev_linear_f32(b.r1, w->reg4_w, w->reg4_b, nullptr, b.reg, BQ, c.code_size, D, D, D, c.code_size, 0, stream));
         }
-        TRY(sbev_linear_f32(b.x3, w->reg0_w, w->reg0_b, nullptr, b.r0, BQ, D, D, D, D, D, 1, stream));
-        TRY(sbev_linear_f32(b.r0, w->reg2_w, w->reg2_b, nullptr, b.r1, BQ, D, D, D, D, D, 1, stream));
-        TRY(sbev_linear_f32(b.r1, w->reg4_w, w->reg4_b, nullptr, b.reg, BQ, c.code_size, D, D, D, c.code_size, 0, stream));
         TRY(sbev_refine_bbox(bbox, b.reg, c.T > 1 ? vel_div : nullptr, box_l, c.B, c.Q, c.code_size, stream));
         // next layer: query_bbox = bbox_pred.detach() (:93), query_feat = this layer's output
         bbox = box_l;

@@ -220,13 +220,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
 // wave, so LDS staging would only add a barrier), runs K/4/2 MFMAs, and the four partial tiles are combined
 // through 16 KiB of LDS into a float4 row-major epilogue.  232 workgroups / 928 waves for [900,256]x[256,256].
 template <int KC>   // KC = K / 4 / 8: float4 k-blocks per wave (8 for K = 256, 16 for K = 512)
-__global__ __launch_bounds__(256) void gemm_nt_f32_small_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+__device__ __forceinline__ void small_tile(const GemmArgs& a, unsigned tile, float* red) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned tiles_n = (a.N + 31) / 32;
-    const unsigned tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const unsigned tm = tile / tiles_n, tn = tile % tiles_n;
     const long long m0 = (long long)tm * 32;
     const int n0 = tn * 32;
     long long ra = m0 + fr;
@@ -286,6 +285,29 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_small_kernel(const GemmArgs a
         for (int q = 0; q < 4; ++q)
             if (n + q < a.N) yp[q] = v[q] + (a.res ? a.res[m * a.ldy + n + q] : 0.f);
     }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void gemm_nt_f32_small_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    small_tile<KC>(a, blockIdx.x, red);
+}
+
+// Up to 3 INDEPENDENT small linears in one launch (e.g. the classification and regression branches, which both hang
+// off the layer output): each costs ~6 us of launch ramp + two dependent memory round trips on its own and keeps a
+// fraction of the CUs busy; side by side they share that latency.  Workgroups are partitioned by tile count.
+struct GroupArgs {
+    GemmArgs p[3];
+    unsigned tile_end[3];   // exclusive prefix sums of the problems' tile counts
+    int n;
+};
+template <int KC>
+__global__ __launch_bounds__(256) void gemm_group_small_kernel(const GroupArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    const unsigned id = blockIdx.x;
+    if (id < g.tile_end[0]) small_tile<KC>(g.p[0], id, red);
+    else if (id < g.tile_end[1]) small_tile<KC>(g.p[1], id - g.tile_end[0], red);
+    else small_tile<KC>(g.p[2], id - g.tile_end[1], red);
 }
 
 struct ReduceArgs {
@@ -406,6 +428,34 @@ extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, false>), dim3((unsigned)small), dim3(256), 0, s, a);
     }
     return sbev::check_launch("sbev_linear_f32");
+}
+
+
+extern "C" int sbev_linear_group_f32(const sbev_linear_problem* probs, int n, sbev_stream_t stream) {
+    SBEV_REQUIRE(probs && n >= 1 && n <= 3, "sbev_linear_group_f32: 1..3 problems per launch (got %d)", n);
+    GroupArgs g{};
+    g.n = n;
+    unsigned end = 0;
+    const int K = probs[0].K;
+    SBEV_REQUIRE(K == 256 || K == 512, "sbev_linear_group_f32: built for K = 256 / 512 (got %d)", K);
+    for (int i = 0; i < 3; ++i) {
+        if (i < n) {
+            const sbev_linear_problem& q = probs[i];
+            SBEV_REQUIRE(q.K == K, "sbev_linear_group_f32: all problems of a group must share K");
+            SBEV_REQUIRE(q.M >= 1 && q.N >= 1 && q.X && q.W && q.Y, "sbev_linear_group_f32: problem %d has null / empty operands", i);
+            SBEV_REQUIRE(q.ldx % 4 == 0 && q.ldw % 4 == 0 && q.ldx >= K && q.ldw >= K && q.ldy >= q.N, "sbev_linear_group_f32: problem %d leading dimensions", i);
+            SBEV_REQUIRE((((uintptr_t)q.X | (uintptr_t)q.W) & 15) == 0, "sbev_linear_group_f32: problem %d X / W not 16-byte aligned", i);
+            g.p[i] = GemmArgs{q.X, q.W, q.bias, q.residual, q.Y, q.M, q.N, q.K, q.ldx, q.ldw, q.ldy, q.K, q.relu};
+            end += (unsigned)(((q.M + 31) / 32) * ((q.N + 31) / 32));
+        }
+        g.tile_end[i] = end;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (K == 256)
+        hipLaunchKernelGGL((gemm_group_small_kernel<8>), dim3(end), dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_group_small_kernel<16>), dim3(end), dim3(256), 0, s, g);
+    return sbev::check_launch("sbev_linear_group_f32");
 }
 
 extern "C" int64_t sbev_linear_splitk_workspace(int64_t M, int N, int splits) {

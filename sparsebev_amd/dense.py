@@ -13,6 +13,7 @@ from . import _lib
 # op -> kernel(s) it launches
 NATIVE = {
     'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
+    'linear_group': 'hip: gemm_group_small_kernel (cls / reg branch levels side by side)',
     'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',
     'linear_ln_relu': 'hip: gemm + LayerNorm/ReLU reducer; Linear(3->D): linear3_ln_relu_kernel',
     'self_attention': 'hip: gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
@@ -89,6 +90,34 @@ def linear(x, w, b, relu=False, residual=None, ln=None, ln_relu=False):
     if ln is not None:
         y = layer_norm(y, ln[0], ln[1], relu=ln_relu)
     return y
+
+
+class _LinearProblem(ctypes.Structure):
+    """struct sbev_linear_problem (include/sbev_hip.h)"""
+    _fields_ = [('X', ctypes.c_void_p), ('W', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('residual', ctypes.c_void_p),
+                ('Y', ctypes.c_void_p), ('M', ctypes.c_int64), ('N', ctypes.c_int32), ('K', ctypes.c_int32),
+                ('ldx', ctypes.c_int64), ('ldw', ctypes.c_int64), ('ldy', ctypes.c_int64), ('relu', ctypes.c_int32)]
+
+
+def linear_group(problems):
+    """Up to 3 independent small linears [(x, w, b, relu), ...] (same K = 256 / 512) in one launch; returns the list
+    of outputs.  Same arithmetic per output tile as linear() on each -- used for the cls / reg branches."""
+    n = len(problems)
+    arr = (_LinearProblem * n)()
+    keep, outs = [], []
+    for i, (x, w, b, relu) in enumerate(problems):
+        _dev(x, w)
+        K, N = x.shape[-1], w.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        w = w.contiguous()
+        y = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+        keep += [x2, w]
+        outs.append(y.reshape(*x.shape[:-1], N))
+        arr[i] = _LinearProblem(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, None, y.data_ptr(),
+                                x2.shape[0], N, K, K, K, N, int(relu))
+    st = _lib.load().sbev_linear_group_f32(ctypes.cast(arr, ctypes.c_void_p), n, _stream())
+    _lib.check(st, 'sbev_linear_group_f32')
+    return outs
 
 
 def layer_norm(x, w, b, eps=1e-5, relu=False, add_after=None):

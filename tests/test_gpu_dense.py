@@ -177,3 +177,39 @@ def test_bf16x3_linear_fp32_class_accuracy(M, N, K, splitk):
     # outputs a few 1e-5 -- fp32-class, two orders of magnitude better than a plain bf16 GEMM
     assert rms < 6e-6 and err < 6e-5, (rms, err)
     assert plain > 30 * err
+
+
+@pytest.mark.gpu
+def test_linear_group_equals_single_launches():
+    """sbev_linear_group_f32: the cls / reg branch levels launched side by side must give bit-identical results to
+    one sbev_linear_f32 per problem (same tile arithmetic), for ragged M / N too."""
+    g = torch.Generator().manual_seed(5)
+    dev = 'cuda:0'
+    for M, Ns, K in [(900, (256, 256), 256), (900, (10, 10), 256), (70, (256, 10, 33), 512), (1, (5,), 256)]:
+        probs = []
+        for i, N in enumerate(Ns):
+            x = torch.randn(M, K, generator=g).to(dev)
+            w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+            b = torch.randn(N, generator=g).to(dev) if i != 1 else None
+            probs.append((x, w, b, i % 2 == 1))
+        outs = dense.linear_group(probs)
+        for (x, w, b, relu), y in zip(probs, outs):
+            ref = dense.linear(x, w, b, relu=relu)
+            assert torch.equal(y, ref), (M, Ns, K)
+            t = x.double() @ w.double().T + (b.double() if b is not None else 0)
+            t = t.clamp_min(0) if relu else t
+            assert (y.double() - t).abs().max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_linear_group_rejects_bad_groups():
+    dev = 'cuda:0'
+    x = torch.zeros(8, 256, device=dev); w = torch.zeros(4, 256, device=dev)
+    x2 = torch.zeros(8, 512, device=dev); w2 = torch.zeros(4, 512, device=dev)
+    with pytest.raises(RuntimeError):
+        dense.linear_group([(x, w, None, False), (x2, w2, None, False)])      # mixed K
+    with pytest.raises(RuntimeError):
+        dense.linear_group([(x, w, None, False)] * 4)                           # more than 3
+    x3 = torch.zeros(8, 128, device=dev); w3 = torch.zeros(4, 128, device=dev)
+    with pytest.raises(RuntimeError):
+        dense.linear_group([(x3, w3, None, False)])                             # K not 256 / 512

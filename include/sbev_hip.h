@@ -337,6 +337,23 @@ int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_decoder_weig
                          const uint8_t* attn_mask, float* cls_out, float* bbox_out,
                          void* workspace, int64_t workspace_bytes, sbev_stream_t stream);
 
+/*
+ * hipGraph capture of one decoder step: the launch sequence of sbev_decoder_forward is static per (config, pointer
+ * set), so it can be recorded once on `stream` (explicit, non-default; nothing executes during the capture) and
+ * replayed per sample.  The graph reads its inputs through the captured device pointers: refresh them in place.
+ * The workspace and every input / output buffer must outlive the graph.  Replaces per-call Python/launch overhead
+ * of the reference's eager module chain (models/sparsebev_transformer.py:86-97).
+ */
+typedef struct sbev_graph sbev_graph;
+int sbev_decoder_capture(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights,
+                         const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
+                         const float* time_diff, const float* lidar2img, const float* vel_div,
+                         const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                         void* workspace, int64_t workspace_bytes, sbev_stream_t stream, sbev_graph** out);
+int sbev_graph_launch(sbev_graph* graph, sbev_stream_t stream);
+int64_t sbev_graph_num_nodes(const sbev_graph* graph);   /* kernel nodes recorded (-1 for NULL) */
+int sbev_graph_destroy(sbev_graph* graph);
+
 /* Bracket every sbev_msmv_fwd launch with HIP events on its stream (enable != 0), and read back + clear the
  * elapsed times in ms (blocks until those launches finished).  Measurement aid for bench.py's roofline figure. */
 int sbev_profile_sampler(int enable);

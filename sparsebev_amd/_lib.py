@@ -75,6 +75,10 @@ SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    'sbev_decoder_capture': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'sbev_graph_launch': (ctypes.c_int, [_vp, _vp]),
+    'sbev_graph_num_nodes': (ctypes.c_int64, [_vp]),
+    'sbev_graph_destroy': (ctypes.c_int, [_vp]),
     'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
 }
 

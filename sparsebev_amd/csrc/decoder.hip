@@ -295,3 +295,64 @@ extern "C" int sbev_profile_sampler_read(float* ms, int max_n) {
     sbev::g_prof_events.clear();
     return n;
 }
+
+// ---- hipGraph capture of one decoder step -----------------------------------------------------------------------
+// The launch sequence is static per (config, pointers): capture it once, replay it per sample.  Inputs are read
+// through the captured device pointers, so the caller refreshes them in place (new queries / matrices / features,
+// or -- with the frame ring -- a new slot table means a new capture per ring phase).
+struct sbev_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    size_t nodes = 0;
+};
+
+extern "C" int sbev_decoder_capture(const sbev_decoder_config* cfg, const sbev_decoder_weights* w,
+                                    const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
+                                    const float* time_diff, const float* lidar2img, const float* vel_div,
+                                    const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                                    void* workspace, int64_t workspace_bytes, sbev_stream_t stream, sbev_graph** out) {
+    SBEV_REQUIRE(out, "sbev_decoder_capture: null output handle");
+    SBEV_REQUIRE(stream, "sbev_decoder_capture: needs an explicit (non-default) stream to capture on");
+    {
+        std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
+        SBEV_REQUIRE(!sbev::g_prof_on, "sbev_decoder_capture: sampler profiling is on (events cannot be read back from a captured graph)");
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    (void)aux();   // create the side stream / events outside the capture
+    TRY(hip_ok(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture"));
+    const int st = sbev_decoder_forward(cfg, w, feats_nhwc, query_bbox, query_feat, time_diff, lidar2img, vel_div, attn_mask,
+                                        cls_out, bbox_out, workspace, workspace_bytes, stream);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);   // always end the capture, also after a failed step
+    if (st != SBEV_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return st;
+    }
+    TRY(hip_ok(e, "hipStreamEndCapture"));
+    sbev_graph* h = new sbev_graph();
+    h->graph = g;
+    (void)hipGraphGetNodes(g, nullptr, &h->nodes);
+    const hipError_t ei = hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        delete h;
+        return hip_ok(ei, "hipGraphInstantiate");
+    }
+    *out = h;
+    return SBEV_OK;
+}
+
+extern "C" int sbev_graph_launch(sbev_graph* g, sbev_stream_t stream) {
+    SBEV_REQUIRE(g && g->exec, "sbev_graph_launch: null graph");
+    return hip_ok(hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream)), "hipGraphLaunch");
+}
+
+extern "C" int64_t sbev_graph_num_nodes(const sbev_graph* g) { return g ? (int64_t)g->nodes : -1; }
+
+extern "C" int sbev_graph_destroy(sbev_graph* g) {
+    if (!g) return SBEV_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return SBEV_OK;
+}

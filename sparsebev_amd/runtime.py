@@ -101,9 +101,7 @@ class DecoderRuntime:
         self._attn_in_rows = attn_in_w.shape[0]
 
     # -- forward -----------------------------------------------------------------------------------------
-    def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
-        """pyramid: transformer.FeaturePyramid; ctx: transformer.DecoderContext.  Returns (cls, bbox) stacked over
-        layers (not nan_to_num'ed)."""
+    def _prepare(self, query_bbox, query_feat, pyramid, ctx, attn_mask):
         sig = self._signature()
         if sig != self._sig:
             self._bind()
@@ -147,12 +145,60 @@ class DecoderRuntime:
         feats = (ctypes.c_void_p * cfg.L)(*[f.data_ptr() for f in pyramid.levels])
         mask = attn_mask.to(device=dev, dtype=torch.uint8).contiguous() if attn_mask is not None else None
         qb, qf = query_bbox.contiguous(), query_feat.contiguous()
-        st = lib.sbev_decoder_forward(ctypes.byref(cfg), ctypes.byref(self._weights), feats, _ptr(qb), _ptr(qf),
-                                      _ptr(ctx.time_diff), _ptr(ctx.lidar2img), _ptr(ctx.vel_div), _ptr(mask),
-                                      _ptr(cls), _ptr(box), ctypes.c_void_p(ws_ptr), need,
-                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        args = (ctypes.byref(cfg), ctypes.byref(self._weights), feats, _ptr(qb), _ptr(qf),
+                _ptr(ctx.time_diff), _ptr(ctx.lidar2img), _ptr(ctx.vel_div), _ptr(mask),
+                _ptr(cls), _ptr(box), ctypes.c_void_p(ws_ptr), need)
+        keep = (cfg, feats, qb, qf, mask, pyramid, ctx, self._ws, self._keep)
+        return args, keep, cls, box
+
+    def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
+        """pyramid: transformer.FeaturePyramid; ctx: transformer.DecoderContext.  Returns (cls, bbox) stacked over
+        layers (not nan_to_num'ed)."""
+        args, _keep, cls, box = self._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask)
+        st = _lib.load().sbev_decoder_forward(*args, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(st, 'sbev_decoder_forward')
         return cls, box
+
+    def capture(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
+        """Record one decoder step into a hipGraph (sbev_decoder_capture) and return a DecoderGraph.  The graph reads
+        its inputs through the captured pointers: refresh ``query_bbox`` / ``query_feat`` / the pyramid levels /
+        ``ctx`` tensors IN PLACE (``.copy_()``), call ``replay()``, read ``graph.cls`` / ``graph.box``.  The runtime's
+        workspace belongs to the graph while it is alive: use another DecoderRuntime for un-captured calls."""
+        if not (query_bbox.is_contiguous() and query_feat.is_contiguous()):
+            raise RuntimeError('capture needs contiguous query tensors (they are read in place on every replay)')
+        args, keep, cls, box = self._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask)
+        side = torch.cuda.Stream(device=query_feat.device)
+        side.wait_stream(torch.cuda.current_stream())
+        handle = ctypes.c_void_p()
+        st = _lib.load().sbev_decoder_capture(*args, ctypes.c_void_p(side.cuda_stream), ctypes.byref(handle))
+        _lib.check(st, 'sbev_decoder_capture')
+        return DecoderGraph(handle, keep, cls, box)
+
+
+class DecoderGraph:
+    """An instantiated hipGraph of one decoder step (see DecoderRuntime.capture)."""
+
+    def __init__(self, handle, keep, cls, box):
+        self._h, self._keep, self.cls, self.box = handle, keep, cls, box
+        self.num_nodes = int(_lib.load().sbev_graph_num_nodes(handle))
+
+    def replay(self):
+        if self._h is None:
+            raise RuntimeError('DecoderGraph was destroyed')
+        st = _lib.load().sbev_graph_launch(self._h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(st, 'sbev_graph_launch')
+        return self.cls, self.box
+
+    def destroy(self):
+        if self._h is not None:
+            _lib.load().sbev_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def profile_sampler(enable):

@@ -233,3 +233,34 @@ def test_other_point_and_frame_counts_vs_oracle(P, T, L, pyr):
                                 sampler=O.msmv_sampling_kernel_semantics)
     assert (cls[0].cpu() - cls_r[0]).abs().max() < TOL
     assert (box[0].cpu() - box_r[0]).abs().max() < TOL
+
+
+def test_captured_graph_replays_bit_identically_and_follows_in_place_updates():
+    """sbev_decoder_capture / sbev_graph_launch: a hipGraph of one decoder step must reproduce the eager runtime bit
+    for bit, and -- reading its inputs through the captured pointers -- follow in-place input updates."""
+    from sparsebev_amd.runtime import DecoderRuntime
+    B, Q, T, L = 1, 64, 4, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 41)
+    metas = S.make_img_metas(B, T, ih, iw)
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=42)]
+    pyr, ctx = FeaturePyramid(feats), DecoderContext(metas, B, torch.device(DEV))
+    bbox_a, feat_a = [t.to(DEV) for t in S.make_queries(B, Q, seed=43)]
+    bbox_b, feat_b = [t.to(DEV) for t in S.make_queries(B, Q, seed=44)]
+    eager = DecoderRuntime(model.decoder)
+    ref_a = [t.clone() for t in eager.forward(bbox_a, feat_a, pyr, ctx)]
+    ref_b = [t.clone() for t in eager.forward(bbox_b, feat_b, pyr, ctx)]
+    assert not torch.equal(ref_a[0], ref_b[0])
+    qb, qf = bbox_a.clone(), feat_a.clone()
+    graph = DecoderRuntime(model.decoder).capture(qb, qf, pyr, ctx)
+    assert graph.num_nodes >= 6 * 20                       # every launch of every layer is a node
+    for _ in range(2):
+        cls, box = graph.replay()
+        assert torch.equal(cls, ref_a[0]) and torch.equal(box, ref_a[1])
+    qb.copy_(bbox_b)
+    qf.copy_(feat_b)
+    cls, box = graph.replay()
+    assert torch.equal(cls, ref_b[0]) and torch.equal(box, ref_b[1])
+    graph.destroy()
+    with pytest.raises(RuntimeError):
+        graph.replay()

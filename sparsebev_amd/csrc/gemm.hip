@@ -310,6 +310,105 @@ __global__ __launch_bounds__(256) void gemm_group_small_kernel(const GroupArgs g
     else small_tile<KC>(g.p[2], id - g.tile_end[1], red);
 }
 
+// ---- W-stationary strip kernel for [M, 256] x [N >= 16384, 256]^T (the adaptive-mixing parameter generator) ---------
+// With 128x128 tiles Q = 900 rows are 7.03 row tiles: 12 % of the MFMA work is padding AND the 1792..2048 tiles
+// quantise to 4 rounds over the 512 resident workgroups (M = 896 costs the same 168 us as M = 1024).  Here a WAVE
+// instead owns a 64-column strip of W for half of all row fragments and keeps that strip (64 x 256 fp32) in its own
+// registers -- 256 of the 512 VGPR+AGPR a wave has at one wave per SIMD, which is all the f32 MFMA needs to run at
+// peak -- while X streams through registers straight from L2 (16 rows x 256 k per fragment, prefetched one fragment
+// ahead).  No LDS, no barrier; the grid is N/128 workgroups (2 strips x 2 row-halves) of equal work = exactly one per
+// CU at N = 32768; the M padding shrinks to ceil(M/16)*16.  v_mfma_f32_16x16x4_f32 with W as the row operand: a lane
+// ends up with 4 CONSECUTIVE output columns of one row, i.e. float4 stores.  k order: lane group fk owns
+// k = 16 j + 4 fk + i, so both operands are 16-byte loads (same trick as mixing.hip).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_strip_kernel(const GemmArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fk = lane >> 4;
+    const long long n0 = (long long)blockIdx.x * 128 + (wave >> 1) * 64;
+    const int half = wave & 1;
+
+    f32x4v w[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf)
+            w[j][cf] = *reinterpret_cast<const f32x4v*>(a.W + (n0 + cf * 16 + fi) * a.ldw + 16 * j + 4 * fk);
+    f32x4v bias4[4];
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf)
+        bias4[cf] = a.bias ? *reinterpret_cast<const f32x4v*>(a.bias + n0 + cf * 16 + 4 * fk) : (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    const int M = (int)a.M;
+    const int last = ((M + 15) >> 4) - 1;
+
+    f32x4v xa[16], xb[16];
+#define SBEV_LOAD_X(dst, f)                                                                         \
+    {                                                                                               \
+        int row_ = 16 * (f) + fi;                                                                   \
+        row_ = row_ < M ? row_ : M - 1;                                                             \
+        const float* p_ = a.X + (long long)row_ * a.ldx + 4 * fk;                                   \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) dst[j] = *reinterpret_cast<const f32x4v*>(p_ + 16 * j); \
+    }
+#define SBEV_STRIP(src)                                                                             \
+    {                                                                                               \
+        _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) acc[cf] = (f32x4v){0.f, 0.f, 0.f, 0.f};    \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+                _Pragma("unroll") for (int cf = 0; cf < 4; ++cf)                                    \
+                    acc[cf] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][cf][i], src[j][i], acc[cf], 0, 0, 0); \
+    }
+#define SBEV_STORE(f)                                                                               \
+    {                                                                                               \
+        const int row_ = 16 * (f) + fi;                                                             \
+        if (row_ < M) {                                                                             \
+            float* y_ = a.Y + (long long)row_ * a.ldy + n0 + 4 * fk;                                \
+            _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) {                                      \
+                f32x4v v_ = acc[cf] + bias4[cf];                                                    \
+                if (a.relu) { v_[0] = fmaxf(v_[0], 0.f); v_[1] = fmaxf(v_[1], 0.f); v_[2] = fmaxf(v_[2], 0.f); v_[3] = fmaxf(v_[3], 0.f); } \
+                *reinterpret_cast<f32x4v*>(y_ + cf * 16) = v_;                                      \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+    // row fragments alternate between the two waves of a strip; which of them starts at 0 flips with the strip so
+    // that the odd extra fragment does not always land on the same SIMD pair.  With ONE wave per SIMD every non-MFMA
+    // instruction is dead matrix-core time, so: two register sets (xa / xb) used alternately (no rotate copies), the
+    // next fragment's X rows requested before each MFMA block, and the stores of fragment f issued at the top of
+    // block f+1 (the loop-top wait then never waits for store acks).
+    f32x4v acc[4];
+    int f = half ^ ((wave >> 1) & 1);
+    if (f > last) return;
+    int fprev = f;
+    SBEV_LOAD_X(xa, f);
+    { const int fn = f + 2 <= last ? f + 2 : last; SBEV_LOAD_X(xb, fn); }
+    __builtin_amdgcn_sched_barrier(0);
+    SBEV_STRIP(xa);
+    f += 2;
+    while (f <= last) {
+        __builtin_amdgcn_sched_barrier(0);
+        { const int fn = f + 2 <= last ? f + 2 : last; SBEV_LOAD_X(xa, fn); }     // unconditional (clamped) prefetch
+        SBEV_STORE(fprev);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch AHEAD of the MFMA block (hipcc sinks it otherwise)
+        SBEV_STRIP(xb);
+        fprev = f;
+        f += 2;
+        if (f > last) break;
+        __builtin_amdgcn_sched_barrier(0);
+        { const int fn = f + 2 <= last ? f + 2 : last; SBEV_LOAD_X(xb, fn); }
+        SBEV_STORE(fprev);
+        __builtin_amdgcn_sched_barrier(0);
+        SBEV_STRIP(xa);
+        fprev = f;
+        f += 2;
+    }
+    SBEV_STORE(fprev);
+#undef SBEV_STORE
+#undef SBEV_LOAD_X
+#undef SBEV_STRIP
+}
+
 struct ReduceArgs {
     const float* slabs;  // [splits, M, N]
     const float* bias;   // [N] or null
@@ -414,7 +513,11 @@ extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias
     const long long big = ((M + 127) / 128) * ((N + 127) / 128);
     SBEV_REQUIRE(big <= 0x3fffffffLL, "sbev_linear_f32: too many tiles");
     const long long small = ((M + 63) / 64) * ((N + 63) / 64);
-    if (K % BK != 0) {  // slow path (never taken by the decoder: its K are 256 / 512 / 32768)
+    if (K == 256 && N % 128 == 0 && N / 128 >= 192 && M < (1 << 24) && ldy % 4 == 0 && ((uintptr_t)Y & 15) == 0 &&
+        (!bias || ((uintptr_t)bias & 15) == 0) && !residual) {
+        // parameter-generator shape: W strips stationary in registers, all rows stream past (see the kernel's header)
+        hipLaunchKernelGGL(gemm_nt_f32_strip_kernel, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);
+    } else if (K % BK != 0) {  // slow path (never taken by the decoder: its K are 256 / 512 / 32768)
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, true>), dim3((unsigned)small), dim3(256), 0, s, a);
     } else if (big >= 256) {   // enough 128x128 tiles to fill the 256 CUs
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 2, 2, false>), dim3((unsigned)big), dim3(256), 0, s, a);

@@ -180,6 +180,22 @@ def test_bf16x3_linear_fp32_class_accuracy(M, N, K, splitk):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M', [1, 15, 16, 17, 33, 900, 1800])
+@pytest.mark.parametrize('N,relu,use_bias', [(32768, False, True), (24576, True, True), (24576, False, False)])
+def test_generator_strip_kernel_ragged_rows(M, N, relu, use_bias):
+    """[M,256] x [N,256]^T with N/128 >= 192 goes to the W-stationary strip kernel (gemm_nt_f32_strip_kernel): every
+    row-fragment remainder (M % 16, odd / even fragment counts for the two row-halves) against fp64."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, 256, generator=g)
+    w = torch.randn(N, 256, generator=g) / 16
+    b = torch.randn(N, generator=g) if use_bias else None
+    y = dense.linear(x.to(DEV), w.to(DEV), b.to(DEV) if use_bias else None, relu=relu)
+    ref = ref_linear(x, w, b, relu)
+    assert y.shape == (M, N)
+    assert (y.cpu().double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.gpu
 def test_linear_group_equals_single_launches():
     """sbev_linear_group_f32: the cls / reg branch levels launched side by side must give bit-identical results to
     one sbev_linear_f32 per problem (same tile arithmetic), for ragged M / N too."""

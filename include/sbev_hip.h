@@ -185,6 +185,8 @@ int sbev_linear_group_f32(const sbev_linear_problem* probs, int n, sbev_stream_t
  * reduction: + bias, optional ReLU, + residual (`query + out`, :379), optional LayerNorm(N) (norm2, :171).
  * workspace: device buffer of sbev_linear_splitk_workspace(M, N, splits) bytes.  N % 4 == 0, N <= 1024.
  */
+/* Recommended number of K splits for sbev_linear_splitk_f32 at this shape (fills the GPU once). */
+int sbev_linear_splitk_plan(int64_t M, int N, int K);
 int64_t sbev_linear_splitk_workspace(int64_t M, int N, int splits);
 int sbev_linear_splitk_f32(const float* X, const float* W, const float* bias, const float* residual,
                            const float* ln_w, const float* ln_b, float ln_eps, float* Y,

@@ -30,12 +30,7 @@ struct Buffers {
     size_t bytes;
 };
 
-int out_proj_splits(long long M, int N, int K) {
-    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    long long s = (512 + tiles - 1) / tiles;
-    if (s > K / 512) s = K / 512;
-    return (int)(s < 1 ? 1 : s);
-}
+int out_proj_splits(long long M, int N, int K) { return sbev_linear_splitk_plan(M, N, K); }
 
 Buffers carve(const sbev_decoder_config& c, void* ws) {
     Carver k(ws);

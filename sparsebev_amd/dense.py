@@ -55,7 +55,7 @@ def _splits_for(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if K < SPLITK_MIN_K or tiles >= 128 or N % 4 or N > 1024:
         return 1
-    return max(1, min(K // 512, (512 + tiles - 1) // tiles))
+    return int(_lib.load().sbev_linear_splitk_plan(M, N, K))
 
 
 def linear(x, w, b, relu=False, residual=None, ln=None, ln_relu=False):

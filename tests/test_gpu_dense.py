@@ -49,6 +49,23 @@ def test_out_proj_splitk_fused_epilogue():
     assert (y2.cpu().double() - ref_linear(x, w, b)).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize('M', [1, 47, 48, 49, 144, 900])
+@pytest.mark.parametrize('N,K', [(256, 32768), (128, 4096), (384, 2048 + 32)])
+def test_splitk_register_tiled_kernel_ragged(M, N, K):
+    """N % 128 == 0, K % 32 == 0 goes to gemm_nt_f32_regtile_kernel (48-row x 128-column wave tasks x K splits):
+    row remainders, uneven split boundaries (K/32 not divisible by the split count), with and without the fused LN."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    lnw, lnb = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    y = dense.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=res.to(DEV))
+    assert (y.cpu().double() - ref_linear(x, w, b, False, res)).abs().max() < 3e-5
+    y = dense.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=res.to(DEV), ln=(lnw.to(DEV), lnb.to(DEV)))
+    assert (y.cpu().double() - ref_linear(x, w, b, False, res, (lnw, lnb))).abs().max() < 1e-4
+
+
 def test_layer_norm_and_relu():
     g = torch.Generator().manual_seed(1)
     x = 3 * torch.randn(2, 450, 256, generator=g) + 1
@@ -179,7 +196,6 @@ def test_bf16x3_linear_fp32_class_accuracy(M, N, K, splitk):
     assert plain > 30 * err
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize('M', [1, 15, 16, 17, 33, 900, 1800])
 @pytest.mark.parametrize('N,relu,use_bias', [(32768, False, True), (24576, True, True), (24576, False, False)])
 def test_generator_strip_kernel_ragged_rows(M, N, relu, use_bias):
@@ -195,7 +211,6 @@ def test_generator_strip_kernel_ragged_rows(M, N, relu, use_bias):
     assert (y.cpu().double() - ref).abs().max() < 2e-5
 
 
-@pytest.mark.gpu
 def test_linear_group_equals_single_launches():
     """sbev_linear_group_f32: the cls / reg branch levels launched side by side must give bit-identical results to
     one sbev_linear_f32 per problem (same tile arithmetic), for ragged M / N too."""
@@ -217,7 +232,6 @@ def test_linear_group_equals_single_launches():
             assert (y.double() - t).abs().max() < 1e-4
 
 
-@pytest.mark.gpu
 def test_linear_group_rejects_bad_groups():
     dev = 'cuda:0'
     x = torch.zeros(8, 256, device=dev); w = torch.zeros(4, 256, device=dev)

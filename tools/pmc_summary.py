@@ -20,7 +20,8 @@ def per_kernel(path, counter):
 
 def short(name):
     for key in ('msmv_fwd_kernel', 'adaptive_mixing_kernel', 'transpose_tiles_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
-                'gemm_nt_f32_small_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3'):
+                'gemm_nt_f32_small_kernel', 'gemm_group_small_kernel', 'gemm_nt_f32_strip_kernel', 'gemm_nt_f32_regtile_kernel',
+                'sample_project_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3'):
         if key in name:
             return key
     return None
@@ -39,8 +40,8 @@ def main():
         res[s] = {'launches_sampled': n, 'FETCH_SIZE_KiB_raw': round(fk, 1), 'WRITE_SIZE_KiB': round(wk, 1),
                   'fetch_bytes_corrected_x2': int(2 * fk * 1024), 'write_bytes': int(wk * 1024),
                   'hbm_bytes_per_launch': int(2 * fk * 1024 + wk * 1024)}
-    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 3 '
-                       '--warmup 1 --no-cpu-baseline`; KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count, validated on '
+    json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 5 '
+                       '--warmup 2 --no-cpu-baseline --no-alt` (tools/profile_round.sh); KiB units; FETCH_SIZE x2 (gfx950 wide-read under-count, validated on '
                        'transpose_tiles_kernel whose true read bytes are known)', 'kernels': res}, open(out, 'w'), indent=1)
     for k, v in sorted(res.items()):
         print('%-28s fetch(corr) %8.1f MB  write %8.1f MB' % (k, v['fetch_bytes_corrected_x2'] / 1e6, v['write_bytes'] / 1e6))

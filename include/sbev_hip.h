@@ -250,6 +250,44 @@ int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* query_bbox, const 
 int sbev_refine_bbox(const float* query_bbox, const float* reg, const float* vel_div, float* out,
                      int B, int Q, int code_size, sbev_stream_t stream);
 
+/* ---- detection head pre / post-processing -------------------------------------------------- */
+
+/*
+ * Decoder inputs at inference (no query denoising).
+ * Replaces: SparseBEVHead.forward's `init_query_bbox.weight.clone()` + the eval branch of prepare_for_dn_input
+ *           (models/sparsebev_head.py:70,123-126,209-211).
+ * query_bbox[b] = init_query_bbox [Q,10];  query_feat[b,q] = [label_row (D-1 values = label_enc.weight[num_classes]), 0].
+ */
+int sbev_head_prepare(const float* init_query_bbox, const float* label_row, float* query_bbox, float* query_feat,
+                      int B, int Q, int D, sbev_stream_t stream);
+
+/*
+ * Decoder boxes -> head output format.
+ * Replaces: models/sparsebev_head.py:85-95 -- xyz * (pc_max - pc_min) + pc_min (two fp32 roundings each, as the
+ *           reference's separate mul and add) and the column reorder to (cx, cy, w, l, cz, h, sin, cos, vx, vy).
+ * bbox_norm / out: [n, 10] rows (n = num_layers * B * Q); in place (out == bbox_norm) is allowed.
+ */
+int sbev_head_denorm(const float* bbox_norm, const double* pc_range, float* out, int64_t n, sbev_stream_t stream);
+
+/*
+ * NMS-free box decoding of the last decoder layer.
+ * Replaces: NMSFreeCoder.decode_single (models/bbox/coders/nms_free_coder.py:37-88) with denormalize_bbox
+ *           (models/bbox/utils.py:26-47), per sample of NMSFreeCoder.decode (:90-111); with bottom_center != 0 also
+ *           the gravity-centre -> bottom-centre shift of SparseBEVHead.get_bboxes (models/sparsebev_head.py:471).
+ * cls_scores [B,Q,num_classes] logits, bbox_preds [B,Q,10] in the head format above.
+ * Top max_num of the Q*num_classes sigmoid scores (score descending; equal scores: lower flat index first -- torch.topk
+ * leaves that order unspecified), label = index % num_classes, box = bbox_preds[index / num_classes] denormalised to
+ * (cx, cy, cz, w, l, h, rot, vx, vy); kept iff the centre lies inside post_center_range [6] (required, like the
+ * reference) and, when use_score_threshold != 0, score > score_threshold.  Kept rows are compacted in order into
+ * boxes [B,max_num,9] / scores [B,max_num] / labels [B,max_num] (int32), the rest zero-filled; count[b] = rows kept.
+ * Limits: Q * num_classes <= 16384 (the per-sample sort lives in one CU's LDS), max_num <= 1024.
+ */
+int sbev_nms_free_decode(const float* cls_scores, const float* bbox_preds, int B, int Q, int num_classes, int max_num,
+                         float score_threshold, int use_score_threshold, const double* post_center_range,
+                         int bottom_center, float* boxes, float* scores, int32_t* labels, int32_t* count,
+                         sbev_stream_t stream);
+
+
 /*
  * Batched NCHW -> NHWC relayout of one pyramid level: in [n_images, channels, hw] -> out [n_images, hw, channels].
  * Replaces: the permute + contiguous feature regroup of the decoder (models/sparsebev_transformer.py:73-85); the

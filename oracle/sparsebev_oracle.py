@@ -381,3 +381,67 @@ def decoder(params, query_bbox, query_feat, mlvl_feats, img_metas, pc_range, num
 # --------------------------------------------------------------------------------------------
 def strip_prefix(state_dict, prefix='decoder.decoder_layer.'):
     return {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+
+
+# --------------------------------------------------------------------------------------------
+# detection-head pre / post-processing
+# --------------------------------------------------------------------------------------------
+def head_prepare(init_query_bbox, label_enc_weight, num_classes, B):
+    """models/sparsebev_head.py:70 + the eval branch of prepare_for_dn_input (:123-126,209-211).
+    init_query_bbox [Q,10], label_enc_weight [num_classes+1, D-1] -> query_bbox [B,Q,10], query_feat [B,Q,D]."""
+    Q = init_query_bbox.shape[0]
+    feat = torch.cat([label_enc_weight[num_classes].repeat(Q, 1), torch.zeros(Q, 1)], dim=1)
+    return init_query_bbox.clone().repeat(B, 1, 1), feat.repeat(B, 1, 1)
+
+
+def head_postprocess(bbox_preds, pc_range):
+    """models/sparsebev_head.py:85-95: centre back to metres (separate fp32 mul and add) and the head's column order
+    (cx, cy, w, l, cz, h, sin, cos, vx, vy).  bbox_preds [..., 10] as the decoder returns them."""
+    b = bbox_preds.clone()
+    b[..., 0] = b[..., 0] * (pc_range[3] - pc_range[0]) + pc_range[0]
+    b[..., 1] = b[..., 1] * (pc_range[4] - pc_range[1]) + pc_range[1]
+    b[..., 2] = b[..., 2] * (pc_range[5] - pc_range[2]) + pc_range[2]
+    return torch.cat([b[..., 0:2], b[..., 3:5], b[..., 2:3], b[..., 5:10]], dim=-1)
+
+
+def denormalize_bbox(nb):
+    """models/bbox/utils.py:26-47: (cx, cy, w, l, cz, h, sin, cos, vx, vy) -> (cx, cy, cz, w, l, h, rot, vx, vy)."""
+    rot = torch.atan2(nb[..., 6:7], nb[..., 7:8])
+    return torch.cat([nb[..., 0:2], nb[..., 4:5], nb[..., 2:4].exp(), nb[..., 5:6].exp(), rot, nb[..., 8:10]], dim=-1)
+
+
+def nms_free_decode_single(cls_scores, bbox_preds, num_classes, max_num, score_threshold, post_center_range):
+    """models/bbox/coders/nms_free_coder.py:37-88.  cls_scores [Q,NC] logits, bbox_preds [Q,10] head format.
+    Ties in the top-k are resolved by (score desc, flat index asc) -- torch.topk leaves them unspecified."""
+    s = cls_scores.sigmoid().reshape(-1)
+    order = sorted(range(s.numel()), key=lambda i: (-float(s[i]), i))[:max_num] if s.numel() <= 4096 else None
+    if order is None:                       # large inputs: stable argsort on the logits (same total order unless
+        key = cls_scores.reshape(-1)        # distinct logits collapse to one fp32 sigmoid value)
+        order = torch.argsort(-key.double(), stable=True)[:max_num].tolist()
+    idx = torch.tensor(order, dtype=torch.long)
+    scores = s[idx]
+    labels = idx % num_classes
+    boxes = denormalize_bbox(bbox_preds[torch.div(idx, num_classes, rounding_mode='trunc')])
+    limit = torch.tensor(post_center_range, dtype=torch.float32)
+    mask = (boxes[..., :3] >= limit[:3]).all(1) & (boxes[..., :3] <= limit[3:]).all(1)
+    if score_threshold:
+        mask &= scores > score_threshold
+    return {'bboxes': boxes[mask], 'scores': scores[mask], 'labels': labels[mask]}
+
+
+def nms_free_decode(all_cls_scores, all_bbox_preds, num_classes, max_num, score_threshold, post_center_range):
+    """models/bbox/coders/nms_free_coder.py:90-111: last decoder layer, one dict per sample."""
+    cls, box = all_cls_scores[-1], all_bbox_preds[-1]
+    return [nms_free_decode_single(cls[i], box[i], num_classes, max_num, score_threshold, post_center_range)
+            for i in range(cls.shape[0])]
+
+
+def get_bboxes(decoded):
+    """models/sparsebev_head.py:463-482 (VERSION v1.0.0): gravity centre -> bottom centre; returns
+    [boxes [n,9], scores, labels] per sample (the reference wraps boxes in LiDARInstance3DBoxes(bboxes, 9))."""
+    out = []
+    for d in decoded:
+        b = d['bboxes'].clone()
+        b[:, 2] = b[:, 2] - b[:, 5] * 0.5
+        out.append([b, d['scores'], d['labels']])
+    return out

@@ -1,0 +1,196 @@
+"""Inference side of ``SparseBEVHead`` and ``NMSFreeCoder`` on the device.
+
+Interface parity with the reference:
+  * ``NMSFreeCoder(pc_range, voxel_size=None, post_center_range=None, max_num=100, score_threshold=None,
+    num_classes=10)`` with ``decode(preds_dicts) -> [{'bboxes', 'scores', 'labels'}, ...]``
+    (``models/bbox/coders/nms_free_coder.py:20-33,90-111``) -- one kernel launch for the whole batch
+    (``sbev_nms_free_decode``: per-sample bitonic top-k in LDS + gather + denormalise + masks + compaction) instead of
+    ~25 small torch ops per sample;
+  * ``SparseBEVHead(num_classes, in_channels, num_query, transformer=dict(type='SparseBEVTransformer', ...),
+    bbox_coder=dict(type='NMSFreeCoder', ...), code_size=10, ...)``: same constructor keywords for the inference-relevant
+    part of ``configs/r50_nuimg_704x256.py:60-90``, same parameter names (``init_query_bbox.weight``,
+    ``label_enc.weight``, ``code_weights``, ``transformer.*``), same ``forward(mlvl_feats, img_metas) -> outs`` dict
+    (``models/sparsebev_head.py:69-117``) and ``get_bboxes(preds_dicts, img_metas)`` (``:463-482``; boxes are returned
+    as a plain ``[n, 9]`` tensor -- mmdet3d's ``LiDARInstance3DBoxes`` wrapper is the caller's).
+Training-only parts (query denoising, Hungarian assignment, losses: ``:128-204,215-461``) are out of scope and raise.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .transformer import SparseBEVTransformer, _Base
+
+try:  # optional: register with the OpenMMLab registries when that stack is present
+    from mmdet.core.bbox.builder import BBOX_CODERS as _CODERS
+    from mmdet.models import HEADS as _HEADS
+except Exception:  # noqa: BLE001
+    _CODERS = _HEADS = None
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError('sparsebev_amd.head needs device tensors (there is no CPU path)')
+        if t.dtype != torch.float32:
+            raise RuntimeError('sparsebev_amd.head needs float32 tensors (got %s)' % t.dtype)
+
+
+def head_prepare(init_query_bbox, label_enc_weight, num_classes, B):
+    """query_bbox [B,Q,10], query_feat [B,Q,D] of the eval branch (models/sparsebev_head.py:70,123-126,209-211)."""
+    _dev(init_query_bbox, label_enc_weight)
+    Q, D = init_query_bbox.shape[0], label_enc_weight.shape[1] + 1
+    row = label_enc_weight[num_classes].contiguous()
+    qb = torch.empty(B, Q, 10, device=row.device, dtype=torch.float32)
+    qf = torch.empty(B, Q, D, device=row.device, dtype=torch.float32)
+    st = _lib.load().sbev_head_prepare(_p(init_query_bbox.contiguous()), _p(row), _p(qb), _p(qf), B, Q, D, _stream())
+    _lib.check(st, 'sbev_head_prepare')
+    return qb, qf
+
+
+def head_postprocess(bbox_preds, pc_range):
+    """Decoder boxes [..., 10] -> the head's output format (models/sparsebev_head.py:85-95)."""
+    _dev(bbox_preds)
+    src = bbox_preds.contiguous()
+    out = torch.empty_like(src)
+    rng = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    st = _lib.load().sbev_head_denorm(_p(src), rng, _p(out), src.numel() // 10, _stream())
+    _lib.check(st, 'sbev_head_denorm')
+    return out
+
+
+def nms_free_decode(cls_scores, bbox_preds, num_classes, max_num, score_threshold, post_center_range, bottom_center=False):
+    """One launch for the batch: padded (boxes [B,max_num,9], scores, labels int32, count [B] int32)."""
+    _dev(cls_scores, bbox_preds)
+    B, Q, NC = cls_scores.shape
+    if NC != num_classes:
+        raise RuntimeError('cls_scores has %d classes, coder was built for %d' % (NC, num_classes))
+    if post_center_range is None:       # nms_free_coder.py:80-84
+        raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range is not None for now!')
+    dev = cls_scores.device
+    boxes = torch.empty(B, max_num, 9, device=dev, dtype=torch.float32)
+    scores = torch.empty(B, max_num, device=dev, dtype=torch.float32)
+    labels = torch.empty(B, max_num, device=dev, dtype=torch.int32)
+    count = torch.empty(B, device=dev, dtype=torch.int32)
+    lim = (ctypes.c_double * 6)(*[float(v) for v in post_center_range])
+    use_thr = 1 if score_threshold else 0                                    # `if self.score_threshold:` (:72)
+    st = _lib.load().sbev_nms_free_decode(_p(cls_scores.contiguous()), _p(bbox_preds.contiguous()), B, Q, NC, int(max_num),
+                                          float(score_threshold or 0.0), use_thr, lim, 1 if bottom_center else 0,
+                                          _p(boxes), _p(scores), _p(labels), _p(count), _stream())
+    _lib.check(st, 'sbev_nms_free_decode')
+    return boxes, scores, labels, count
+
+
+class NMSFreeCoder:
+    """models/bbox/coders/nms_free_coder.py:8-111."""
+
+    def __init__(self, pc_range, voxel_size=None, post_center_range=None, max_num=100, score_threshold=None, num_classes=10):
+        self.pc_range = pc_range
+        self.voxel_size = voxel_size
+        self.post_center_range = post_center_range
+        self.max_num = max_num
+        self.score_threshold = score_threshold
+        self.num_classes = num_classes
+
+    def encode(self):
+        pass
+
+    def _decode(self, preds_dicts, bottom_center):
+        cls, box = preds_dicts['all_cls_scores'][-1], preds_dicts['all_bbox_preds'][-1]
+        boxes, scores, labels, count = nms_free_decode(cls, box, self.num_classes, self.max_num, self.score_threshold,
+                                                       self.post_center_range, bottom_center)
+        counts = count.tolist()             # the one device -> host sync (the reference's boolean indexing syncs per sample)
+        return [{'bboxes': boxes[i, :n], 'scores': scores[i, :n], 'labels': labels[i, :n].long()} for i, n in enumerate(counts)]
+
+    def decode_single(self, cls_scores, bbox_preds):
+        return self._decode({'all_cls_scores': cls_scores[None, None], 'all_bbox_preds': bbox_preds[None, None]}, False)[0]
+
+    def decode(self, preds_dicts):
+        return self._decode(preds_dicts, False)
+
+
+def _register(registry, cls):
+    if registry is not None:
+        try:
+            return registry.register_module()(cls)
+        except KeyError:        # the reference's own class is already registered under this name
+            return cls
+    return cls
+
+
+NMSFreeCoder = _register(_CODERS, NMSFreeCoder)
+
+
+class SparseBEVHead(_Base):
+    """Inference-only ``SparseBEVHead`` (models/sparsebev_head.py:14-117,463-482)."""
+
+    def __init__(self, *args, num_classes, in_channels, num_query=900, query_denoising=True, query_denoising_groups=10,
+                 bbox_coder=None, code_size=10, code_weights=(1.0,) * 10, transformer=None, train_cfg=None,
+                 test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        self.num_classes, self.in_channels, self.embed_dims = num_classes, in_channels, in_channels
+        self.num_query, self.code_size = num_query, code_size
+        self.dn_enabled, self.dn_group_num = query_denoising, query_denoising_groups
+        self.train_cfg, self.test_cfg = train_cfg or {}, test_cfg or dict(max_per_img=100)
+        self.fp16_enabled = False
+        self.code_weights = nn.Parameter(torch.tensor(list(code_weights), dtype=torch.float32), requires_grad=False)
+        coder = dict(bbox_coder or {})
+        if coder.pop('type', 'NMSFreeCoder') != 'NMSFreeCoder':
+            raise ValueError('sparsebev_amd.SparseBEVHead decodes with NMSFreeCoder only')
+        self.bbox_coder = NMSFreeCoder(**coder)
+        self.pc_range = self.bbox_coder.pc_range
+        tr = dict(transformer or {})
+        if tr.pop('type', 'SparseBEVTransformer') != 'SparseBEVTransformer':
+            raise ValueError('sparsebev_amd.SparseBEVHead drives SparseBEVTransformer only')
+        self.transformer = SparseBEVTransformer(**tr)
+        self._init_layers()
+
+    def _init_layers(self):
+        """:49-67 -- queries on a sqrt(Q) x sqrt(Q) BEV grid, z = 0, h = 1.5 (log), zero velocity."""
+        self.init_query_bbox = nn.Embedding(self.num_query, 10)
+        self.label_enc = nn.Embedding(self.num_classes + 1, self.embed_dims - 1)
+        grid = int(math.sqrt(self.num_query))
+        assert grid * grid == self.num_query
+        with torch.no_grad():
+            w = self.init_query_bbox.weight
+            w[:, 2:3].zero_()
+            w[:, 8:10].zero_()
+            w[:, 5:6].fill_(1.5)
+            xx, yy = torch.meshgrid(torch.arange(grid), torch.arange(grid), indexing='ij')
+            w[:, :2] = ((torch.stack([xx, yy], dim=-1).float() + 0.5) / grid).reshape(-1, 2)
+
+    def init_weights(self):
+        self.transformer.init_weights()
+
+    def forward(self, mlvl_feats, img_metas):
+        if self.training:
+            raise NotImplementedError('sparsebev_amd.SparseBEVHead is the inference head: query denoising / losses '
+                                      '(models/sparsebev_head.py:128-204,215-461) are out of scope -- call .eval()')
+        B = mlvl_feats.B if hasattr(mlvl_feats, 'levels') else mlvl_feats[0].shape[0]
+        with torch.no_grad():
+            query_bbox, query_feat = head_prepare(self.init_query_bbox.weight, self.label_enc.weight, self.num_classes, B)
+            cls_scores, bbox_preds = self.transformer(query_bbox, query_feat, mlvl_feats, attn_mask=None, img_metas=img_metas)
+            bbox_preds = head_postprocess(bbox_preds, self.pc_range)
+        return {'all_cls_scores': cls_scores, 'all_bbox_preds': bbox_preds, 'enc_cls_scores': None, 'enc_bbox_preds': None}
+
+    def get_bboxes(self, preds_dicts, img_metas=None, rescale=False):
+        """:463-482 (VERSION v1.0.0): [[boxes [n,9] with bottom-centre z, scores, labels], ...]; the gravity -> bottom
+        centre shift is done inside the decode kernel."""
+        dec = self.bbox_coder._decode(preds_dicts, True)
+        return [[d['bboxes'], d['scores'], d['labels']] for d in dec]
+
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError('training losses are out of scope (SURVEY.md section 8f rank 4)')
+
+
+SparseBEVHead = _register(_HEADS, SparseBEVHead)

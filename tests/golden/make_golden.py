@@ -261,5 +261,41 @@ def main():
                  params_checksum=S.checksum(params), feats_checksum=S.checksum(feats))
 
 
+def main_head():
+    """G9: the reference's NMSFreeCoder.decode (models/bbox/coders/nms_free_coder.py) and denormalize_bbox
+    (models/bbox/utils.py), executed as they are -- the only stand-ins are mmdet's registry decorator and the empty
+    BaseBBoxCoder base class the coder file imports.  `python tests/golden/make_golden.py head` writes only G9."""
+    class _Registry:
+        def register_module(self):
+            return lambda cls: cls
+
+    _stub('models', REF + '/models'); _stub('models.bbox', REF + '/models/bbox'); _stub('models.bbox.coders', REF + '/models/bbox/coders')
+    _stub('mmdet'); _stub('mmdet.core'); _stub('mmdet.core.bbox', BaseBBoxCoder=object)
+    _stub('mmdet.core.bbox.builder', BBOX_CODERS=_Registry())
+    coder_mod = importlib.import_module('models.bbox.coders.nms_free_coder')
+    butils = importlib.import_module('models.bbox.utils')
+    pc_range = S.PC_RANGE
+    post = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]                     # configs/r50_nuimg_704x256.py:80-87
+    for tag, B, Q, NC, max_num, thr in (('c2', 2, 900, 10, 300, 0.05), ('small', 3, 36, 10, 100, None), ('few', 1, 16, 3, 48, 0.3)):
+        g = torch.Generator().manual_seed(900 + Q)
+        cls = torch.randn(2, B, Q, NC, generator=g) * 2 - 2.5           # mostly below the threshold, like a trained head
+        box = torch.randn(2, B, Q, 10, generator=g)
+        box[..., 0:2] = box[..., 0:2] * 40                              # some centres outside +-61.2 m
+        box[..., 4] = box[..., 4] * 6                                   # some cz outside +-10 m
+        box[..., 2:4] = box[..., 2:4] * 0.3 + 0.5
+        box[..., 5] = box[..., 5] * 0.3 + 0.4
+        coder = coder_mod.NMSFreeCoder(pc_range, post_center_range=post, max_num=max_num, score_threshold=thr, num_classes=NC)
+        dec = coder.decode({'all_cls_scores': cls, 'all_bbox_preds': box})
+        arrays = dict(cls=cls, box=box, cfg=np.array([B, Q, NC, max_num]), thr=np.array(-1.0 if thr is None else thr),
+                      post=np.array(post), denorm_all=butils.denormalize_bbox(box[-1]))
+        for i, d in enumerate(dec):
+            arrays['bboxes%d' % i], arrays['scores%d' % i], arrays['labels%d' % i] = d['bboxes'], d['scores'], d['labels']
+        save('g9_nms_free_' + tag, **arrays)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'head':
+        main_head()
+    else:
+        main()
+        main_head()

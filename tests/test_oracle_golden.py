@@ -173,3 +173,35 @@ def test_g8_sampler_backward_restatement(tag):
     scale = max(1.0, g['grad_loc_xy'].abs().max().item())
     assert (gl[..., :2] - g['grad_loc_xy']).abs().max() < TOL * scale
     assert gl[..., 2].abs().max() == 0
+
+
+@pytest.mark.parametrize('tag', ['c2', 'small', 'few'])
+def test_g9_nms_free_decode_restatement(tag):
+    """oracle.nms_free_decode / denormalize_bbox vs the reference's NMSFreeCoder.decode run on the same tensors."""
+    g = load_golden('g9_nms_free_' + tag)
+    B, Q, NC, max_num = [int(v) for v in g['cfg']]
+    thr = float(g['thr'])
+    thr = None if thr < 0 else thr
+    assert torch.equal(O.denormalize_bbox(g['box'][-1]), g['denorm_all'])
+    dec = O.nms_free_decode(g['cls'], g['box'], NC, max_num, thr, [float(v) for v in g['post']])
+    assert len(dec) == B
+    for i, d in enumerate(dec):
+        assert torch.equal(d['labels'], g['labels%d' % i])
+        assert torch.equal(d['scores'], g['scores%d' % i])
+        assert torch.equal(d['bboxes'], g['bboxes%d' % i])
+    kept = sum(len(d['scores']) for d in dec)
+    assert 0 < kept < B * max_num            # both masks are exercised
+
+
+def test_head_prepare_and_postprocess_restatement():
+    """Shapes / values of the head's eval-branch query init and of its output re-formatting (no golden: the head class
+    itself needs mmdet's DETRHead; the six arithmetic lines are restated from models/sparsebev_head.py:85-95)."""
+    g = torch.Generator().manual_seed(5)
+    init, lab = torch.rand(16, 10, generator=g), torch.randn(11, 255, generator=g)
+    qb, qf = O.head_prepare(init, lab, 10, 3)
+    assert qb.shape == (3, 16, 10) and qf.shape == (3, 16, 256)
+    assert torch.equal(qb[2], init) and torch.equal(qf[1, 7, :255], lab[10]) and float(qf[..., 255].abs().max()) == 0.0
+    box = torch.rand(2, 3, 16, 10, generator=g)
+    out = O.head_postprocess(box, S.PC_RANGE)
+    assert torch.equal(out[..., 0], box[..., 0] * 102.4 + (-51.2)) and torch.equal(out[..., 4], box[..., 2] * 8.0 + (-5.0))
+    assert torch.equal(out[..., 2:4], box[..., 3:5]) and torch.equal(out[..., 5:], box[..., 5:])

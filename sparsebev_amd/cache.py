@@ -33,15 +33,22 @@ class FrameFeatureCache:
                         for f in frame_feats]
 
     def push(self, frame_feats):
-        """frame_feats: list[L] of [B, 6, C, H_l, W_l] fp32 device tensors = the neck's output for the 6 NEW images."""
+        """frame_feats: list[L] of [B, 6, C, H_l, W_l] device tensors = the neck's output for the 6 NEW images.
+        fp32 NCHW memory is relayouted by the transpose kernel; channels-last memory (what a channels_last conv stack
+        emits; fp32 / fp16 / bf16) is already in the ring's layout and only copied (and widened) into its slot."""
         if self.buffers is None:
             self._alloc(frame_feats)
         slot = len(self.order) if len(self.order) < self.n_slots else self.order.pop()      # free slot, else evict the oldest
         lib = _lib.load()
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for f, buf in zip(frame_feats, self.buffers):
-            if not f.is_cuda or f.dtype != torch.float32 or f.shape[0] != self.B or f.shape[1] != N_VIEWS:
-                raise RuntimeError('frame features must be fp32 device tensors [B, 6, C, H, W]')
+            if not f.is_cuda or f.shape[0] != self.B or f.shape[1] != N_VIEWS:
+                raise RuntimeError('frame features must be device tensors [B, 6, C, H, W]')
+            if f.stride(2) == 1 and f[0].is_contiguous(memory_format=torch.channels_last):      # NHWC memory: zero relayout
+                buf[:, slot].copy_(f.permute(0, 1, 3, 4, 2))
+                continue
+            if f.dtype != torch.float32:
+                raise RuntimeError('NCHW frame features must be fp32 (channels-last inputs may be fp16 / bf16)')
             f = f.contiguous()
             C, H, W = f.shape[2:]
             for b in range(self.B):

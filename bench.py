@@ -55,6 +55,9 @@ CONFIGS = {
     'c3': ('r50_704x256', 400, 8, 8, torch.float32),
     'c4': ('r101_1408x512', 900, 8, 4, torch.float32),
     'c1': ('r50_704x256', 100, 1, 1, torch.float32),
+    # configs[4] at one sample per GPU: ViT-scale 1600x640 maps, 5 levels, bf16 feature STORAGE (fp32 math), channels-last
+    # as a bf16 neck would emit them (2.1 GB of features per sample): the large-feature-map HBM stress
+    'c5': ('eva02_1600x640', 900, 8, 1, torch.bfloat16),
 }
 
 
@@ -193,7 +196,8 @@ def main():
     shard = SampleShard(rank, world)
     # per-rank synthetic inputs (seed = rank), generated on the device and left resident
     feats = S.make_features(B, T, sizes, seed=rank, device=device, dtype=fdtype)
-    if args.nhwc:
+    if args.nhwc or fdtype != torch.float32:
+        args.nhwc = True
         feats = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
     bbox, qfeat = S.make_queries(B, Q, seed=rank)
     bbox, qfeat = bbox.to(device), qfeat.to(device)

@@ -114,6 +114,99 @@ __global__ __launch_bounds__(256) void msmv_bwd_kernel(const BwdArgs a) {
     }
 }
 
+
+// ---- C == 64 fast path (the decoder's 64 channels per group) ------------------------------------------------------
+// Same ownership (one wave per (b', q)) but lane = CHANNEL and the 4 bilinear corners live in registers: every load
+// and every atomic instruction covers one corner's 64 contiguous channels = two full 128-byte lines, and the channel
+// dot products need no cross-lane work until the per-point DPP sums.  One point at a time: all 4*L corner taps of the
+// point are requested up front as unconditional (clamped) loads, then consumed.
+// Bound: the L2 atomic units.  Config 2 issues 118 M float atomics per call and runs at 370 us = 318 G atomics/s
+// = ~1.2 per L2-channel clock (128 channels), with clustered (projected) and with uniformly random sample locations
+// alike -- so it is the atomic ALU rate, not same-address contention, and only fewer atomic dwords would go faster.
+// Occupancy is what keeps that pipe full, so the kernel is kept small (32-bit offsets, no multi-point staging): a
+// 4-point-chunk version needed 312 registers (1 wave per SIMD) and took 848 us; 16-byte-per-lane loads with
+// stride-16-byte atomics 1635 us (4x more cache lines per instruction); the generic corner x 16-channel kernel 395 us.
+template <int L>
+__global__ __launch_bounds__(256) void msmv_bwd_c64_kernel(const BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wave = (long long)blockIdx.x * 4 + wv;
+    if (wave >= a.n_waves) return;
+    const long long bp = wave / a.Q;
+    const long long bo = bp / a.gdiv, gi = bp - bo * a.gdiv;
+    const int P = a.P;
+    const float* __restrict__ locq = a.loc + wave * P * 3;
+    const float* __restrict__ wq = a.w + wave * P * L;
+    const float* __restrict__ gq = a.gout + wave * 64 * P + lane * P;        // this lane's channel row of [C, P]
+    const float nm1 = (float)(a.N - 1);
+    const float* fb[L];
+    float* gb[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {                     // (b', group) base of every level: the rest fits 32 bits (checked by the host)
+        const long long o = bo * a.stride_bo[l] + gi * a.stride_g + lane;
+        fb[l] = a.feat[l] + o;
+        gb[l] = a.gfeat[l] + o;
+    }
+
+    for (int p = 0; p < P; ++p) {
+        const float x = locq[p * 3 + 0], y = locq[p * 3 + 1];
+        int view = (int)roundf(locq[p * 3 + 2] * nm1);
+        view = min(max(view, 0), a.N - 1);
+        const float g = gq[p];
+        float v[L][4], lhs[L], lws[L];
+        int off[L][4], msk[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int H = a.H[l], W = a.W[l];
+            const float h_im = y * (float)(H - 1), w_im = x * (float)(W - 1);
+            const bool lvl_ok = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            lhs[l] = h_im - hf;
+            lws[l] = w_im - wf;
+            const int vb = view * (int)a.stride_v[l];
+            int mk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int hc = (int)hf + (k >> 1), wc = (int)wf + (k & 1);
+                const bool inb = lvl_ok && hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
+                mk |= inb ? (1 << k) : 0;
+                off[l][k] = vb + (min(max(hc, 0), H - 1) * W + min(max(wc, 0), W - 1)) * (int)a.stride_px;
+                v[l][k] = fb[l][off[l][k]];
+            }
+            msk[l] = mk;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float gx = 0.f, gy = 0.f, gwl[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float lh = lhs[l], lw = lws[l], hh = 1.f - lh, hw = 1.f - lw;
+            const int mk = msk[l];
+            // out-of-map corners contribute 0 to every sum: mask the VALUE, as the reference does (:54-67)
+            const float m0 = mk & 1 ? v[l][0] : 0.f, m1 = mk & 2 ? v[l][1] : 0.f, m2 = mk & 4 ? v[l][2] : 0.f, m3 = mk & 8 ? v[l][3] : 0.f;
+            const float wl = wq[p * L + l];
+            gwl[l] = g * ((hh * hw * m0 + hh * lw * m1) + (lh * hw * m2 + lh * lw * m3));
+            gx += g * (hh * (m1 - m0) + lh * (m3 - m2)) * (wl * (float)(a.W[l] - 1));
+            gy += g * (hw * (m2 - m0) + lw * (m3 - m1)) * (wl * (float)(a.H[l] - 1));
+            const float gv = wl * g;
+            if (mk & 1) atomicAdd(gb[l] + off[l][0], hh * hw * gv);      // global_atomic_add_f32, no return; wave-uniform guards
+            if (mk & 2) atomicAdd(gb[l] + off[l][1], hh * lw * gv);
+            if (mk & 4) atomicAdd(gb[l] + off[l][2], lh * hw * gv);
+            if (mk & 8) atomicAdd(gb[l] + off[l][3], lh * lw * gv);
+        }
+        gx = sbev::wave_sum_dpp(gx);
+        gy = sbev::wave_sum_dpp(gy);
+#pragma unroll
+        for (int l = 0; l < L; ++l) gwl[l] = sbev::wave_sum_dpp(gwl[l]);
+        if (lane == 0) {
+            float* o = a.gloc + (wave * P + p) * 3;
+            o[0] = gx; o[1] = gy; o[2] = 0.f;
+            float* ow = a.gw + (wave * P + p) * L;
+#pragma unroll
+            for (int l = 0; l < L; ++l) ow[l] = gwl[l];
+        }
+    }
+}
+
 template <int L>
 int launch_bwd(const BwdArgs& a, hipStream_t s) {
     const long long blocks = (a.n_waves + 3) / 4;
@@ -121,7 +214,13 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
         sbev::set_error("sbev_msmv_bwd: B'*Q too large");
         return SBEV_EINVAL;
     }
-    hipLaunchKernelGGL(msmv_bwd_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    bool fast = a.C == 64 && a.stride_px < (1 << 20);
+    for (int l = 0; l < L; ++l)      // everything below the (b', group) base must fit a 32-bit offset
+        fast = fast && a.stride_v[l] * a.N + (long long)a.H[l] * a.W[l] * a.stride_px < 0x7fffffffLL;
+    if (fast)
+        hipLaunchKernelGGL(msmv_bwd_c64_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(msmv_bwd_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return sbev::check_launch("sbev_msmv_bwd");
 }
 

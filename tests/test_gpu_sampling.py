@@ -220,3 +220,28 @@ def test_msmv_backward_full_size_vs_oracle_sample():
     assert (lc.grad[b:b + 1].cpu() - gl).abs().max() < 5e-4 * max(1.0, gl.abs().max().item())
     for a, r in zip(fl, gf):
         assert (a.grad[b:b + 1].cpu() - r).abs().max() < 5e-4
+
+
+@pytest.mark.parametrize('P,L,C', [(6, 4, 64), (1, 5, 64), (9, 2, 64), (5, 3, 24)])
+def test_msmv_backward_point_tails_and_both_kernels_vs_oracle(P, L, C):
+    """Backward with point counts that are not multiples of the 4-point chunk (C = 64 fast kernel) and a channel count
+    that takes the generic kernel; coordinates include out-of-map taps and exact grid points."""
+    from oracle import sparsebev_oracle as O
+    g = torch.Generator().manual_seed(P * 10 + L)
+    sizes = [(9, 14), (5, 7), (3, 4), (2, 2), (1, 3)][:L]
+    Bp, Q = 3, 10
+    feats = [torch.randn(Bp, 6, h, w, C, generator=g) for h, w in sizes]
+    loc = torch.rand(Bp, Q, P, 3, generator=g) * 1.3 - 0.15
+    loc[..., 2] = torch.randint(0, 6, (Bp, Q, P), generator=g).float() / 5
+    loc[0, 0, 0, :2] = torch.tensor([0.0, 1.0])
+    loc[0, 1, 0, :2] = torch.tensor([0.5, 0.5])
+    wts = torch.softmax(torch.randn(Bp, Q, P, L, generator=g), -1)
+    gout = torch.randn(Bp, Q, C, P, generator=g)
+    fl = [f.to(DEV).requires_grad_(True) for f in feats]
+    lc, ww = loc.to(DEV).requires_grad_(True), wts.to(DEV).requires_grad_(True)
+    ops.msmv_sampling(fl, lc, ww).backward(gout.to(DEV))
+    gf, gl, gw = O.msmv_sampling_backward(feats, loc, wts, gout)
+    assert (ww.grad.cpu() - gw).abs().max() < 1e-4
+    assert (lc.grad.cpu() - gl).abs().max() < 1e-4 * max(1.0, gl.abs().max().item())
+    for a_, r in zip(fl, gf):
+        assert (a_.grad.cpu() - r).abs().max() < 1e-4

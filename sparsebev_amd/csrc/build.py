@@ -18,6 +18,8 @@ UNITS = {
     # hardware float atomics (global_atomic_add_f32) for the grad_value scatter instead of a CAS loop
     'msmv_sampling_bwd.hip': ['-munsafe-fp-atomics'],
     'gemm.hip': [],
+    # VGPR-form MFMAs: the kernel fits 256 VGPRs, AGPR-form costs 144 accumulator copies per loop iteration
+    'gemm_regtile.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
     'gemm_bf16x3.hip': [],
     'mixing.hip': [],
     'attention.hip': [],

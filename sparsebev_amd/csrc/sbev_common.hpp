@@ -30,6 +30,10 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// gemm_regtile.hip: the split-K partial-slab GEMM of sbev_linear_splitk_f32 for N % 128 == 0, K % 32 == 0
+int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
+                          int splits, hipStream_t stream);
+
 // optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
 void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1);

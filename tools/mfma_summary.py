@@ -1,0 +1,44 @@
+"""Summarise a rocprofv3 `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace` pass (tools/profile_round.sh)
+into profiles/<round>_mfma_summary.json: per kernel, MFMA-pipe utilisation = busy cycles summed over the SIMDs /
+(GUI-active cycles x 1024 SIMDs) -- rocprofv3's own `MfmaUtil` expression -- and the shader clock the launch ran at
+(GUI-active cycles / traced duration).  Usage: python tools/mfma_summary.py <counter_csv> <kernel_trace_csv> <out_json>"""
+import collections
+import csv
+import json
+import sys
+
+SIMDS = 256 * 4
+
+
+def main():
+    counters, trace, out = sys.argv[1:4]
+    dur = {}
+    for r in csv.DictReader(open(trace)):
+        dur[r['Dispatch_Id']] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9
+    per = collections.defaultdict(dict)
+    name = {}
+    for r in csv.DictReader(open(counters)):
+        per[r['Dispatch_Id']][r['Counter_Name']] = per[r['Dispatch_Id']].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+        name[r['Dispatch_Id']] = r['Kernel_Name']
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0])
+    for d, c in per.items():
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c or d not in dur:
+            continue
+        a = agg[name[d].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')]
+        a[0] += c['SQ_VALU_MFMA_BUSY_CYCLES']; a[1] += c['GRBM_GUI_ACTIVE']; a[2] += dur[d]; a[3] += 1
+    res = {}
+    for k, (busy, gui, t, n) in agg.items():
+        if busy <= 0 or n == 0:
+            continue
+        res[k] = {'launches': n, 'mfma_busy_cycles_per_launch': round(busy / n), 'gui_active_cycles_per_launch': round(gui / n),
+                  'avg_us_under_pmc': round(1e6 * t / n, 2), 'mfma_util_pct': round(100 * busy / (gui * SIMDS), 1),
+                  'clock_ghz': round(gui / t / 1e9, 3) if t > 0 else None}
+    json.dump({'note': 'MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * 1024 SIMDs); clock = GRBM_GUI_ACTIVE / traced '
+                       'duration; counter passes serialise kernels, durations are NOT comparable with un-profiled runs', 'kernels': res},
+              open(out, 'w'), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]['mfma_util_pct']):
+        print('%-44s util %5.1f %%  clock %s GHz  %8.1f us  (%d launches)' % (k[:44], v['mfma_util_pct'], v['clock_ghz'], v['avg_us_under_pmc'], v['launches']))
+
+
+if __name__ == '__main__':
+    main()

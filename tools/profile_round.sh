@@ -16,3 +16,4 @@ find $OUT -name "*.csv" | head -20
 for c in c1 c3 c4; do python $R/bench.py --config $c --no-cpu-baseline --no-alt --steps 30 2>/dev/null | tail -1 | cut -c1-200; done
 python $R/bench.py --nhwc --no-cpu-baseline --no-alt --steps 50 2>/dev/null | tail -1 | cut -c1-200
 python $R/bench.py --online --no-cpu-baseline --no-alt --steps 50 2>/dev/null | tail -1 | cut -c1-200
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $R/bench.py --no-cpu-baseline --no-alt --steps 5 --warmup 2 > $OUT/pmc_mfma.log 2>&1

@@ -270,8 +270,9 @@ class SparseBEVTransformerDecoder(_Base):
         super().__init__(init_cfg)
         self.num_layers, self.pc_range = num_layers, list(pc_range)
         self._runtime = None
-        self.overlap = False        # opt-in two-stream fork/join in the C++ runtime (generator GEMM || sampling chain): measured
-                                    # +1 % samples/s at c2 -- the kernels time-share the CUs -- and it doubles the sampler's wall time
+        self.overlap = False        # opt-in two-stream fork/join in the C++ runtime (1: generator GEMM || sampling chain, 2: only the
+                                    # classification branch aside): measured -3 % samples/s at c2 -- the big kernels fill every CU, and
+                                    # the forked path cannot use the grouped branch launches
         self.gemm_mode = 0          # 0 = exact fp32 MFMA (default); 1 = opt-in 3 x bf16 split for the two big mixing GEMMs
         self.decoder_layer = SparseBEVTransformerDecoderLayer(embed_dims, num_frames, num_points, num_levels,
                                                               num_classes, code_size, pc_range=pc_range)

@@ -250,38 +250,6 @@ int sbev_sasa_f32(const float* qkvt, int64_t ld, const float* query_bbox, const 
 int sbev_refine_bbox(const float* query_bbox, const float* reg, const float* vel_div, float* out,
                      int B, int Q, int code_size, sbev_stream_t stream);
 
-/* ---- row-wise operator chains (one launch for a run of per-query ops) -------------------------------------------- */
-
-/*
- * A workgroup owns 16 rows and executes `ops` in order; activations live in three LDS buffers (0, 1, 2: 16 rows x 512
- * floats each), only what an op names in out_g reaches HBM.  Replaces runs of nn.Linear / LayerNorm / ReLU / residual
- * add / refine_bbox between the big kernels of a decoder layer (models/sparsebev_transformer.py:116-153,162-187, the
- * mmcv FFN and the MultiheadAttention in/out projections).  Per op, in this order:
- *   LOAD     dst[:, 0:N] = W_rows[M, ld_in]                      (W = source rows)
- *   LINEAR   y = src[:, 0:K] . W[N,K]^T + bias; ReLU if relu; y += res_buf (LDS) ; y += res_g rows (HBM)
- *   LINEAR3  y = src[:, 0:3] . W[N,3]^T + bias; ReLU if relu     (the position encoder's first layer)
- *   REFINE   y = refine_bbox(reg = src[:, 0:N], previous boxes = W rows [M, ld_in]); y[8:] /= aux[row / aux_i] if aux
- *   then, for LOAD / LINEAR / LINEAR3 with ln != 0: y = LayerNorm_N(y) * ln_w + ln_b; ReLU if ln == 2;
- *                                                     y += add_buf (LDS); y += add_g rows (HBM)
- *   y -> dst (if to_lds) and -> out_g rows [M, ld_out] (if out_g).
- * LINEAR: K in {128, 256, 384, 512}, N <= 1024 (N <= 512 and N % 4 == 0 to stay in LDS), src != dst.
- */
-enum { SBEV_CHAIN_LOAD = 0, SBEV_CHAIN_LINEAR = 1, SBEV_CHAIN_LINEAR3 = 2, SBEV_CHAIN_REFINE = 3 };
-#define SBEV_CHAIN_MAX_OPS 14
-typedef struct sbev_chain_op {
-    const float* W;
-    const float* bias;
-    const float* res_g;
-    const float* ln_w;
-    const float* ln_b;
-    const float* add_g;
-    float* out_g;
-    const float* aux;
-    int64_t ld_in, ld_res, ld_add, ld_out;
-    int32_t kind, K, N, src, dst, relu, res_buf, ln, add_buf, to_lds, aux_i, reserved;
-} sbev_chain_op;
-int sbev_row_chain(const sbev_chain_op* ops, int n_ops, int64_t M, float ln_eps, sbev_stream_t stream);
-
 /* ---- detection head pre / post-processing -------------------------------------------------- */
 
 /*

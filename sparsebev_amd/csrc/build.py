@@ -24,7 +24,6 @@ UNITS = {
     'mixing.hip': [],
     'attention.hip': [],
     'layout.hip': [],
-    'rowchain.hip': [],
     'head.hip': ['-ffp-contract=off'],   # __fmul_rn / __fadd_rn are plain * and + in HIP: keep them unfused
     'decoder.hip': [],
     # bit-exact projection: no FMA contraction anywhere in this file

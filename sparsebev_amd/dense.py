@@ -14,7 +14,6 @@ from . import _lib
 NATIVE = {
     'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
     'linear_group': 'hip: gemm_group_small_kernel (cls / reg branch levels side by side)',
-    'row_chain': 'hip: row_chain_kernel (runs of Linear / LayerNorm / ReLU / residual / refine per 16-row workgroup, v_mfma_f32_16x16x4_f32)',
     'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',
     'linear_ln_relu': 'hip: gemm + LayerNorm/ReLU reducer; Linear(3->D): linear3_ln_relu_kernel',
     'self_attention': 'hip: gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
@@ -119,47 +118,6 @@ def linear_group(problems):
     st = _lib.load().sbev_linear_group_f32(ctypes.cast(arr, ctypes.c_void_p), n, _stream())
     _lib.check(st, 'sbev_linear_group_f32')
     return outs
-
-
-class ChainOp(ctypes.Structure):
-    """struct sbev_chain_op (include/sbev_hip.h)"""
-    _fields_ = [(n, ctypes.c_void_p) for n in ('W', 'bias', 'res_g', 'ln_w', 'ln_b', 'add_g', 'out_g', 'aux')] + \
-               [(n, ctypes.c_int64) for n in ('ld_in', 'ld_res', 'ld_add', 'ld_out')] + \
-               [(n, ctypes.c_int32) for n in ('kind', 'K', 'N', 'src', 'dst', 'relu', 'res_buf', 'ln', 'add_buf', 'to_lds', 'aux_i', 'reserved')]
-
-
-CHAIN_LOAD, CHAIN_LINEAR, CHAIN_LINEAR3, CHAIN_REFINE = 0, 1, 2, 3
-
-
-def chain_op(kind, W, N, K=0, src=0, dst=0, bias=None, relu=False, res_buf=-1, res_g=None, ln=None, ln_relu=False,
-             add_buf=-1, add_g=None, out_g=None, to_lds=True, aux=None, aux_i=0):
-    """One op of a row chain (see sbev_row_chain in include/sbev_hip.h).  Tensor arguments are 2-D fp32 device tensors
-    (rows x columns, last dim contiguous); the caller keeps them alive until the launch."""
-    o = ChainOp()
-    o.kind, o.K, o.N, o.src, o.dst, o.relu = kind, K, N, src, dst, int(relu)
-    o.res_buf, o.add_buf, o.to_lds, o.aux_i = res_buf, add_buf, int(to_lds), aux_i
-    o.ln = 0 if ln is None else (2 if ln_relu else 1)
-    o.W, o.bias = W.data_ptr(), bias.data_ptr() if bias is not None else None
-    if kind in (CHAIN_LOAD, CHAIN_REFINE):
-        o.ld_in = W.stride(0)
-    if res_g is not None:
-        o.res_g, o.ld_res = res_g.data_ptr(), res_g.stride(0)
-    if ln is not None:
-        o.ln_w, o.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
-    if add_g is not None:
-        o.add_g, o.ld_add = add_g.data_ptr(), add_g.stride(0)
-    if out_g is not None:
-        o.out_g, o.ld_out = out_g.data_ptr(), out_g.stride(0)
-    if aux is not None:
-        o.aux = aux.data_ptr()
-    return o
-
-
-def row_chain(ops, M, eps=1e-5):
-    """Run a list of ChainOp over M rows in one launch (csrc/rowchain.hip)."""
-    arr = (ChainOp * len(ops))(*ops)
-    st = _lib.load().sbev_row_chain(ctypes.cast(arr, ctypes.c_void_p), len(ops), M, eps, _stream())
-    _lib.check(st, 'sbev_row_chain')
 
 
 def layer_norm(x, w, b, eps=1e-5, relu=False, add_after=None):

@@ -8,6 +8,7 @@ import json
 import sys
 
 SIMDS = 256 * 4
+XCDS = 8        # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs of the device
 
 
 def main():
@@ -24,8 +25,8 @@ def main():
     for d, c in per.items():
         if 'SQ_VALU_MFMA_BUSY_CYCLES' not in c or 'GRBM_GUI_ACTIVE' not in c or d not in dur:
             continue
-        a = agg[name[d].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')]
-        a[0] += c['SQ_VALU_MFMA_BUSY_CYCLES']; a[1] += c['GRBM_GUI_ACTIVE']; a[2] += dur[d]; a[3] += 1
+        a = agg[name[d].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]]
+        a[0] += c['SQ_VALU_MFMA_BUSY_CYCLES']; a[1] += c['GRBM_GUI_ACTIVE'] / XCDS; a[2] += dur[d]; a[3] += 1
     res = {}
     for k, (busy, gui, t, n) in agg.items():
         if busy <= 0 or n == 0:
@@ -33,7 +34,7 @@ def main():
         res[k] = {'launches': n, 'mfma_busy_cycles_per_launch': round(busy / n), 'gui_active_cycles_per_launch': round(gui / n),
                   'avg_us_under_pmc': round(1e6 * t / n, 2), 'mfma_util_pct': round(100 * busy / (gui * SIMDS), 1),
                   'clock_ghz': round(gui / t / 1e9, 3) if t > 0 else None}
-    json.dump({'note': 'MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * 1024 SIMDs); clock = GRBM_GUI_ACTIVE / traced '
+    json.dump({'note': 'MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE per XCD * 1024 SIMDs); clock = GRBM_GUI_ACTIVE per XCD / traced '
                        'duration; counter passes serialise kernels, durations are NOT comparable with un-profiled runs', 'kernels': res},
               open(out, 'w'), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]['mfma_util_pct']):

@@ -29,6 +29,7 @@ from sparsebev_amd.parallel import SampleShard, init_distributed   # noqa: E402
 from sparsebev_amd.transformer import SparseBEVTransformer         # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak (same guide, matrix-core table)
 
 
 def pmc_traffic(kernel='msmv_fwd_kernel'):
@@ -110,6 +111,17 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0):
     return {'value': round(n / dt, 4), 'unit': 'samples/s', 'cores': cores_used, 'kind': 'port',
             'sample': '%d timed decoder samples (1 warm-up) at %s Q=%d T=%d bs=1, oracle grid_sample path, '
                       'torch intra-op threads=%d (fastest of a 1-layer sweep) on a %d-core host' % (n, pyr, Q, T, cores_used, cores)}
+
+
+def mfma_util():
+    """MFMA-pipe utilisation per kernel from the committed PMC summary (tools/mfma_summary.py), {} when absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    try:
+        names = sorted(f for f in os.listdir(path) if f.endswith('_mfma_summary.json'))
+        d = json.load(open(os.path.join(path, names[-1])))['kernels']
+        return {k: v['mfma_util_pct'] / 100.0 for k, v in d.items()}
+    except Exception:   # noqa: BLE001
+        return {}
 
 
 def detector_standin(args, T, L, Q, B, ih, iw, sizes, device, transformer):
@@ -232,6 +244,11 @@ def main():
     shard.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sorted(runtime.read_sampler_ms())
+    runtime.profile_sampler(6)                   # a few extra steps (outside the timed region) with the two mixing GEMMs bracketed
+    for _ in range(min(10, args.steps)):
+        step()
+    torch.cuda.synchronize()
+    gemm_ms = [sorted(runtime.read_kernel_ms(k)) for k in (1, 2)]
     runtime.profile_sampler(False)
     checksum = float(cls.double().abs().sum().item() + box.double().abs().sum().item())
 
@@ -286,6 +303,20 @@ def main():
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
                          'algorithmic_bytes_per_launch': npts * bytes_per_pt},
         }
+        # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event
+        # measurement, priced against the f32-input MFMA peak; PMC MFMA-pipe utilisation from profiles/ when present
+        if args.gemm == 'f32' and all(gemm_ms):
+            D_, G_, Cg_, Pin_, Pout_ = 256, 4, 64, T * 4, 128
+            flops = 2.0 * B * Q * D_ * (G_ * (Cg_ * Cg_ + Pin_ * Pout_))          # generator; the out-projection has G*Pout*Cg*D = the same at Pin = 32
+            flops2 = 2.0 * B * Q * D_ * (G_ * Pout_ * Cg_)
+            util = mfma_util()
+            out['roofline_mfma'] = [
+                {'kernel': name, 'bound': 'mfma', 'achieved': round(fl / (sum(ms) / len(ms) * 1e-3) / 1e12, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
+                 'unit': 'TFLOP/s', 'frac': round(fl / (sum(ms) / len(ms) * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                 'launches': len(ms), 'avg_us': round(sum(ms) / len(ms) * 1e3, 2), 'algorithmic_flop_per_launch': fl,
+                 'mfma_pipe_util_pmc': util.get(key)}
+                for name, key, fl, ms in (('gemm_nt_f32_strip_kernel (mixing parameter generator)', 'gemm_nt_f32_strip_kernel<false>', flops, gemm_ms[0]),
+                                          ('gemm_nt_f32_regtile_kernel (mixing out-projection, split-K)', 'gemm_nt_f32_regtile_kernel', flops2, gemm_ms[1]))]
         if alt is not None:
             out['alt_bf16x3'] = alt
         if detector is not None:

@@ -394,10 +394,13 @@ int sbev_graph_launch(sbev_graph* graph, sbev_stream_t stream);
 int64_t sbev_graph_num_nodes(const sbev_graph* graph);   /* kernel nodes recorded (-1 for NULL) */
 int sbev_graph_destroy(sbev_graph* graph);
 
-/* Bracket every sbev_msmv_fwd launch with HIP events on its stream (enable != 0), and read back + clear the
- * elapsed times in ms (blocks until those launches finished).  Measurement aid for bench.py's roofline figure. */
+/* Bracket launches with HIP events on their stream -- `enable` is a bit mask of kinds: 1 = every sbev_msmv_fwd launch,
+ * 2 = the parameter-generator GEMM, 4 = the out-projection GEMM, 0 = off -- and read back + clear the elapsed times in ms
+ * (blocks until those launches finished).  Measurement aid for bench.py's roofline figures. */
 int sbev_profile_sampler(int enable);
 int sbev_profile_sampler_read(float* ms, int max_n);
+/* Same for the other bracketed launches: kind 0 = sampler, 1 = parameter-generator GEMM, 2 = out-projection GEMM. */
+int sbev_profile_read(int kind, float* ms, int max_n);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,7 @@ SIGNATURES = {
     'sbev_head_denorm': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _vp, ctypes.c_int64, _vp]),
     'sbev_nms_free_decode': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                             ctypes.POINTER(ctypes.c_double), ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'sbev_profile_read': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int]),
     'sbev_linear_splitk_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
 }

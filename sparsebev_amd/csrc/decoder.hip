@@ -251,45 +251,54 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     return SBEV_OK;
 }
 
-// ---- sampler launch timing (HIP events on the launch stream), used by bench.py for the roofline figure ------
+// ---- kernel launch timing (HIP events on the launch stream), used by bench.py for the roofline figures --------
+// kind 0 = sampler (msmv_fwd_kernel), 1 = parameter-generator GEMM (strip kernel), 2 = out-projection GEMM (register tile)
 namespace sbev {
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static int g_prof_mask = 0;          // bit k: bracket launches of kind k
+struct ProfEvent { hipEvent_t e0, e1; int kind; };
+static std::vector<ProfEvent> g_prof_events;
 
-bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_on) return false;
+    if (!((g_prof_mask >> kind) & 1)) return false;
     if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) return false;
     (void)hipEventRecord(*e0, s);
     return true;
 }
-void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int kind) {
     (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_events.emplace_back(e0, e1);
+    g_prof_events.push_back({e0, e1, kind});
 }
 }  // namespace sbev
 
 extern "C" int sbev_profile_sampler(int enable) {
     std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
-    sbev::g_prof_on = enable != 0;
+    sbev::g_prof_mask = enable;          // 0 off, 1 sampler only, bit 1 / 2: the two mixing GEMMs
     return SBEV_OK;
 }
 
-extern "C" int sbev_profile_sampler_read(float* ms, int max_n) {
+extern "C" int sbev_profile_read(int kind, float* ms, int max_n) {
     std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
     int n = 0;
+    std::vector<sbev::ProfEvent> keep;
     for (auto& ev : sbev::g_prof_events) {
+        if (ev.kind != kind) {
+            keep.push_back(ev);
+            continue;
+        }
         float t = 0.f;
-        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess && ms && n < max_n)
+        if (hipEventSynchronize(ev.e1) == hipSuccess && hipEventElapsedTime(&t, ev.e0, ev.e1) == hipSuccess && ms && n < max_n)
             ms[n++] = t;
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.e0);
+        (void)hipEventDestroy(ev.e1);
     }
-    sbev::g_prof_events.clear();
+    sbev::g_prof_events.swap(keep);
     return n;
 }
+
+extern "C" int sbev_profile_sampler_read(float* ms, int max_n) { return sbev_profile_read(0, ms, max_n); }
 
 // ---- hipGraph capture of one decoder step -----------------------------------------------------------------------
 // The launch sequence is static per (config, pointers): capture it once, replay it per sample.  Inputs are read
@@ -310,7 +319,7 @@ extern "C" int sbev_decoder_capture(const sbev_decoder_config* cfg, const sbev_d
     SBEV_REQUIRE(stream, "sbev_decoder_capture: needs an explicit (non-default) stream to capture on");
     {
         std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
-        SBEV_REQUIRE(!sbev::g_prof_on, "sbev_decoder_capture: sampler profiling is on (events cannot be read back from a captured graph)");
+        SBEV_REQUIRE(sbev::g_prof_mask == 0, "sbev_decoder_capture: sampler profiling is on (events cannot be read back from a captured graph)");
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     (void)aux();   // create the side stream / events outside the capture

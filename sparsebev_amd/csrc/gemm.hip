@@ -521,10 +521,13 @@ extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias
     if (K == 256 && N % 128 == 0 && N / 128 >= 192 && M < (1 << 24) && ldy % 4 == 0 && ((uintptr_t)Y & 15) == 0 &&
         (!bias || ((uintptr_t)bias & 15) == 0) && !residual) {
         // parameter-generator shape: W strips stationary in registers, all rows stream past (see the kernel's header)
+        hipEvent_t e0, e1;
+        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
         if (relu)
             hipLaunchKernelGGL(gemm_nt_f32_strip_kernel<true>, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(gemm_nt_f32_strip_kernel<false>, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);
+        if (prof) sbev::profile_end(s, e0, e1, 1);
     } else if (K % BK != 0) {  // slow path (never taken by the decoder: its K are 256 / 512 / 32768)
         hipLaunchKernelGGL((gemm_nt_f32_kernel<false, 1, 1, true>), dim3((unsigned)small), dim3(256), 0, s, a);
     } else if (big >= 256) {   // enough 128x128 tiles to fill the 256 CUs

@@ -112,7 +112,10 @@ int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t 
     const long long tasks = (long long)t.rgs * t.cgs * splits;
     SBEV_REQUIRE(tasks <= 0x3fffffffLL, "sbev_linear_splitk_f32: too many tasks");
     t.tasks = (unsigned)tasks;
+    hipEvent_t e0, e1;
+    const bool prof = profile_begin(stream, &e0, &e1, 2);
     hipLaunchKernelGGL(gemm_nt_f32_regtile_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, t);
+    if (prof) profile_end(stream, e0, e1, 2);
     return check_launch("sbev_linear_splitk_f32 (gemm)");
 }
 }  // namespace sbev

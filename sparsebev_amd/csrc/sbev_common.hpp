@@ -35,8 +35,8 @@ int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t 
                           int splits, hipStream_t stream);
 
 // optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
-bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
-void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind = 0);
+void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int kind = 0);   // kind: 0 sampler, 1 generator GEMM, 2 out-projection GEMM
 
 // Sum over the 64 lanes of a wave without LDS traffic (ds_bpermute-based __shfl_xor costs an LDS round trip per
 // step, which is pure exposed latency when only a few waves share a SIMD): 4 DPP steps reduce each 16-lane row

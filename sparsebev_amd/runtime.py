@@ -202,10 +202,16 @@ class DecoderGraph:
 
 
 def profile_sampler(enable):
-    _lib.load().sbev_profile_sampler(1 if enable else 0)
+    """enable: False / True (sampler launches only) or an int mask (1 sampler | 2 generator GEMM | 4 out-projection GEMM)."""
+    _lib.load().sbev_profile_sampler(int(enable))
+
+
+def read_kernel_ms(kind, max_n=4096):
+    """Elapsed ms of the bracketed launches of one kind (0 sampler, 1 generator GEMM, 2 out-projection GEMM)."""
+    buf = (ctypes.c_float * max_n)()
+    n = _lib.load().sbev_profile_read(kind, buf, max_n)
+    return [buf[i] for i in range(n)]
 
 
 def read_sampler_ms(max_n=4096):
-    buf = (ctypes.c_float * max_n)()
-    n = _lib.load().sbev_profile_sampler_read(buf, max_n)
-    return [buf[i] for i in range(n)]
+    return read_kernel_ms(0, max_n)

@@ -29,6 +29,7 @@ from sparsebev_amd.parallel import SampleShard, init_distributed   # noqa: E402
 from sparsebev_amd.transformer import SparseBEVTransformer         # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0      # best measured device copy rate in the same guide (SURVEY.md section 8d asks for both)
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak (same guide, matrix-core table)
 
 
@@ -298,6 +299,7 @@ def main():
             'roofline': {'kernel': 'msmv_fwd_kernel (adaptive sampling gather)', 'bound': 'hbm',
                          'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBPS, 4),
+                         'frac_of_measured_copy_peak': round(achieved / HBM_COPY_GBPS, 4),
                          'traffic': (pmc_traffic() or (None, None))[0] if args.config == 'c2' else None,
                          'traffic_source': 'profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % (pmc_traffic() or (None, 'none'))[1],
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),

@@ -5,12 +5,21 @@
 //     y = relu(layer_norm_[Pout,C]( S[Pout,Pin] @ y[Pin,C] ))    adaptive point mixing
 // M and S are the per-query dynamic weights produced by the parameter-generator Linear (sbev_linear_f32).
 //
-// One 256-thread workgroup per (b*Q + q, g).  x, M, S are staged once into LDS with 16-byte coalesced loads
-// (40 KiB at C=64, Pin=32, Pout=128), both matmuls run on v_mfma_f32_16x16x4_f32 (exact fp32), wave w owns the
-// 16-channel column slab w of both outputs, the LayerNorm statistics are two-pass (mean, then centred
-// variance) block reductions, the intermediate never leaves LDS, and the [Pout,C] result is transposed through
-// LDS so the workgroup writes its 32 KiB output as one contiguous run of 16-byte stores.
-// Bound: HBM (72 KiB moved per ~3k MFMA cycles of work).
+// One 256-thread workgroup per (b*Q + q, g); both matmuls run on v_mfma_f32_16x16x4_f32 (exact fp32), wave w owns the
+// 16-channel column slab w of both outputs.  The kernel is HBM-bound (72 KiB moved per ~3k MFMA cycles of work: a
+// load-and-store-only version of it runs at 47 us = 5.6 TB/s for config 2), so everything is about keeping bytes in
+// flight and the dependent chain of one workgroup short (73 -> 54 us):
+//   * Pin % 16 == 0 (the decoder's case): the MFMA fragments of x and of this wave's 16 columns of M are loaded straight
+//     from HBM into registers -- matmul 1 waits for no LDS staging and no barrier;
+//   * y1 never leaves registers: the B fragment matmul 2 needs from a lane is exactly what that lane's matmul-1
+//     accumulators hold (same rows 4 fk + j, same column);
+//   * S is requested at kernel start, parked in registers and written to LDS behind matmul 1, in front of the
+//     LayerNorm-1 exchange whose barriers publish it; LDS carries only S and the output staging: 34.8 KiB, 4 workgroups
+//     per CU (was 44.5 KiB / 3);
+//   * LayerNorm statistics: per-wave (sum, centred M2) by DPP sums, ONE LDS exchange per LayerNorm merged with Chan's
+//     parallel-variance formula (as stable as two-pass, half the barriers);
+//   * the [Pout,C] result is transposed through LDS so the workgroup writes its 32 KiB as contiguous 16-byte stores.
+// Other Pin keep the generic path (x, M, S staged in LDS, y1 through LDS).
 #include "sbev_common.hpp"
 
 namespace {
@@ -42,17 +51,42 @@ __device__ __forceinline__ float block_sum(float v, float* red, int wave, int la
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// LayerNorm statistics of the whole block with ONE LDS exchange: every wave reduces its own slab to (sum, M2 about its
+// own mean) with DPP sums (no barrier), the four (sum, M2) pairs are merged with Chan's parallel-variance formula --
+// as stable as the two-pass form, half the barriers.  n_w = elements per wave, n = 4 n_w.  `red` = 8 floats of LDS.
+__device__ __forceinline__ void block_mean_rstd(float s_w, float m2_w, float n_w, float eps, float* red, int wave, int lane,
+                                                float& mean, float& rstd) {
+    __syncthreads();                      // protect `red` from the previous use (and fence the LDS reads before it)
+    if (lane == 0) {
+        red[wave] = s_w;
+        red[4 + wave] = m2_w;
+    }
+    __syncthreads();
+    const float n = 4.f * n_w;
+    mean = ((red[0] + red[1]) + (red[2] + red[3])) / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float d = red[w] / n_w - mean;
+        m2 += red[4 + w] + n_w * d * d;
+    }
+    rstd = rsqrtf(m2 / n + eps);
+}
+
 template <int RT, bool WIDE>   // RT = ceil(Pin / 16) row tiles of matmul 1; WIDE: Pin % 16 == 0 (b128 A reads in matmul 2)
 __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
     const int lds_s = Pin + 4;                                  // S row stride
-    float* red = smem;                                          // [4] block-reduction scratch (never aliased)
-    float* Xs = smem + 4;                                       // [RT*16][LDA]  (dead after matmul 1)
-    float* Y1 = smem + 4;                                       // [RT*16][LDB]  aliases Xs: written after LayerNorm 1
-    float* Ms = Y1 + RT * 16 * LDB;                             // [C][LDB]
-    float* Ss = Ms + C * LDB;                                   // [POUT][lds_s]
-    float* Yo = smem + 4;                                       // [POUT][LDY], aliases everything after matmul 2
+    // WIDE (Pin % 16 == 0, the decoder's case): the x fragments come straight from HBM into registers and y1 never leaves
+    // them (the B fragment of matmul 2 is exactly what the lane's own matmul-1 accumulators hold), so LDS only carries
+    // S (and the output staging): 34.8 KiB -> 4 workgroups per CU instead of 3, and nothing waits for a staging barrier.
+    float* red = smem;                                          // [8] block-reduction scratch (never aliased)
+    float* Xs = smem + 8;                                       // [RT*16][LDA]  (generic path only; dead after matmul 1)
+    float* Y1 = smem + 8;                                       // [RT*16][LDB]  (generic path only) aliases Xs
+    float* Ms = Y1 + (WIDE ? 0 : RT * 16 * LDB);                // [C][LDB]  (generic path only)
+    float* Ss = Ms + (WIDE ? 0 : C * LDB);                                   // [POUT][lds_s]
+    float* Yo = smem + 8;                                       // [POUT][LDY], aliases everything after matmul 2
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,23 +96,48 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     const float* sg = pg + C * C;
 
     // ---- stage x, M, S (coalesced float4) --------------------------------------------------------------
-    for (int i = tid; i < RT * 16 * (C / 4); i += 256) {
+    const int fi = lane & 15, fk = lane >> 4;                   // fragment row/col index, k sub-index
+    f32x4 xf[WIDE ? RT : 1][C / 16];                            // WIDE: A fragments of matmul 1, x[r*16 + fi][16 blk + 4 fk ..]
+    if (WIDE) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int blk = 0; blk < C / 16; ++blk)
+                xf[r][blk] = *reinterpret_cast<const f32x4*>(xg + (r * 16 + fi) * C + 16 * blk + 4 * fk);
+    }
+    for (int i = tid; i < (WIDE ? 0 : RT * 16 * (C / 4)); i += 256) {
         const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < Pin) v = *reinterpret_cast<const float4*>(xg + r * C + c4);
         *reinterpret_cast<float4*>(&Xs[r * LDA + c4]) = v;      // rows >= Pin are zero padding
     }
-    for (int i = tid; i < C * (C / 4); i += 256) {
+    // WIDE: the B fragments of matmul 1 (this wave's 16 columns of M, 4 KiB) also go straight to registers -- matmul 1
+    // then depends on no LDS staging and no barrier at all
+    float mf[WIDE ? C / 16 : 1][4];
+    if (WIDE) {
+#pragma unroll
+        for (int blk = 0; blk < C / 16; ++blk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mf[blk][j] = pg[(16 * blk + 4 * fk + j) * C + wave * 16 + fi];
+    }
+    for (int i = tid; i < (WIDE ? 0 : C * (C / 4)); i += 256) {
         const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
         *reinterpret_cast<float4*>(&Ms[r * LDB + c4]) = *reinterpret_cast<const float4*>(pg + r * C + c4);
     }
-    for (int i = tid; i < POUT * Pin / 4; i += 256) {
+    // S is not needed before matmul 2: WIDE requests it now but parks it in registers (2 RT float4 per thread) and writes
+    // it to LDS behind matmul 1, in front of the LayerNorm-1 exchange whose barriers publish it -- its HBM latency hides
+    // behind matmul 1 and the staging barrier only waits for M
+    f32x4 sreg[WIDE ? 2 * RT : 1];
+    if (WIDE) {
+#pragma unroll
+        for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (tid + 256 * k) * 4);
+    }
+    for (int i = tid; i < (WIDE ? 0 : POUT * Pin / 4); i += 256) {
         const int r = (i * 4) / Pin, c4 = (i * 4) % Pin;
         *reinterpret_cast<float4*>(&Ss[r * lds_s + c4]) = *reinterpret_cast<const float4*>(sg + i * 4);
     }
-    __syncthreads();
+    if (!WIDE) __syncthreads();
 
-    const int fi = lane & 15, fk = lane >> 4;                   // fragment row/col index, k sub-index
     const int cw = wave * 16;                                   // this wave's channel slab
 
     // ---- matmul 1: y1[Pin, 64] = x[Pin, 64] @ M[64, 64]; wave w -> columns [16w, 16w+16) ----------------
@@ -91,50 +150,65 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     for (int blk = 0; blk < C / 16; ++blk) {
         float bq[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bq[j] = Ms[(16 * blk + 4 * fk + j) * LDB + cw + fi];
+        for (int j = 0; j < 4; ++j) bq[j] = WIDE ? mf[blk][j] : Ms[(16 * blk + 4 * fk + j) * LDB + cw + fi];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&Xs[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bq[0], acc1[r], 0, 0, 0);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bq[1], acc1[r], 0, 0, 0);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bq[2], acc1[r], 0, 0, 0);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bq[3], acc1[r], 0, 0, 0);
+            f32x4 a4;
+            if (WIDE) a4 = xf[r][blk];
+            else a4 = *reinterpret_cast<const f32x4*>(&Xs[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], bq[0], acc1[r], 0, 0, 0);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], bq[1], acc1[r], 0, 0, 0);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], bq[2], acc1[r], 0, 0, 0);
+            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], bq[3], acc1[r], 0, 0, 0);
         }
     }
     // C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg
     // ---- LayerNorm over all Pin*64 elements (no affine, biased variance), ReLU --------------------------
-    const float n1 = (float)(Pin * C);
+    const float nw1 = (float)(Pin * 16);                       // this wave's 16 columns x Pin rows
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += (r * 16 + fk * 4 + e) < Pin ? acc1[r][e] : 0.f;
-    const float mean1 = block_sum(s, red, wave, lane) / n1;
+    s = wave_sum(s);
+    const float mw1 = s / nw1;
     float qv = 0.f;
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float d = acc1[r][e] - mean1;
+            const float d = acc1[r][e] - mw1;
             qv += (r * 16 + fk * 4 + e) < Pin ? d * d : 0.f;
         }
-    const float rstd1 = rsqrtf(block_sum(qv, red, wave, lane) / n1 + a.eps);
+    qv = wave_sum(qv);
+    if (WIDE) {
+#pragma unroll
+        for (int k = 0; k < 2 * RT; ++k) {
+            const int i4 = (tid + 256 * k) * 4;
+            *reinterpret_cast<f32x4*>(&Ss[(i4 / Pin) * lds_s + i4 % Pin]) = sreg[k];
+        }
+    }
+    float mean1, rstd1;
+    block_mean_rstd(s, qv, nw1, a.eps, red, wave, lane, mean1, rstd1);
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            Y1[(r * 16 + fk * 4 + e) * LDB + cw + fi] = fmaxf((acc1[r][e] - mean1) * rstd1, 0.f);
-    __syncthreads();
+        for (int e = 0; e < 4; ++e) {
+            acc1[r][e] = fmaxf((acc1[r][e] - mean1) * rstd1, 0.f);      // y1[r*16 + 4 fk + e][cw + fi]
+            if (!WIDE) Y1[(r * 16 + fk * 4 + e) * LDB + cw + fi] = acc1[r][e];
+        }
+    if (!WIDE) __syncthreads();
 
     // ---- matmul 2: y2[128, 64] = S[128, Pin] @ y1[Pin, 64]; wave w -> columns [16w, 16w+16), 8 row tiles -
     f32x4 acc2[POUT / 16];
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (WIDE) {
-        for (int blk = 0; blk < Pin / 16; ++blk) {
+#pragma unroll
+        for (int blk = 0; blk < RT; ++blk) {                    // Pin / 16 == RT
             float bq[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bq[j] = Y1[(16 * blk + 4 * fk + j) * LDB + cw + fi];
+            for (int j = 0; j < 4; ++j) bq[j] = acc1[blk][j];   // y1[16 blk + 4 fk + j][cw + fi]: this lane's own accumulators
 #pragma unroll
             for (int r = 0; r < POUT / 16; ++r) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&Ss[(r * 16 + fi) * lds_s + 16 * blk + 4 * fk]);
@@ -155,23 +229,27 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
         }
     }
     // ---- LayerNorm over 128*64 elements, ReLU ------------------------------------------------------------
-    const float n2 = (float)(POUT * C);
+    const float nw2 = (float)(POUT * 16);
     s = 0.f;
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += acc2[r][e];
-    const float mean2 = block_sum(s, red, wave, lane) / n2;     // (its barriers also fence the Ss/Y1 reads above)
+    s = wave_sum(s);
+    const float mw2 = s / nw2;
     qv = 0.f;
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float d = acc2[r][e] - mean2;
+            const float d = acc2[r][e] - mw2;
             qv += d * d;
         }
-    const float rstd2 = rsqrtf(block_sum(qv, red, wave, lane) / n2 + a.eps);
-    // ---- transpose through LDS, then one contiguous 32 KiB store ------------------------------------------
+    qv = wave_sum(qv);
+    float mean2, rstd2;
+    block_mean_rstd(s, qv, nw2, a.eps, red, wave, lane, mean2, rstd2);       // (its barriers also fence the Ss / Y1 reads above)
+    // ---- transpose through LDS, then one contiguous 32 KiB store (direct 4-row x 64-B stores from the accumulators and
+    // staging in two 64-row halves for a smaller LDS footprint both measured no better) ------------------------------
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r)
 #pragma unroll
@@ -189,10 +267,10 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
 template <int RT, bool WIDE>
 int launch_mix_w(const MixArgs& a, hipStream_t s) {
     const int Pin = a.Pin;
-    size_t floats = (size_t)RT * 16 * LDB + C * LDB + POUT * (Pin + 4);
+    size_t floats = (size_t)(WIDE ? 0 : RT * 16 * LDB + C * LDB) + POUT * (Pin + 4);
     const size_t out_floats = (size_t)POUT * LDY;
     if (floats < out_floats) floats = out_floats;
-    const size_t bytes = (floats + 4) * sizeof(float);
+    const size_t bytes = (floats + 8) * sizeof(float);
     auto k = adaptive_mixing_kernel<RT, WIDE>;
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

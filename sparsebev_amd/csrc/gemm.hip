@@ -581,14 +581,9 @@ inline bool regtile_ok(int64_t M, int N, int K) { return N % 128 == 0 && K % 32 
 // to 128 x 128 tiles x splits ~ 512 workgroups.
 extern "C" int sbev_linear_splitk_plan(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 1;
-    long long s;
-    if (regtile_ok(M, N, K)) {
-        const long long units = ((M + 47) / 48) * (N / 128);
-        s = 1024 / units;
-    } else {
-        const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        s = (512 + tiles - 1) / tiles;
-    }
+    if (regtile_ok(M, N, K)) return sbev::regtile_plan(M, N, K);      // gemm_regtile.hip
+    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    long long s = (512 + tiles - 1) / tiles;
     if (s > K / 512) s = K / 512;
     return (int)(s < 1 ? 1 : s);
 }

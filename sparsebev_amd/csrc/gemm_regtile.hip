@@ -9,6 +9,14 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef SBEV_RT_FR
+#define SBEV_RT_FR 3
+#endif
+constexpr int FR = SBEV_RT_FR;            // 16-row fragments per wave task
+constexpr int TROWS = 16 * FR;            // rows per wave task
+constexpr int WPE = FR >= 3 ? 1 : 2;      // waves per SIMD the register budget allows (FR = 2 at two waves per SIMD measured
+                                          // 2x SLOWER: 10 fragment-shaped loads per 64 MFMAs saturate the load path)
+
 // ---- register-tiled split-K kernel for the out-projection [M, K = 32768] x [256, K]^T --------------------------------
 // Same reasoning as the strip kernel, other shape: 8 x 2 tiles of 128 x 128 times 32 K-splits are exactly one round of
 // 512 workgroups, so the 12 % row padding of Q = 900 is paid in full.  Here the unit of work is a WAVE task =
@@ -29,7 +37,7 @@ struct RegTileArgs {
     unsigned tasks;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_f32_regtile_kernel(const RegTileArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_nt_f32_regtile_kernel(const RegTileArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fi = lane & 15, fk = lane >> 4;
@@ -45,33 +53,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int p0 = (a.pairs * sp) / a.splits, p1 = (a.pairs * (sp + 1)) / a.splits;     // pairs * splits < 2^31 (host-checked)
     const int M = (int)a.M;
 
-    const float* xp[3];
+    const float* xp[FR];
 #pragma unroll
-    for (int fr = 0; fr < 3; ++fr) {
-        int row = rg * 48 + fr * 16 + fi;
+    for (int fr = 0; fr < FR; ++fr) {
+        int row = rg * TROWS + fr * 16 + fi;
         row = row < M ? row : M - 1;
         xp[fr] = a.X + (long long)row * a.ldx + 4 * fk;
     }
     const float* wp = a.W + (long long)(cg * 128 + fi) * a.ldw + 4 * fk;
     const long long w16 = 16 * a.ldw;
 
-    f32x4v acc[3][8];
+    f32x4v acc[FR][8];
 #pragma unroll
-    for (int fr = 0; fr < 3; ++fr)
+    for (int fr = 0; fr < FR; ++fr)
 #pragma unroll
         for (int cf = 0; cf < 8; ++cf) acc[fr][cf] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    f32x4v xa[3], wa[8], xb[3], wb[8];
+    f32x4v xa[FR], wa[8], xb[FR], wb[8];
 #define SBEV_RT_LOAD(xd, wd, kk)                                                                    \
     {                                                                                               \
         const int k_ = (kk) < kend ? (kk) : kend;       /* clamped: the load past the split is a dummy */ \
-        _Pragma("unroll") for (int fr = 0; fr < 3; ++fr) xd[fr] = *reinterpret_cast<const f32x4v*>(xp[fr] + k_); \
+        _Pragma("unroll") for (int fr = 0; fr < FR; ++fr) xd[fr] = *reinterpret_cast<const f32x4v*>(xp[fr] + k_); \
         _Pragma("unroll") for (int cf = 0; cf < 8; ++cf) wd[cf] = *reinterpret_cast<const f32x4v*>(wp + cf * w16 + k_); \
         __builtin_amdgcn_sched_barrier(0);              /* loads stay ahead of the MFMA block */    \
     }
 #define SBEV_RT_MMA(xs, ws)                                                                         \
     {                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-            _Pragma("unroll") for (int fr = 0; fr < 3; ++fr)                                        \
+            _Pragma("unroll") for (int fr = 0; fr < FR; ++fr)                                       \
                 _Pragma("unroll") for (int cf = 0; cf < 8; ++cf)                                    \
                     acc[fr][cf] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[cf][i], xs[fr][i], acc[fr][cf], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -92,8 +100,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef SBEV_RT_MMA
     float* out = a.P + ((long long)sp * a.M) * a.N + cg * 128 + 4 * fk;
 #pragma unroll
-    for (int fr = 0; fr < 3; ++fr) {
-        const int row = rg * 48 + fr * 16 + fi;
+    for (int fr = 0; fr < FR; ++fr) {
+        const int row = rg * TROWS + fr * 16 + fi;
         if (row < M) {
 #pragma unroll
             for (int cf = 0; cf < 8; ++cf)
@@ -108,7 +116,7 @@ namespace sbev {
 int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
                           int splits, hipStream_t stream) {
     SBEV_REQUIRE((long long)(K / 32) * (splits + 1) < 0x7fffffffLL, "sbev_linear_splitk_f32: K * splits too large");
-    RegTileArgs t{X, W, slabs, M, N, K, ldx, ldw, (int)((M + 47) / 48), N / 128, splits, K / 32, 0u};
+    RegTileArgs t{X, W, slabs, M, N, K, ldx, ldw, (int)((M + TROWS - 1) / TROWS), N / 128, splits, K / 32, 0u};
     const long long tasks = (long long)t.rgs * t.cgs * splits;
     SBEV_REQUIRE(tasks <= 0x3fffffffLL, "sbev_linear_splitk_f32: too many tasks");
     t.tasks = (unsigned)tasks;
@@ -117,5 +125,13 @@ int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t 
     hipLaunchKernelGGL(gemm_nt_f32_regtile_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, stream, t);
     if (prof) profile_end(stream, e0, e1, 2);
     return check_launch("sbev_linear_splitk_f32 (gemm)");
+}
+
+// K splits that fill the wave slots (1024 SIMDs x WPE) exactly once with (TROWS rows x 128 columns x K/splits) tasks
+int regtile_plan(int64_t M, int N, int K) {
+    const long long units = ((M + TROWS - 1) / TROWS) * (N / 128);
+    long long s = (1024LL * WPE) / units;
+    if (s > K / 512) s = K / 512;
+    return (int)(s < 1 ? 1 : s);
 }
 }  // namespace sbev

@@ -34,6 +34,8 @@ constexpr int kWave = 64;  // CDNA wavefront
 int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
                           int splits, hipStream_t stream);
 
+int regtile_plan(int64_t M, int N, int K);
+
 // optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind = 0);
 void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int kind = 0);   // kind: 0 sampler, 1 generator GEMM, 2 out-projection GEMM

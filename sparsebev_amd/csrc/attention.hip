@@ -14,8 +14,12 @@
 // softmax is the online (running max / running sum) form, and P goes from the MFMA C layout to the A layout
 // through a per-wave 4-KiB LDS patch.  1.3 GFLOP per layer-sample: latency-, not throughput-critical.
 #include "sbev_common.hpp"
+#include "small_ops.hpp"
 
 namespace {
+
+using sbev_ops::MiscArgs;
+using sbev_ops::refine_rows;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -269,36 +273,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
     }
 }
 
-struct MiscArgs {
-    const float* bbox;      // [BQ,10]
-    const float* reg;       // [BQ,code]
-    const float* vel_div;   // [B] or null
-    float* out;             // [BQ,code]
-    long long BQ;
-    int Q, code;
-};
-
-// refine_bbox + velocity / time_diff (models/sparsebev_transformer.py:155-160,179-183; inverse_sigmoid
-// models/utils.py:87-102)
-__global__ void refine_kernel(const MiscArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.BQ) return;
-    const float* r = a.reg + i * a.code;
-    float* o = a.out + i * a.code;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float p = a.bbox[i * 10 + d];
-        p = fminf(fmaxf(p, 0.f), 1.f);
-        const float logit = logf(fmaxf(p, 1e-5f) / fmaxf(1.f - p, 1e-5f));
-        const float z = r[d] + logit;
-        o[d] = 1.f / (1.f + expf(-z));
-    }
-    for (int d = 3; d < a.code; ++d) {
-        float v = r[d];
-        if (d >= 8 && a.vel_div) v = v / a.vel_div[i / a.Q];
-        o[d] = v;
-    }
-}
+__global__ __launch_bounds__(256) void refine_kernel(const MiscArgs a) { refine_rows(a, blockIdx.x); }
 
 }  // namespace
 

@@ -151,11 +151,13 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
 
     const float* bbox = query_bbox;
     const float* feat = query_feat;
+    bool pe0_done = false;             // the previous layer's tail already ran this layer's first position-encoder stage
     for (int layer = 0; layer < c.num_layers; ++layer) {
         float* cls_l = cls_out + (int64_t)layer * BQ * c.num_classes;
         float* box_l = bbox_out + (int64_t)layer * BQ * c.code_size;
         // position encoder -> x = feat + pos                                   (sparsebev_transformer.py:166-167)
-        TRY(sbev_linear3_ln_relu_f32(bbox, 10, w->pe0_w, w->pe0_b, w->pe1_g, w->pe1_b, eps, b.t0, BQ, D, stream));
+        if (!pe0_done) TRY(sbev_linear3_ln_relu_f32(bbox, layer == 0 ? 10 : c.code_size, w->pe0_w, w->pe0_b, w->pe1_g, w->pe1_b, eps, b.t0, BQ, D, stream));
+        pe0_done = false;
         TRY(sbev_linear_f32(b.t0, w->pe3_w, w->pe3_b, nullptr, b.t1, BQ, D, D, D, D, D, 0, stream));
         TRY(sbev_layer_norm_f32(b.t1, w->pe4_g, w->pe4_b, eps, feat, b.x, BQ, D, 1, stream));
         // scale-adaptive self attention + norm1                                (:169)
@@ -218,15 +220,24 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // to the op-by-op path); large batches have enough tiles per linear anyway
         const bool grouped = !fork && (D == 256 || D == 512) && ((BQ + 127) / 128) * ((D + 127) / 128) < 256;
         if (grouped) {
+            // 5 launches for the 9 ops of the two branches + refine (+ the next layer's first position-encoder stage):
+            // ops that do not depend on each other share a launch (gemm.hip: group / pair kernels, same arithmetic as alone)
             const sbev_linear_problem g1[2] = {prob(b.x3, w->cls0_w, w->cls0_b, b.c0, D, 0), prob(b.x3, w->reg0_w, w->reg0_b, b.r0, D, 1)};
             TRY(sbev_linear_group_f32(g1, 2, stream));
-            TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, stream));
-            const sbev_linear_problem g2[2] = {prob(b.c1, w->cls3_w, w->cls3_b, b.c0, D, 0), prob(b.r0, w->reg2_w, w->reg2_b, b.r1, D, 1)};
-            TRY(sbev_linear_group_f32(g2, 2, stream));
-            TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, stream));
-            const sbev_linear_problem g3[2] = {prob(b.c1, w->cls6_w, w->cls6_b, cls_l, c.num_classes, 0),
+            TRY(sbev::launch_ln_and_linear(b.c0, w->cls1_g, w->cls1_b, eps, 1, b.c1, BQ, D,
+                                           b.r0, w->reg2_w, w->reg2_b, b.r1, D, D, 1, s_main));
+            const sbev_linear_problem g2[2] = {prob(b.c1, w->cls3_w, w->cls3_b, b.c0, D, 0),
                                                prob(b.r1, w->reg4_w, w->reg4_b, b.reg, c.code_size, 0)};
-            TRY(sbev_linear_group_f32(g3, 2, stream));
+            TRY(sbev_linear_group_f32(g2, 2, stream));
+            TRY(sbev::launch_ln_and_refine(b.c0, w->cls4_g, w->cls4_b, eps, 1, b.c1, BQ, D,
+                                           bbox, b.reg, c.T > 1 ? vel_div : nullptr, box_l, c.Q, c.code_size, s_main));
+            if (layer + 1 < c.num_layers) {   // the next layer's Linear(3->D)+LayerNorm+ReLU only needs box_l
+                TRY(sbev::launch_linear_and_lin3(b.c1, w->cls6_w, w->cls6_b, cls_l, BQ, c.num_classes, D, 0,
+                                                 box_l, c.code_size, w->pe0_w, w->pe0_b, w->pe1_g, w->pe1_b, eps, b.t0, D, s_main));
+                pe0_done = true;
+            } else {
+                TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, stream));
+            }
         } else {   // s_aux == stream unless forked
             TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
             TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
@@ -241,7 +252,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(sbev_linear_f32(b.r0, w->reg2_w, w->reg2_b, nullptr, b.r1, BQ, D, D, D, D, D, 1, stream));
             TRY(sbev_linear_f32(b.r1, w->reg4_w, w->reg4_b, nullptr, b.reg, BQ, c.code_size, D, D, D, c.code_size, 0, stream));
         }
-        TRY(sbev_refine_bbox(bbox, b.reg, c.T > 1 ? vel_div : nullptr, box_l, c.B, c.Q, c.code_size, stream));
+        if (!grouped) TRY(sbev_refine_bbox(bbox, b.reg, c.T > 1 ? vel_div : nullptr, box_l, c.B, c.Q, c.code_size, stream));
         // next layer: query_bbox = bbox_pred.detach() (:93), query_feat = this layer's output
         bbox = box_l;
         // x3 is read by the next layer only as `feat` in its third launch and rewritten only by its norm3: no copy

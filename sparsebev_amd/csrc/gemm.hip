@@ -17,8 +17,12 @@
 // out-projection; sbev_splitk_reduce_* combines them in the next kernel's prologue (a launch boundary is
 // cheaper than an in-launch cross-XCD hand-off at this size, cdna_hip_programming.md section 5).
 #include "sbev_common.hpp"
+#include "small_ops.hpp"
 
 namespace {
+
+using sbev_ops::ReduceArgs;
+using sbev_ops::reduce_rows;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -414,96 +418,91 @@ __global__ __launch_bounds__(256) SBEV_ONE_WAVE_PER_EU void gemm_nt_f32_strip_ke
 #undef SBEV_STRIP
 }
 
-struct ReduceArgs {
-    const float* slabs;  // [splits, M, N]
-    const float* bias;   // [N] or null
-    const float* res;    // [M, N] or null
-    const float* ln_w;   // [N] or null -> no LayerNorm
-    const float* ln_b;
-    const float* post;   // [M, N] or null: added after LayerNorm / ReLU  (x = query_feat + pos-encoding form)
-    float* Y;            // [M, N]
-    long long M;
-    int N, splits, relu;
-    float eps;
-};
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) { reduce_rows(a, blockIdx.x); }
 
-// one wave per output row (N <= 1024, N % 4 == 0): sum the split-K slabs, + bias, (+ residual), optional
-// LayerNorm over the row (two-pass in registers), optional ReLU.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.M) return;
-    constexpr int MAXV = 4;                              // float4 chunks per lane: N <= 64*4*4 = 1024
-    float4 v[MAXV];
-    const int nvec = a.N / 4;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c) {
-        const int i4 = lane + 64 * c;
-        v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i4 < nvec) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int z = 0; z < a.splits; ++z) {
-                const float4 p = *reinterpret_cast<const float4*>(a.slabs + ((long long)z * a.M + row) * a.N + i4 * 4);
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-            }
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + i4 * 4);
-                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
-            }
-            if (a.relu && !a.ln_w) {
-                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-            }
-            if (a.res) {
-                const float4 r = *reinterpret_cast<const float4*>(a.res + row * a.N + i4 * 4);
-                acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
-            }
-            v[c] = acc;
-            s += (acc.x + acc.y) + (acc.z + acc.w);
-        }
-    }
-    if (a.ln_w) {
-        s = sbev::wave_sum_dpp(s);
-        const float mean = s / (float)a.N;
-        float q = 0.f;
-#pragma unroll
-        for (int c = 0; c < MAXV; ++c)
-            if (lane + 64 * c < nvec) {
-                const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
-                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-            }
-        q = sbev::wave_sum_dpp(q);
-        const float rstd = rsqrtf(q / (float)a.N + a.eps);
-#pragma unroll
-        for (int c = 0; c < MAXV; ++c) {
-            const int i4 = lane + 64 * c;
-            if (i4 < nvec) {
-                const float4 g = *reinterpret_cast<const float4*>(a.ln_w + i4 * 4);
-                const float4 b = *reinterpret_cast<const float4*>(a.ln_b + i4 * 4);
-                float4 o;
-                o.x = (v[c].x - mean) * rstd * g.x + b.x;
-                o.y = (v[c].y - mean) * rstd * g.y + b.y;
-                o.z = (v[c].z - mean) * rstd * g.z + b.z;
-                o.w = (v[c].w - mean) * rstd * g.w + b.w;
-                if (a.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                v[c] = o;
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c) {
-        const int i4 = lane + 64 * c;
-        if (i4 < nvec) {
-            if (a.post) {
-                const float4 r = *reinterpret_cast<const float4*>(a.post + row * a.N + i4 * 4);
-                v[c].x += r.x; v[c].y += r.y; v[c].z += r.z; v[c].w += r.w;
-            }
-            *reinterpret_cast<float4*>(a.Y + row * a.N + i4 * 4) = v[c];
-        }
-    }
+// ---- two INDEPENDENT small ops in one launch ----------------------------------------------------------------------
+// A tiny kernel costs ~5 us of launch + drain whatever it does (measured: 4.8 us per launch for back-to-back INDEPENDENT
+// small GEMMs in one stream), so the branch tail of a layer pairs ops that do not depend on each other: the LayerNorm of
+// the classification branch runs beside the next regression Linear, the second one beside refine_bbox, and the final
+// classification Linear beside the next layer's Linear(3->D)+LayerNorm.  Workgroups [0, blocks_a) run op A, the rest
+// op B; each op is the same device function its stand-alone kernel calls (identical arithmetic).
+enum { PAIR_GEMM = 1, PAIR_REDUCE = 2, PAIR_REFINE = 3, PAIR_LIN3 = 4 };
+struct PairArgs {
+    GemmArgs gemm;
+    ReduceArgs red;
+    sbev_ops::MiscArgs refine;
+    sbev_ops::PosArgs lin3;
+    unsigned blocks_a;
+    int kind_a, kind_b;
+};
+template <int KC>
+__global__ __launch_bounds__(256) void pair_kernel(const PairArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    const bool first = blockIdx.x < p.blocks_a;
+    const int kind = first ? p.kind_a : p.kind_b;
+    const unsigned b = first ? blockIdx.x : blockIdx.x - p.blocks_a;
+    if (kind == PAIR_GEMM) small_tile<KC>(p.gemm, b, red);
+    else if (kind == PAIR_REDUCE) reduce_rows(p.red, b);
+    else if (kind == PAIR_REFINE) sbev_ops::refine_rows(p.refine, b);
+    else sbev_ops::lin3_rows(p.lin3, b);
 }
 
 }  // namespace
+
+
+namespace {
+unsigned blocks_of(int kind, const PairArgs& p) {
+    switch (kind) {
+        case PAIR_GEMM: return (unsigned)(((p.gemm.M + 31) / 32) * ((p.gemm.N + 31) / 32));
+        case PAIR_REDUCE: return (unsigned)((p.red.M + 3) / 4);
+        case PAIR_REFINE: return (unsigned)((p.refine.BQ + 255) / 256);
+        default: return (unsigned)((p.lin3.M + 3) / 4);
+    }
+}
+int launch_pair(PairArgs& p, hipStream_t s, const char* what) {
+    p.blocks_a = blocks_of(p.kind_a, p);
+    const unsigned total = p.blocks_a + blocks_of(p.kind_b, p);
+    const int K = (p.kind_a == PAIR_GEMM || p.kind_b == PAIR_GEMM) ? p.gemm.K : 256;
+    if (K == 512)
+        hipLaunchKernelGGL((pair_kernel<16>), dim3(total), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((pair_kernel<8>), dim3(total), dim3(256), 0, s, p);
+    return sbev::check_launch(what);
+}
+}  // namespace
+
+namespace sbev {
+// true when sbev_linear_f32 would run [M, K] x [N, K]^T on the 32 x 32 small-tile kernel (the pairs use the same tiles)
+bool small_linear_shape(int64_t M, int N, int K) {
+    return (K == 256 || K == 512) && K % 32 == 0 && ((M + 127) / 128) * ((N + 127) / 128) < 256 &&
+           !(K == 256 && N % 128 == 0 && N / 128 >= 192);
+}
+int launch_ln_and_linear(const float* X, const float* ln_w, const float* ln_b, float eps, int ln_relu, float* Yln, int64_t M, int N,
+                         const float* Xg, const float* W, const float* bias, float* Yg, int Ng, int K, int relu, hipStream_t s) {
+    PairArgs p{};
+    p.kind_a = PAIR_GEMM; p.kind_b = PAIR_REDUCE;       // the GEMM tiles first: they are the longer workgroups
+    p.gemm = GemmArgs{Xg, W, bias, nullptr, Yg, M, Ng, K, K, K, Ng, K, relu};
+    p.red = ReduceArgs{X, nullptr, nullptr, ln_w, ln_b, nullptr, Yln, M, N, 1, ln_relu, eps};
+    return launch_pair(p, s, "sbev_decoder (LayerNorm || Linear)");
+}
+int launch_ln_and_refine(const float* X, const float* ln_w, const float* ln_b, float eps, int ln_relu, float* Yln, int64_t M, int N,
+                         const float* bbox, const float* reg, const float* vel_div, float* out, int Q, int code, hipStream_t s) {
+    PairArgs p{};
+    p.kind_a = PAIR_REDUCE; p.kind_b = PAIR_REFINE;
+    p.red = ReduceArgs{X, nullptr, nullptr, ln_w, ln_b, nullptr, Yln, M, N, 1, ln_relu, eps};
+    p.refine = sbev_ops::MiscArgs{bbox, reg, vel_div, out, M, Q, code};
+    return launch_pair(p, s, "sbev_decoder (LayerNorm || refine_bbox)");
+}
+int launch_linear_and_lin3(const float* Xg, const float* W, const float* bias, float* Yg, int64_t M, int Ng, int K, int relu,
+                           const float* x3, int64_t ldx3, const float* w3, const float* b3, const float* ln_w, const float* ln_b,
+                           float eps, float* y3, int N3, hipStream_t s) {
+    PairArgs p{};
+    p.kind_a = PAIR_GEMM; p.kind_b = PAIR_LIN3;
+    p.gemm = GemmArgs{Xg, W, bias, nullptr, Yg, M, Ng, K, K, K, Ng, K, relu};
+    p.lin3 = sbev_ops::PosArgs{x3, w3, b3, ln_w, ln_b, y3, M, N3, (int)ldx3, eps};
+    return launch_pair(p, s, "sbev_decoder (Linear || Linear3+LayerNorm)");
+}
+}  // namespace sbev
 
 extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias, const float* residual, float* Y,
                                int64_t M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldy, int relu,

@@ -6,8 +6,12 @@
 // transpose -- 64 channels x 64 pixels per workgroup through LDS, 16-byte global accesses on both sides --
 // and it is skipped entirely when the neck already emits channels-last memory.  Pure HBM traffic: 2 x bytes.
 #include "sbev_common.hpp"
+#include "small_ops.hpp"
 
 namespace {
+
+using sbev_ops::PosArgs;
+using sbev_ops::lin3_rows;
 
 struct TrArgs {
     const float* in;   // [N, R, S]   (R = channels, S = H*W pixels)
@@ -64,68 +68,7 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const TrArgs a) {
     }
 }
 
-struct PosArgs {
-    const float* x;     // [M, ldx] (first 3 columns used)
-    const float* w;     // [N, 3]
-    const float* b;     // [N]
-    const float* ln_w;  // [N]
-    const float* ln_b;
-    float* y;           // [M, N]
-    long long M;
-    int N, ldx;
-    float eps;
-};
-
-// Linear(3 -> N) + LayerNorm(N) + ReLU, one wave per row (N <= 1024, N % 4 == 0): 3 FMAs per output are not
-// a GEMM.  (position_encoder[0..2], models/sparsebev_transformer.py:116-119)
-__global__ __launch_bounds__(256) void linear3_ln_relu_kernel(const PosArgs a) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.M) return;
-    const float x0 = a.x[row * a.ldx], x1 = a.x[row * a.ldx + 1], x2 = a.x[row * a.ldx + 2];
-    constexpr int MAXV = 4;
-    float v[MAXV][4];
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c) {
-        const int n0 = (lane + 64 * c) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = 0.f;
-            if (n0 + e < a.N) {
-                const float* w = a.w + (long long)(n0 + e) * 3;
-                t = ((x0 * w[0] + x1 * w[1]) + x2 * w[2]) + a.b[n0 + e];
-                s += t;
-            }
-            v[c][e] = t;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)a.N;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if ((lane + 64 * c) * 4 + e < a.N) {
-                const float d = v[c][e] - mean;
-                q += d * d;
-            }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q / (float)a.N + a.eps);
-#pragma unroll
-    for (int c = 0; c < MAXV; ++c) {
-        const int n0 = (lane + 64 * c) * 4;
-        if (n0 < a.N) {
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[c][e] - mean) * rstd * a.ln_w[n0 + e] + a.ln_b[n0 + e], 0.f);
-            *reinterpret_cast<float4*>(a.y + row * a.N + n0) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-}
+__global__ __launch_bounds__(256) void linear3_ln_relu_kernel(const PosArgs a) { lin3_rows(a, blockIdx.x); }
 
 }  // namespace
 

@@ -36,6 +36,16 @@ int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t 
 
 int regtile_plan(int64_t M, int N, int K);
 
+// gemm.hip: pairs of independent small ops of a decoder layer's tail in ONE launch (see pair_kernel)
+bool small_linear_shape(int64_t M, int N, int K);
+int launch_ln_and_linear(const float* X, const float* ln_w, const float* ln_b, float eps, int ln_relu, float* Yln, int64_t M, int N,
+                         const float* Xg, const float* W, const float* bias, float* Yg, int Ng, int K, int relu, hipStream_t s);
+int launch_ln_and_refine(const float* X, const float* ln_w, const float* ln_b, float eps, int ln_relu, float* Yln, int64_t M, int N,
+                         const float* bbox, const float* reg, const float* vel_div, float* out, int Q, int code, hipStream_t s);
+int launch_linear_and_lin3(const float* Xg, const float* W, const float* bias, float* Yg, int64_t M, int Ng, int K, int relu,
+                           const float* x3, int64_t ldx3, const float* w3, const float* b3, const float* ln_w, const float* ln_b,
+                           float eps, float* y3, int N3, hipStream_t s);
+
 // optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind = 0);
 void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int kind = 0);   // kind: 0 sampler, 1 generator GEMM, 2 out-projection GEMM

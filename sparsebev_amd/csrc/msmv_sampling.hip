@@ -63,12 +63,28 @@ __device__ __forceinline__ float corner_reduce_scatter(float i0, float i1, float
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-template <int L, typename FT, int OUT>
+// QPW > 1 (only for P <= 4, C <= 64: one chunk per query): a wave walks QPW consecutive (b', q) items and requests the
+// NEXT item's coordinates / level weights while it works on the current one, so each item costs one exposed memory round
+// trip (its feature taps) instead of two (coordinates, then taps).  PMC on the QPW = 1 kernel: 45 % of the wave cycles sit
+// in s_waitcnt, and bf16 features (half the bytes) ran no faster than fp32 -- latency-, not bandwidth-bound.
+#ifndef SBEV_MSMV_QPW
+#define SBEV_MSMV_QPW 2
+#endif
+template <int L, typename FT, int OUT, int QPW>
 __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long wave = (long long)blockIdx.x * 4 + wv;  // = b' * Q + q  (wave-uniform)
-    if (wave >= a.n_waves) return;
+    const long long item0 = ((long long)blockIdx.x * 4 + wv) * QPW;
+    if (item0 >= a.n_waves) return;
+    float lv_pref = 0.f;
+    if (QPW > 1) {
+        if (lane < a.P * 3) lv_pref = a.loc[item0 * a.P * 3 + lane];
+        if (lane >= 16 && lane < 16 + a.P * L) lv_pref = a.w[item0 * a.P * L + (lane - 16)];
+    }
+#pragma unroll 1
+    for (int qi = 0; qi < QPW; ++qi) {
+    const long long wave = item0 + qi;                       // = b' * Q + q  (wave-uniform)
+    if (wave >= a.n_waves) break;
     const long long bp = wave / a.Q;
     const int q = (int)(wave - bp * a.Q);
     const int k = lane >> 4;
@@ -99,8 +115,19 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
             // vmcnt(0) -- draining every earlier tap: 99 us instead of 64.)
             const int npts = min(4, P - p0);
             float lv = 0.f;
-            if (lane < npts * 3) lv = locq[p0 * 3 + lane];
-            if (lane >= 16 && lane < 16 + npts * L) lv = wq[p0 * L + (lane - 16)];
+            if (QPW > 1) {
+                lv = lv_pref;
+                if (qi + 1 < QPW) {                              // unconditional (clamped) request for the next item
+                    const long long wn = wave + 1 < a.n_waves ? wave + 1 : wave;
+                    float nx = 0.f;
+                    if (lane < P * 3) nx = a.loc[wn * P * 3 + lane];
+                    if (lane >= 16 && lane < 16 + P * L) nx = a.w[wn * P * L + (lane - 16)];
+                    lv_pref = nx;
+                }
+            } else {
+                if (lane < npts * 3) lv = locq[p0 * 3 + lane];
+                if (lane >= 16 && lane < 16 + npts * L) lv = wq[p0 * L + (lane - 16)];
+            }
             // Phase 1 -- tap geometry, computed ONCE per wave with the lanes as (tap, corner) pairs instead of
             // redundantly in all 64 lanes (gfx9 has no scalar float ALU, so "wave-uniform" math costs full VALU rate;
             // the first version spent ~1500 VALU instructions per query there and was VALU-, not memory-bound):
@@ -211,11 +238,15 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
             }
         }
     }
+    }   // item loop
 }
 
 template <int L, typename FT>
 int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
-    const long long blocks = (a.n_waves + 3) / 4;
+    // pipelined items per wave when a query is a single chunk and there are enough items to keep every SIMD fed
+    const bool pipe = a.P <= 4 && a.C <= 64 && a.n_waves >= 4LL * 1024 * SBEV_MSMV_QPW;
+    const long long waves = pipe ? (a.n_waves + SBEV_MSMV_QPW - 1) / SBEV_MSMV_QPW : a.n_waves;
+    const long long blocks = (waves + 3) / 4;
     if (blocks <= 0) return SBEV_OK;
     if (blocks > 0x7fffffffLL) {
         sbev::set_error("sbev_msmv_fwd: B'*Q = %lld too large for one launch", a.n_waves);
@@ -223,10 +254,13 @@ int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
     }
     hipEvent_t e0, e1;
     const bool prof = sbev::profile_begin(s, &e0, &e1);
-    if (out_layout == SBEV_OUT_REF)
-        hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (out_layout == SBEV_OUT_REF) {
+        if (pipe) hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF, SBEV_MSMV_QPW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else {
+        if (pipe) hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX, SBEV_MSMV_QPW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
     if (prof) sbev::profile_end(s, e0, e1);
     return sbev::check_launch("sbev_msmv_fwd");
 }

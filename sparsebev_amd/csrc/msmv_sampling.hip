@@ -85,16 +85,20 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
     for (int qi = 0; qi < QPW; ++qi) {
     const long long wave = item0 + qi;                       // = b' * Q + q  (wave-uniform)
     if (wave >= a.n_waves) break;
-    const long long bp = wave / a.Q;
-    const int q = (int)(wave - bp * a.Q);
+    // index arithmetic in 32 bits (n_waves < 2^31, host-checked): every 64-bit division here is ~100 scalar instructions,
+    // and five of them per item were the majority of the kernel's instruction count (the kernel is issue-bound)
+    const unsigned uw = (unsigned)wave;
+    const unsigned bp = uw / (unsigned)a.Q;
+    const int q = (int)(uw - bp * (unsigned)a.Q);
     const int k = lane >> 4;
     const int j4 = (lane & 15) * 4;
-    long long bo = bp / a.gdiv;
-    const long long gi = bp - bo * a.gdiv;
+    unsigned ubo = bp / (unsigned)a.gdiv;
+    const long long gi = bp - ubo * (unsigned)a.gdiv;
     if (a.ring_T) {                                          // (b, t) -> (b, slot[t]) in the per-frame feature ring
-        const long long b = bo / a.ring_T;
-        bo = b * a.n_slots + a.slots[(int)(bo - b * a.ring_T)];
+        const unsigned b = ubo / (unsigned)a.ring_T;
+        ubo = b * (unsigned)a.n_slots + (unsigned)a.slots[(int)(ubo - b * (unsigned)a.ring_T)];
     }
+    const long long bo = ubo;
     const int P = a.P, C = a.C;
     const float* __restrict__ locq = a.loc + wave * P * 3;
     const float* __restrict__ wq = a.w + wave * P * L;
@@ -227,10 +231,10 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
                 s.y = corner_reduce_scatter(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
                 s.z = corner_reduce_scatter(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
                 s.w = corner_reduce_scatter(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
-                const long long bt = bp / a.G;
-                const int g = (int)(bp - bt * a.G);
-                const long long b = bt / a.T;
-                const int t = (int)(bt - b * a.T);
+                const unsigned bt = bp / (unsigned)a.G;
+                const int g = (int)(bp - bt * (unsigned)a.G);
+                const long long b = bt / (unsigned)a.T;
+                const int t = (int)(bt - (unsigned)b * (unsigned)a.T);
                 if (chan_ok && p0 + k < P) {
                     float* o = a.out + ((((b * a.Q + q) * a.G + g) * a.T + t) * (long long)P + p0 + k) * C + c0 + j4;
                     *reinterpret_cast<float4*>(o) = s;
@@ -248,7 +252,7 @@ int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
     const long long waves = pipe ? (a.n_waves + SBEV_MSMV_QPW - 1) / SBEV_MSMV_QPW : a.n_waves;
     const long long blocks = (waves + 3) / 4;
     if (blocks <= 0) return SBEV_OK;
-    if (blocks > 0x7fffffffLL) {
+    if (blocks > 0x7fffffffLL || a.n_waves > 0x7fffffffLL) {
         sbev::set_error("sbev_msmv_fwd: B'*Q = %lld too large for one launch", a.n_waves);
         return SBEV_EINVAL;
     }

@@ -310,6 +310,7 @@ extern "C" int sbev_refine_bbox(const float* query_bbox, const float* reg, const
     MiscArgs a{};
     a.bbox = query_bbox; a.reg = reg; a.vel_div = vel_div; a.out = out;
     a.BQ = (long long)B * Q; a.Q = Q; a.code = code_size;
+    SBEV_REQUIRE(a.BQ <= 0x7fffffffLL, "sbev_refine_bbox: too many rows");
     hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((a.BQ + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_refine_bbox");
 }

@@ -27,12 +27,14 @@ __global__ __launch_bounds__(256) void project_select_kernel(const ProjArgs a) {
     const long long total = (long long)a.B * a.T * a.Q * GP;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int gp = (int)(idx % GP);
-    long long r = idx / GP;
-    const int q = (int)(r % a.Q);
-    r /= a.Q;
-    const int t = (int)(r % a.T);
-    const int b = (int)(r / a.T);
+    // 32-bit index split (total < 2^31, host-checked): 64-bit per-thread divisions are ~100 VALU instructions each
+    const unsigned ui = (unsigned)idx;
+    unsigned r = ui / (unsigned)GP;
+    const int gp = (int)(ui - r * (unsigned)GP);
+    const unsigned r2 = r / (unsigned)a.Q;
+    const int q = (int)(r - r2 * (unsigned)a.Q);
+    const int b = (int)(r2 / (unsigned)a.T);
+    const int t = (int)(r2 - (unsigned)b * (unsigned)a.T);
 
     const float* pt = a.pts + ((((long long)b * a.Q + q) * a.T + t) * GP + gp) * 3;
     const float x = pt[0], y = pt[1], z = pt[2];
@@ -87,10 +89,12 @@ __global__ __launch_bounds__(256) void sampling_front_kernel(const FrontArgs a) 
     const long long total = (long long)a.B * a.Q * GP;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int gp = (int)(idx % GP);
-    const long long bq = idx / GP;
-    const int q = (int)(bq % a.Q);
-    const int b = (int)(bq / a.Q);
+    const unsigned ui = (unsigned)idx;                    // total < 2^31 (host-checked)
+    const unsigned ubq = ui / (unsigned)GP;
+    const int gp = (int)(ui - ubq * (unsigned)GP);
+    const long long bq = ubq;
+    const int b = (int)(ubq / (unsigned)a.Q);
+    const int q = (int)(ubq - (unsigned)b * (unsigned)a.Q);
     const float* bb = a.bbox + bq * 10;
 
     if (a.pts) {
@@ -161,12 +165,14 @@ __global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) 
     const long long total = (long long)a.B * a.T * a.Q * GP;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int gp = (int)(idx % GP);
-    long long r = idx / GP;
-    const int q = (int)(r % a.Q);
-    r /= a.Q;
-    const int t = (int)(r % a.T);
-    const int b = (int)(r / a.T);
+    // 32-bit index split (total < 2^31, host-checked): 64-bit per-thread divisions are ~100 VALU instructions each
+    const unsigned ui = (unsigned)idx;
+    unsigned r = ui / (unsigned)GP;
+    const int gp = (int)(ui - r * (unsigned)GP);
+    const unsigned r2 = r / (unsigned)a.Q;
+    const int q = (int)(r - r2 * (unsigned)a.Q);
+    const int b = (int)(r2 / (unsigned)a.T);
+    const int t = (int)(r2 - (unsigned)b * (unsigned)a.T);
     const long long bq = (long long)b * a.Q + q;
     const float* bb = a.bbox + bq * 10;
     const int g = gp / a.P, p = gp - g * a.P;
@@ -235,7 +241,7 @@ extern "C" int sbev_project_select(const float* sample_points, const float* lida
     ProjArgs a{sample_points, lidar2img, loc_bp, dump_uvh, dump_valid, i_view, B, Q, T, N, G, P, image_h, image_w, eps};
     const long long total = (long long)B * T * Q * G * P;
     const long long blocks = (total + 255) / 256;
-    SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_project_select: too many points");
+    SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_project_select: too many points");
     hipLaunchKernelGGL(project_select_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_project_select");
 }
@@ -263,6 +269,7 @@ extern "C" int sbev_sampling_front(const float* query_bbox, const float* offset,
     }
     a.B = B; a.Q = Q; a.T = T; a.G = G; a.P = P; a.L = L;
     const long long total = (long long)B * Q * G * P;
+    SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_sampling_front: too many points");
     const long long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(sampling_front_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_sampling_front");
@@ -291,7 +298,7 @@ extern "C" int sbev_sample_and_project(const float* query_bbox, const float* off
     a.image_h = image_h; a.image_w = image_w; a.eps = eps;
     const long long total = (long long)B * T * Q * G * P;
     const long long blocks = (total + 255) / 256;
-    SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_sample_and_project: too many points");
+    SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_sample_and_project: too many points");
     hipLaunchKernelGGL(sample_project_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_sample_and_project");
 }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void refine_rows(const MiscArgs& a, unsigned block) {
     }
     for (int d = 3; d < a.code; ++d) {
         float v = r[d];
-        if (d >= 8 && a.vel_div) v = v / a.vel_div[i / a.Q];
+        if (d >= 8 && a.vel_div) v = v / a.vel_div[(unsigned)i / (unsigned)a.Q];     // BQ < 2^31 (host-checked)
         o[d] = v;
     }
 }

@@ -146,21 +146,23 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     for (int r = 0; r < RT; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // K is walked in blocks of 16: lane group fk owns k = 16*blk + 4*fk + j (j = 0..3), so an A fragment is ONE
     // 16-byte LDS read per 4 MFMAs (any k <-> (step, lane group) bijection is a valid order for A and B together)
+    // consecutive MFMAs go to DIFFERENT accumulators (j outer, r inner): four back-to-back MFMAs on one accumulator are a
+    // dependent chain, and PMC showed 56 % of the wave cycles of this kernel as issue stalls
 #pragma unroll
     for (int blk = 0; blk < C / 16; ++blk) {
         float bq[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bq[j] = WIDE ? mf[blk][j] : Ms[(16 * blk + 4 * fk + j) * LDB + cw + fi];
+        f32x4 a4[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            f32x4 a4;
-            if (WIDE) a4 = xf[r][blk];
-            else a4 = *reinterpret_cast<const f32x4*>(&Xs[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], bq[0], acc1[r], 0, 0, 0);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], bq[1], acc1[r], 0, 0, 0);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], bq[2], acc1[r], 0, 0, 0);
-            acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], bq[3], acc1[r], 0, 0, 0);
+            if (WIDE) a4[r] = xf[r][blk];
+            else a4[r] = *reinterpret_cast<const f32x4*>(&Xs[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r][j], bq[j], acc1[r], 0, 0, 0);
     }
     // C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg
     // ---- LayerNorm over all Pin*64 elements (no affine, biased variance), ReLU --------------------------
@@ -209,14 +211,13 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
             float bq[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[j] = acc1[blk][j];   // y1[16 blk + 4 fk + j][cw + fi]: this lane's own accumulators
+            f32x4 a4[POUT / 16];
 #pragma unroll
-            for (int r = 0; r < POUT / 16; ++r) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&Ss[(r * 16 + fi) * lds_s + 16 * blk + 4 * fk]);
-                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bq[0], acc2[r], 0, 0, 0);
-                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bq[1], acc2[r], 0, 0, 0);
-                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bq[2], acc2[r], 0, 0, 0);
-                acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bq[3], acc2[r], 0, 0, 0);
-            }
+            for (int r = 0; r < POUT / 16; ++r) a4[r] = *reinterpret_cast<const f32x4*>(&Ss[(r * 16 + fi) * lds_s + 16 * blk + 4 * fk]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < POUT / 16; ++r) acc2[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r][j], bq[j], acc2[r], 0, 0, 0);
         }
     } else {
         for (int k0 = 0; k0 < Pin; k0 += 4) {

@@ -78,3 +78,15 @@ def test_product_has_no_cpu_fallback():
             if fn.endswith('.py'):
                 text = open(os.path.join(root, fn)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text and 'oracle.' not in text, fn
+
+
+def test_splitk_plan_is_a_pure_host_function(lib):
+    """sbev_linear_splitk_plan: K splits that fill the GPU once.  Config 2's out-projection (900 x 256 x 32768) runs as
+    19 row groups x 2 column groups x 26 splits = 988 wave tasks on the 1024 one-wave-per-SIMD slots."""
+    plan = lib.sbev_linear_splitk_plan
+    assert plan(900, 256, 32768) == 26
+    assert plan(3600, 256, 32768) == 6 and plan(3200, 256, 32768) == 7          # configs 4 and 3 (75 / 67 row groups)
+    assert plan(36, 256, 32768) == 64                                           # capped: at least 512 of K per split
+    assert plan(900, 250, 32768) >= 1 and plan(900, 256, 1000) == 1             # shapes of the generic tile kernel / tiny K
+    assert plan(0, 256, 32768) == 1 and plan(900, 0, 32768) == 1
+    assert lib.sbev_linear_splitk_workspace(900, 256, 26) == 900 * 256 * 26 * 4

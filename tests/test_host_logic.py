@@ -75,3 +75,38 @@ def test_synthetic_rig_hit_statistics():
     hits = valid.sum(2)
     assert 0.85 < (hits >= 1).float().mean() < 0.99
     assert 0.01 < (hits >= 2).float().mean() < 0.15
+
+
+def test_head_module_host_side():
+    """SparseBEVHead / NMSFreeCoder host logic without a GPU: reference parameter names, the query grid of
+    models/sparsebev_head.py:49-67, config-dict handling, loud failures (training, CPU tensors)."""
+    from oracle import sparsebev_oracle as O
+    from sparsebev_amd.head import NMSFreeCoder, SparseBEVHead, head_prepare
+    post = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+    head = SparseBEVHead(num_classes=10, in_channels=256, num_query=900, code_size=10, code_weights=[2.0, 2.0] + [1.0] * 8,
+                         transformer=dict(type='SparseBEVTransformer', embed_dims=256, num_frames=8, num_points=4, num_layers=6,
+                                          num_levels=4, num_classes=10, code_size=10, pc_range=S.PC_RANGE),
+                         bbox_coder=dict(type='NMSFreeCoder', post_center_range=post, max_num=300, score_threshold=0.05,
+                                         num_classes=10, pc_range=S.PC_RANGE))
+    keys = set(head.state_dict())
+    assert {'init_query_bbox.weight', 'label_enc.weight', 'code_weights'} <= keys and len(keys) == 51
+    assert all(k.startswith('transformer.decoder.decoder_layer.') for k in keys - {'init_query_bbox.weight', 'label_enc.weight', 'code_weights'})
+    w = head.init_query_bbox.weight.detach()
+    assert w.shape == (900, 10) and head.label_enc.weight.shape == (11, 255)
+    ii, jj = torch.meshgrid(torch.arange(30), torch.arange(30), indexing='ij')
+    assert torch.equal(w[:, 0], ((ii.reshape(-1).float() + 0.5) / 30)) and torch.equal(w[:, 1], ((jj.reshape(-1).float() + 0.5) / 30))
+    assert float(w[:, 2].abs().max()) == 0 and float(w[:, 8:].abs().max()) == 0 and torch.all(w[:, 5] == 1.5)
+    assert isinstance(head.bbox_coder, NMSFreeCoder) and head.bbox_coder.max_num == 300 and head.pc_range == S.PC_RANGE
+    assert not head.code_weights.requires_grad and head.code_weights[0] == 2.0
+    # the oracle's restatement of the eval-branch query init agrees with the module's parameters
+    qb, qf = O.head_prepare(w, head.label_enc.weight.detach(), 10, 2)
+    assert qb.shape == (2, 900, 10) and qf.shape == (2, 900, 256) and torch.equal(qf[0, 5, :255], head.label_enc.weight[10].detach())
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        head_prepare(w, head.label_enc.weight.detach(), 10, 1)              # CPU tensors: the product has no fallback
+    with pytest.raises(NotImplementedError):
+        head.train()(S.make_features(1, 8, S.PYRAMIDS['tiny'][2]), S.make_img_metas(1, 8, 256, 704))
+    with pytest.raises(NotImplementedError):
+        head.loss()
+    with pytest.raises(ValueError):
+        SparseBEVHead(num_classes=10, in_channels=256, bbox_coder=dict(type='DETR3DCoder', pc_range=S.PC_RANGE),
+                      transformer=dict(type='SparseBEVTransformer', embed_dims=256, pc_range=S.PC_RANGE))

@@ -245,3 +245,22 @@ def test_msmv_backward_point_tails_and_both_kernels_vs_oracle(P, L, C):
     assert (lc.grad.cpu() - gl).abs().max() < 1e-4 * max(1.0, gl.abs().max().item())
     for a_, r in zip(fl, gf):
         assert (a_.grad.cpu() - r).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pipelined_items_equal_single_items(dtype):
+    """Above 8192 (b', q) items the kernel walks two items per wave with the second one's coordinates prefetched; below
+    it handles one per wave.  Same inputs through both code paths (one big call vs the same queries in slices small
+    enough to take the one-item path) must agree bit for bit, also for an odd item count and bf16 storage."""
+    g = torch.Generator().manual_seed(99)
+    sizes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    Bp, Q, P, L, C = 7, 1999, 4, 4, 64                      # 13 993 items: odd, > 8192
+    feats = [torch.randn(Bp, 6, h, w, C, generator=g).to(DEV).to(dtype) for h, w in sizes]
+    loc = torch.rand(Bp, Q, P, 3, generator=g) * 1.2 - 0.1
+    loc[..., 2] = torch.randint(0, 6, (Bp, Q, P), generator=g).float() / 5
+    wts = torch.softmax(torch.randn(Bp, Q, P, L, generator=g), -1)
+    loc, wts = loc.to(DEV), wts.to(DEV)
+    big = ops.msmv_sampling(feats, loc, wts)
+    parts = [ops.msmv_sampling(feats, loc[:, s:s + 500].contiguous(), wts[:, s:s + 500].contiguous()) for s in range(0, Q, 500)]
+    assert all(p.shape[0] * p.shape[1] < 8192 for p in parts)
+    assert torch.equal(big, torch.cat(parts, dim=1))

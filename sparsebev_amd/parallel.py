@@ -34,6 +34,17 @@ def init_distributed(n_gpus_requested=1, backend=None):
     return rank, world, device
 
 
+def reduce_mean(tensor):
+    """Average a tensor over all ranks -- mmdet's ``reduce_mean`` as the head's losses use it for ``num_total_pos`` /
+    ``cls_avg_factor`` (models/sparsebev_head.py:247,374-384; SURVEY.md 8f rank 4).  One small all-reduce (SUM) over RCCL;
+    the input is left untouched; a single process returns it as is."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensor
+    out = tensor.clone()
+    dist.all_reduce(out.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
+    return out
+
+
 class SampleShard:
     """Which samples this rank owns, and the metric reduction at the end."""
 

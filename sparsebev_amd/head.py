@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from .transformer import SparseBEVTransformer, _Base
+from .utils import VERSION
 
 try:  # optional: register with the OpenMMLab registries when that stack is present
     from mmdet.core.bbox.builder import BBOX_CODERS as _CODERS
@@ -186,6 +187,7 @@ class SparseBEVHead(_Base):
     def get_bboxes(self, preds_dicts, img_metas=None, rescale=False):
         """:463-482 (VERSION v1.0.0): [[boxes [n,9] with bottom-centre z, scores, labels], ...]; the gravity -> bottom
         centre shift is done inside the decode kernel."""
+        VERSION.require_supported()
         dec = self.bbox_coder._decode(preds_dicts, True)
         return [[d['bboxes'], d['scores'], d['labels']] for d in dec]
 

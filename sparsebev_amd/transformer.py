@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import dense, ops
-from .utils import DUMP
+from .utils import DUMP, VERSION
 
 try:  # optional: register with mmdet's registry when the OpenMMLab stack is present
     from mmcv.runner import BaseModule as _Base
@@ -325,6 +325,7 @@ class SparseBEVTransformer(_Base):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise NotImplementedError('sparsebev_amd implements the inference forward of the decoder; the backward '
                                       '(SURVEY.md section 8f) is not built yet -- call in eval() under torch.no_grad()')
+        VERSION.require_supported()
         with torch.no_grad():
             cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=layerwise)
             return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)

@@ -32,5 +32,13 @@ class Version:
     def __init__(self):
         self.name = 'v1.0.0'
 
+    def require_supported(self):
+        """Called on every forward: a checkpoint that sets the old convention (val.py:128-129 of the reference) must not be
+        run silently with the wrong rotation sign / box layout."""
+        if self.name != 'v1.0.0':
+            raise NotImplementedError("sparsebev_amd implements the 'v1.0.0' box / rotation convention only (VERSION.name = %r): "
+                                      "rotation_3d_in_axis and get_bboxes differ for 'v0.17.1' (models/utils.py:66-77, "
+                                      "models/sparsebev_head.py:472-476)" % (self.name,))
+
 
 VERSION = Version()

@@ -110,3 +110,15 @@ def test_head_module_host_side():
     with pytest.raises(ValueError):
         SparseBEVHead(num_classes=10, in_channels=256, bbox_coder=dict(type='DETR3DCoder', pc_range=S.PC_RANGE),
                       transformer=dict(type='SparseBEVTransformer', embed_dims=256, pc_range=S.PC_RANGE))
+
+
+def test_old_box_convention_is_refused_not_miscomputed():
+    from sparsebev_amd.utils import VERSION
+    m = SparseBEVTransformer(256, num_frames=1, pc_range=S.PC_RANGE).eval()
+    bbox, feat = S.make_queries(1, 4)
+    VERSION.name = 'v0.17.1'
+    try:
+        with pytest.raises(NotImplementedError, match='v1.0.0'):
+            m(bbox, feat, S.make_features(1, 1, S.PYRAMIDS['tiny'][2]), None, S.make_img_metas(1, 1, 256, 704))
+    finally:
+        VERSION.name = 'v1.0.0'

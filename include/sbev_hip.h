@@ -54,6 +54,17 @@ const char* sbev_last_error(void);
 int sbev_device_count(void);
 
 /*
+ * Box / rotation convention of the checkpoint, a process-wide switch like the reference's `VERSION` global
+ * (models/utils.py:320-325, set from checkpoint['version'] in val.py:128-129): it changes the rotation sign of the sample
+ * offsets (rotation_3d_in_axis, models/utils.py:66-77) and the box layout SparseBEVHead.get_bboxes returns
+ * (models/sparsebev_head.py:472-476).  Read at launch time by sbev_sampling_front, sbev_sample_and_project,
+ * sbev_decoder_forward and sbev_nms_free_decode (bottom_center != 0).  Default SBEV_BOX_V1_0_0.
+ */
+enum { SBEV_BOX_V1_0_0 = 0, SBEV_BOX_V0_17_1 = 1 };
+int sbev_set_box_convention(int convention);
+int sbev_get_box_convention(void);
+
+/*
  * Multi-scale multi-view bilinear sampling, forward.
  * Replaces: _ms_deform_attn_cuda_c2345_forward / _ms_deform_attn_cuda_c23456_forward
  *           (models/csrc/msmv_sampling/msmv_sampling.cpp:98-210, kernels msmv_sampling_forward.cu:75-267)

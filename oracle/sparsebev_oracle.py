@@ -45,13 +45,18 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
+VERSION_NAME = 'v1.0.0'     # the reference's module-global VERSION.name (models/utils.py:320-325); tests may set 'v0.17.1'
+
+
 def make_sample_points(query_bbox, offset, pc_range):
-    """models/sparsebev_sampling.py:8-24 with models/utils.py:49-84 (VERSION 'v1.0.0' rotation).
+    """models/sparsebev_sampling.py:8-24 with models/utils.py:49-84 (rotation sign per VERSION: :66-77).
 
     query_bbox [B,Q,10]; offset [B,Q,GP,3] -> [B,Q,GP,3] metres."""
     xyz, wlh, yaw, _ = decode_bbox(query_bbox, pc_range)
     d = wlh[:, :, None, :] * offset
     c, s = torch.cos(yaw), torch.sin(yaw)                      # [B,Q,1]
+    if VERSION_NAME == 'v0.17.1':
+        s = -s
     dx = d[..., 0] * c + d[..., 1] * (-s)
     dy = d[..., 0] * s + d[..., 1] * c
     rotated = torch.stack([dx, dy, d[..., 2]], dim=-1)
@@ -437,11 +442,15 @@ def nms_free_decode(all_cls_scores, all_bbox_preds, num_classes, max_num, score_
 
 
 def get_bboxes(decoded):
-    """models/sparsebev_head.py:463-482 (VERSION v1.0.0): gravity centre -> bottom centre; returns
+    """models/sparsebev_head.py:463-482: gravity centre -> bottom centre (+ the 'v0.17.1' w/l swap and yaw flip); returns
     [boxes [n,9], scores, labels] per sample (the reference wraps boxes in LiDARInstance3DBoxes(bboxes, 9))."""
     out = []
     for d in decoded:
         b = d['bboxes'].clone()
         b[:, 2] = b[:, 2] - b[:, 5] * 0.5
+        if VERSION_NAME == 'v0.17.1':                           # :472-476
+            w, l = b[:, 3].clone(), b[:, 4].clone()
+            b[:, 3], b[:, 4] = l, w
+            b[:, 6] = -b[:, 6] - math.pi / 2
         out.append([b, d['scores'], d['labels']])
     return out

@@ -23,6 +23,8 @@ _vp = ctypes.c_void_p
 # name -> (restype, argtypes); mirrors include/sbev_hip.h one to one
 SIGNATURES = {
     'sbev_abi_version': (ctypes.c_int, []),
+    'sbev_set_box_convention': (ctypes.c_int, [ctypes.c_int]),
+    'sbev_get_box_convention': (ctypes.c_int, []),
     'sbev_last_error': (ctypes.c_char_p, []),
     'sbev_device_count': (ctypes.c_int, []),
     'sbev_msmv_fwd': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,

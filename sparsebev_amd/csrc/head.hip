@@ -123,6 +123,12 @@ __global__ __launch_bounds__(1024) void nms_free_decode_kernel(const DecodeArgs 
         keep = bx[0] >= a.lim[0] && bx[1] >= a.lim[1] && bx[2] >= a.lim[2] && bx[0] <= a.lim[3] && bx[1] <= a.lim[4] && bx[2] <= a.lim[5];
         if (a.use_thr) keep = keep && score > a.thr;
         if (a.bottom) bx[2] = __fsub_rn(bx[2], __fmul_rn(bx[5], 0.5f));  // gravity centre -> bottom centre (sparsebev_head.py:471)
+        if (a.bottom == 2) {                                              // 'v0.17.1' layout (sparsebev_head.py:472-476)
+            const float w = bx[3];
+            bx[3] = bx[4];
+            bx[4] = w;
+            bx[6] = __fsub_rn(-bx[6], 1.5707963267948966f);
+        }
     }
     // ---- order-preserving compaction (boxes3d[mask]) ---------------------------------------------------------------
     const unsigned long long ballot = __ballot(keep);
@@ -200,7 +206,8 @@ extern "C" int sbev_nms_free_decode(const float* cls_scores, const float* bbox_p
     DecodeArgs a{};
     a.cls = cls_scores; a.bbox = bbox_preds; a.boxes = boxes; a.scores = scores; a.labels = labels; a.count = count;
     a.Q = Q; a.NC = num_classes; a.max_num = max_num;
-    a.use_thr = use_score_threshold != 0; a.thr = score_threshold; a.bottom = bottom_center != 0;
+    a.use_thr = use_score_threshold != 0; a.thr = score_threshold;
+    a.bottom = bottom_center == 0 ? 0 : (sbev::box_convention() == SBEV_BOX_V0_17_1 ? 2 : 1);
     for (int i = 0; i < 6; ++i) a.lim[i] = (float)post_center_range[i];     // torch.tensor(list) is fp32
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n <= 2048)

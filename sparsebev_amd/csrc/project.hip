@@ -80,6 +80,7 @@ struct FrontArgs {
     float* w_bp;            // [B*G*T,Q,P,L] or null
     float pc_lo[3], pc_span[3];
     int B, Q, T, G, P, L;
+    float rot_sign;         // +1: 'v1.0.0' rotation (x cos - y sin, x sin + y cos); -1: 'v0.17.1' (models/utils.py:66-77)
 };
 
 // one thread per (b, q, gp): decodes the box once, emits the T warped copies of its sample point and the
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void sampling_front_kernel(const FrontArgs a) 
         const float cy = bb[1] * a.pc_span[1] + a.pc_lo[1];
         const float cz = bb[2] * a.pc_span[2] + a.pc_lo[2];
         const float yaw = atan2f(bb[6], bb[7]);
-        const float cs = cosf(yaw), sn = sinf(yaw);
+        const float cs = cosf(yaw), sn = a.rot_sign * sinf(yaw);      // x (+-1) is exact
         const float* of = a.offset + bq * a.ld_off + gp * 3;
         const float dx = expf(bb[3]) * of[0], dy = expf(bb[4]) * of[1], dz = expf(bb[5]) * of[2];
         // rotation about z, v1.0.0 convention: x' = x cos - y sin ; y' = x sin + y cos
@@ -153,6 +154,7 @@ struct FusedArgs {
     float pc_lo[3], pc_span[3];
     int B, Q, T, N, G, P, L;
     float image_h, image_w, eps;
+    float rot_sign;         // see FrontArgs
 };
 
 // sampling_front_kernel + project_select_kernel in one launch (the decoder runtime's path): one thread per
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) 
     const float cy = bb[1] * a.pc_span[1] + a.pc_lo[1];
     const float cz = bb[2] * a.pc_span[2] + a.pc_lo[2];
     const float yaw = atan2f(bb[6], bb[7]);
-    const float cs = cosf(yaw), sn = sinf(yaw);
+    const float cs = cosf(yaw), sn = a.rot_sign * sinf(yaw);
     const float* of = a.offset + bq * a.ld_off + gp * 3;
     const float dx = expf(bb[3]) * of[0], dy = expf(bb[4]) * of[1], dz = expf(bb[5]) * of[2];
     const float px = cx + (dx * cs + dy * (-sn));
@@ -268,6 +270,7 @@ extern "C" int sbev_sampling_front(const float* query_bbox, const float* offset,
         a.pc_span[i] = (float)(pc_range[3 + i] - pc_range[i]);    // difference taken in double first (models/bbox/utils.py:69-71)
     }
     a.B = B; a.Q = Q; a.T = T; a.G = G; a.P = P; a.L = L;
+    a.rot_sign = sbev::box_convention() == SBEV_BOX_V0_17_1 ? -1.f : 1.f;
     const long long total = (long long)B * Q * G * P;
     SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_sampling_front: too many points");
     const long long blocks = (total + 255) / 256;
@@ -296,6 +299,7 @@ extern "C" int sbev_sample_and_project(const float* query_bbox, const float* off
     }
     a.B = B; a.Q = Q; a.T = T; a.N = N; a.G = G; a.P = P; a.L = L;
     a.image_h = image_h; a.image_w = image_w; a.eps = eps;
+    a.rot_sign = sbev::box_convention() == SBEV_BOX_V0_17_1 ? -1.f : 1.f;
     const long long total = (long long)B * T * Q * G * P;
     const long long blocks = (total + 255) / 256;
     SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_sample_and_project: too many points");

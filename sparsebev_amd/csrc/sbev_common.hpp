@@ -10,6 +10,7 @@
 namespace sbev {
 
 void set_error(const char* fmt, ...);
+int box_convention();    // SBEV_BOX_* (process-wide, like the reference's VERSION global)
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

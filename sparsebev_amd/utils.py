@@ -26,19 +26,33 @@ DUMP = DumpConfig()
 
 
 class Version:
-    """Checkpoint convention switch (models/utils.py:320-325).  Only 'v1.0.0' (the default, and the only
-    convention any shipped config uses) is implemented by the HIP kernels."""
+    """Checkpoint convention switch (models/utils.py:320-325): ``VERSION.name`` is 'v1.0.0' (default) or 'v0.17.1'
+    (set from ``checkpoint['version']``, val.py:128-129).  It flips the rotation sign of the sample offsets
+    (rotation_3d_in_axis, models/utils.py:66-77) and the box layout of ``get_bboxes`` (models/sparsebev_head.py:472-476);
+    assigning it forwards the choice to the library (``sbev_set_box_convention``), which reads it at launch time."""
+    _CODES = {'v1.0.0': 0, 'v0.17.1': 1}
 
     def __init__(self):
-        self.name = 'v1.0.0'
+        self._name = 'v1.0.0'
+
+    @property
+    def name(self):
+        return self._name
+
+    @name.setter
+    def name(self, value):
+        if value not in self._CODES:
+            raise NotImplementedError("unknown box convention %r (the reference knows 'v1.0.0' and 'v0.17.1')" % (value,))
+        from . import _lib
+        _lib.check(_lib.load().sbev_set_box_convention(self._CODES[value]), 'sbev_set_box_convention')
+        self._name = value
 
     def require_supported(self):
-        """Called on every forward: a checkpoint that sets the old convention (val.py:128-129 of the reference) must not be
-        run silently with the wrong rotation sign / box layout."""
-        if self.name != 'v1.0.0':
-            raise NotImplementedError("sparsebev_amd implements the 'v1.0.0' box / rotation convention only (VERSION.name = %r): "
-                                      "rotation_3d_in_axis and get_bboxes differ for 'v0.17.1' (models/utils.py:66-77, "
-                                      "models/sparsebev_head.py:472-476)" % (self.name,))
+        """The library and the Python switch must agree (someone may have called sbev_set_box_convention directly)."""
+        from . import _lib
+        if _lib.load().sbev_get_box_convention() != self._CODES[self._name]:
+            raise RuntimeError('VERSION.name = %r but libsbev_hip.so is set to convention %d'
+                               % (self._name, _lib.load().sbev_get_box_convention()))
 
 
 VERSION = Version()

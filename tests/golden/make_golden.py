@@ -293,9 +293,29 @@ def main_head():
         save('g9_nms_free_' + tag, **arrays)
 
 
+def main_version():
+    """G10: the reference's make_sample_points / rotation_3d_in_axis under VERSION.name = 'v0.17.1' (models/utils.py:66-77),
+    the convention old checkpoints select (val.py:128-129).  `python tests/golden/make_golden.py version` writes only G10."""
+    tr, smp, wrap, utils = import_reference()
+    g = torch.Generator().manual_seed(1017)
+    bbox, _ = S.make_queries(2, 16, seed=1018)
+    bbox[..., 6:8] = torch.randn(2, 16, 2, generator=g)
+    offset = torch.randn(2, 16, 16, 3, generator=g)
+    out = {}
+    for name in ('v1.0.0', 'v0.17.1'):
+        utils.VERSION.name = name
+        out[name] = smp.make_sample_points(bbox, offset, S.PC_RANGE)
+    utils.VERSION.name = 'v1.0.0'
+    assert (out['v1.0.0'] - out['v0.17.1']).abs().max() > 1e-2
+    save('g10_sample_points_versions', query_bbox=bbox, offset=offset, pts_v1=out['v1.0.0'], pts_v017=out['v0.17.1'])
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'head':
         main_head()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'version':
+        main_version()
     else:
         main()
         main_head()
+        main_version()

@@ -264,3 +264,51 @@ def test_pipelined_items_equal_single_items(dtype):
     parts = [ops.msmv_sampling(feats, loc[:, s:s + 500].contiguous(), wts[:, s:s + 500].contiguous()) for s in range(0, Q, 500)]
     assert all(p.shape[0] * p.shape[1] < 8192 for p in parts)
     assert torch.equal(big, torch.cat(parts, dim=1))
+
+
+def test_g10_old_box_convention_front_kernel_and_decoder_layer():
+    """VERSION.name = 'v0.17.1' (old checkpoints, val.py:128-129): the sample-point kernel against the reference recording
+    (G10) and one decoder layer + get_bboxes against the oracle under the same switch."""
+    import copy
+    from oracle import sparsebev_oracle as O
+    from sparsebev_amd.utils import VERSION
+    from sparsebev_amd.transformer import SparseBEVTransformer
+    from sparsebev_amd import head as H
+    g = load_golden('g10_sample_points_versions')
+    B, Q, GP = g['offset'].shape[:3]
+    td = torch.zeros(B, 1)
+    logits = torch.zeros(B, Q, GP * 4)
+    try:
+        for name, key in (('v1.0.0', 'pts_v1'), ('v0.17.1', 'pts_v017')):
+            VERSION.name = name
+            pts, _ = ops.sampling_front(g['query_bbox'].to(DEV), g['offset'].reshape(B, Q, GP * 3).to(DEV), logits.to(DEV), td.to(DEV),
+                                        S.PC_RANGE, T=1, G=4, P=4, L=4)
+            assert (pts.cpu().reshape(B, Q, GP, 3) - g[key]).abs().max() < 1e-4, name
+        VERSION.name = O.VERSION_NAME = 'v0.17.1'
+        T, L, Qn = 2, 4, 36
+        ih, iw, sizes = S.PYRAMIDS['tiny']
+        params = S.make_params(81, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+        m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=1, num_levels=L, num_classes=10, code_size=10, pc_range=S.PC_RANGE)
+        m.load_state_dict({'decoder.decoder_layer.' + k: v for k, v in params.items()})
+        m = m.to(DEV).eval()
+        bbox, feat = S.make_queries(1, Qn, seed=82)
+        feats = S.make_features(1, T, sizes, seed=83)
+        metas = S.make_img_metas(1, T, ih, iw)
+        cls, box = m(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
+        rc, rb, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1)
+        assert (cls[0].cpu() - rc[0]).abs().max() < TOL and (box[0].cpu() - rb[0]).abs().max() < TOL
+        O.VERSION_NAME = 'v1.0.0'
+        rc1, _, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1)
+        assert (rc1[0] - rc[0]).abs().max() > 1e-3                       # the switch matters
+        O.VERSION_NAME = 'v0.17.1'
+        # get_bboxes: w / l swapped, yaw -> -yaw - pi/2
+        post = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+        gen = torch.Generator().manual_seed(84)
+        c2 = torch.randn(1, 1, 50, 10, generator=gen)
+        b2 = torch.randn(1, 1, 50, 10, generator=gen)
+        coder = H.NMSFreeCoder(S.PC_RANGE, post_center_range=post, max_num=20, score_threshold=None, num_classes=10)
+        got = coder._decode({'all_cls_scores': c2.to(DEV), 'all_bbox_preds': b2.to(DEV)}, True)[0]
+        ref = O.get_bboxes(O.nms_free_decode(c2, b2, 10, 20, None, post))[0]
+        assert torch.equal(got['labels'].cpu(), ref[2]) and (got['bboxes'].cpu() - ref[0]).abs().max() < 2e-5
+    finally:
+        VERSION.name = O.VERSION_NAME = 'v1.0.0'

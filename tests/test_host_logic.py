@@ -112,13 +112,20 @@ def test_head_module_host_side():
                       transformer=dict(type='SparseBEVTransformer', embed_dims=256, pc_range=S.PC_RANGE))
 
 
-def test_old_box_convention_is_refused_not_miscomputed():
+def test_version_switch_reaches_the_library():
+    """VERSION.name mirrors the reference's module-global switch and forwards to sbev_set_box_convention."""
+    from sparsebev_amd import _lib
     from sparsebev_amd.utils import VERSION
-    m = SparseBEVTransformer(256, num_frames=1, pc_range=S.PC_RANGE).eval()
-    bbox, feat = S.make_queries(1, 4)
-    VERSION.name = 'v0.17.1'
+    lib = _lib.load()
+    assert VERSION.name == 'v1.0.0' and lib.sbev_get_box_convention() == 0
     try:
-        with pytest.raises(NotImplementedError, match='v1.0.0'):
-            m(bbox, feat, S.make_features(1, 1, S.PYRAMIDS['tiny'][2]), None, S.make_img_metas(1, 1, 256, 704))
+        VERSION.name = 'v0.17.1'
+        assert lib.sbev_get_box_convention() == 1
+        VERSION.require_supported()
+        with pytest.raises(NotImplementedError):
+            VERSION.name = 'v2'
+        assert VERSION.name == 'v0.17.1'
     finally:
         VERSION.name = 'v1.0.0'
+    assert lib.sbev_get_box_convention() == 0
+    assert lib.sbev_set_box_convention(7) != 0 and b'convention' in lib.sbev_last_error()

@@ -205,3 +205,15 @@ def test_head_prepare_and_postprocess_restatement():
     out = O.head_postprocess(box, S.PC_RANGE)
     assert torch.equal(out[..., 0], box[..., 0] * 102.4 + (-51.2)) and torch.equal(out[..., 4], box[..., 2] * 8.0 + (-5.0))
     assert torch.equal(out[..., 2:4], box[..., 3:5]) and torch.equal(out[..., 5:], box[..., 5:])
+
+
+def test_g10_sample_points_both_box_conventions():
+    """make_sample_points under VERSION 'v1.0.0' and 'v0.17.1' (rotation sign, models/utils.py:66-77) vs the reference."""
+    g = load_golden('g10_sample_points_versions')
+    try:
+        for name, key in (('v1.0.0', 'pts_v1'), ('v0.17.1', 'pts_v017')):
+            O.VERSION_NAME = name
+            got = O.make_sample_points(g['query_bbox'], g['offset'], S.PC_RANGE)
+            assert (got - g[key]).abs().max() < 1e-5, name
+    finally:
+        O.VERSION_NAME = 'v1.0.0'

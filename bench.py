@@ -241,6 +241,7 @@ def main():
     checksum = 0.0
     for _ in range(args.steps):
         cls, box = step()
+    host_issue = time.perf_counter() - t0         # host time to ISSUE the K steps (well below `elapsed` = the host runs ahead)
     torch.cuda.synchronize()
     shard.barrier()
     elapsed = time.perf_counter() - t0
@@ -289,6 +290,7 @@ def main():
             'value': round(samples / elapsed_max, 3), 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed_max / args.steps, 4),
+            'host_issue_ms_per_step': round(1e3 * host_issue / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + (' (mixing GEMMs: 3xbf16 split, f32 accumulate)' if args.gemm == 'bf16x3' else ''),
             'data': 'synthetic',

@@ -15,6 +15,7 @@ and the 2x-feature-bytes regroup copy (``:73-85``) is replaced by one NCHW->NHWC
 all when the neck already produces channels-last features).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -243,6 +244,41 @@ class FeaturePyramid:
         return ops.msmv_sampling_nhwc(self.levels, self.B, T, G, loc, w_bp, out_layout=ops.OUT_MIX)
 
 
+class _PinnedUpload:
+    """Host -> device upload of the small per-call constants without stalling the host: a pageable `.to(device)` returns
+    only once the copy has executed, i.e. after everything queued before it -- the host then cannot run ahead of the
+    device and every step starts with an idle gap of one launch latency.  A ring of page-locked staging buffers (one
+    event each, waited for only when the ring wraps onto a copy still in flight) keeps the upload asynchronous."""
+
+    DEPTH = 8
+
+    def __init__(self):
+        self._rings = {}
+
+    def __call__(self, arr, device):
+        t, device = torch.from_numpy(arr), torch.device(device)
+        if device.type != 'cuda' or os.environ.get('SBEV_PAGEABLE_UPLOAD') == '1':
+            return t.to(device)
+        key = (tuple(arr.shape), arr.dtype.str, device.index)
+        ring = self._rings.get(key)
+        if ring is None:
+            ring = self._rings[key] = {'next': 0, 'slots': [None] * self.DEPTH}
+        i = ring['next']
+        ring['next'] = (i + 1) % self.DEPTH
+        slot = ring['slots'][i]
+        if slot is None:
+            slot = ring['slots'][i] = [torch.empty(t.shape, dtype=t.dtype).pin_memory(), torch.cuda.Event()]
+        else:
+            slot[1].synchronize()
+        slot[0].copy_(t)
+        out = slot[0].to(device, non_blocking=True)
+        slot[1].record(torch.cuda.current_stream(device))
+        return out
+
+
+_upload = _PinnedUpload()
+
+
 class DecoderContext:
     """Per-call constants: time_diff, lidar2img, image size (models/sparsebev_transformer.py:60-70,276)."""
 
@@ -250,14 +286,14 @@ class DecoderContext:
         ts = np.array([m['img_timestamp'] for m in img_metas], dtype=np.float64).reshape(B, -1, N_VIEWS)
         td = np.mean(ts[:, :1, :] - ts, axis=-1).astype(np.float32)                # [B,T]; float64 mean then fp32
         l2i = np.asarray([m['lidar2img'] for m in img_metas]).astype(np.float32)   # [B,T*N,4,4]
-        self.time_diff = torch.from_numpy(td).to(device)
-        self.lidar2img = torch.from_numpy(l2i).to(device)
+        self.time_diff = _upload(td, device)
+        self.lidar2img = _upload(l2i, device)
         self.image_h, self.image_w = img_metas[0]['img_shape'][0][:2]
         # velocity divisor of :179-183: time_diff[:,1] with values < 1e-5 replaced by 1 (only when T > 1)
         if td.shape[1] > 1:
             d = td[:, 1].copy()
             d[d < 1e-5] = 1.0
-            self.vel_div = torch.from_numpy(d).to(device)
+            self.vel_div = _upload(d, device)
         else:
             self.vel_div = None
 

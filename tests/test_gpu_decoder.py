@@ -2,6 +2,7 @@
 recorded from the reference decoder, teacher-forced per layer (1e-4) and free-running (sanity bound)."""
 import copy
 
+import numpy as np
 import pytest
 import torch
 
@@ -311,3 +312,24 @@ def test_full_size_config2_properties():
     perm = torch.randperm(Q, generator=torch.Generator().manual_seed(74)).to(DEV)
     clsp, boxp = model(bbox[:, perm].contiguous(), feat[:, perm].contiguous(), feats, None, copy.deepcopy(metas))
     assert (clsp[0] - cls[0][:, perm]).abs().max() < TOL and (boxp[0] - box[0][:, perm]).abs().max() < TOL
+
+
+def test_per_call_constants_survive_the_pinned_upload_ring():
+    # DecoderContext stages time_diff / lidar2img through a ring of page-locked buffers (asynchronous upload): more
+    # contexts than ring slots, built back to back while the device is busy, must each keep their own values
+    from sparsebev_amd.transformer import _PinnedUpload
+    B, T = 1, 8
+    busy = torch.randn(4096, 4096, device=DEV)
+    ctxs, want = [], []
+    for i in range(3 * _PinnedUpload.DEPTH):
+        metas = S.make_img_metas(B, T, 256, 704)
+        for m in metas:
+            m['lidar2img'] = [a + np.float32(i) for a in m['lidar2img']]      # a different set of matrices per context
+        for _ in range(4):
+            busy = busy @ busy * 1e-3                      # keep the stream ahead of the uploads
+        ctxs.append(DecoderContext(metas, B, torch.device(DEV)))
+        want.append(np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+    torch.cuda.synchronize()
+    for c, w in zip(ctxs, want):
+        assert np.array_equal(c.lidar2img.cpu().numpy(), w)
+    assert not np.array_equal(want[0], want[1])

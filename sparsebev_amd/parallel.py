@@ -22,6 +22,8 @@ def init_distributed(n_gpus_requested=1, backend=None):
     if world != max(n_gpus_requested, 1) and world > 1:
         raise RuntimeError('--gpus %d but WORLD_SIZE=%d' % (n_gpus_requested, world))
     use_gpu = torch.cuda.is_available()
+    if os.environ.get('SBEV_SHARE_GPU') == '1':      # test hook: every rank on GPU 0, metric reduction over gloo (RCCL refuses
+        local, backend = 0, 'gloo'                    # two ranks on one device) -- exercises the N > 1 bench path on a 1-GPU box
     device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)

@@ -41,9 +41,13 @@ struct MsmvArgs {
     int slots[SBEV_MAX_FRAMES];
 };
 
-__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 load4(const unsigned short* p) {  // 4 x bf16 -> fp32 (exact)
-    const uint2 r = *reinterpret_cast<const uint2*>(p);
+// A tap is kept in its storage form until it is consumed: 4 bf16 channels stay two registers while the 4 * L loads of a
+// chunk are in flight (converted tap by tap in phase 3), which is what decides the waves per SIMD of this latency-bound
+// kernel (c5, L = 5: 71.5 -> 59 us; L = 4 bf16: 39.9 -> 34.5 us).
+__device__ __forceinline__ float4 load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ uint2 load_raw(const unsigned short* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 widen(const float4 r) { return r; }
+__device__ __forceinline__ float4 widen(const uint2 r) {  // 4 x bf16 -> fp32 (exact)
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
                        __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
 }
@@ -70,8 +74,20 @@ __device__ __forceinline__ float corner_reduce_scatter(float i0, float i1, float
 #ifndef SBEV_MSMV_QPW
 #define SBEV_MSMV_QPW 2
 #endif
+// Waves per SIMD asked of the register allocator: with bf16 taps the 5-level kernel lands 2 registers above the 3-wave
+// budget (170 vs 168), which the allocator closes when told to (4 spilled registers; 59.2 -> 58.0 us at c5).  Not for
+// L = 4: 134 -> 128 registers for a 4th wave costs 8 spills and measured 40.0 vs 34.5 us.  fp32 is left alone.
+template <int L, typename FT>
+constexpr int msmv_min_waves() {
+#ifdef SBEV_MSMV_NO_BF16_WAVES
+    return 1;
+#else
+    return (sizeof(FT) == 2 && L >= 5) ? 3 : 1;
+#endif
+}
+
 template <int L, typename FT, int OUT, int QPW>
-__global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(msmv_min_waves<L, FT>()))) void msmv_fwd_kernel(const MsmvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long item0 = ((long long)blockIdx.x * 4 + wv) * QPW;
@@ -185,12 +201,12 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
                     tcoef[pp][l] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(s_coef[t / 16])));
                     toff[pp][l] = __builtin_amdgcn_ds_bpermute(src, s_off[t / 16]);
                 }
-            float4 tv[4][L];
+            decltype(load_raw(base[0])) tv[4][L];
             __builtin_amdgcn_sched_barrier(0);     // pin the phases: hipcc otherwise re-interleaves loads, waits and math
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-                for (int l = 0; l < L; ++l) tv[pp][l] = load4(base[l] + (toff[pp][l] & 0x7fffffff));   // always a valid address
+                for (int l = 0; l < L; ++l) tv[pp][l] = load_raw(base[l] + (toff[pp][l] & 0x7fffffff));   // always a valid address
             __builtin_amdgcn_sched_barrier(0);
             float4 acc[4];
 #pragma unroll
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(256) void msmv_fwd_kernel(const MsmvArgs a) {
                 acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    float4 v = tv[pp][l];
+                    float4 v = widen(tv[pp][l]);
                     if (toff[pp][l] < 0 || !chan_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);   // outside the map: exactly 0
                     const float coef = tcoef[pp][l];
                     acc[pp].x = fmaf(coef, v.x, acc[pp].x);

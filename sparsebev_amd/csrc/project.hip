@@ -160,8 +160,8 @@ struct FusedArgs {
 // sampling_front_kernel + project_select_kernel in one launch (the decoder runtime's path): one thread per
 // (b, t, q, gp) rebuilds its 3-D sample point from the box and the offset (the same expressions, in the same
 // -ffp-contract=off translation unit, so the point -- and therefore the hit mask -- is bit-identical to the
-// two-kernel path) and projects it; the [B,Q,T,GP,3] point tensor never exists.  Threads with t == 0 also
-// write the level softmax of their (g, p) into the T weight rows of group g.
+// two-kernel path) and projects it; the [B,Q,T,GP,3] point tensor never exists.  Every thread also writes the level
+// softmax of its (g, p) into row t of group g's T weight rows.
 __global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) {
     const int GP = a.G * a.P;
     const long long total = (long long)a.B * a.T * a.Q * GP;
@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) 
     o[1] = sv;
     o[2] = __fdiv_rn((float)view, (float)(a.N - 1));
 
-    if (t == 0) {
+    // level softmax of (g, p): every frame's thread recomputes it (L expf) and writes ITS row t of group g's T weight
+    // rows, instead of the t == 0 threads writing all T rows (their 56 workgroups were the kernel's tail)
+    {
         const float* lg = a.logits + bq * a.ld_logit + gp * a.L;
         float mx = lg[0];
         for (int l = 1; l < a.L; ++l) mx = fmaxf(mx, lg[l]);
@@ -222,11 +224,9 @@ __global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) 
             e[l] = expf(lg[l] - mx);
             sum += e[l];
         }
-        for (int tp = 0; tp < a.T; ++tp) {
-            const long long row = ((long long)b * a.G + g) * a.T + tp;
-            float* ow = a.w_bp + ((row * a.Q + q) * a.P + p) * a.L;
-            for (int l = 0; l < a.L; ++l) ow[l] = e[l] / sum;
-        }
+        const long long row = ((long long)b * a.G + g) * a.T + t;
+        float* ow = a.w_bp + ((row * a.Q + q) * a.P + p) * a.L;
+        for (int l = 0; l < a.L; ++l) ow[l] = e[l] / sum;
     }
 }
 

@@ -211,6 +211,21 @@ int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, fl
                         const float* add_after, float* Y, int64_t M, int N, int relu, sbev_stream_t stream);
 
 /*
+ * LayerNorm as the prologue of the Linear that consumes it:
+ *   Xn = relu?(LayerNorm(X; ln_w, ln_b, eps)) (+ ln_add),   Y = act(Xn W^T + bias) (+ residual);  Xn is also stored.
+ * Replaces: a norm immediately followed by a Linear on its output -- the position encoder's last LayerNorm + ReLU, the
+ *           `query_feat + query_pos` add and the attention in_proj (models/sparsebev_transformer.py:117-121,166-169;
+ *           mmcv MultiheadAttention in_proj), norm1 + the sampling offset / scale-weight Linear (:169-170,262-268), norm3 +
+ *           the first Linear of the cls / reg branches (:172-175,132-147).
+ * X, Xn [M, K] dense; ln_add [M, K] or NULL; W [N, ldw]; Y / residual [M, ldy].  One launch when K == 256 and the
+ * shape is one sbev_linear_f32 runs on its 32 x 32 small-tile kernel (every decoder shape); otherwise
+ * sbev_layer_norm_f32 + sbev_linear_f32.  Pointers 16-byte aligned.
+ */
+int sbev_ln_linear_f32(const float* X, const float* ln_w, const float* ln_b, float ln_eps, int ln_relu,
+                       const float* ln_add, float* Xn, const float* W, const float* bias, const float* residual,
+                       float* Y, int64_t M, int N, int K, int64_t ldw, int64_t ldy, int relu, sbev_stream_t stream);
+
+/*
  * sbev_sampling_front + sbev_project_select fused into one launch (what the decoder runtime uses): the intermediate
  * [B,Q,T,G*P,3] sample-point tensor never exists.  Same arithmetic in the same no-FMA translation unit, so loc_bp and
  * weights_bp are bit-identical to the two-call path (tested).  No DUMP outputs: use the two calls for the debug taps.

@@ -45,6 +45,9 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'sbev_layer_norm_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, ctypes.c_int64, ctypes.c_int,
                                            ctypes.c_int, _vp]),
+    'sbev_ln_linear_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int, _vp]),
     'sbev_adaptive_mixing_f32': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_float, _vp]),
     'sbev_sasa_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double), _vp, _vp,

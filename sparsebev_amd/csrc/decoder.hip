@@ -159,12 +159,17 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         if (!pe0_done) TRY(sbev_linear3_ln_relu_f32(bbox, layer == 0 ? 10 : c.code_size, w->pe0_w, w->pe0_b, w->pe1_g, w->pe1_b, eps, b.t0, BQ, D, stream));
         pe0_done = false;
         TRY(sbev_linear_f32(b.t0, w->pe3_w, w->pe3_b, nullptr, b.t1, BQ, D, D, D, D, D, 0, stream));
-        TRY(sbev_layer_norm_f32(b.t1, w->pe4_g, w->pe4_b, eps, feat, b.x, BQ, D, 1, stream));
-        // scale-adaptive self attention + norm1                                (:169)
-        TRY(sbev_linear_f32(b.x, w->attn_in_w, w->attn_in_b, nullptr, b.qkvt, BQ, c.attn_in_rows, D, D, D, c.attn_in_rows, 0, stream));
+        // Three of the layer's LayerNorms run as the PROLOGUE of the small-tile Linear that consumes them
+        // (sbev_ln_linear_f32: one launch instead of two, the normalised rows are stored for the other readers):
+        // here the position encoder's last norm (+ ReLU, + query_feat) -> x, with the attention in-projection
+        TRY(sbev_ln_linear_f32(b.t1, w->pe4_g, w->pe4_b, eps, 1, feat, b.x, w->attn_in_w, w->attn_in_b, nullptr, b.qkvt,
+                               BQ, c.attn_in_rows, D, D, c.attn_in_rows, 0, stream));
+        // scale-adaptive self attention                                         (:169)
         TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
         TRY(sbev_linear_f32(b.att, w->attn_out_w, w->attn_out_b, b.x, b.t1, BQ, D, D, D, D, D, 0, stream));
-        TRY(sbev_layer_norm_f32(b.t1, w->norm1_g, w->norm1_b, eps, nullptr, b.x1, BQ, D, 0, stream));
+        // norm1 -> x1, with the Linear of the sampling offsets / level logits      (:169-170)
+        TRY(sbev_ln_linear_f32(b.t1, w->norm1_g, w->norm1_b, eps, 0, nullptr, b.x1, w->samp_w, w->samp_b, nullptr, b.so,
+                               BQ, soN, D, D, soN, 0, stream));
         // fork: parameter generator (needs only x1) on the aux stream, beside the sampling chain
         hipEvent_t ev_pg = nullptr;
         if (fork_pg) {
@@ -181,7 +186,6 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(hip_ok(hipEventRecord(ev_pg, ax.stream), "hipEventRecord"));
         }
         // adaptive spatio-temporal sampling                                     (:170)
-        TRY(sbev_linear_f32(b.x1, w->samp_w, w->samp_b, nullptr, b.so, BQ, soN, D, D, D, soN, 0, stream));
         TRY(sbev_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
                                     c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
         if (c.n_slots > 0)
@@ -204,13 +208,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // FFN + norm3                                                           (:172)
         TRY(sbev_linear_f32(b.x2, w->ffn0_w, w->ffn0_b, nullptr, b.h, BQ, c.ffn, D, D, D, c.ffn, 1, stream));
         TRY(sbev_linear_f32(b.h, w->ffn1_w, w->ffn1_b, b.x2, b.t1, BQ, D, c.ffn, c.ffn, c.ffn, D, 0, stream));
-        TRY(sbev_layer_norm_f32(b.t1, w->norm3_g, w->norm3_b, eps, nullptr, b.x3, BQ, D, 0, stream));
+        // norm3 -> x3 is the prologue of the branches' first Linear (below)
         // classification branch (output only) on the aux stream; regression branch + box refinement on the main one (:174-183)
-        if (fork) {
-            hipEvent_t e = next_ev();
-            TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
-            TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
-        }
         // the two branches are independent chains of small linears: each level of them shares one grouped launch
         // (with `fork` the classification branch goes to the aux stream instead)
         auto prob = [&](const float* X, const float* W, const float* bias, float* Y, int N, int relu) {
@@ -219,11 +218,18 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // only while sbev_linear_f32 would pick the same small-tile kernel for each of them (keeps the results identical
         // to the op-by-op path); large batches have enough tiles per linear anyway
         const bool grouped = !fork && (D == 256 || D == 512) && ((BQ + 127) / 128) * ((D + 127) / 128) < 256;
+        const sbev::LnPrologue norm3{w->norm3_g, w->norm3_b, eps, 0, nullptr, b.x3};
         if (grouped) {
-            // 5 launches for the 9 ops of the two branches + refine (+ the next layer's first position-encoder stage):
+            // 5 launches for norm3 + the 9 ops of the two branches + refine (+ the next layer's first position-encoder stage):
             // ops that do not depend on each other share a launch (gemm.hip: group / pair kernels, same arithmetic as alone)
-            const sbev_linear_problem g1[2] = {prob(b.x3, w->cls0_w, w->cls0_b, b.c0, D, 0), prob(b.x3, w->reg0_w, w->reg0_b, b.r0, D, 1)};
-            TRY(sbev_linear_group_f32(g1, 2, stream));
+            const sbev_linear_problem g1[2] = {prob(b.t1, w->cls0_w, w->cls0_b, b.c0, D, 0), prob(b.t1, w->reg0_w, w->reg0_b, b.r0, D, 1)};
+            if (sbev::ln_linear_fusable(BQ, D, D)) {
+                TRY(sbev::launch_linear_group(g1, 2, &norm3, s_main));
+            } else {
+                TRY(sbev_layer_norm_f32(b.t1, w->norm3_g, w->norm3_b, eps, nullptr, b.x3, BQ, D, 0, stream));
+                const sbev_linear_problem g1x[2] = {prob(b.x3, w->cls0_w, w->cls0_b, b.c0, D, 0), prob(b.x3, w->reg0_w, w->reg0_b, b.r0, D, 1)};
+                TRY(sbev_linear_group_f32(g1x, 2, stream));
+            }
             TRY(sbev::launch_ln_and_linear(b.c0, w->cls1_g, w->cls1_b, eps, 1, b.c1, BQ, D,
                                            b.r0, w->reg2_w, w->reg2_b, b.r1, D, D, 1, s_main));
             const sbev_linear_problem g2[2] = {prob(b.c1, w->cls3_w, w->cls3_b, b.c0, D, 0),
@@ -239,7 +245,14 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                 TRY(sbev_linear_f32(b.c1, w->cls6_w, w->cls6_b, nullptr, cls_l, BQ, c.num_classes, D, D, D, c.num_classes, 0, stream));
             }
         } else {   // s_aux == stream unless forked
-            TRY(sbev_linear_f32(b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
+            // norm3 + the classification branch's first Linear on the main stream (x3 is read by both branches) ...
+            TRY(sbev_ln_linear_f32(b.t1, w->norm3_g, w->norm3_b, eps, 0, nullptr, b.x3, w->cls0_w, w->cls0_b, nullptr, b.c0,
+                                   BQ, D, D, D, D, 0, stream));
+            if (fork) {   // ... then the rest of it aside
+                hipEvent_t e = next_ev();
+                TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
+                TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
+            }
             TRY(sbev_layer_norm_f32(b.c0, w->cls1_g, w->cls1_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));
             TRY(sbev_linear_f32(b.c1, w->cls3_w, w->cls3_b, nullptr, b.c0, BQ, D, D, D, D, D, 0, s_aux));
             TRY(sbev_layer_norm_f32(b.c0, w->cls4_g, w->cls4_b, eps, nullptr, b.c1, BQ, D, 1, s_aux));

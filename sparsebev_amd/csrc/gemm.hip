@@ -16,6 +16,7 @@
 // 64 MFMAs of 64 cycles each: invisible).  Split-K (grid.z) writes fp32 partial slabs for the K=32768
 // out-projection; sbev_splitk_reduce_* combines them in the next kernel's prologue (a launch boundary is
 // cheaper than an in-launch cross-XCD hand-off at this size, cdna_hip_programming.md section 5).
+#include <cstdlib>
 #include "sbev_common.hpp"
 #include "small_ops.hpp"
 
@@ -41,6 +42,13 @@ struct GemmArgs {
     long long ldx, ldw, ldy;
     int k_per_split;     // multiple of BK
     int relu;
+    // LayerNorm prologue (small-tile kernel only, K == 256 == the LayerNorm width): X rows are normalised on the way in
+    const float* ln_g = nullptr;    // [K] or null -> plain linear
+    const float* ln_b = nullptr;    // [K]
+    const float* ln_add = nullptr;  // [M, ldx] or null: added after LayerNorm (+ ReLU)
+    float* xn_out = nullptr;        // [M, ldx] or null: the normalised rows, written by the workgroups of column tile 0
+    float ln_eps = 0.f;
+    int ln_relu = 0;
 };
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs (MI355X_MICROARCH.md), so give
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const GemmArgs a) {
 // wave pulls its A / B fragments straight from global memory (L2-resident operands, each element used once per
 // wave, so LDS staging would only add a barrier), runs K/4/2 MFMAs, and the four partial tiles are combined
 // through 16 KiB of LDS into a float4 row-major epilogue.  232 workgroups / 928 waves for [900,256]x[256,256].
+constexpr int SMALL_LDS_FLOATS = 4 * 16 * 64 + 256 + 512;      // split-K exchange area + the LayerNorm prologue's row statistics + gamma | beta
 template <int KC>   // KC = K / 4 / 8: float4 k-blocks per wave (8 for K = 256, 16 for K = 512)
 __device__ __forceinline__ void small_tile(const GemmArgs& a, unsigned tile, float* red) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -243,6 +252,61 @@ __device__ __forceinline__ void small_tile(const GemmArgs& a, unsigned tile, flo
     for (int i = 0; i < KC; ++i) {       // all loads in flight before the first MFMA
         fa[i] = *reinterpret_cast<const float4*>(xp + i * 8);
         fb[i] = *reinterpret_cast<const float4*>(wp + i * 8);
+    }
+    if constexpr (KC == 8) {
+        // LayerNorm prologue: the 4 waves of the workgroup hold its 32 rows x 256 k between them (wave = a 64-k slice,
+        // lane (fr, fh) = row fr, 32 of those k), so the producer's stand-alone LayerNorm launch (~6 us for 0.9 MB) becomes
+        // two 4-way LDS exchanges of row statistics here.  Two-pass variance, as the stand-alone kernel.
+        if (a.ln_g) {
+            float* stat = red + 4 * 16 * 64;                  // 2 x [4 waves][32 rows], behind the split-K exchange area
+            float* gb = stat + 256;                           // gamma | beta staged once per workgroup: holding them in
+            gb[tid] = a.ln_g[tid];                            // registers from the top (64 per lane) halves the resident
+            gb[256 + tid] = a.ln_b[tid];                      // workgroups per CU and the 725-tile in-projection needs 2 rounds
+            const int kb = wave * 64 + 4 * fh;
+            float4 ad[KC];
+            if (a.ln_add) {                                   // one uniform branch around all 8 requests
+#pragma unroll
+                for (int i = 0; i < KC; ++i) ad[i] = *reinterpret_cast<const float4*>(a.ln_add + ra * a.ldx + kb + i * 8);
+            } else {
+#pragma unroll
+                for (int i = 0; i < KC; ++i) ad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) sm += (fa[i].x + fa[i].y) + (fa[i].z + fa[i].w);
+            sm += __shfl_xor(sm, 32);
+            if (fh == 0) stat[wave * 32 + fr] = sm;
+            __syncthreads();
+            const float mean = ((stat[fr] + stat[32 + fr]) + (stat[64 + fr] + stat[96 + fr])) * (1.f / 256.f);
+            float qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                const float dx = fa[i].x - mean, dy = fa[i].y - mean, dz = fa[i].z - mean, dw = fa[i].w - mean;
+                qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            qq += __shfl_xor(qq, 32);
+            if (fh == 0) stat[128 + wave * 32 + fr] = qq;
+            __syncthreads();
+            const float var = ((stat[128 + fr] + stat[160 + fr]) + (stat[192 + fr] + stat[224 + fr])) * (1.f / 256.f);
+            const float rstd = rsqrtf(var + a.ln_eps);
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gb + kb + i * 8);
+                const float4 b4 = *reinterpret_cast<const float4*>(gb + 256 + kb + i * 8);
+                float4 o;
+                o.x = (fa[i].x - mean) * rstd * g4.x + b4.x;
+                o.y = (fa[i].y - mean) * rstd * g4.y + b4.y;
+                o.z = (fa[i].z - mean) * rstd * g4.z + b4.z;
+                o.w = (fa[i].w - mean) * rstd * g4.w + b4.w;
+                if (a.ln_relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                o.x += ad[i].x; o.y += ad[i].y; o.z += ad[i].z; o.w += ad[i].w;
+                fa[i] = o;
+            }
+            if (a.xn_out && tn == 0 && (m0 + fr) < a.M) {
+#pragma unroll
+                for (int i = 0; i < KC; ++i) *reinterpret_cast<float4*>(a.xn_out + ra * a.ldx + kb + i * 8) = fa[i];
+            }
+        }
     }
     f32x16 acc;
 #pragma unroll
@@ -293,7 +357,7 @@ __device__ __forceinline__ void small_tile(const GemmArgs& a, unsigned tile, flo
 
 template <int KC>
 __global__ __launch_bounds__(256) void gemm_nt_f32_small_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[SMALL_LDS_FLOATS];
     small_tile<KC>(a, blockIdx.x, red);
 }
 
@@ -307,7 +371,7 @@ struct GroupArgs {
 };
 template <int KC>
 __global__ __launch_bounds__(256) void gemm_group_small_kernel(const GroupArgs g) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[SMALL_LDS_FLOATS];
     const unsigned id = blockIdx.x;
     if (id < g.tile_end[0]) small_tile<KC>(g.p[0], id, red);
     else if (id < g.tile_end[1]) small_tile<KC>(g.p[1], id - g.tile_end[0], red);
@@ -437,7 +501,7 @@ struct PairArgs {
 };
 template <int KC>
 __global__ __launch_bounds__(256) void pair_kernel(const PairArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[SMALL_LDS_FLOATS];
     const bool first = blockIdx.x < p.blocks_a;
     const int kind = first ? p.kind_a : p.kind_b;
     const unsigned b = first ? blockIdx.x : blockIdx.x - p.blocks_a;
@@ -544,7 +608,35 @@ extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias
 }
 
 
+namespace sbev {
+bool ln_linear_fusable(int64_t M, int N, int K) {
+    static const bool off = getenv("SBEV_NO_LN_FUSE") != nullptr;      // A/B switch: the two launches the prologue replaces
+    return !off && K == 256 && small_linear_shape(M, N, K);
+}
+}  // namespace sbev
+
 extern "C" int sbev_linear_group_f32(const sbev_linear_problem* probs, int n, sbev_stream_t stream) {
+    return sbev::launch_linear_group(probs, n, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int sbev_ln_linear_f32(const float* X, const float* ln_w, const float* ln_b, float ln_eps, int ln_relu,
+                                  const float* ln_add, float* Xn, const float* W, const float* bias, const float* residual,
+                                  float* Y, int64_t M, int N, int K, int64_t ldw, int64_t ldy, int relu, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 1 && K >= 4 && K % 4 == 0 && K <= 1024, "sbev_ln_linear_f32: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && ln_w && ln_b && Xn && W && Y, "sbev_ln_linear_f32: null pointer");
+    if (sbev::ln_linear_fusable(M, N, K)) {
+        const sbev_linear_problem q{X, W, bias, residual, Y, M, N, K, K, ldw, ldy, relu};
+        const sbev::LnPrologue ln{ln_w, ln_b, ln_eps, ln_relu, ln_add, Xn};
+        return sbev::launch_linear_group(&q, 1, &ln, reinterpret_cast<hipStream_t>(stream));
+    }
+    // shapes the small-tile kernel does not take: the two launches it replaces
+    int st = sbev_layer_norm_f32(X, ln_w, ln_b, ln_eps, ln_add, Xn, M, K, ln_relu, stream);
+    if (st != SBEV_OK) return st;
+    return sbev_linear_f32(Xn, W, bias, residual, Y, M, N, K, K, ldw, ldy, relu, stream);
+}
+
+int sbev::launch_linear_group(const sbev_linear_problem* probs, int n, const LnPrologue* ln, hipStream_t s) {
     SBEV_REQUIRE(probs && n >= 1 && n <= 3, "sbev_linear_group_f32: 1..3 problems per launch (got %d)", n);
     GroupArgs g{};
     g.n = n;
@@ -559,11 +651,19 @@ extern "C" int sbev_linear_group_f32(const sbev_linear_problem* probs, int n, sb
             SBEV_REQUIRE(q.ldx % 4 == 0 && q.ldw % 4 == 0 && q.ldx >= K && q.ldw >= K && q.ldy >= q.N, "sbev_linear_group_f32: problem %d leading dimensions", i);
             SBEV_REQUIRE((((uintptr_t)q.X | (uintptr_t)q.W) & 15) == 0, "sbev_linear_group_f32: problem %d X / W not 16-byte aligned", i);
             g.p[i] = GemmArgs{q.X, q.W, q.bias, q.residual, q.Y, q.M, q.N, q.K, q.ldx, q.ldw, q.ldy, q.K, q.relu};
+            if (ln) {
+                SBEV_REQUIRE(K == 256 && q.X == probs[0].X && q.M == probs[0].M && q.ldx == K,
+                             "sbev_ln_linear_f32: the LayerNorm prologue needs K = 256 and one dense X shared by the group");
+                SBEV_REQUIRE(((((uintptr_t)ln->g | (uintptr_t)ln->b | (uintptr_t)ln->add | (uintptr_t)ln->xn)) & 15) == 0,
+                             "sbev_ln_linear_f32: gamma / beta / add / Xn must be 16-byte aligned");
+                g.p[i].ln_g = ln->g; g.p[i].ln_b = ln->b; g.p[i].ln_add = ln->add;
+                g.p[i].xn_out = i == 0 ? ln->xn : nullptr;
+                g.p[i].ln_eps = ln->eps; g.p[i].ln_relu = ln->relu;
+            }
             end += (unsigned)(((q.M + 31) / 32) * ((q.N + 31) / 32));
         }
         g.tile_end[i] = end;
     }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (K == 256)
         hipLaunchKernelGGL((gemm_group_small_kernel<8>), dim3(end), dim3(256), 0, s, g);
     else

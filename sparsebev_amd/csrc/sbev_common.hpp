@@ -47,6 +47,19 @@ int launch_linear_and_lin3(const float* Xg, const float* W, const float* bias, f
                            const float* x3, int64_t ldx3, const float* w3, const float* b3, const float* ln_w, const float* ln_b,
                            float eps, float* y3, int N3, hipStream_t s);
 
+// gemm.hip: LayerNorm as the PROLOGUE of the small-tile linears that consume it (sbev_ln_linear_f32); a group launch
+// shares one prologue between its problems (they all read the same X)
+struct LnPrologue {
+    const float* g;
+    const float* b;
+    float eps;
+    int relu;
+    const float* add;   // [M, 256] or null: added after LayerNorm (+ ReLU)
+    float* xn;          // [M, 256]: the normalised rows, written once (problem 0's column-tile-0 workgroups)
+};
+int launch_linear_group(const sbev_linear_problem* probs, int n, const LnPrologue* ln, hipStream_t s);
+bool ln_linear_fusable(int64_t M, int N, int K);
+
 // optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind = 0);
 void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int kind = 0);   // kind: 0 sampler, 1 generator GEMM, 2 out-projection GEMM

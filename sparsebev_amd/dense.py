@@ -15,6 +15,7 @@ NATIVE = {
     'linear': 'hip: gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32), split-K + fused bias/ReLU/residual/LayerNorm reducer',
     'linear_group': 'hip: gemm_group_small_kernel (cls / reg branch levels side by side)',
     'layer_norm': 'hip: splitk_reduce_kernel (1 slab)',
+    'ln_linear': 'hip: gemm_group_small_kernel with the LayerNorm prologue (row statistics exchanged through LDS)',
     'linear_ln_relu': 'hip: gemm + LayerNorm/ReLU reducer; Linear(3->D): linear3_ln_relu_kernel',
     'self_attention': 'hip: gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
     'adaptive_mixing': 'hip: gemm (generator) + adaptive_mixing_kernel (v_mfma_f32_16x16x4_f32) + split-K gemm (out-proj, fused residual + LayerNorm)',
@@ -120,6 +121,28 @@ def linear_group(problems):
     return outs
 
 
+def ln_linear(x, ln_w, ln_b, w, b, eps=1e-5, ln_relu=False, add_after=None, relu=False, residual=None):
+    """xn = relu?(LayerNorm(x)) (+ add_after);  y = act(xn @ w.T + b) (+ residual).  Returns (xn, y).  One launch:
+    the LayerNorm is the prologue of the Linear's small-tile kernel (csrc/gemm.hip), the way the decoder runtime runs
+    the position encoder's last norm + attention in_proj, norm1 + the sampling Linear and norm3 + the branch heads."""
+    _dev(x, ln_w, ln_b, w)
+    K, N = x.shape[-1], w.shape[0]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    w = w.contiguous()
+    aa = add_after.reshape(-1, K).contiguous() if add_after is not None else None
+    rr = residual.reshape(-1, N).contiguous() if residual is not None else None
+    xn = torch.empty_like(x2)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    st = _lib.load().sbev_ln_linear_f32(_p(x2), _p(ln_w), _p(ln_b), eps, int(ln_relu), _p(aa), _p(xn), _p(w), _p(b), _p(rr), _p(y),
+                                        M, N, K, K, N, int(relu), _stream())
+    _lib.check(st, 'sbev_ln_linear_f32')
+    return xn.reshape(x.shape), y.reshape(*lead, N)
+
+
 def layer_norm(x, w, b, eps=1e-5, relu=False, add_after=None):
     """relu?(LayerNorm(x)) (+ add_after)"""
     _dev(x, w, b)
@@ -171,7 +194,7 @@ def _cat_rows(*tensors):
 
 
 def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b, out_w, out_b, tau_w, tau_b,
-                                  pre_attn_mask=None, ln=None):
+                                  pre_attn_mask=None, ln=None, qkvt=None):
     """models/sparsebev_transformer.py:210-228,236-248 + mmcv MultiheadAttention(batch_first) = x + MHA(x),
     optionally followed by LayerNorm (ln = norm1 of the decoder layer).
 
@@ -185,9 +208,8 @@ def scale_adaptive_self_attention(query_bbox, x, pc_range, num_heads, in_w, in_b
     pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
     if (3 * D + num_heads) % 4 != 0:
         raise RuntimeError('3*embed_dims + num_heads must be a multiple of 4')
-    w_all = _cat_rows(in_w, tau_w)
-    b_all = _cat_rows(in_b, tau_b)
-    qkvt = linear(x, w_all, b_all)                           # [B,Q,3D+H(+pad)]
+    if qkvt is None:                                         # else: produced by ln_linear() together with x
+        qkvt = linear(x, _cat_rows(in_w, tau_w), _cat_rows(in_b, tau_b))   # [B,Q,3D+H(+pad)]
     mask = None
     if pre_attn_mask is not None:
         mask = pre_attn_mask.to(device=x.device, dtype=torch.uint8).contiguous()

@@ -79,7 +79,12 @@ class SparseBEVSelfAttention(_Base):
         nn.init.zeros_(self.gen_tau.weight)
         nn.init.uniform_(self.gen_tau.bias, 0.0, 2.0)
 
-    def forward(self, query_bbox, query_feat, pre_attn_mask=None, ln=None):
+    def in_proj_packed(self):
+        """(weight, bias) of the one in-projection GEMM: q | k | v | tau rows."""
+        a = self.attention.attn
+        return dense._cat_rows(a.in_proj_weight, self.gen_tau.weight), dense._cat_rows(a.in_proj_bias, self.gen_tau.bias)
+
+    def forward(self, query_bbox, query_feat, pre_attn_mask=None, ln=None, qkvt=None):
         a = self.attention.attn
         if DUMP.enabled:     # sasa_tau tap (models/sparsebev_transformer.py:218-219); debug path only
             w4 = torch.cat([self.gen_tau.weight, self.gen_tau.weight.new_zeros((-self.num_heads) % 4, query_feat.shape[-1])], 0)
@@ -88,7 +93,7 @@ class SparseBEVSelfAttention(_Base):
         return dense.scale_adaptive_self_attention(
             query_bbox, query_feat, self.pc_range, self.num_heads,
             a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-            self.gen_tau.weight, self.gen_tau.bias, pre_attn_mask, ln=ln)
+            self.gen_tau.weight, self.gen_tau.bias, pre_attn_mask, ln=ln, qkvt=qkvt)
 
 
 class SparseBEVSampling(_Base):
@@ -106,12 +111,16 @@ class SparseBEVSampling(_Base):
         nn.init.zeros_(self.sampling_offset.weight)
         nn.init.uniform_(self.sampling_offset.bias, -0.5, 0.5)
 
-    def forward(self, query_bbox, query_feat, feats, ctx):
+    def packed(self):
+        """(weight, bias) of the one Linear for both generators: [256] -> G*P*3 offsets | G*P*L level logits."""
+        return (dense._cat_rows(self.sampling_offset.weight, self.scale_weights.weight),
+                dense._cat_rows(self.sampling_offset.bias, self.scale_weights.bias))
+
+    def forward(self, query_bbox, query_feat, feats, ctx, both=None):
         """feats: FeaturePyramid (channels-last, resident); ctx: DecoderContext.  -> [B,Q,G,T*P,C]"""
         T, G, P, L = self.num_frames, self.num_groups, self.num_points, self.num_levels
-        # one fused Linear for both generators: [B,Q,256] x [256, G*P*3 + G*P*L]
-        both = dense.linear(query_feat, dense._cat_rows(self.sampling_offset.weight, self.scale_weights.weight),
-                            dense._cat_rows(self.sampling_offset.bias, self.scale_weights.bias))
+        if both is None:                                            # else: produced by ln_linear() together with query_feat
+            both = dense.linear(query_feat, *self.packed())
         n_off = G * P * 3
         offset, logits = both[..., :n_off], both[..., n_off:]       # column slices of the packed rows (no copy)
         pts, w_bp = ops.sampling_front(query_bbox, offset, logits, ctx.time_diff, self.pc_range, T, G, P, L)
@@ -187,15 +196,21 @@ class SparseBEVTransformerDecoderLayer(_Base):
     def forward(self, query_bbox, query_feat, feats, attn_mask, ctx):
         pe = self.position_encoder
         pos = dense.linear_ln_relu(query_bbox, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)   # reads columns 0:3
-        x = dense.layer_norm(dense.linear(pos, pe[3].weight, pe[3].bias), pe[4].weight, pe[4].bias, relu=True, add_after=query_feat)
-        x = self.self_attn(query_bbox, x, attn_mask, ln=(self.norm1.weight, self.norm1.bias))
-        sampled = self.sampling(query_bbox, x, feats, ctx)
+        # three of the layer's LayerNorms run as the PROLOGUE of the Linear that consumes them (dense.ln_linear, the same
+        # launches as the C++ runtime): position-encoder norm (+ ReLU, + query_feat) -> attention in_proj; norm1 ->
+        # sampling generators; norm3 -> first Linear of the classification branch
+        x, qkvt = dense.ln_linear(dense.linear(pos, pe[3].weight, pe[3].bias), pe[4].weight, pe[4].bias,
+                                  *self.self_attn.in_proj_packed(), ln_relu=True, add_after=query_feat)
+        pre1 = self.self_attn(query_bbox, x, attn_mask, qkvt=qkvt)                  # x + attention, norm1 follows
+        x, both = dense.ln_linear(pre1, self.norm1.weight, self.norm1.bias, *self.sampling.packed())
+        sampled = self.sampling(query_bbox, x, feats, ctx, both=both)
         x = self.mixing(sampled, x, ln=(self.norm2.weight, self.norm2.bias))       # norm2 fused into the out-proj reducer
         f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]
         h = dense.linear(x, f0.weight, f0.bias, relu=True)
-        x = dense.layer_norm(dense.linear(h, f1.weight, f1.bias, residual=x), self.norm3.weight, self.norm3.bias)
         cb, rb = self.cls_branch, self.reg_branch
-        c = dense.linear_ln_relu(x, cb[0].weight, cb[0].bias, cb[1].weight, cb[1].bias)
+        x, c = dense.ln_linear(dense.linear(h, f1.weight, f1.bias, residual=x), self.norm3.weight, self.norm3.bias,
+                               cb[0].weight, cb[0].bias)
+        c = dense.layer_norm(c, cb[1].weight, cb[1].bias, relu=True)
         c = dense.linear_ln_relu(c, cb[3].weight, cb[3].bias, cb[4].weight, cb[4].bias)
         cls_score = dense.linear(c, cb[6].weight, cb[6].bias)
         r = dense.linear(x, rb[0].weight, rb[0].bias, relu=True)

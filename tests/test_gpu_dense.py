@@ -243,3 +243,43 @@ def test_linear_group_rejects_bad_groups():
     x3 = torch.zeros(8, 128, device=dev); w3 = torch.zeros(4, 128, device=dev)
     with pytest.raises(RuntimeError):
         dense.linear_group([(x3, w3, None, False)])                             # K not 256 / 512
+
+
+@pytest.mark.parametrize('M,N,ln_relu,with_add,relu', [(900, 776, True, True, False), (900, 112, False, False, False),
+                                                        (900, 256, False, False, True), (37, 40, True, False, False), (3200, 128, False, True, False)])
+def test_layer_norm_as_linear_prologue(M, N, ln_relu, with_add, relu):
+    # dense.ln_linear (one launch, row statistics exchanged through LDS inside the consumer's tiles) against the two
+    # launches it replaces; the stored normalised rows against the stand-alone LayerNorm
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, 256, generator=g) * 3 + 0.7).to(DEV)
+    lw, lb = (torch.rand(256, generator=g) + 0.5).to(DEV), (torch.randn(256, generator=g) * 0.1).to(DEV)
+    w, b = (torch.randn(N, 256, generator=g) * 0.05).to(DEV), torch.randn(N, generator=g).to(DEV)
+    add = torch.randn(M, 256, generator=g).to(DEV) if with_add else None
+    xn, y = dense.ln_linear(x, lw, lb, w, b, ln_relu=ln_relu, add_after=add, relu=relu)
+    xn_ref = dense.layer_norm(x, lw, lb, relu=ln_relu, add_after=add)
+    y_ref = dense.linear(xn_ref, w, b, relu=relu)
+    assert (xn - xn_ref).abs().max().item() < 5e-6
+    assert (y - y_ref).abs().max().item() < 2e-5
+    # and against plain torch on the host
+    xc = torch.nn.functional.layer_norm(x.cpu().double(), (256,), lw.cpu().double(), lb.cpu().double(), 1e-5)
+    if ln_relu:
+        xc = xc.relu()
+    if add is not None:
+        xc = xc + add.cpu().double()
+    yc = xc @ w.cpu().double().T + b.cpu().double()
+    if relu:
+        yc = yc.relu()
+    assert (xn.cpu().double() - xc).abs().max().item() < 2e-5
+    assert (y.cpu().double() - yc).abs().max().item() < 1e-4
+    # the consumer of the stored rows sees exactly what the prologue fed the MFMAs
+    assert torch.equal(dense.linear(xn, w, b, relu=relu), y)
+
+
+def test_layer_norm_prologue_falls_back_outside_the_small_tile_shapes():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 512, generator=g).to(DEV)                       # K = 512: LayerNorm + Linear as two launches
+    lw, lb = torch.rand(512, generator=g).to(DEV), torch.randn(512, generator=g).to(DEV)
+    w, b = (torch.randn(96, 512, generator=g) * 0.05).to(DEV), torch.randn(96, generator=g).to(DEV)
+    xn, y = dense.ln_linear(x, lw, lb, w, b)
+    xn_ref = dense.layer_norm(x, lw, lb)
+    assert torch.equal(xn, xn_ref) and torch.equal(y, dense.linear(xn_ref, w, b))

@@ -217,9 +217,9 @@ int sbev_layer_norm_f32(const float* X, const float* ln_w, const float* ln_b, fl
  *           `query_feat + query_pos` add and the attention in_proj (models/sparsebev_transformer.py:117-121,166-169;
  *           mmcv MultiheadAttention in_proj), norm1 + the sampling offset / scale-weight Linear (:169-170,262-268), norm3 +
  *           the first Linear of the cls / reg branches (:172-175,132-147).
- * X, Xn [M, K] dense; ln_add [M, K] or NULL; W [N, ldw]; Y / residual [M, ldy].  One launch when K == 256 and the
- * shape is one sbev_linear_f32 runs on its 32 x 32 small-tile kernel (every decoder shape); otherwise
- * sbev_layer_norm_f32 + sbev_linear_f32.  Pointers 16-byte aligned.
+ * X, Xn [M, K] dense; ln_add [M, K] or NULL; W [N, ldw]; Y / residual [M, ldy].  One launch when K == 256, M <= 2048 and
+ * the shape is one sbev_linear_f32 runs on its 32 x 32 small-tile kernel (each column tile re-normalises its rows, so the
+ * prologue only pays while rows are few); otherwise sbev_layer_norm_f32 + sbev_linear_f32.  Pointers 16-byte aligned.
  */
 int sbev_ln_linear_f32(const float* X, const float* ln_w, const float* ln_b, float ln_eps, int ln_relu,
                        const float* ln_add, float* Xn, const float* W, const float* bias, const float* residual,

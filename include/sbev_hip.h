@@ -368,7 +368,9 @@ typedef struct sbev_decoder_config {
     int32_t frame_slots[SBEV_MAX_FRAMES]; /* ring only: physical slot of logical frame t (see sbev_msmv_fwd_ring) */
     int32_t overlap;                    /* != 0: run the parameter-generator GEMM and the classification branch on an
                                            internal second stream (created once per process) beside the sampling chain /
-                                           regression branch, joined back into `stream` with events */
+                                           regression branch, joined back into `stream` with events.  The side stream and
+                                           its events are process-wide: calls with overlap != 0 must not run concurrently
+                                           from several host threads (overlap == 0, the default, has no shared state) */
     double pc_range[6];
 } sbev_decoder_config;
 

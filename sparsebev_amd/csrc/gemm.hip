@@ -707,8 +707,7 @@ extern "C" int sbev_linear_splitk_f32(const float* X, const float* W, const floa
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int used;
     if (regtile_ok(M, N, K) && splits <= K / 32) {
-        used = splits;
-        int st = sbev::launch_splitk_regtile(X, W, workspace, M, N, K, ldx, ldw, splits, s);     // gemm_regtile.hip
+        int st = sbev::launch_splitk_regtile(X, W, workspace, M, N, K, ldx, ldw, splits, &used, s);     // gemm_regtile.hip
         if (st != SBEV_OK) return st;
         ReduceArgs r{workspace, bias, residual, ln_w, ln_b, nullptr, Y, M, N, used, relu, ln_eps};
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, r);

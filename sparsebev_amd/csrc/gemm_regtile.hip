@@ -3,6 +3,7 @@
 // 256 architectural VGPRs; with the default AGPR-form MFMAs hipcc keeps half of the accumulators in VGPRs across the
 // loop back-edge and copies them to AGPRs and back EVERY iteration (144 serial v_accvgpr_* per 192 MFMAs: 140 -> 130 us
 // at Q = 900 once they are gone).
+#include <cstdlib>
 #include "sbev_common.hpp"
 
 namespace {
@@ -35,6 +36,7 @@ struct RegTileArgs {
     long long ldx, ldw;
     int rgs, cgs, splits, pairs;   // row groups (48), column groups (128), K splits, K / 32
     unsigned tasks;
+    int fold;                      // 2: the two waves of a pair own K splits 2s / 2s + 1 of ONE tile and write their sum (slab s)
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_nt_f32_regtile_kernel(const RegTileArgs a) {
@@ -46,10 +48,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const unsigned full = nb >> 3, rem = nb & 7, x = b & 7;
     const unsigned logical = x * full + (x < rem ? x : rem) + (b >> 3);
     const unsigned task = logical * 4 + wave;
-    if (task >= a.tasks) return;
-    const int rg = task % a.rgs;
-    const unsigned t2 = task / a.rgs;
-    const int cg = t2 % a.cgs, sp = t2 / a.cgs;
+    // fold == 2: waves (0, 1) and (2, 3) of a workgroup are PAIRS on one output tile with adjacent K splits; the odd wave
+    // hands its partial tile over through LDS and the even one writes the sum: half the slabs to write here and to read in
+    // the reducer (24 -> 12 MB each at Q = 900), in a fixed order (bit-reproducible, unlike atomics).
+    __shared__ f32x4v fold_buf[2][FR * 8][64];
+    const bool active = task < a.tasks;
+    if (a.fold == 1 && !active) return;
+    const unsigned tc = active ? task : a.tasks - 1;       // a spare wave of the last workgroup repeats the last task (it has
+    const unsigned unit = a.fold == 2 ? tc >> 1 : tc;      // to reach the barrier below) and writes nothing
+    const int rg = unit % a.rgs;
+    const unsigned t2 = unit / a.rgs;
+    const int cg = t2 % a.cgs;
+    const int sp_out = t2 / a.cgs;
+    const int sp = a.fold == 2 ? 2 * sp_out + (int)(tc & 1) : sp_out;
     const int p0 = (a.pairs * sp) / a.splits, p1 = (a.pairs * (sp + 1)) / a.splits;     // pairs * splits < 2^31 (host-checked)
     const int M = (int)a.M;
 
@@ -98,7 +109,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 #undef SBEV_RT_LOAD
 #undef SBEV_RT_MMA
-    float* out = a.P + ((long long)sp * a.M) * a.N + cg * 128 + 4 * fk;
+    if (a.fold == 2) {
+        const int pr = wave >> 1;
+        if (active && (wave & 1)) {
+#pragma unroll
+            for (int fr = 0; fr < FR; ++fr)
+#pragma unroll
+                for (int cf = 0; cf < 8; ++cf) fold_buf[pr][fr * 8 + cf][lane] = acc[fr][cf];
+        }
+        __syncthreads();
+        if (!active || (wave & 1)) return;
+#pragma unroll
+        for (int fr = 0; fr < FR; ++fr)
+#pragma unroll
+            for (int cf = 0; cf < 8; ++cf) acc[fr][cf] += fold_buf[pr][fr * 8 + cf][lane];
+    }
+    float* out = a.P + ((long long)sp_out * a.M) * a.N + cg * 128 + 4 * fk;
 #pragma unroll
     for (int fr = 0; fr < FR; ++fr) {
         const int row = rg * TROWS + fr * 16 + fi;
@@ -114,9 +140,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
 namespace sbev {
 int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
-                          int splits, hipStream_t stream) {
+                          int splits, int* slabs_written, hipStream_t stream) {
     SBEV_REQUIRE((long long)(K / 32) * (splits + 1) < 0x7fffffffLL, "sbev_linear_splitk_f32: K * splits too large");
-    RegTileArgs t{X, W, slabs, M, N, K, ldx, ldw, (int)((M + TROWS - 1) / TROWS), N / 128, splits, K / 32, 0u};
+    static const bool no_fold = getenv("SBEV_NO_SPLIT_FOLD") != nullptr;       // A/B switch
+    const int fold = (splits % 2 == 0 && !no_fold) ? 2 : 1;
+    *slabs_written = splits / fold;
+    RegTileArgs t{X, W, slabs, M, N, K, ldx, ldw, (int)((M + TROWS - 1) / TROWS), N / 128, splits, K / 32, 0u, fold};
     const long long tasks = (long long)t.rgs * t.cgs * splits;
     SBEV_REQUIRE(tasks <= 0x3fffffffLL, "sbev_linear_splitk_f32: too many tasks");
     t.tasks = (unsigned)tasks;

@@ -32,8 +32,9 @@ inline int check_launch(const char* what) {
 constexpr int kWave = 64;  // CDNA wavefront
 
 // gemm_regtile.hip: the split-K partial-slab GEMM of sbev_linear_splitk_f32 for N % 128 == 0, K % 32 == 0
+// (writes *slabs_written <= splits partial slabs: pairs of K splits are summed inside the kernel when splits is even)
 int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
-                          int splits, hipStream_t stream);
+                          int splits, int* slabs_written, hipStream_t stream);
 
 int regtile_plan(int64_t M, int N, int K);
 

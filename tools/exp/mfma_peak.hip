@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int NACC, int WPE>
 __global__ __launch_bounds__(256 * (WPE > 1 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k(float* out, int iters, float a0, float b0) {
@@ -23,7 +25,8 @@ __global__ __launch_bounds__(256 * (WPE > 1 ? 2 : 1)) __attribute__((amdgpu_wave
 }
 
 // 16 MFMAs (4 accumulators) + ONE memory instruction per group, as in the strip GEMM's steady state: kind 0 none,
-// 1 global_load_dwordx4 (L2-resident), 2 global_load_dword, 3 ds_read_b128, 4 global_store_dwordx4
+// 1 global_load_dwordx4 (L2-resident), 2 global_load_dword, 3 ds_read_b128, 4 global_store_dwordx4,
+// 5 global_load_lds_dwordx4 (direct to LDS), 6 = 5 + a ds_read_b128 (the LDS-staged operand stream)
 template <int KIND, int WPE, int VG>
 __global__ __launch_bounds__(256 * WPE) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void km(float* buf, float* out, int iters, float a0, float b0) {
     __shared__ f32x4v lds[1024];
@@ -50,6 +53,9 @@ __global__ __launch_bounds__(256 * WPE) __attribute__((amdgpu_waves_per_eu(WPE, 
             if (KIND == 2) r[u][0] = reinterpret_cast<const float*>(p)[u * 256];
             if (KIND == 3) r[u] = lds[(threadIdx.x + u * 64) & 1023];
             if (KIND == 4) q[u * 256] = acc[u & 3];
+            if (KIND == 5 || KIND == 6)      // direct-to-LDS load: no VGPR return
+                __builtin_amdgcn_global_load_lds((gptr_t)(p + u * 256), (lptr_t)(lds + (((threadIdx.x & 0x3c0) + (u & 1) * 512) & 1023)), 16, 0, 0);
+            if (KIND == 6) r[u] = lds[(threadIdx.x + u * 64) & 1023];
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -116,5 +122,10 @@ int main() {
     runm<1, 2, 4>("2 waves/SIMD: 16 MFMA + 1 global_load_dwordx4");
     runm<3, 2, 2>("2 waves/SIMD: 8 MFMA + 1 ds_read_b128");
     runm<1, 1, 2>("1 wave/SIMD: 8 MFMA + 1 global_load_dwordx4");
+    runm<5>("16 MFMA + 1 global_load_lds_dwordx4");
+    runm<6>("16 MFMA + 1 load_lds + 1 ds_read_b128");
+    runm<5, 2, 2>("2 waves/SIMD: 8 MFMA + 1 load_lds");
+    runm<6, 2, 2>("2 waves/SIMD: 8 MFMA + 1 load_lds + 1 ds_read");
+    runm<3, 2, 4>("2 waves/SIMD: 16 MFMA + 1 ds_read_b128");
     return 0;
 }

@@ -482,105 +482,6 @@ __global__ __launch_bounds__(256) SBEV_ONE_WAVE_PER_EU void gemm_nt_f32_strip_ke
 #undef SBEV_STRIP
 }
 
-// ---- variant: two waves per SIMD, X staged through LDS ------------------------------------------------------------------
-// tools/exp/mfma_peak.hip: what an operand stream costs the matrix core is the VGPR write-back -- 87 cycles for a
-// global_load_dwordx4 at one wave per SIMD, 23-38 for a ds_read_b128 at two, 16 for a direct-to-LDS load.  So: 8 waves per
-// workgroup (two per SIMD), a wave keeps a 32-column strip of W (128 registers) for one half of the row fragments, the 4
-// waves of a half share each X fragment through LDS (every wave fetches a quarter of it with global_load_lds_dwordx4, laid
-// out so that chunk j of the fragment IS the B operand of lane (fi, fk): xbuf[half][stage][j][lane]), one workgroup barrier
-// per fragment, two stages.
-typedef __attribute__((address_space(1))) const void* sbev_gptr_t;
-typedef __attribute__((address_space(3))) void* sbev_lptr_t;
-
-template <bool RELU>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_f32_strip2_kernel(const GemmArgs a) {
-    __shared__ f32x4v xbuf[2][2][16][64];                    // 64 KiB
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fi = lane & 15, fk = lane >> 4;
-    const int cgp = wave & 3, half = wave >> 2;
-    const long long n0 = (long long)blockIdx.x * 128 + cgp * 32;
-
-    f32x4v w[16][2];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int cf = 0; cf < 2; ++cf)
-            w[j][cf] = *reinterpret_cast<const f32x4v*>(a.W + (n0 + cf * 16 + fi) * a.ldw + 16 * j + 4 * fk);
-    f32x4v bias4[2];
-#pragma unroll
-    for (int cf = 0; cf < 2; ++cf)
-        bias4[cf] = a.bias ? *reinterpret_cast<const f32x4v*>(a.bias + n0 + cf * 16 + 4 * fk) : (f32x4v){0.f, 0.f, 0.f, 0.f};
-
-    const int M = (int)a.M;
-    const int nfrag = (M + 15) >> 4;
-    const int mine = (nfrag - half + 1) >> 1;                // fragments half, half + 2, ... of this row half
-    const int iters = (nfrag + 1) >> 1;                      // barrier count is the same for both halves
-
-    // this wave's quarter (chunks 4 cgp .. 4 cgp + 3) of fragment f into stage st: lane (fi, fk) fetches the 16 bytes
-    // X[16 f + fi][16 j + 4 fk ..], the hardware drops them at xbuf[half][st][j] + lane
-    auto prefetch = [&](int t, int st) {
-        int row = 16 * (half + 2 * t) + fi;
-        row = row < M ? row : M - 1;
-        const float* p = a.X + (long long)row * a.ldx + 4 * fk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = cgp * 4 + q;
-            __builtin_amdgcn_global_load_lds((sbev_gptr_t)(p + 16 * j), (sbev_lptr_t)&xbuf[half][st][j][0], 16, 0, 0);
-        }
-    };
-
-    f32x4v acc[2], done[2];
-    done[0] = done[1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    if (mine > 0) prefetch(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < iters; ++t) {
-        const bool live = t < mine;
-        if (t + 1 < mine) prefetch(t + 1, (t + 1) & 1);
-        if (t > 0 && t - 1 < mine) {                         // the previous fragment's rows go out now: their stores have a
-            const int row = 16 * (half + 2 * (t - 1)) + fi;  // whole block to complete before the wait at its end
-            if (row < M) {
-                float* y = a.Y + (long long)row * a.ldy + n0 + 4 * fk;
-#pragma unroll
-                for (int cf = 0; cf < 2; ++cf) *reinterpret_cast<f32x4v*>(y + cf * 16) = done[cf];
-            }
-        }
-        if (live) {
-            const f32x4v* xs = &xbuf[half][t & 1][0][lane];
-            acc[0] = bias4[0];
-            acc[1] = bias4[1];
-            f32x4v xc = xs[0];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const f32x4v xn = xs[(j + 1 < 16 ? j + 1 : j) * 64];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int cf = 0; cf < 2; ++cf)
-                        acc[cf] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][cf][i], xc[i], acc[cf], 0, 0, 0);
-                xc = xn;
-            }
-#pragma unroll
-            for (int cf = 0; cf < 2; ++cf) {
-                f32x4v v = acc[cf];
-                if (RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                done[cf] = v;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's quarter of the next fragment has landed
-        __syncthreads();                                     // ... everyone's has, and everyone is done reading this stage
-    }
-    if (mine > 0) {
-        const int row = 16 * (half + 2 * (mine - 1)) + fi;
-        if (row < M && iters - 1 < mine) {                   // (a half with one fragment fewer stored its last one in the loop)
-            float* y = a.Y + (long long)row * a.ldy + n0 + 4 * fk;
-#pragma unroll
-            for (int cf = 0; cf < 2; ++cf) *reinterpret_cast<f32x4v*>(y + cf * 16) = done[cf];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs a) { reduce_rows(a, blockIdx.x); }
 
 // ---- two INDEPENDENT small ops in one launch ----------------------------------------------------------------------
@@ -685,12 +586,7 @@ extern "C" int sbev_linear_f32(const float* X, const float* W, const float* bias
         // parameter-generator shape: W strips stationary in registers, all rows stream past (see the kernel's header)
         hipEvent_t e0, e1;
         const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-        static const bool strip2 = getenv("SBEV_STRIP2") != nullptr;      // A/B: the two-waves-per-SIMD / LDS-staged variant
-        if (strip2 && relu)
-            hipLaunchKernelGGL(gemm_nt_f32_strip2_kernel<true>, dim3((unsigned)(N / 128)), dim3(512), 0, s, a);
-        else if (strip2)
-            hipLaunchKernelGGL(gemm_nt_f32_strip2_kernel<false>, dim3((unsigned)(N / 128)), dim3(512), 0, s, a);
-        else if (relu)
+        if (relu)
             hipLaunchKernelGGL(gemm_nt_f32_strip_kernel<true>, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(gemm_nt_f32_strip_kernel<false>, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);

@@ -37,6 +37,12 @@ def test_decoder_context_matches_oracle_prologue():
     exp = td[:, 1].clone()
     exp[exp < 1e-5] = 1.0
     assert torch.equal(ctx.vel_div, exp)
+    # the three constants are segments of ONE packed upload: contiguous views at 16-byte boundaries with the metas' values
+    import numpy as np
+    assert np.array_equal(ctx.lidar2img.numpy(), np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+    for t in (ctx.time_diff, ctx.lidar2img, ctx.vel_div):
+        assert t.is_contiguous() and t.data_ptr() % 16 == 0
+    assert ctx.lidar2img.data_ptr() - ctx.time_diff.data_ptr() == 4 * ((B * T + 3) // 4 * 4)
     assert 'time_diff' not in metas[0]                                     # the reference mutates img_metas[0]; we do not
     # T == 1: no velocity division (models/sparsebev_transformer.py:180)
     assert DecoderContext(S.make_img_metas(1, 1, 256, 704), 1, torch.device('cpu')).vel_div is None

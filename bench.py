@@ -22,6 +22,7 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+PROFILE_EVERY = 5      # sampler launches are bracketed with HIP events in every 5th step of the timed region (see main)
 sys.path.insert(0, ROOT)
 
 from sparsebev_amd import runtime, synthetic as S                  # noqa: E402
@@ -234,7 +235,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    runtime.profile_sampler(True)                # HIP events around every sampler launch, on its stream
+    # HIP events around the sampler launches, on their stream, in every 5th step of the timed region: the two records
+    # around a launch leave ~5.6 us of idle stream each (kernel trace), i.e. bracketing all six launches of every step
+    # would cost `value` 2 %
+    runtime.profile_stride(PROFILE_EVERY)
+    runtime.profile_sampler(True)
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -246,6 +251,7 @@ def main():
     shard.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sorted(runtime.read_sampler_ms())
+    runtime.profile_stride(1)
     runtime.profile_sampler(6)                   # a few extra steps (outside the timed region) with the two mixing GEMMs bracketed
     for _ in range(min(10, args.steps)):
         step()
@@ -305,6 +311,7 @@ def main():
                          'traffic': (pmc_traffic() or (None, None))[0] if args.config == 'c2' else None,
                          'traffic_source': 'profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % (pmc_traffic() or (None, 'none'))[1],
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
+                         'event_sampling': 'HIP events around the sampler launches of every %dth step of the timed region' % PROFILE_EVERY,
                          'algorithmic_bytes_per_launch': npts * bytes_per_pt},
         }
         # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event

@@ -427,6 +427,10 @@ int sbev_graph_destroy(sbev_graph* graph);
  * (blocks until those launches finished).  Measurement aid for bench.py's roofline figures. */
 int sbev_profile_sampler(int enable);
 int sbev_profile_sampler_read(float* ms, int max_n);
+/* The events are not free (two records around a launch leave ~5.6 us of idle stream each -- 2 % of a decoder step for the
+ * six sampler launches): bracket the launches of only every n-th sbev_decoder_forward call (n = 1: every call, the default).
+ * Resets the call counter, so the first call after it is a bracketed one. */
+int sbev_profile_stride(int every_n_calls);
 /* Same for the other bracketed launches: kind 0 = sampler, 1 = parameter-generator GEMM, 2 = out-projection GEMM. */
 int sbev_profile_read(int kind, float* ms, int max_n);
 

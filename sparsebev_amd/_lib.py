@@ -60,6 +60,7 @@ SIGNATURES = {
     'sbev_decoder_forward': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, ctypes.c_int64, _vp]),
     'sbev_profile_sampler': (ctypes.c_int, [ctypes.c_int]),
+    'sbev_profile_stride': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_sampler_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     'sbev_splitk_reduce_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, _vp]),

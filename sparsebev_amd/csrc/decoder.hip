@@ -103,6 +103,14 @@ inline int hip_ok(hipError_t e, const char* what) {
 
 }  // namespace
 
+namespace sbev {
+struct ProfCallScope {      // see sbev_profile_stride below
+    bool prev;
+    ProfCallScope();
+    ~ProfCallScope();
+};
+}  // namespace sbev
+
 extern "C" int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg) {
     if (validate(cfg) != SBEV_OK) return -1;
     return (int64_t)carve(*cfg, nullptr).bytes;
@@ -117,6 +125,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const sbev_decoder_config& c = *cfg;
     SBEV_REQUIRE(w && feats_nhwc && query_bbox && query_feat && time_diff && lidar2img && cls_out && bbox_out && workspace,
                  "sbev_decoder_forward: null pointer");
+    const sbev::ProfCallScope prof_scope;     // with sbev_profile_stride(n): only every n-th call's launches are bracketed
     SBEV_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sbev_decoder_forward: workspace must be 256-byte aligned");
     SBEV_REQUIRE(cfg->gemm_mode != SBEV_GEMM_BF16X3 || (w->pg_w2 && w->op_w2), "sbev_decoder_forward: gemm_mode bf16x3 needs pg_w2 / op_w2");
     const Buffers b = carve(c, workspace);
@@ -280,12 +289,15 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
 namespace sbev {
 static std::mutex g_prof_mu;
 static int g_prof_mask = 0;          // bit k: bracket launches of kind k
+static int g_prof_stride = 1;        // inside sbev_decoder_forward: bracket only every n-th call (the events are not free: two
+static long long g_prof_calls = 0;   // records around a launch leave ~5.6 us of idle stream each, 2 % of a step for the sampler)
+static thread_local bool tl_prof_skip = false;
 struct ProfEvent { hipEvent_t e0, e1; int kind; };
 static std::vector<ProfEvent> g_prof_events;
 
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!((g_prof_mask >> kind) & 1)) return false;
+    if (!((g_prof_mask >> kind) & 1) || tl_prof_skip) return false;
     if (hipEventCreate(e0) != hipSuccess || hipEventCreate(e1) != hipSuccess) return false;
     (void)hipEventRecord(*e0, s);
     return true;
@@ -296,6 +308,23 @@ void profile_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int kind) {
     g_prof_events.push_back({e0, e1, kind});
 }
 }  // namespace sbev
+
+// decides at the top of a decoder call whether its launches are bracketed; restores the flag on every exit path
+namespace sbev {
+ProfCallScope::ProfCallScope() : prev(tl_prof_skip) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_mask != 0 && g_prof_stride > 1) tl_prof_skip = (g_prof_calls++ % g_prof_stride) != 0;
+}
+ProfCallScope::~ProfCallScope() { tl_prof_skip = prev; }
+}  // namespace sbev
+
+extern "C" int sbev_profile_stride(int every_n_calls) {
+    SBEV_REQUIRE(every_n_calls >= 1, "sbev_profile_stride: need n >= 1 (got %d)", every_n_calls);
+    std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
+    sbev::g_prof_stride = every_n_calls;
+    sbev::g_prof_calls = 0;
+    return SBEV_OK;
+}
 
 extern "C" int sbev_profile_sampler(int enable) {
     std::lock_guard<std::mutex> lk(sbev::g_prof_mu);

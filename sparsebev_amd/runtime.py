@@ -206,6 +206,11 @@ def profile_sampler(enable):
     _lib.load().sbev_profile_sampler(int(enable))
 
 
+def profile_stride(every_n_calls):
+    """Bracket the launches of only every n-th decoder call (the event records themselves cost ~2 % of a step)."""
+    _lib.check(_lib.load().sbev_profile_stride(int(every_n_calls)), 'sbev_profile_stride')
+
+
 def read_kernel_ms(kind, max_n=4096):
     """Elapsed ms of the bracketed launches of one kind (0 sampler, 1 generator GEMM, 2 out-projection GEMM)."""
     buf = (ctypes.c_float * max_n)()

@@ -333,3 +333,33 @@ def test_per_call_constants_survive_the_pinned_upload_ring():
     for c, w in zip(ctxs, want):
         assert np.array_equal(c.lidar2img.cpu().numpy(), w)
     assert not np.array_equal(want[0], want[1])
+
+
+def test_profile_stride_brackets_every_nth_call_only():
+    # sbev_profile_stride: the event records around a launch are not free, so bench.py brackets the sampler in every 5th
+    # timed step only; here: stride 3 over 7 calls -> calls 0, 3, 6 are bracketed, num_layers sampler launches each
+    from sparsebev_amd import runtime as rt
+    from sparsebev_amd.runtime import DecoderRuntime
+    B, Q, T, L = 1, 64, 4, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 51)
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=52)]
+    pyr, ctx = FeaturePyramid(feats), DecoderContext(S.make_img_metas(B, T, ih, iw), B, torch.device(DEV))
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=53)]
+    run = DecoderRuntime(model.decoder)
+    ref = [t.clone() for t in run.forward(bbox, feat, pyr, ctx)]
+    rt.read_sampler_ms()                                       # drop anything an earlier test left behind
+    try:
+        rt.profile_stride(3)
+        rt.profile_sampler(True)
+        for _ in range(7):
+            out = run.forward(bbox, feat, pyr, ctx)
+        torch.cuda.synchronize()
+        ms = rt.read_sampler_ms()
+    finally:
+        rt.profile_sampler(False)
+        rt.profile_stride(1)
+    assert len(ms) == 3 * model.decoder.num_layers and all(0 < m < 10 for m in ms)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])       # bracketing changes no result
+    with pytest.raises(Exception):
+        rt.profile_stride(0)

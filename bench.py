@@ -34,23 +34,36 @@ HBM_COPY_GBPS = 6290.0      # best measured device copy rate in the same guide (
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak (same guide, matrix-core table)
 
 
-def pmc_traffic(kernel='msmv_fwd_kernel'):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE passes of this same command; KiB units; FETCH_SIZE x2 gfx950 correction -- see
-    tools/pmc_summary.py).  PMC counters cannot be collected from inside the timed process, so this is the last
-    profiled value, or None if no profile has been committed."""
-    best = None
+def pmc_profile(config, kernel='msmv_fwd_kernel'):
+    """Counter record of `kernel` for this bench config from the committed rocprofv3 PMC summaries: separate --pmc
+    FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum passes of this same command (tools/profile_pmc.sh;
+    KiB units, FETCH_SIZE x2 gfx950 correction -- tools/pmc_summary.py).  PMC counters cannot be collected from inside
+    the timed process, so this is the last committed profile of the SAME config: profiles/<round>_pmc_<config>.json
+    (newest round wins).  Returns (record, file name) or (None, None)."""
     pdir = os.path.join(ROOT, 'profiles')
+    best = (None, None)
     if os.path.isdir(pdir):
+        legacy = {'c2': '_pmc_summary.json', 'c5': '_c5_pmc_summary.json'}.get(config)
         for fn in sorted(os.listdir(pdir)):
-            if fn.endswith('_pmc_summary.json'):
+            if fn.endswith('_pmc_%s.json' % config) or (legacy and fn.endswith(legacy) and fn.split('_')[0] + legacy == fn):
                 try:
                     k = json.load(open(os.path.join(pdir, fn)))['kernels'].get(kernel)
                     if k:
-                        best = (k['hbm_bytes_per_launch'], fn)
+                        best = (k, fn)
                 except Exception:      # noqa: BLE001
                     pass
     return best
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
 
 CONFIGS = {
     # name: (pyramid, Q, T, per-GPU batch, feature dtype)           -- SURVEY.md section 8 config table
@@ -73,7 +86,7 @@ def build_model(T, L, device):
     return m.to(device).eval()
 
 
-def cpu_baseline(cfg, model_state, max_seconds=30.0):
+def cpu_baseline(cfg, model_state, max_seconds=30.0, thread_sweep=(8, 16, 32, 64, 128, 256)):
     """The reference's native-PyTorch path (grid_sample sampler + eager ops), restated in oracle/ and
     validated against golden vectors, timed on this box's host cores.  Bounded sample: 1 warm-up + up to 3
     timed samples or ~max_seconds, whichever comes first."""
@@ -89,7 +102,7 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0):
         # torch's intra-op pool does not scale to every core of a big host (256 threads is ~20x SLOWER than 32
         # here): calibrate the thread count on one decoder layer, keep the fastest -- the baseline at its best.
         best = None
-        for nt in [n for n in (8, 16, 32, 64, 128, 256) if n <= cores] or [cores]:
+        for nt in [n for n in thread_sweep if n <= cores] or [cores]:
             torch.set_num_threads(nt)
             O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1)
             t0 = time.perf_counter()
@@ -111,8 +124,29 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0):
         dt = time.perf_counter() - t0
     cores_used = threads
     return {'value': round(n / dt, 4), 'unit': 'samples/s', 'cores': cores_used, 'kind': 'port',
+            'cpu_model': cpu_model(), 'host_cores': cores,
             'sample': '%d timed decoder samples (1 warm-up) at %s Q=%d T=%d bs=1, oracle grid_sample path, '
                       'torch intra-op threads=%d (fastest of a 1-layer sweep) on a %d-core host' % (n, pyr, Q, T, cores_used, cores)}
+
+
+def gpu_quick(config, device, steps=30, warmup=5):
+    """decoder samples/s of another config (same method as the timed region, fewer steps): used for the c1 leg next to its
+    CPU baseline -- c1 is the reference's own CPU-runnable case (BASELINE.json configs[0]), never `value`."""
+    pyr, Q, T, B, fdtype = CONFIGS[config]
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    model = build_model(T, len(sizes), device)
+    feats = S.make_features(B, T, sizes, seed=0, device=device, dtype=fdtype)
+    bbox, qfeat = [t.to(device) for t in S.make_queries(B, Q, seed=0)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    for _ in range(warmup):
+        model(bbox, qfeat, list(feats), None, copy.deepcopy(metas))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model(bbox, qfeat, list(feats), None, copy.deepcopy(metas))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return round(steps * B / dt, 2), model
 
 
 def mfma_util():
@@ -191,7 +225,8 @@ def main():
     ap.add_argument('--nhwc', action='store_true', help='features already channels-last in HBM (zero-copy input)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--online', action='store_true', help='streaming mode: per step only ONE new frame (6 images) is relayouted into the per-frame feature ring (cache.FrameFeatureCache); the other T-1 frames stay resident')
-    ap.add_argument('--detector', action='store_true', help='also report a LABELLED detector-level samples/s: stock-PyTorch ResNet-50 + FPN stand-in (tools/backbone_standin.py, fp16) on the 6 new images -> frame ring -> SparseBEVHead -> NMS-free decode (online mode, like the reference FPS)')
+    ap.add_argument('--no-detector', action='store_true', help='skip the labelled detector-level stand-in figure (default N=1 c2 run reports it)')
+    ap.add_argument('--detector', action='store_true', help='force the detector figure for other configs too: also report a LABELLED detector-level samples/s: stock-PyTorch ResNet-50 + FPN stand-in (tools/backbone_standin.py, fp16) on the 6 new images -> frame ring -> SparseBEVHead -> NMS-free decode (online mode, like the reference FPS)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
     ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
     ap.add_argument('--gemm', default='f32', choices=['f32', 'bf16x3'],
@@ -279,18 +314,31 @@ def main():
                'max_abs_dev_vs_exact_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
 
     detector = None
-    if args.detector and world == 1:
-        detector = detector_standin(args, T, L, Q, B, ih, iw, sizes, device, model)
+    if world == 1 and (args.detector or (args.config == 'c2' and not args.no_detector and not args.online)):
+        try:
+            detector = detector_standin(args, T, L, Q, B, ih, iw, sizes, device, model)
+        except Exception as e:      # noqa: BLE001  (a labelled secondary figure must never take the metric line down)
+            detector = {'error': repr(e)[:300]}
 
     # the one collective: metric all-reduce (MAX of elapsed, SUM of samples / checksum) over RCCL
-    elapsed_max, samples, checksum_sum = shard.reduce_metrics(elapsed, args.steps * B, checksum)
+    elapsed_max, samples, checksum_sum, elapsed_min = shard.reduce_metrics(elapsed, args.steps * B, checksum, per_rank=True)
 
     if rank == 0:
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        npts = B * T * 4 * Q * 4                                   # B' * Q * P sampled points per launch
+        smp = model.decoder.decoder_layer.sampling
+        G_, P_, Cg_ = smp.num_groups, smp.num_points, 256 // smp.num_groups
+        npts = B * T * G_ * Q * P_                                 # B' * Q * P sampled points per launch
         sf = 2 if fdtype == torch.bfloat16 else 4
-        bytes_per_pt = L * 4 * 64 * sf + 12 + 4 * L + 64 * 4       # SURVEY.md section 8d byte model
-        achieved = npts * bytes_per_pt / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        bytes_per_pt = L * 4 * Cg_ * sf + 12 + 4 * L + Cg_ * 4     # SURVEY.md section 8d byte model
+        alg_bytes = npts * bytes_per_pt
+        alg_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # physical HBM-side rate: PMC bytes per launch (fabric-side L2 requests = HBM + Infinity-Cache traffic) of the last
+        # committed profile of THIS config over the live HIP-event time -- a fraction of the 8 TB/s peak by construction.
+        # The section-8d algorithmic rate prices every tap as a miss and therefore exceeds the pin rate whenever taps hit in
+        # L2: it is reported beside it with the implied hit fraction, never as `frac`.
+        pmc, pmc_file = pmc_profile(args.config)
+        traffic = pmc['hbm_bytes_per_launch'] if pmc else None
+        hbm_gbps = traffic / (avg_ms * 1e-3) / 1e9 if (traffic and avg_ms > 0) else None
         out = {
             'metric': 'decoder samples/sec (6-cam T=%d %dq %s, 6 layers, features resident in HBM)' % (T, Q, pyr),
             'value': round(samples / elapsed_max, 3), 'unit': 'samples/s',
@@ -304,20 +352,29 @@ def main():
                                    '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
                        'checksum': checksum_sum},
+            # per-rank spread (weak scaling: every rank runs the same per-GPU batch): slowest / fastest rank's own rate
+            'per_rank_samples_per_s': {'min': round(args.steps * B / elapsed_max, 3), 'max': round(args.steps * B / elapsed_min, 3)},
             'roofline': {'kernel': 'msmv_fwd_kernel (adaptive sampling gather)', 'bound': 'hbm',
-                         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBPS, 4),
-                         'frac_of_measured_copy_peak': round(achieved / HBM_COPY_GBPS, 4),
-                         'traffic': (pmc_traffic() or (None, None))[0] if args.config == 'c2' else None,
-                         'traffic_source': 'profiles/%s (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)' % (pmc_traffic() or (None, 'none'))[1],
+                         'achieved': round(hbm_gbps, 1) if hbm_gbps else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': round(hbm_gbps / HBM_PEAK_GBPS, 4) if hbm_gbps else None,
+                         'frac_of_measured_copy_peak': round(hbm_gbps / HBM_COPY_GBPS, 4) if hbm_gbps else None,
+                         'traffic': traffic,
+                         'traffic_source': ('profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, bytes per launch, same config'
+                                            % pmc_file) if pmc else 'no committed PMC profile for this config',
+                         'achieved_is': 'PMC bytes per launch / live HIP-event time per launch (physical, <= peak); achieved_algorithmic is the '
+                                        'SURVEY 8d byte model (every tap priced as a miss) over the same time',
+                         'achieved_algorithmic': round(alg_gbps, 1),
+                         'algorithmic_over_peak': round(alg_gbps / HBM_PEAK_GBPS, 4),
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'cache_served_fraction': round(1.0 - traffic / alg_bytes, 4) if traffic else None,
+                         'l2_hit_ratio_pmc': pmc.get('l2_hit_ratio') if pmc else None,
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
-                         'event_sampling': 'HIP events around the sampler launches of every %dth step of the timed region' % PROFILE_EVERY,
-                         'algorithmic_bytes_per_launch': npts * bytes_per_pt},
+                         'event_sampling': 'HIP events around the sampler launches of every %dth step of the timed region' % PROFILE_EVERY},
         }
         # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event
         # measurement, priced against the f32-input MFMA peak; PMC MFMA-pipe utilisation from profiles/ when present
         if args.gemm == 'f32' and all(gemm_ms):
-            D_, G_, Cg_, Pin_, Pout_ = 256, 4, 64, T * 4, 128
+            D_, Pin_, Pout_ = 256, T * P_, 128
             flops = 2.0 * B * Q * D_ * (G_ * (Cg_ * Cg_ + Pin_ * Pout_))          # generator; the out-projection has G*Pout*Cg*D = the same at Pin = 32
             flops2 = 2.0 * B * Q * D_ * (G_ * Pout_ * Cg_)
             util = mfma_util()
@@ -335,6 +392,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, model.state_dict())
             out['gpu_over_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
+            if args.config == 'c2':
+                # the CPU baseline at c1 too (BASELINE.json configs[0], the reference's own CPU-runnable case), with
+                # the HIP path at the same shape beside it
+                try:
+                    c1_gpu, c1_model = gpu_quick('c1', device)
+                    c1 = cpu_baseline(CONFIGS['c1'], c1_model.state_dict(), max_seconds=10.0, thread_sweep=(4, 8, 16, 32))
+                    c1['gpu_value'] = c1_gpu
+                    c1['gpu_over_cpu'] = round(c1_gpu / c1['value'], 1)
+                    out['cpu_baseline']['c1'] = c1
+                except Exception as e:      # noqa: BLE001
+                    out['cpu_baseline']['c1'] = {'error': repr(e)[:300]}
         print(json.dumps(out))
     shard.shutdown()
 

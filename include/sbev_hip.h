@@ -10,8 +10,10 @@
  *     work is enqueued on `stream` (NULL = the legacy default stream, which is what the reference's
  *     `<<<grid, block>>>` launches use: models/csrc/msmv_sampling/msmv_sampling_forward.cu:290).
  *   - Stateless and thread-safe for distinct streams.
- *   - All index arithmetic is 64-bit (the reference's 32-bit offsets overflow at
- *     B'*N*H*W*C >= 2^31: msmv_sampling_forward.cu:127).
+ *   - Feature addressing is 64-bit at the sample-batch level (base = b' * stride_bo, so pyramids beyond 2^31 elements
+ *     work; the reference's 32-bit offsets overflow at B'*N*H*W*C >= 2^31: msmv_sampling_forward.cu:127).  The
+ *     offset of a tap INSIDE one sample-batch slab, (N-1)*stride_v + (H*W-1)*stride_px + C, is 32-bit and
+ *     host-checked (SBEV_EINVAL beyond 2^31 - 1), as are item / row counts (B'*Q < 2^31).
  * Reference interfaces replaced are cited per function as file:line inside the reference checkout.
  */
 #ifndef SBEV_HIP_H
@@ -351,7 +353,7 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
                               sbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Whole-decoder runtime: ONE call enqueues every kernel of every layer (26 launches per layer) on `stream`.
+ * Whole-decoder runtime: ONE call enqueues every kernel of every layer (18 launches per layer) on `stream`.
  * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward
  *           (models/sparsebev_transformer.py:56-101,162-193) at inference.
  * ---------------------------------------------------------------------------------------------------------- */

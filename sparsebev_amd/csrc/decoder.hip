@@ -65,7 +65,9 @@ int validate(const sbev_decoder_config* c) {
     SBEV_REQUIRE(c->D % (4 * c->G) == 0 && c->D % c->H == 0 && c->D / c->H == 32, "sbev_decoder: embed_dims %d / heads %d (head_dim must be 32)", c->D, c->H);
     SBEV_REQUIRE(c->D / c->G == 64 && c->out_points == 128, "sbev_decoder: built for 64 channels per group and 128 out points");
     SBEV_REQUIRE(c->attn_in_rows >= 3 * c->D + c->H && c->attn_in_rows % 4 == 0, "sbev_decoder: attn_in_rows %d", c->attn_in_rows);
-    SBEV_REQUIRE(c->code_size >= 10 && c->num_layers >= 1 && c->num_classes >= 1 && c->ffn % 4 == 0, "sbev_decoder: head sizes");
+    // every box kernel (sasa, sampling_front, refine, linear3) reads query_bbox rows with a stride of 10 floats
+    SBEV_REQUIRE(c->code_size == 10, "sbev_decoder: code_size %d (the box kernels are built for the 10-wide box code)", c->code_size);
+    SBEV_REQUIRE(c->num_layers >= 1 && c->num_classes >= 1 && c->ffn % 4 == 0, "sbev_decoder: head sizes");
     SBEV_REQUIRE(c->gemm_mode == SBEV_GEMM_F32 || c->gemm_mode == SBEV_GEMM_BF16X3, "sbev_decoder: gemm_mode %d", c->gemm_mode);
     return SBEV_OK;
 }

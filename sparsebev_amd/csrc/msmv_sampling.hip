@@ -313,19 +313,26 @@ static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int
     SBEV_REQUIRE(stride_px % 4 == 0 && stride_g % 4 == 0, "sbev_msmv_fwd: pixel/group strides must be multiples of 4 elements");
     if (out_layout == SBEV_OUT_MIX)
         SBEV_REQUIRE(T >= 1 && G >= 1 && Bp % ((int64_t)T * G) == 0, "sbev_msmv_fwd: B'=%lld is not B*T*G (T=%d, G=%d)", (long long)Bp, T, G);
-    if (Bp == 0 || Q == 0) return SBEV_OK;
-    SBEV_REQUIRE(loc && weights && out, "sbev_msmv_fwd: null loc/weights/out");
+    const bool empty = Bp == 0 || Q == 0;          // an empty call still validates its level descriptors
+    SBEV_REQUIRE(empty || (loc && weights && out), "sbev_msmv_fwd: null loc/weights/out");
     MsmvArgs a{};
     for (int l = 0; l < L; ++l) {
-        SBEV_REQUIRE(feats[l] != nullptr, "sbev_msmv_fwd: feats[%d] is null", l);
+        SBEV_REQUIRE(empty || feats[l] != nullptr, "sbev_msmv_fwd: feats[%d] is null", l);
         SBEV_REQUIRE(hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_msmv_fwd: level %d has empty map", l);
         SBEV_REQUIRE(stride_bo[l] % 4 == 0 && stride_v[l] % 4 == 0, "sbev_msmv_fwd: level %d strides must be multiples of 4 elements", l);
+        // the kernel keeps a tap's offset INSIDE one sample-batch slab (view * stride_v + pixel * stride_px) in 32 bits with
+        // bit 31 as its "outside the map" flag; the slab base itself is 64-bit.  Refuse maps one slab of which does not fit.
+        SBEV_REQUIRE(stride_v[l] >= 0 && stride_px >= 0 &&
+                         (int64_t)(N - 1) * stride_v[l] + ((int64_t)hw[2 * l] * hw[2 * l + 1] - 1) * stride_px + C <= 0x7fffffffLL,
+                     "sbev_msmv_fwd: level %d: one (sample-batch) slab spans %lld elements, the in-slab tap offset is 32-bit (limit 2^31 - 1)",
+                     l, (long long)((int64_t)(N - 1) * stride_v[l] + ((int64_t)hw[2 * l] * hw[2 * l + 1] - 1) * stride_px + C));
         a.feat[l] = feats[l];
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
         a.stride_bo[l] = stride_bo[l];
         a.stride_v[l] = stride_v[l];
     }
+    if (empty) return SBEV_OK;
     a.stride_g = stride_g;
     a.stride_px = stride_px;
     a.loc = loc;

@@ -241,6 +241,8 @@ def refine_bbox(query_bbox, reg, vel_div):
     models/utils.py:87-102)."""
     _dev(query_bbox, reg)
     B, Q, code = reg.shape
+    if code != 10 or query_bbox.shape[-1] != 10:
+        raise RuntimeError('refine_bbox: the box kernels are built for the 10-wide box code (got code_size=%d)' % code)
     out = torch.empty_like(reg)
     st = _lib.load().sbev_refine_bbox(_p(query_bbox.contiguous()), _p(reg.contiguous()), _p(vel_div), _p(out), B, Q, code, _stream())
     _lib.check(st, 'sbev_refine_bbox')

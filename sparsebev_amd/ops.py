@@ -29,10 +29,27 @@ def _need_device(*tensors):
             raise RuntimeError('sparsebev_amd ops need device tensors (no CPU fallback); got a %s tensor' % t.device)
 
 
+def _check_sampling_args(feats, sampling_locations, scale_weights, Bp, what):
+    """The argument checks of msmv_sampling.cpp:106-125 shared by every sampler entry point: the kernel reinterprets
+    loc / weights as fp32 rows of 3 / L floats, so anything else must be refused here."""
+    if not 1 <= len(feats) <= 5:
+        raise RuntimeError('%s supports 1..5 feature levels, got %d' % (what, len(feats)))
+    if sampling_locations.dtype != torch.float32 or scale_weights.dtype != torch.float32:
+        raise RuntimeError('sampling_loc / attn_weight must be float32')
+    if sampling_locations.dim() != 4 or sampling_locations.shape[-1] != 3 or sampling_locations.shape[0] != Bp:
+        raise RuntimeError('sampling_loc must be [B, Q, P, 3]')
+    _, Q, P, _ = sampling_locations.shape
+    if tuple(scale_weights.shape) != (Bp, Q, P, len(feats)):
+        raise RuntimeError('attn_weight must be [B, Q, P, %d]' % len(feats))
+    if P > 32:
+        raise RuntimeError('num_point exceed limits')
+    return Q, P
+
+
 def _no_grad_only(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError('sparsebev_amd: the sampling backward (SURVEY.md section 8f rank 1) is not built yet; '
-                                  'call under torch.no_grad()')
+        raise NotImplementedError('sparsebev_amd: this entry point is forward-only; the differentiable forms are '
+                                  'ops.msmv_sampling (reference layout) and the decoder module in train() mode')
 
 
 def _msmv_launch(feats, hw, feat_dtype, Bp, N, C, Q, P, gdiv, stride_bo, stride_g, stride_v, stride_px,
@@ -119,8 +136,6 @@ def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_
     reference's autograd Functions."""
     feats = list(mlvl_feats)
     _need_device(sampling_locations, scale_weights, *feats)
-    if not 1 <= len(feats) <= 5:
-        raise RuntimeError('msmv_sampling supports 1..5 feature levels, got %d' % len(feats))
     for f in feats:
         if not f.is_contiguous():
             raise RuntimeError('value tensor has to be contiguous')
@@ -130,16 +145,8 @@ def msmv_sampling(mlvl_feats, sampling_locations, scale_weights, out_layout=OUT_
         raise RuntimeError('sampling_loc tensor has to be contiguous')
     if not scale_weights.is_contiguous():
         raise RuntimeError('attn_weight tensor has to be contiguous')
-    if sampling_locations.dtype != torch.float32 or scale_weights.dtype != torch.float32:
-        raise RuntimeError('sampling_loc / attn_weight must be float32')
-    Bp = feats[0].shape[0]
-    _, Q, P, three = sampling_locations.shape
-    if three != 3 or sampling_locations.shape[0] != Bp:
-        raise RuntimeError('sampling_loc must be [B, Q, P, 3]')
-    if tuple(scale_weights.shape) != (Bp, Q, P, len(feats)):
-        raise RuntimeError('attn_weight must be [B, Q, P, %d]' % len(feats))
-    if P > 32:
-        raise RuntimeError('num_point exceed limits')
+    Bp = feats[0].shape[0] if feats else 0
+    _check_sampling_args(feats, sampling_locations, scale_weights, Bp, 'msmv_sampling')
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (sampling_locations, scale_weights, *feats))
     if needs_grad:
         if out_layout != OUT_REF:
@@ -157,10 +164,11 @@ def msmv_sampling_nhwc(feats_nhwc, B, T, G, sampling_locations, scale_weights, o
     _need_device(sampling_locations, scale_weights, *feats)
     _no_grad_only(sampling_locations, scale_weights, *feats)
     N = N_VIEWS
-    Bp, Q, P, _ = sampling_locations.shape
-    if Bp != B * T * G:
-        raise RuntimeError('sampling_loc batch %d != B*T*G = %d' % (Bp, B * T * G))
+    Bp = B * T * G
+    Q, P = _check_sampling_args(feats, sampling_locations, scale_weights, Bp, 'msmv_sampling_nhwc')
     GC = feats[0].shape[-1]
+    if GC % G != 0 or (GC // G) % 4 != 0:
+        raise RuntimeError('nhwc feature channels %d must split into G=%d groups of a multiple of 4 channels' % (GC, G))
     C = GC // G
     for f in feats:
         if not f.is_contiguous() or f.dim() != 4 or f.shape[0] != B * T * N or f.shape[-1] != GC:
@@ -184,12 +192,18 @@ def msmv_sampling_ring(levels, B, T, G, frame_slots, n_slots, sampling_locations
     _need_device(sampling_locations, scale_weights, *feats)
     _no_grad_only(sampling_locations, scale_weights, *feats)
     N = N_VIEWS
-    Bp, Q, P, _ = sampling_locations.shape
-    if Bp != B * T * G:
-        raise RuntimeError('sampling_loc batch %d != B*T*G = %d' % (Bp, B * T * G))
+    Bp = B * T * G
+    Q, P = _check_sampling_args(feats, sampling_locations, scale_weights, Bp, 'msmv_sampling_ring')
     GC = feats[0].shape[-1]
+    if GC % G != 0 or (GC // G) % 4 != 0:
+        raise RuntimeError('ring feature channels %d must split into G=%d groups of a multiple of 4 channels' % (GC, G))
     C = GC // G
     L = len(feats)
+    for f in feats:
+        if not f.is_contiguous() or f.dim() != 4 or f.shape[0] != B * n_slots * N or f.shape[-1] != GC:
+            raise RuntimeError('ring feature level must be contiguous [B*n_slots*6, H, W, G*C]')
+    if len(frame_slots) != T:
+        raise RuntimeError('frame_slots must name one slot per frame (T=%d)' % T)
     hw = [(f.shape[1], f.shape[2]) for f in feats]
     sslot = [N * h * w * GC for h, w in hw]
     sv = [h * w * GC for h, w in hw]

@@ -12,10 +12,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(n_gpus_requested=1, backend=None):
+def init_distributed(n_gpus_requested=1, backend=None, force_group=False):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run sets them),
-    bind this process to its GPU and create the process group when WORLD_SIZE > 1.
-    Returns (rank, world_size, device)."""
+    bind this process to its GPU and create the process group when WORLD_SIZE > 1 (or when ``force_group`` asks for a
+    one-rank group: the RCCL communicator, its device binding and the collectives below then run exactly as with N ranks
+    -- how the 1-GPU test box executes this branch).  Returns (rank, world_size, device)."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -27,8 +28,9 @@ def init_distributed(n_gpus_requested=1, backend=None):
     device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this driver
         backend = backend or ('nccl' if use_gpu else 'gloo')
         kw = {'device_id': device} if (use_gpu and backend == 'nccl') else {}
@@ -40,7 +42,7 @@ def reduce_mean(tensor):
     """Average a tensor over all ranks -- mmdet's ``reduce_mean`` as the head's losses use it for ``num_total_pos`` /
     ``cls_avg_factor`` (models/sparsebev_head.py:247,374-384; SURVEY.md 8f rank 4).  One small all-reduce (SUM) over RCCL;
     the input is left untouched; a single process returns it as is."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return tensor
     out = tensor.clone()
     dist.all_reduce(out.div_(dist.get_world_size()), op=dist.ReduceOp.SUM)
@@ -66,26 +68,36 @@ class SampleShard:
             return torch.device('cuda', torch.cuda.current_device())
         return torch.device('cpu')
 
-    def barrier(self):
-        if self.world > 1:
-            dist.barrier()
+    def _grouped(self):
+        """Collectives run whenever a process group exists (also a one-rank group); without one the rank is alone."""
+        return dist.is_available() and dist.is_initialized()
 
-    def reduce_metrics(self, elapsed_s, samples_done, checksum):
-        """(max elapsed over ranks, total samples, sum of per-rank output checksums).  Two tiny all-reduces
-        (MAX and SUM) of fp64 scalars: latency-bound, link bandwidth irrelevant."""
-        if self.world == 1:
-            return float(elapsed_s), float(samples_done), float(checksum)
+    def barrier(self):
+        if self._grouped():
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
+
+    def reduce_metrics(self, elapsed_s, samples_done, checksum, per_rank=False):
+        """(max elapsed over ranks, total samples, sum of per-rank output checksums[, min elapsed over ranks]).  Two tiny
+        all-reduces (MAX and SUM) of fp64 scalars: latency-bound, link bandwidth irrelevant.  MAX over (elapsed, -elapsed)
+        yields the slowest and the fastest rank in the same collective."""
+        if not self._grouped():
+            out = (float(elapsed_s), float(samples_done), float(checksum))
+            return out + (float(elapsed_s),) if per_rank else out
         dev = self._device()
-        t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed_s, -elapsed_s], dtype=torch.float64, device=dev)
         s = torch.tensor([samples_done, checksum], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        return float(t[0]), float(s[0]), float(s[1])
+        out = (float(t[0]), float(s[0]), float(s[1]))
+        return out + (-float(t[1]),) if per_rank else out
 
     def gather_results(self, local_results, n_samples):
         """All ranks' per-sample results in global sample order (mirrors multi_gpu_test(gpu_collect=True),
         val.py:132): local_results[i] belongs to global sample rank + i*world."""
-        if self.world == 1:
+        if not self._grouped():
             return list(local_results)[:n_samples]
         bucket = [None] * self.world
         dist.all_gather_object(bucket, list(local_results))
@@ -98,5 +110,5 @@ class SampleShard:
         return out
 
     def shutdown(self):
-        if self.world > 1 and dist.is_initialized():
+        if self._grouped():
             dist.destroy_process_group()

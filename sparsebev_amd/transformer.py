@@ -165,6 +165,8 @@ class SparseBEVTransformerDecoderLayer(_Base):
     def __init__(self, embed_dims, num_frames=8, num_points=4, num_levels=4, num_classes=10, code_size=10,
                  num_cls_fcs=2, num_reg_fcs=2, pc_range=(), init_cfg=None):
         super().__init__(init_cfg)
+        if code_size != 10:     # sasa / sampling_front / refine / linear3 kernels read query_bbox rows of 10 floats (every reference config uses 10)
+            raise ValueError('sparsebev_amd is built for code_size == 10 (cx, cy, cz, w, l, h, sin, cos, vx, vy); got %d' % code_size)
         self.embed_dims, self.num_classes, self.code_size, self.pc_range = embed_dims, num_classes, code_size, list(pc_range)
         D = embed_dims
         self.position_encoder = nn.Sequential(nn.Linear(3, D), nn.LayerNorm(D), nn.ReLU(inplace=True),

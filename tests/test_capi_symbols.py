@@ -90,3 +90,32 @@ def test_splitk_plan_is_a_pure_host_function(lib):
     assert plan(900, 250, 32768) >= 1 and plan(900, 256, 1000) == 1             # shapes of the generic tile kernel / tiny K
     assert plan(0, 256, 32768) == 1 and plan(900, 0, 32768) == 1
     assert lib.sbev_linear_splitk_workspace(900, 256, 26) == 900 * 256 * 26 * 4
+
+
+def test_sampler_refuses_a_slab_beyond_the_32bit_in_slab_offset():
+    """Argument validation only (returns before any HIP call, so it runs without a GPU): the forward sampler keeps a
+    tap's offset inside one sample-batch slab in 32 bits; a level whose slab does not fit must be refused, not mis-read."""
+    import ctypes
+    from sparsebev_amd import _lib
+    lib = _lib.load()
+    fake = ctypes.c_void_p(0x1000)
+    feats = (ctypes.c_void_p * 1)(fake)
+    for H, W, ok_expected in ((1024, 1024, True), (8192, 8192, False)):
+        C = 64
+        hw = (ctypes.c_int32 * 2)(H, W)
+        sbo = (ctypes.c_int64 * 1)(6 * H * W * C)
+        sv = (ctypes.c_int64 * 1)(H * W * C)
+        # Bp = 0: a valid call returns OK before touching the device; an invalid one must fail in validation first
+        st = lib.sbev_msmv_fwd(feats, hw, 1, 0, 0, 6, C, 4, 4, 1, sbo, 0, sv, C, fake, fake, fake, 0, 1, 1, None)
+        if ok_expected:
+            assert st == 0, lib.sbev_last_error()
+        else:
+            assert st != 0 and b'32-bit' in lib.sbev_last_error()
+
+
+def test_transformer_refuses_other_code_sizes():
+    import pytest
+    from sparsebev_amd.transformer import SparseBEVTransformer
+    from sparsebev_amd import synthetic as S
+    with pytest.raises(ValueError):
+        SparseBEVTransformer(256, num_frames=2, num_levels=4, code_size=11, pc_range=S.PC_RANGE)

@@ -22,7 +22,8 @@ def _worker(rank, world, port, q):
     # each rank "processes" its samples: result = f(global index)
     local = [{'sample': i, 'value': float(i * i)} for i in mine]
     shard.barrier()
-    elapsed, total, chk = shard.reduce_metrics(1.0 + r, len(mine), sum(x['value'] for x in local))
+    elapsed, total, chk, fastest = shard.reduce_metrics(1.0 + r, len(mine), sum(x['value'] for x in local), per_rank=True)
+    assert fastest == 1.0                                      # MIN over ranks rides in the same MAX all-reduce
     gathered = shard.gather_results(local, 7)
     npos = torch.tensor([3.0 + 4.0 * r])                       # num_total_pos of this rank
     mean = reduce_mean(npos)

@@ -49,7 +49,7 @@ def test_out_proj_splitk_fused_epilogue():
     assert (y2.cpu().double() - ref_linear(x, w, b)).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('M', [1, 47, 48, 49, 144, 900])
+@pytest.mark.parametrize('M', [1, 47, 48, 49, 144, 900, 3200, 3600])      # 3200 / 3600 = B*Q of BASELINE configs c3 / c4
 @pytest.mark.parametrize('N,K', [(256, 32768), (128, 4096), (384, 2048 + 32)])
 def test_splitk_register_tiled_kernel_ragged(M, N, K):
     """N % 128 == 0, K % 32 == 0 goes to gemm_nt_f32_regtile_kernel (48-row x 128-column wave tasks x K splits):
@@ -84,12 +84,12 @@ def test_linear_rejects_cpu_and_misaligned():
         dense.linear(torch.zeros(4, 3, device=DEV), torch.zeros(4, 3, device=DEV), None)
 
 
-@pytest.mark.parametrize('Pin', [4, 8, 32, 60])
-def test_adaptive_mixing_core_vs_fp64(Pin):
+@pytest.mark.parametrize('Pin,BQ', [(4, 37), (8, 37), (32, 37), (60, 37), (32, 3200), (32, 3600)])
+def test_adaptive_mixing_core_vs_fp64(Pin, BQ):
     import ctypes
     from sparsebev_amd import _lib
     g = torch.Generator().manual_seed(Pin)
-    BQ, G, C, Pout = 37, 4, 64, 128
+    G, C, Pout = 4, 64, 128
     x = torch.randn(BQ, G, Pin, C, generator=g)
     prm = torch.randn(BQ, G, C * C + Pout * Pin, generator=g) * 0.3
     M = prm[..., : C * C].reshape(BQ, G, C, C).double()
@@ -196,7 +196,7 @@ def test_bf16x3_linear_fp32_class_accuracy(M, N, K, splitk):
     assert plain > 30 * err
 
 
-@pytest.mark.parametrize('M', [1, 15, 16, 17, 33, 900, 1800])
+@pytest.mark.parametrize('M', [1, 15, 16, 17, 33, 900, 1800, 3200, 3600])
 @pytest.mark.parametrize('N,relu,use_bias', [(32768, False, True), (24576, True, True), (24576, False, False)])
 def test_generator_strip_kernel_ragged_rows(M, N, relu, use_bias):
     """[M,256] x [N,256]^T with N/128 >= 192 goes to the W-stationary strip kernel (gemm_nt_f32_strip_kernel): every
@@ -246,7 +246,9 @@ def test_linear_group_rejects_bad_groups():
 
 
 @pytest.mark.parametrize('M,N,ln_relu,with_add,relu', [(900, 776, True, True, False), (900, 112, False, False, False),
-                                                        (900, 256, False, False, True), (37, 40, True, False, False), (3200, 128, False, True, False)])
+                                                        (900, 256, False, False, True), (37, 40, True, False, False), (3200, 128, False, True, False),
+                                                        (3200, 776, True, True, False), (3600, 776, True, True, False), (3600, 112, False, False, False),
+                                                        (2048, 256, False, False, True), (2049, 256, False, False, True)])
 def test_layer_norm_as_linear_prologue(M, N, ln_relu, with_add, relu):
     # dense.ln_linear (one launch, row statistics exchanged through LDS inside the consumer's tiles) against the two
     # launches it replaces; the stored normalised rows against the stand-alone LayerNorm

@@ -233,6 +233,8 @@ def main():
                     help='f32 = exact f32-input MFMA (default); bf16x3 = opt-in 3 x bf16 split of the two big mixing GEMMs')
     args = ap.parse_args()
 
+    torch.set_grad_enabled(False)     # inference benchmark, like the reference's timing.py / val.py (with grad enabled the
+                                      # module takes its differentiable path, as the reference's nn.Module would)
     rank, world, device = init_distributed(args.gpus)
     cfg = CONFIGS[args.config]
     pyr, Q, T, B, fdtype = cfg

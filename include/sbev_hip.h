@@ -353,6 +353,81 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
                               sbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Training: backward passes of the decoder layer.
+ * Replaces: torch autograd through SparseBEVTransformerDecoderLayer.forward and the activation-checkpointed
+ *           inner_forward()s (models/sparsebev_transformer.py:162-193,231-234,313-317,383-387).  Every entry point is the
+ *           hand-written backward of one forward entry point above; sparsebev_amd/autograd.py chains them.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Layout-generic fp32 MFMA GEMM:  C[M,N] (+)= sum_k A(m,k) B(k,n),  A(m,k) = a_kmajor ? A[k*lda+m] : A[m*lda+k],
+ * B(k,n) = b_kmajor ? B[k*ldb+n] : B[n*ldb+k].  For nn.Linear y = x W^T:  grad_x = sbev_gemm_f32(grad_y, 0, ., W, 1, .),
+ * grad_W = sbev_gemm_f32(grad_y, 1, ., x, 1, .).  `workspace` (sbev_gemm_f32_workspace bytes, may be NULL when that is 0)
+ * holds split-K slabs for few-tile / long-K shapes; results are bit-reproducible (no atomics). */
+int64_t sbev_gemm_f32_workspace(int64_t M, int N, int64_t K);
+int sbev_gemm_f32(const float* A, int a_kmajor, int64_t lda, const float* B, int b_kmajor, int64_t ldb,
+                  float* C, int64_t ldc, int64_t M, int N, int64_t K, int accumulate,
+                  float* workspace, sbev_stream_t stream);
+
+/* dZ = dY * (Y > 0) (Y = a ReLU's forward output, NULL: dZ = dY; dZ may be NULL or alias dY) and db[n] = sum_m dZ[m,n]
+ * (NULL: skipped).  Rows have stride ld. */
+int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
+                       sbev_stream_t stream);
+
+/* LayerNorm(+ReLU) backward over the last dim (N % 4 == 0, N <= 1024): X is the LayerNorm INPUT; stats = [M,2] scratch. */
+int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                        float* dX, float* dgamma, float* dbeta, float* stats, int64_t M, int N, sbev_stream_t stream);
+
+/* sbev_linear3_ln_relu_f32 that also stores the Linear's pre-LayerNorm output `pre` [M,N] (may be NULL). */
+int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const float* w, const float* b,
+                                const float* ln_w, const float* ln_b, float eps, float* y, float* pre,
+                                int64_t M, int N, sbev_stream_t stream);
+
+/* Backward of sbev_adaptive_mixing_f32 (the forward is recomputed inside): grad_y [BQ,G,Pout,C] ->
+ * grad_x [BQ,G,Pin,C], grad_params [BQ,G,C*C+Pout*Pin]. */
+int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
+                                 int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
+
+/* Training forward of sbev_sasa_f32 with attention dropout (mmcv MultiheadAttention attn_drop; keep decisions are a
+ * hash of (seed, b, h, i, j)), and the backward of either forward: grad_out [B,Q,H*32] -> grad_qkvt [B,Q,ld]
+ * (q | k | v | tau columns, padding zeroed).  `out` is the forward output; workspace = 2*B*H*Q floats. */
+int sbev_sasa_train_fwd_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                            const uint8_t* mask, float* out, int B, int Q, int H, int head_dim,
+                            float attn_drop, uint64_t seed, sbev_stream_t stream);
+int sbev_sasa_bwd_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                      const uint8_t* mask, const float* out, const float* grad_out, float* grad_qkvt,
+                      float* workspace, int B, int Q, int H, int head_dim, float attn_drop, uint64_t seed,
+                      sbev_stream_t stream);
+
+/* sbev_msmv_bwd with (a) grad_out in either output layout of sbev_msmv_fwd (SBEV_OUT_REF / SBEV_OUT_MIX with T, G) and
+ * (b) grad_feats == NULL when the features need no gradient (no atomics are issued at all). */
+int sbev_msmv_bwd_ex(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
+                     int64_t Bp, int N, int C, int Q, int P,
+                     int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                     const float* loc, const float* weights, const float* grad_out, int grad_out_layout, int T, int G,
+                     float* grad_loc, float* grad_weights, sbev_stream_t stream);
+
+/* Backward of sbev_project_select: grad_loc [B*T*G,Q,P,3] -> grad_points [B,Q,T,G*P,3] through the camera the forward
+ * selected (re-selected bit-exactly).  models/sparsebev_sampling.py:49-114. */
+int sbev_project_select_bwd(const float* sample_points, const float* lidar2img, const float* grad_loc,
+                            int B, int Q, int T, int N, int G, int P, float image_h, float image_w, float eps,
+                            float* grad_points, sbev_stream_t stream);
+
+/* Backward of sbev_sampling_front: grad_points [B,Q,T,G*P,3] and grad_weights_bp [B*G*T,Q,P,L] (either may be NULL) ->
+ * grad_offset (first G*P*3 columns) and grad_logits (first G*P*L columns) of rows with stride ld_grad -- e.g. the two
+ * column blocks of one packed [B*Q, G*P*(3+L)] gradient --, grad_bbox [B*Q,10] (or NULL; velocity is detached). */
+int sbev_sampling_front_bwd(const float* query_bbox, const float* offset, int64_t ld_off, const float* logits, int64_t ld_logit,
+                            const double* pc_range, int B, int Q, int T, int G, int P, int L,
+                            const float* grad_points, const float* grad_weights_bp,
+                            float* grad_offset, float* grad_logits, int64_t ld_grad, float* grad_bbox, sbev_stream_t stream);
+
+/* Backward of sbev_refine_bbox (code_size 10): grad_out, the forward's `out` and the proposal -> grad_reg, grad_bbox (NULL ok). */
+int sbev_refine_bbox_bwd(const float* grad_out, const float* out, const float* query_bbox, const float* vel_div,
+                         float* grad_reg, float* grad_bbox, int B, int Q, sbev_stream_t stream);
+
+/* y = x * keep / (1 - p), keep_i = hash(seed, i) >= p: the mmcv FFN dropouts; the backward is the same call on grad_y. */
+int sbev_dropout_f32(const float* x, float* y, int64_t n, uint64_t seed, float p, sbev_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Whole-decoder runtime: ONE call enqueues every kernel of every layer (18 launches per layer) on `stream`.
  * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward
  *           (models/sparsebev_transformer.py:56-101,162-193) at inference.

@@ -248,7 +248,7 @@ def sampling_front(params, query_bbox, query_feat, time_diff, pc_range, T, P, L)
     off = F.linear(query_feat, params['sampling.sampling_offset.weight'], params['sampling.sampling_offset.bias'])
     pts = make_sample_points(query_bbox, off.view(B, Q, G * P, 3), pc_range)          # [B,Q,GP,3]
     pts = pts.reshape(B, Q, 1, G, P, 3).expand(B, Q, T, G, P, 3)
-    shift = query_bbox[..., 8:10][:, :, None, :] * time_diff[:, None, :, None]         # [B,Q,T,2]
+    shift = query_bbox[..., 8:10].detach()[:, :, None, :] * time_diff[:, None, :, None]   # [B,Q,T,2]; vel detached (:288)
     pts = torch.cat([pts[..., 0:2] - shift[:, :, :, None, None, :], pts[..., 2:3]], dim=-1)
     sw = F.linear(query_feat, params['sampling.scale_weights.weight'], params['sampling.scale_weights.bias'])
     sw = torch.softmax(sw.view(B, Q, G, 1, P, L), dim=-1).expand(B, Q, G, T, P, L)
@@ -282,7 +282,7 @@ def self_attention(params, query_bbox, query_feat, pc_range, pre_attn_mask=None)
     (batch_first, identity + attn; wraps torch.nn.MultiheadAttention -- restated here explicitly)."""
     B, Q, D = query_feat.shape
     hd = D // N_HEADS
-    xy = decode_bbox(query_bbox, pc_range)[0][..., :2]
+    xy = decode_bbox(query_bbox.detach(), pc_range)[0][..., :2]                      # calc_bbox_dists is @torch.no_grad (:236)
     dist = -torch.norm(xy[:, :, None, :] - xy[:, None, :, :], dim=-1)               # [B,Q,Q]
     tau = F.linear(query_feat, params['self_attn.gen_tau.weight'], params['self_attn.gen_tau.bias'])
     bias = dist[:, None] * tau.permute(0, 2, 1)[..., None]                           # [B,H,Q,Q], tau indexed by row

@@ -92,6 +92,31 @@ SIGNATURES = {
     'sbev_profile_read': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int]),
     'sbev_linear_splitk_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    'sbev_gemm_f32_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
+    'sbev_gemm_f32': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int64,
+                                     ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
+    'sbev_bias_relu_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, _vp]),
+    'sbev_layer_norm_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp, _vp,
+                                           ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_linear3_ln_relu_ex_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp,
+                                                   ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_adaptive_mixing_bwd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_float, _vp]),
+    'sbev_sasa_train_fwd_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double), _vp, _vp,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, _vp]),
+    'sbev_sasa_bwd_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp, _vp, _vp,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, _vp]),
+    'sbev_msmv_bwd_ex': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _c_i32p, ctypes.c_int,
+                                        ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,
+                                        _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    'sbev_project_select_bwd': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    'sbev_sampling_front_bwd': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_double),
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'sbev_refine_bbox_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_dropout_f32': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, _vp]),
 }
 
 _lib = None

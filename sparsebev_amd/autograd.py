@@ -1,0 +1,352 @@
+"""Differentiable forms of the decoder-layer ops: torch.autograd.Function wrappers whose forward AND backward are the
+hand-written gfx950 kernels of libsbev_hip.so.
+
+The reference trains through the decoder with plain autograd and recomputes the sampling / mixing / attention
+``inner_forward`` under ``torch.utils.checkpoint`` (models/sparsebev_transformer.py:231-234,313-317,383-387).  Here every
+op of ``SparseBEVTransformerDecoderLayer.forward`` (:162-193) has an explicit backward kernel behind the C ABI
+(include/sbev_hip.h, "Training" block), and the three checkpointed blocks keep the same policy by construction: their
+Functions save only their small inputs and re-run the forward kernels inside ``backward`` (the 118 MB dynamic-parameter and
+mixed-activation tensors of adaptive mixing are never kept across the forward pass).
+
+PyTorch is used for what it is here for -- device memory, streams, and the autograd graph between the Functions; no ATen
+math kernel computes anything on this path except the parameter ``cat`` / output ``stack`` / ``nan_to_num`` plumbing.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, dense, ops
+
+_EPS = 1e-5
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- the two GEMMs of every Linear backward (csrc/gemm_any.hip) -----------------------------------------------------
+def gemm(A, a_kmajor, lda, B, b_kmajor, ldb, M, N, K, out=None, ldc=None, accumulate=False):
+    """C[M,N] (+)= sum_k A(m,k) B(k,n) with either operand row-major (k contiguous) or k-major; see sbev_gemm_f32."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        ldc = N
+    need = lib.sbev_gemm_f32_workspace(M, N, K)
+    ws = torch.empty(need // 4, device=A.device, dtype=torch.float32) if need > 0 else None
+    st = lib.sbev_gemm_f32(_p(A), int(a_kmajor), lda, _p(B), int(b_kmajor), ldb, _p(out), ldc, M, N, K, int(accumulate), _p(ws), _stream())
+    _lib.check(st, 'sbev_gemm_f32')
+    return out
+
+
+def _linear_grads(gy2, x2, w, need_x, need_w):
+    """gy2 [M,N], x2 [M,K], w [N,K] -> (grad_x [M,K] | None, grad_w [N,K] | None)"""
+    M, N = gy2.shape
+    K = w.shape[1]
+    gx = gemm(gy2, False, N, w, True, K, M, K, N) if need_x else None          # grad_y . W
+    gw = gemm(gy2, True, N, x2, True, K, N, K, M) if need_w else None           # grad_y^T . x
+    return gx, gw
+
+
+def _bias_relu_bwd(gy2, y2, want_db):
+    """(masked grad, bias grad): gy * (y > 0) when y2 is the ReLU output (else gy itself) and its column sums."""
+    M, N = gy2.shape
+    if y2 is None and not want_db:
+        return gy2, None
+    gz = torch.empty_like(gy2) if y2 is not None else None
+    db = torch.empty(N, device=gy2.device, dtype=torch.float32) if want_db else None
+    st = _lib.load().sbev_bias_relu_bwd(_p(gy2), _p(y2), _p(gz), _p(db), M, N, N, _stream())
+    _lib.check(st, 'sbev_bias_relu_bwd')
+    return (gz if gz is not None else gy2), db
+
+
+class Linear(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual): forward = dense.linear (gemm.hip), backward = gemm_any.hip + bias_relu_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, residual):
+        # the ReLU mask is read off the output, which a residual would shift; the decoder layer never combines the two
+        if relu and residual is not None:
+            raise RuntimeError('autograd.Linear: relu together with a residual is not supported')
+        y = dense.linear(x, w, b, relu=relu, residual=residual)
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        N, K = w.shape
+        gy2 = _c(gy).reshape(-1, N)
+        x2 = _c(x).reshape(-1, K)
+        gz, db = _bias_relu_bwd(gy2, y.reshape(-1, N) if ctx.relu else None, ctx.has_b and ctx.needs_input_grad[2])
+        gx, gw = _linear_grads(gz, x2, _c(w), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (gx.reshape(x.shape) if gx is not None else None, gw, db, None, gy if ctx.has_res and ctx.needs_input_grad[4] else None)
+
+
+def linear(x, w, b, relu=False, residual=None):
+    return Linear.apply(x, w, b, relu, residual)
+
+
+class LayerNorm(torch.autograd.Function):
+    """relu?(LayerNorm(x)) (+ add_after): forward = dense.layer_norm, backward = sbev_layer_norm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, relu, add_after):
+        y = dense.layer_norm(x, g, b, relu=relu, add_after=add_after)
+        ctx.relu = bool(relu)
+        ctx.has_add = add_after is not None
+        ctx.save_for_backward(x, g, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g, b = ctx.saved_tensors
+        N = x.shape[-1]
+        gy2, x2 = _c(gy).reshape(-1, N), _c(x).reshape(-1, N)
+        M = x2.shape[0]
+        gx = torch.empty_like(x2)
+        dg, dbeta = torch.empty_like(g), torch.empty_like(b)
+        stats = torch.empty(max(M, 1), 2, device=x.device, dtype=torch.float32)
+        st = _lib.load().sbev_layer_norm_bwd(_p(gy2), _p(x2), _p(_c(g)), _p(_c(b)), _EPS, int(ctx.relu), _p(gx), _p(dg), _p(dbeta),
+                                             _p(stats), M, N, _stream())
+        _lib.check(st, 'sbev_layer_norm_bwd')
+        return gx.reshape(x.shape), dg, dbeta, None, gy if ctx.has_add and ctx.needs_input_grad[4] else None
+
+
+def layer_norm(x, g, b, relu=False, add_after=None):
+    return LayerNorm.apply(x, g, b, relu, add_after)
+
+
+class Linear3LnRelu(torch.autograd.Function):
+    """relu(LayerNorm(bbox[..., :3] W^T + b)) -- position_encoder[0..2] (models/sparsebev_transformer.py:116-119)."""
+
+    @staticmethod
+    def forward(ctx, bbox, w, b, lnw, lnb):
+        N = w.shape[0]
+        ld = bbox.shape[-1]
+        x2 = _c(bbox).reshape(-1, ld)
+        M = x2.shape[0]
+        y = torch.empty(M, N, device=bbox.device, dtype=torch.float32)
+        pre = torch.empty(M, N, device=bbox.device, dtype=torch.float32)
+        st = _lib.load().sbev_linear3_ln_relu_ex_f32(_p(x2), ld, _p(_c(w)), _p(b), _p(lnw), _p(lnb), _EPS, _p(y), _p(pre), M, N, _stream())
+        _lib.check(st, 'sbev_linear3_ln_relu_ex_f32')
+        ctx.save_for_backward(x2, w, lnw, lnb, pre)
+        ctx.bshape = bbox.shape
+        return y.reshape(*bbox.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, lnw, lnb, pre = ctx.saved_tensors
+        N = w.shape[0]
+        M, ld = x2.shape
+        gy2 = _c(gy).reshape(-1, N)
+        gpre = torch.empty_like(pre)
+        dg, dbeta = torch.empty_like(lnw), torch.empty_like(lnb)
+        stats = torch.empty(max(M, 1), 2, device=gy.device, dtype=torch.float32)
+        lib = _lib.load()
+        _lib.check(lib.sbev_layer_norm_bwd(_p(gy2), _p(pre), _p(_c(lnw)), _p(_c(lnb)), _EPS, 1, _p(gpre), _p(dg), _p(dbeta), _p(stats),
+                                           M, N, _stream()), 'sbev_layer_norm_bwd')
+        _, db = _bias_relu_bwd(gpre, None, True)
+        gw = gemm(gpre, True, N, x2, True, ld, N, 3, M)                    # grad_pre^T [N,M] . bbox[:, :3]
+        gb = None
+        if ctx.needs_input_grad[0]:
+            gb = torch.zeros(M, ld, device=gy.device, dtype=torch.float32)
+            gemm(gpre, False, N, _c(w), True, 3, M, 3, N, out=gb, ldc=ld)  # grad_pre . W -> columns 0..2 of the box grad
+            gb = gb.reshape(ctx.bshape)
+        return gb, gw, db, dg, dbeta
+
+
+class SasaCore(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) - dist * tau (+ DN mask)) v on the packed q | k | v | tau rows (attention.hip /
+    attention_bwd.hip).  query_bbox only feeds the no-grad distance term (calc_bbox_dists is @torch.no_grad)."""
+
+    @staticmethod
+    def forward(ctx, qkvt, query_bbox, mask, pc_range, num_heads, attn_drop, seed):
+        B, Q, ld = qkvt.shape
+        qkvt = _c(qkvt)
+        bbox = _c(query_bbox.detach())
+        hd = 32
+        Dm = num_heads * hd
+        att = torch.empty(B, Q, Dm, device=qkvt.device, dtype=torch.float32)
+        pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+        lib = _lib.load()
+        if attn_drop > 0.0:
+            st = lib.sbev_sasa_train_fwd_f32(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), B, Q, num_heads, hd, float(attn_drop), int(seed), _stream())
+            _lib.check(st, 'sbev_sasa_train_fwd_f32')
+        else:
+            _lib.check(lib.sbev_sasa_f32(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), B, Q, num_heads, hd, _stream()), 'sbev_sasa_f32')
+        ctx.save_for_backward(qkvt, bbox, mask, att)
+        ctx.cfg = (pc_range, num_heads, float(attn_drop), int(seed))
+        return att
+
+    @staticmethod
+    def backward(ctx, gatt):
+        qkvt, bbox, mask, att = ctx.saved_tensors
+        pc_range, H, p, seed = ctx.cfg
+        B, Q, ld = qkvt.shape
+        gq = torch.empty_like(qkvt)
+        ws = torch.empty(2 * B * H * Q, device=qkvt.device, dtype=torch.float32)
+        pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+        st = _lib.load().sbev_sasa_bwd_f32(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), _p(_c(gatt)), _p(gq), _p(ws), B, Q, H, 32,
+                                           p, seed, _stream())
+        _lib.check(st, 'sbev_sasa_bwd_f32')
+        return gq, None, None, None, None, None, None
+
+
+class AdaptiveMixing(torch.autograd.Function):
+    """AdaptiveMixing.inner_forward (models/sparsebev_transformer.py:351-381) as ONE node that keeps only its inputs: the
+    dynamic parameters [B*Q, 32768] and the mixed activations [B*Q, 32768] are recomputed in backward -- the reference's
+    checkpoint policy (:383-387) -- so 29.5 MB instead of 265 MB per layer stay alive at config 2."""
+
+    @staticmethod
+    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points):
+        y = dense.adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points)       # = query + out_proj(mix)
+        ctx.save_for_backward(x, query, pg_w, pg_b, op_w, op_b)
+        ctx.out_points = out_points
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, query, pg_w, pg_b, op_w, op_b = ctx.saved_tensors
+        B, Q, G, Pin, C = x.shape
+        D = query.shape[-1]
+        BQ = B * Q
+        lib = _lib.load()
+        x = _c(x)
+        q2 = _c(query).reshape(BQ, D)
+        gy2 = _c(gy).reshape(BQ, D)
+        # recompute: dynamic parameters and mixed activations (the two forward launches)
+        params = dense.linear(q2, pg_w, pg_b)                                            # [BQ, G*(C*C + Pout*Pin)]
+        NP = params.shape[1]
+        NM = G * ctx.out_points * C
+        mixed = torch.empty(BQ, NM, device=x.device, dtype=torch.float32)
+        _lib.check(lib.sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, ctx.out_points, _EPS, _stream()),
+                   'sbev_adaptive_mixing_f32')
+        # out-projection backward
+        _, gb_op = _bias_relu_bwd(gy2, None, True)
+        gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, True)
+        del mixed
+        # mixing core backward
+        gx = torch.empty_like(x)
+        gparams = torch.empty_like(params)
+        _lib.check(lib.sbev_adaptive_mixing_bwd_f32(_p(x), _p(params), _p(gmixed), _p(gx), _p(gparams), BQ, G, Pin, C, ctx.out_points,
+                                                    _EPS, _stream()), 'sbev_adaptive_mixing_bwd_f32')
+        del gmixed, params
+        # parameter generator backward; `query +` residual passes gy through
+        _, gb_pg = _bias_relu_bwd(gparams, None, True)
+        _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
+        gq = gy2.clone()                                                                  # the `query +` residual ...
+        gemm(gparams, False, NP, _c(pg_w), True, D, BQ, D, NP, out=gq, ldc=D, accumulate=True)   # ... + grad_params . W_pg
+        gq = gq.reshape(query.shape)
+        return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None
+
+
+class Sampling(torch.autograd.Function):
+    """SparseBEVSampling.inner_forward after its two Linears (models/sparsebev_transformer.py:270-311): sample points,
+    velocity warp, level softmax, projection + view selection (sampling_4d front half), multi-scale gather.  Saves only
+    (query_bbox, packed offsets | logits); points, locations and weights are recomputed in backward.
+
+    Feature gradients are accumulated by atomics into ONE buffer per level shared by all layers of a decoder call
+    (``pyramid.grad_levels``) and handed to autograd by the last backward to run."""
+
+    @staticmethod
+    def forward(ctx, query_bbox, both, pyramid, dctx, cfg, *orig_feats):
+        T, G, P, L, pc_range = cfg
+        n_off = G * P * 3
+        bbox = _c(query_bbox)
+        both = _c(both)
+        offset, logits = both[..., :n_off], both[..., n_off:]
+        pts, w_bp = ops.sampling_front(bbox, offset, logits, dctx.time_diff, pc_range, T, G, P, L)
+        loc = ops.project_select(pts, dctx.lidar2img, dctx.image_h, dctx.image_w, G, P)
+        out = pyramid.sample(loc, w_bp, T, G)
+        ctx.save_for_backward(bbox, both)
+        ctx.pyramid, ctx.dctx, ctx.cfg = pyramid, dctx, cfg
+        ctx.n_feats = len(orig_feats)
+        ctx.feat_grad = any(f.requires_grad for f in orig_feats)
+        if ctx.feat_grad:
+            pyramid.pending_backward = getattr(pyramid, 'pending_backward', 0) + 1
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        bbox, both = ctx.saved_tensors
+        pyr, dctx = ctx.pyramid, ctx.dctx
+        T, G, P, L, pc_range = ctx.cfg
+        B, Q = bbox.shape[:2]
+        n_off = G * P * 3
+        offset, logits = both[..., :n_off], both[..., n_off:]
+        pts, w_bp = ops.sampling_front(bbox, offset, logits, dctx.time_diff, pc_range, T, G, P, L)
+        loc = ops.project_select(pts, dctx.lidar2img, dctx.image_h, dctx.image_w, G, P)
+        gfeat_levels = pyr.grad_buffers() if ctx.feat_grad else None
+        gloc, gw = pyr.sample_backward(loc, w_bp, _c(gout), T, G, gfeat_levels)
+        lib = _lib.load()
+        gpts = torch.empty_like(pts)
+        _lib.check(lib.sbev_project_select_bwd(_p(pts), _p(_c(dctx.lidar2img)), _p(gloc), B, Q, T, ops.N_VIEWS, G, P,
+                                               float(dctx.image_h), float(dctx.image_w), 1e-5, _p(gpts), _stream()), 'sbev_project_select_bwd')
+        gboth = torch.empty(B, Q, both.shape[-1], device=bbox.device, dtype=torch.float32)     # offsets | logits, packed like `both`
+        gbbox = torch.empty(B, Q, 10, device=bbox.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+        ld = both.shape[-1]
+        st = lib.sbev_sampling_front_bwd(_p(bbox), _p(both), ld, ctypes.c_void_p(both.data_ptr() + 4 * n_off), ld, pc, B, Q, T, G, P, L,
+                                         _p(gpts), _p(gw), _p(gboth), ctypes.c_void_p(gboth.data_ptr() + 4 * n_off), ld, _p(gbbox), _stream())
+        _lib.check(st, 'sbev_sampling_front_bwd')
+        gfeats = [None] * ctx.n_feats
+        if ctx.feat_grad:
+            pyr.pending_backward -= 1
+            if pyr.pending_backward == 0:
+                gfeats = pyr.take_feature_grads()
+        return (gbbox, gboth, None, None, None, *gfeats)
+
+
+class RefineBbox(torch.autograd.Function):
+    """refine_bbox + velocity / time_diff (models/sparsebev_transformer.py:155-160,179-183)."""
+
+    @staticmethod
+    def forward(ctx, query_bbox, reg, vel_div):
+        out = dense.refine_bbox(query_bbox, reg, vel_div)
+        ctx.save_for_backward(_c(query_bbox), out, vel_div)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        bbox, out, vel_div = ctx.saved_tensors
+        B, Q, _ = out.shape
+        greg = torch.empty_like(out)
+        gb = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        st = _lib.load().sbev_refine_bbox_bwd(_p(_c(gout)), _p(out), _p(bbox), _p(vel_div), _p(greg), _p(gb), B, Q, _stream())
+        _lib.check(st, 'sbev_refine_bbox_bwd')
+        return gb, greg, None
+
+
+class Dropout(torch.autograd.Function):
+    """x * keep / (1 - p) with a counter-based mask (sbev_dropout_f32); the backward re-generates the mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().sbev_dropout_f32(_p(x), _p(y), x.numel(), int(seed), float(p), _stream()), 'sbev_dropout_f32')
+        ctx.cfg = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        p, seed = ctx.cfg
+        gy = _c(gy)
+        gx = torch.empty_like(gy)
+        _lib.check(_lib.load().sbev_dropout_f32(_p(gy), _p(gx), gy.numel(), seed, p, _stream()), 'sbev_dropout_f32')
+        return gx, None, None
+
+
+def dropout(x, p, seed):
+    return Dropout.apply(x, p, seed) if p > 0.0 else x

@@ -1,0 +1,269 @@
+// Scale-adaptive self attention, BACKWARD (and the training forward with attention dropout) -- gfx950.
+//
+// SURVEY.md section 8f rank 4.  The reference differentiates SparseBEVSelfAttention.inner_forward through autograd and
+// recomputes it under torch.utils.checkpoint (models/sparsebev_transformer.py:210-234); torch.nn.MultiheadAttention
+// materialises the [B*8, Q, Q] probabilities for that.  Here nothing of size Q x Q exists in either direction:
+//     S_ij = (q_i . k_j) / sqrt(d) - dist_ij * tau_ih   (-inf under the DN mask),   P = softmax_j(S),   O_i = sum_j Pd_ij v_j
+//     Pd = dropout(P)  (training, attn_drop = 0.1: mmcv MultiheadAttention, models/sparsebev_transformer.py:202)
+//     dV_j = sum_i Pd_ij dO_i        dPd_ij = dO_i . v_j        dS_ij = P_ij (keep_ij dPd_ij / (1-p) - D_i),  D_i = dO_i . O_i
+//     dq_i = sum_j dS_ij k_j / sqrt(d)     dk_j = sum_i dS_ij q_i / sqrt(d)     dtau_ih = -sum_j dS_ij dist_ij
+// (dist carries no gradient: calc_bbox_dists is @torch.no_grad, :236-248.)
+// Two deterministic passes, flash-attention style: a ROW kernel (thread = one query of one head; online softmax over key
+// tiles staged in LDS, then dq / dtau and the row's log-sum-exp + D_i) and a COLUMN kernel (thread = one key; loops over
+// query tiles, accumulates dk / dv).  No atomics.  The dropout keep decision is a hash of (seed, b, h, i, j), so forward
+// and both backward kernels regenerate the same mask.  1.3 GFLOP forward per layer-sample: plain VALU math is enough.
+#include "sbev_common.hpp"
+
+namespace {
+
+constexpr int HD = 32;
+constexpr int TILE = 64;
+
+struct SasaBwdArgs {
+    const float* qkvt;          // [B, Q, ld]: q | k | v | tau
+    const float* bbox;          // [B, Q, 10]
+    float lo[2], span[2];
+    const unsigned char* mask;  // [Q, Q] or null
+    const float* O;             // [B, Q, D]    forward output (backward only)
+    const float* dO;            // [B, Q, D]
+    float* out;                 // forward mode: O [B, Q, D]
+    float* dqkvt;               // [B, Q, ld]
+    float* lse;                 // [B, H, Q]
+    float* dvec;                // [B, H, Q]
+    int B, Q, H, ld;
+    float scale;
+    float p_drop, inv_keep;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ unsigned mix32(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ bool keep_of(const SasaBwdArgs& a, unsigned thr, int b, int h, int i, int j) {
+    const unsigned long long idx = (((unsigned long long)b * a.H + h) * a.Q + i) * a.Q + j;
+    return mix32(a.seed * 0x100000001b3ull + idx) >= thr;
+}
+
+// grid = (ceil(Q / 64), H, B), 64 threads: thread = query row.  FWD: writes O (training forward with dropout);
+// !FWD: writes dq, dtau (and zeroes the padding columns), lse, dvec.
+template <bool FWD>
+__global__ __launch_bounds__(64) void sasa_row_kernel(const SasaBwdArgs a) {
+    __shared__ float Ks[TILE][HD + 1], Vs[TILE][HD + 1], Cs[TILE][2];
+    const int lane = threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = a.H * HD;
+    const int i = blockIdx.x * 64 + lane;
+    const bool live = i < a.Q;
+    const int ic = live ? i : a.Q - 1;
+    const float* base = a.qkvt + (long long)b * a.Q * a.ld;
+    const unsigned thr = (unsigned)((double)a.p_drop * 4294967296.0);
+    float q[HD], go[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        q[d] = base[(long long)ic * a.ld + h * HD + d] * a.scale;
+        go[d] = FWD ? 0.f : a.dO[((long long)b * a.Q + ic) * D + h * HD + d];
+        acc[d] = 0.f;
+    }
+    const float cx = a.bbox[((long long)b * a.Q + ic) * 10] * a.span[0] + a.lo[0];
+    const float cy = a.bbox[((long long)b * a.Q + ic) * 10 + 1] * a.span[1] + a.lo[1];
+    const float tau = base[(long long)ic * a.ld + 3 * D + h];
+    float dsum = 0.f;
+    if (!FWD) {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dsum += go[d] * a.O[((long long)b * a.Q + ic) * D + h * HD + d];
+    }
+    float m = -INFINITY, l = 0.f, dtau = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k0 = 0; k0 < a.Q; k0 += TILE) {
+            __syncthreads();
+            {
+                const int kj = min(k0 + lane, a.Q - 1);
+                const float* row = base + (long long)kj * a.ld + h * HD;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    Ks[lane][d] = row[D + d];
+                    Vs[lane][d] = row[2 * D + d];
+                }
+                Cs[lane][0] = a.bbox[((long long)b * a.Q + kj) * 10] * a.span[0] + a.lo[0];
+                Cs[lane][1] = a.bbox[((long long)b * a.Q + kj) * 10 + 1] * a.span[1] + a.lo[1];
+            }
+            __syncthreads();
+            const int nk = min(TILE, a.Q - k0);
+            for (int jj = 0; jj < nk; ++jj) {
+                const int j = k0 + jj;
+                if (a.mask && a.mask[(long long)ic * a.Q + j]) continue;
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) s += q[d] * Ks[jj][d];
+                const float dx = cx - Cs[jj][0], dy = cy - Cs[jj][1];
+                const float dist = sqrtf(dx * dx + dy * dy);
+                s -= dist * tau;
+                if (pass == 0) {
+                    const float mn = fmaxf(m, s);
+                    l = l * __expf(m - mn) + __expf(s - mn);
+                    m = mn;
+                } else {
+                    const float p = __expf(s - m) / l;
+                    const bool keep = a.p_drop > 0.f ? keep_of(a, thr, b, h, ic, j) : true;
+                    if (FWD) {
+                        if (keep) {
+                            const float pd = p * a.inv_keep;
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) acc[d] += pd * Vs[jj][d];
+                        }
+                    } else {
+                        float dp = 0.f;
+                        if (keep) {
+#pragma unroll
+                            for (int d = 0; d < HD; ++d) dp += go[d] * Vs[jj][d];
+                            dp *= a.inv_keep;
+                        }
+                        const float ds = p * (dp - dsum);
+#pragma unroll
+                        for (int d = 0; d < HD; ++d) acc[d] += ds * Ks[jj][d];
+                        dtau -= ds * dist;
+                    }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    if (FWD) {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) a.out[((long long)b * a.Q + i) * D + h * HD + d] = acc[d];
+    } else {
+        float* g = a.dqkvt + ((long long)b * a.Q + i) * a.ld;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) g[h * HD + d] = acc[d] * a.scale;
+        g[3 * D + h] = dtau;
+        if (h == 0)
+            for (int c = 3 * D + a.H; c < a.ld; ++c) g[c] = 0.f;
+        a.lse[((long long)b * a.H + h) * a.Q + i] = m + __logf(l);
+        a.dvec[((long long)b * a.H + h) * a.Q + i] = dsum;
+    }
+}
+
+// grid = (ceil(Q / 64), H, B), 64 threads: thread = key column j; writes dk_j, dv_j.
+__global__ __launch_bounds__(64) void sasa_col_kernel(const SasaBwdArgs a) {
+    __shared__ float Qs[TILE][HD + 1], Gs[TILE][HD + 1], Rs[TILE][5];   // Rs: cx, cy, tau, lse, dvec of the query
+    const int lane = threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = a.H * HD;
+    const int j = blockIdx.x * 64 + lane;
+    const bool live = j < a.Q;
+    const int jc = live ? j : a.Q - 1;
+    const float* base = a.qkvt + (long long)b * a.Q * a.ld;
+    const unsigned thr = (unsigned)((double)a.p_drop * 4294967296.0);
+    float k[HD], v[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        k[d] = base[(long long)jc * a.ld + D + h * HD + d];
+        v[d] = base[(long long)jc * a.ld + 2 * D + h * HD + d];
+        dk[d] = dv[d] = 0.f;
+    }
+    const float kx = a.bbox[((long long)b * a.Q + jc) * 10] * a.span[0] + a.lo[0];
+    const float ky = a.bbox[((long long)b * a.Q + jc) * 10 + 1] * a.span[1] + a.lo[1];
+    for (int i0 = 0; i0 < a.Q; i0 += TILE) {
+        __syncthreads();
+        {
+            const int qi = min(i0 + lane, a.Q - 1);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                Qs[lane][d] = base[(long long)qi * a.ld + h * HD + d] * a.scale;
+                Gs[lane][d] = a.dO[((long long)b * a.Q + qi) * D + h * HD + d];
+            }
+            Rs[lane][0] = a.bbox[((long long)b * a.Q + qi) * 10] * a.span[0] + a.lo[0];
+            Rs[lane][1] = a.bbox[((long long)b * a.Q + qi) * 10 + 1] * a.span[1] + a.lo[1];
+            Rs[lane][2] = base[(long long)qi * a.ld + 3 * D + h];
+            Rs[lane][3] = a.lse[((long long)b * a.H + h) * a.Q + qi];
+            Rs[lane][4] = a.dvec[((long long)b * a.H + h) * a.Q + qi];
+        }
+        __syncthreads();
+        const int ni = min(TILE, a.Q - i0);
+        for (int ii = 0; ii < ni; ++ii) {
+            const int i = i0 + ii;
+            if (a.mask && a.mask[(long long)i * a.Q + jc]) continue;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                s += Qs[ii][d] * k[d];
+                dp += Gs[ii][d] * v[d];
+            }
+            const float dx = Rs[ii][0] - kx, dy = Rs[ii][1] - ky;
+            s -= sqrtf(dx * dx + dy * dy) * Rs[ii][2];
+            const float p = __expf(s - Rs[ii][3]);
+            const bool keep = a.p_drop > 0.f ? keep_of(a, thr, b, h, i, jc) : true;
+            const float pd = keep ? p * a.inv_keep : 0.f;
+            const float ds = p * ((keep ? dp * a.inv_keep : 0.f) - Rs[ii][4]);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dv[d] += pd * Gs[ii][d];
+                dk[d] += ds * Qs[ii][d];          // Qs is pre-scaled by 1/sqrt(d)
+            }
+        }
+    }
+    if (!live) return;
+    float* g = a.dqkvt + ((long long)b * a.Q + j) * a.ld;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        g[D + h * HD + d] = dk[d];
+        g[2 * D + h * HD + d] = dv[d];
+    }
+}
+
+int fill(SasaBwdArgs& a, const float* qkvt, int64_t ld, const float* bbox, const double* pc_range, const uint8_t* mask,
+         int B, int Q, int H, int head_dim, float p_drop, uint64_t seed, const char* who) {
+    SBEV_REQUIRE(B >= 0 && Q >= 0 && H >= 1, "%s: bad sizes", who);
+    SBEV_REQUIRE(head_dim == HD, "%s: built for head_dim 32 (got %d)", who, head_dim);
+    SBEV_REQUIRE(ld >= 3 * H * HD + H, "%s: row stride %lld must be >= 3*H*32 + H", who, (long long)ld);
+    SBEV_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "%s: need 0 <= attn_drop < 1", who);
+    SBEV_REQUIRE((int64_t)Q * Q * H * (B > 0 ? B : 1) >= 0, "%s: overflow", who);
+    a.qkvt = qkvt; a.bbox = bbox; a.mask = mask;
+    a.B = B; a.Q = Q; a.H = H; a.ld = (int)ld; a.scale = 1.0f / sqrtf((float)HD);
+    a.p_drop = p_drop; a.inv_keep = 1.f / (1.f - p_drop); a.seed = seed;
+    for (int i = 0; i < 2; ++i) {
+        a.lo[i] = (float)pc_range[i];
+        a.span[i] = (float)(pc_range[3 + i] - pc_range[i]);
+    }
+    return SBEV_OK;
+}
+
+}  // namespace
+
+extern "C" int sbev_sasa_train_fwd_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                                       const uint8_t* mask, float* out, int B, int Q, int H, int head_dim,
+                                       float attn_drop, uint64_t seed, sbev_stream_t stream) {
+    SasaBwdArgs a{};
+    int st = fill(a, qkvt, ld, query_bbox, pc_range, mask, B, Q, H, head_dim, attn_drop, seed, "sbev_sasa_train_fwd_f32");
+    if (st != SBEV_OK) return st;
+    if (B == 0 || Q == 0) return SBEV_OK;
+    SBEV_REQUIRE(qkvt && query_bbox && pc_range && out, "sbev_sasa_train_fwd_f32: null pointer");
+    a.out = out;
+    hipLaunchKernelGGL(sasa_row_kernel<true>, dim3((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_sasa_train_fwd_f32");
+}
+
+extern "C" int sbev_sasa_bwd_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                                 const uint8_t* mask, const float* out, const float* grad_out, float* grad_qkvt,
+                                 float* workspace, int B, int Q, int H, int head_dim, float attn_drop, uint64_t seed,
+                                 sbev_stream_t stream) {
+    SasaBwdArgs a{};
+    int st = fill(a, qkvt, ld, query_bbox, pc_range, mask, B, Q, H, head_dim, attn_drop, seed, "sbev_sasa_bwd_f32");
+    if (st != SBEV_OK) return st;
+    if (B == 0 || Q == 0) return SBEV_OK;
+    SBEV_REQUIRE(qkvt && query_bbox && pc_range && out && grad_out && grad_qkvt && workspace, "sbev_sasa_bwd_f32: null pointer");
+    a.O = out; a.dO = grad_out; a.dqkvt = grad_qkvt;
+    a.lse = workspace;                                   // [B, H, Q]
+    a.dvec = workspace + (long long)B * H * Q;           // [B, H, Q]
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(sasa_row_kernel<false>, grid, dim3(64), 0, s, a);
+    st = sbev::check_launch("sbev_sasa_bwd_f32 (rows)");
+    if (st != SBEV_OK) return st;
+    hipLaunchKernelGGL(sasa_col_kernel, grid, dim3(64), 0, s, a);
+    return sbev::check_launch("sbev_sasa_bwd_f32 (columns)");
+}

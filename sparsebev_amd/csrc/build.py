@@ -21,6 +21,10 @@ UNITS = {
     # VGPR-form MFMAs: the kernel fits 256 VGPRs, AGPR-form costs 144 accumulator copies per loop iteration
     'gemm_regtile.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
     'gemm_bf16x3.hip': [],
+    'gemm_any.hip': [],                  # layout-generic GEMM: grad_x / grad_W of every Linear (training)
+    'mixing_bwd.hip': [],
+    'attention_bwd.hip': [],
+    'backward_ops.hip': ['-ffp-contract=off'],   # re-runs project.hip's individually rounded projection to re-select the camera
     'mixing.hip': [],
     'attention.hip': [],
     'layout.hip': [],

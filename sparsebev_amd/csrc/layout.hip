@@ -99,3 +99,15 @@ extern "C" int sbev_linear3_ln_relu_f32(const float* x, int64_t ldx, const float
     hipLaunchKernelGGL(linear3_ln_relu_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_linear3_ln_relu_f32");
 }
+
+// Same launch, additionally storing the Linear's pre-LayerNorm output (training forward: the backward pass needs it).
+extern "C" int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const float* w, const float* b,
+                                           const float* ln_w, const float* ln_b, float eps, float* y, float* pre,
+                                           int64_t M, int N, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024 && ldx >= 3, "sbev_linear3_ln_relu_ex_f32: need N %% 4 == 0, N <= 1024, ldx >= 3");
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(x && w && b && ln_w && ln_b && y, "sbev_linear3_ln_relu_ex_f32: null pointer");
+    PosArgs a{x, w, b, ln_w, ln_b, y, M, N, (int)ldx, eps, pre};
+    hipLaunchKernelGGL(linear3_ln_relu_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_linear3_ln_relu_ex_f32");
+}

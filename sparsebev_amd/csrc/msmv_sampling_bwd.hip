@@ -24,7 +24,9 @@ struct BwdArgs {
     long long stride_g, stride_px;
     const float* loc;
     const float* w;
-    const float* gout;     // [B',Q,C,P]
+    const float* gout;     // [B',Q,C,P] (reference layout) or [B,Q,G,T*P,C] (mixing layout, b' = (b*T + t)*G + g)
+    int gout_mix, T, G;    // gout_mix != 0: mixing layout
+    int want_gfeat;        // 0: grad_value is not needed (frozen features): no atomics at all
     float* gloc;           // [B',Q,P,3]
     float* gw;             // [B',Q,P,L]
     long long n_waves;
@@ -49,7 +51,14 @@ __global__ __launch_bounds__(256) void msmv_bwd_kernel(const BwdArgs a) {
     const int P = a.P, C = a.C;
     const float* __restrict__ locq = a.loc + wave * P * 3;
     const float* __restrict__ wq = a.w + wave * P * L;
+    // element (c, p) of this item's grad_out: gq[c * gs_c + p * gs_p]
     const float* __restrict__ gq = a.gout + wave * C * P;
+    long long gs_c = P, gs_p = 1;
+    if (a.gout_mix) {
+        const long long q = wave - bp * a.Q, bt = bp / a.G, g = bp - bt * a.G, b = bt / a.T, t = bt - b * a.T;
+        gq = a.gout + ((((b * a.Q + q) * a.G + g) * a.T + t) * (long long)P) * C;
+        gs_c = 1; gs_p = C;
+    }
     const float nm1 = (float)(a.N - 1);
 
     for (int p = 0; p < P; ++p) {
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256) void msmv_bwd_kernel(const BwdArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int c = c0 + j + 16 * i;
                 cok[i] = c < C;
-                g[i] = cok[i] ? gq[c * P + p] : 0.f;
+                g[i] = cok[i] ? gq[c * gs_c + p * gs_p] : 0.f;
             }
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void msmv_bwd_kernel(const BwdArgs a) {
                     const int c = c0 + j + 16 * i;
                     if (inb && cok[i]) {
                         dot += g[i] * f[c];
-                        atomicAdd(gf + c, cw * wl * g[i]);               // global_atomic_add_f32 (-munsafe-fp-atomics)
+                        if (a.want_gfeat) atomicAdd(gf + c, cw * wl * g[i]);   // global_atomic_add_f32 (-munsafe-fp-atomics)
                     }
                 }
                 gwl[l] += cw * dot;                                      // d/d weight_l = sum_c g_c * bilinear_c
@@ -138,6 +147,12 @@ __global__ __launch_bounds__(256) void msmv_bwd_c64_kernel(const BwdArgs a) {
     const float* __restrict__ locq = a.loc + wave * P * 3;
     const float* __restrict__ wq = a.w + wave * P * L;
     const float* __restrict__ gq = a.gout + wave * 64 * P + lane * P;        // this lane's channel row of [C, P]
+    int gs_p = 1;
+    if (a.gout_mix) {                                                        // [B,Q,G,T*P,C]: point rows of 64 channels
+        const long long q = wave - bp * a.Q, bt = bp / a.G, g = bp - bt * a.G, b = bt / a.T, t = bt - b * a.T;
+        gq = a.gout + ((((b * a.Q + q) * a.G + g) * a.T + t) * (long long)P) * 64 + lane;
+        gs_p = 64;
+    }
     const float nm1 = (float)(a.N - 1);
     const float* fb[L];
     float* gb[L];
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(256) void msmv_bwd_c64_kernel(const BwdArgs a) {
         const float x = locq[p * 3 + 0], y = locq[p * 3 + 1];
         int view = (int)roundf(locq[p * 3 + 2] * nm1);
         view = min(max(view, 0), a.N - 1);
-        const float g = gq[p];
+        const float g = gq[p * gs_p];
         float v[L][4], lhs[L], lws[L];
         int off[L][4], msk[L];
 #pragma unroll
@@ -188,6 +203,7 @@ __global__ __launch_bounds__(256) void msmv_bwd_c64_kernel(const BwdArgs a) {
             gx += g * (hh * (m1 - m0) + lh * (m3 - m2)) * (wl * (float)(a.W[l] - 1));
             gy += g * (hw * (m2 - m0) + lw * (m3 - m1)) * (wl * (float)(a.H[l] - 1));
             const float gv = wl * g;
+            if (!a.want_gfeat) continue;
             if (mk & 1) atomicAdd(gb[l] + off[l][0], hh * hw * gv);      // global_atomic_add_f32, no return; wave-uniform guards
             if (mk & 2) atomicAdd(gb[l] + off[l][1], hh * lw * gv);
             if (mk & 4) atomicAdd(gb[l] + off[l][2], lh * hw * gv);
@@ -226,22 +242,26 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sbev_msmv_bwd(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
-                             int64_t Bp, int N, int C, int Q, int P,
-                             int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
-                             const float* loc, const float* weights, const float* grad_out,
-                             float* grad_loc, float* grad_weights, sbev_stream_t stream) {
-    SBEV_REQUIRE(feats && grad_feats && hw && stride_bo && stride_v, "sbev_msmv_bwd: null descriptor array");
+static int msmv_bwd_impl(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
+                         int64_t Bp, int N, int C, int Q, int P,
+                         int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                         const float* loc, const float* weights, const float* grad_out, int grad_out_layout, int T, int G,
+                         float* grad_loc, float* grad_weights, sbev_stream_t stream) {
+    SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_msmv_bwd: null descriptor array");
     SBEV_REQUIRE(L >= 1 && L <= SBEV_MAX_LEVELS, "sbev_msmv_bwd: L=%d", L);
     SBEV_REQUIRE(P >= 1 && P <= SBEV_MAX_POINTS, "sbev_msmv_bwd: num_point exceed limits (P=%d)", P);
     SBEV_REQUIRE(C >= 1 && N >= 1 && Q >= 0 && Bp >= 0 && gdiv >= 1, "sbev_msmv_bwd: bad sizes");
+    SBEV_REQUIRE(grad_out_layout == SBEV_OUT_REF || grad_out_layout == SBEV_OUT_MIX, "sbev_msmv_bwd: grad_out_layout %d", grad_out_layout);
+    if (grad_out_layout == SBEV_OUT_MIX)
+        SBEV_REQUIRE(T >= 1 && G >= 1 && Bp % ((int64_t)T * G) == 0, "sbev_msmv_bwd: B'=%lld is not B*T*G (T=%d, G=%d)", (long long)Bp, T, G);
     if (Bp == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(loc && weights && grad_out && grad_loc && grad_weights, "sbev_msmv_bwd: null pointer");
     BwdArgs a{};
+    a.want_gfeat = grad_feats != nullptr;
     for (int l = 0; l < L; ++l) {
-        SBEV_REQUIRE(feats[l] && grad_feats[l], "sbev_msmv_bwd: level %d pointer is null", l);
+        SBEV_REQUIRE(feats[l] && (!grad_feats || grad_feats[l]), "sbev_msmv_bwd: level %d pointer is null", l);
         a.feat[l] = static_cast<const float*>(feats[l]);
-        a.gfeat[l] = static_cast<float*>(grad_feats[l]);
+        a.gfeat[l] = grad_feats ? static_cast<float*>(grad_feats[l]) : const_cast<float*>(static_cast<const float*>(feats[l]));   // never written when !want_gfeat
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
         a.stride_bo[l] = stride_bo[l];
@@ -249,6 +269,7 @@ extern "C" int sbev_msmv_bwd(const void* const* feats, void* const* grad_feats, 
     }
     a.stride_g = stride_g; a.stride_px = stride_px;
     a.loc = loc; a.w = weights; a.gout = grad_out; a.gloc = grad_loc; a.gw = grad_weights;
+    a.gout_mix = grad_out_layout == SBEV_OUT_MIX; a.T = T; a.G = G;
     a.n_waves = Bp * Q;
     a.N = N; a.C = C; a.Q = Q; a.P = P; a.gdiv = gdiv;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -259,4 +280,23 @@ extern "C" int sbev_msmv_bwd(const void* const* feats, void* const* grad_feats, 
         case 4: return launch_bwd<4>(a, s);
         default: return launch_bwd<5>(a, s);
     }
+}
+
+extern "C" int sbev_msmv_bwd(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
+                             int64_t Bp, int N, int C, int Q, int P,
+                             int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                             const float* loc, const float* weights, const float* grad_out,
+                             float* grad_loc, float* grad_weights, sbev_stream_t stream) {
+    SBEV_REQUIRE(grad_feats != nullptr, "sbev_msmv_bwd: null descriptor array");
+    return msmv_bwd_impl(feats, grad_feats, hw, L, Bp, N, C, Q, P, gdiv, stride_bo, stride_g, stride_v, stride_px, loc, weights,
+                         grad_out, SBEV_OUT_REF, 1, 1, grad_loc, grad_weights, stream);
+}
+
+extern "C" int sbev_msmv_bwd_ex(const void* const* feats, void* const* grad_feats, const int32_t* hw, int L,
+                                int64_t Bp, int N, int C, int Q, int P,
+                                int gdiv, const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                const float* loc, const float* weights, const float* grad_out, int grad_out_layout, int T, int G,
+                                float* grad_loc, float* grad_weights, sbev_stream_t stream) {
+    return msmv_bwd_impl(feats, grad_feats, hw, L, Bp, N, C, Q, P, gdiv, stride_bo, stride_g, stride_v, stride_px, loc, weights,
+                         grad_out, grad_out_layout, T, G, grad_loc, grad_weights, stream);
 }

@@ -138,6 +138,7 @@ struct PosArgs {
     long long M;
     int N, ldx;
     float eps;
+    float* pre = nullptr;   // [M, N] or null: the Linear's output BEFORE LayerNorm (kept for the backward pass in training)
 };
 
 // Linear(3 -> N) + LayerNorm(N) + ReLU, one wave per row (N <= 1024, N % 4 == 0): 3 FMAs per output are not
@@ -163,6 +164,7 @@ __device__ __forceinline__ void lin3_rows(const PosArgs& a, unsigned block) {
             }
             v[c][e] = t;
         }
+        if (a.pre && n0 < a.N) *reinterpret_cast<float4*>(a.pre + row * a.N + n0) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);

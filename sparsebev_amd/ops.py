@@ -185,6 +185,37 @@ def msmv_sampling_nhwc(feats_nhwc, B, T, G, sampling_locations, scale_weights, o
     return out
 
 
+def msmv_sampling_nhwc_backward(feats_nhwc, B, T, G, sampling_locations, scale_weights, grad_out, grad_feats=None,
+                                grad_layout=OUT_MIX):
+    """Backward of msmv_sampling_nhwc (sbev_msmv_bwd_ex): grad_out in the forward's output layout ->
+    (grad_loc [B',Q,P,3], grad_weights [B',Q,P,L]); grad wrt the features is ACCUMULATED (atomics) into ``grad_feats``
+    (list of fp32 buffers shaped like feats_nhwc) or skipped entirely when it is None (frozen features)."""
+    feats = list(feats_nhwc)
+    _need_device(sampling_locations, scale_weights, grad_out, *feats)
+    if _feat_dtype(feats) != _F32:
+        raise NotImplementedError('the sampling backward needs fp32 feature maps (bf16 storage is an inference format)')
+    N = N_VIEWS
+    Bp = B * T * G
+    Q, P = _check_sampling_args(feats, sampling_locations, scale_weights, Bp, 'msmv_sampling_nhwc_backward')
+    GC = feats[0].shape[-1]
+    C = GC // G
+    L = len(feats)
+    hw = [(f.shape[1], f.shape[2]) for f in feats]
+    gloc = torch.empty_like(sampling_locations)
+    gw = torch.empty_like(scale_weights)
+    lib = _lib.load()
+    c_feats = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    c_gfeats = (ctypes.c_void_p * L)(*[g.data_ptr() for g in grad_feats]) if grad_feats is not None else None
+    c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
+    c_sbo = (ctypes.c_int64 * L)(*[N * h * w * GC for h, w in hw])
+    c_sv = (ctypes.c_int64 * L)(*[h * w * GC for h, w in hw])
+    st = lib.sbev_msmv_bwd_ex(c_feats, c_gfeats, c_hw, L, Bp, N, C, Q, P, G, c_sbo, C, c_sv, GC,
+                              _ptr(sampling_locations.contiguous()), _ptr(scale_weights.contiguous()), _ptr(grad_out.contiguous()),
+                              grad_layout, T, G, _ptr(gloc), _ptr(gw), _stream())
+    _lib.check(st, 'sbev_msmv_bwd_ex')
+    return gloc, gw
+
+
 def msmv_sampling_ring(levels, B, T, G, frame_slots, n_slots, sampling_locations, scale_weights, out_layout=OUT_MIX):
     """Sampler over the online frame ring (cache.FrameFeatureCache): levels[l] = [B*n_slots*6, H, W, G*C]; logical frame
     t of a sample is read from physical slot frame_slots[t] (sbev_msmv_fwd_ring)."""

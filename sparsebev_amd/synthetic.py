@@ -172,3 +172,10 @@ def checksum(tensors):
     if torch.is_tensor(tensors):
         tensors = [tensors]
     return float(sum(t.detach().double().abs().sum().item() for t in tensors))
+
+
+def grad_sample_indices(numel, n=8192, seed=1234):
+    """The fixed subset of a big gradient tensor that fixture G11 keeps (flat indices, seeded); None = all of it."""
+    if numel <= 70000:
+        return None
+    return torch.randperm(numel, generator=torch.Generator().manual_seed(seed + numel % 1000))[:n]

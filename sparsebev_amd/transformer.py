@@ -21,6 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import dense, ops
 from .utils import DUMP, VERSION
 
@@ -71,6 +72,7 @@ class SparseBEVSelfAttention(_Base):
         super().__init__(init_cfg)
         self.pc_range = list(pc_range)
         self.num_heads = num_heads
+        self.attn_drop = float(dropout)      # mmcv MultiheadAttention(embed_dims, num_heads, attn_drop=dropout): active in train() only
         self.attention = _AttentionParams(embed_dims, num_heads)
         self.gen_tau = nn.Linear(embed_dims, num_heads)
 
@@ -176,6 +178,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
                                           num_levels=num_levels, pc_range=pc_range)
         self.mixing = AdaptiveMixing(in_dim=D, in_points=num_points * num_frames, n_groups=N_GROUPS, out_points=OUT_POINTS)
         self.ffn = _FFNParams(D, FFN_CHANNELS)
+        self.ffn_drop = 0.1                  # mmcv FFN(ffn_drop=0.1): active in train() only
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(D), nn.LayerNorm(D), nn.LayerNorm(D)
         cls = []
         for _ in range(num_cls_fcs):
@@ -194,6 +197,53 @@ class SparseBEVTransformerDecoderLayer(_Base):
         self.sampling.init_weights()
         self.mixing.init_weights()
         nn.init.constant_(self.cls_branch[-1].bias, float(-math.log((1 - 0.01) / 0.01)))   # bias_init_with_prob(0.01)
+
+    def forward_train(self, query_bbox, query_feat, feats, attn_mask, ctx, orig_feats=()):
+        """The same layer with every op as a differentiable node (sparsebev_amd.autograd: HIP forward + HIP backward),
+        unfused where a fused inference launch would hide an activation the backward needs.  Dropout (attention
+        probabilities 0.1, the two FFN dropouts 0.1 -- mmcv defaults the reference's layer is built with,
+        models/sparsebev_transformer.py:125,202) is active like in the reference's train() mode; set ``self.self_attn.attn_drop``
+        / ``self.ffn_drop`` to 0 for deterministic gradients."""
+        pe, sa, smp, mix = self.position_encoder, self.self_attn, self.sampling, self.mixing
+        att = sa.attention.attn
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (sa.attn_drop > 0 or self.ffn_drop > 0) else 0
+        pos = AG.Linear3LnRelu.apply(query_bbox, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)
+        x = AG.layer_norm(AG.linear(pos, pe[3].weight, pe[3].bias), pe[4].weight, pe[4].bias, relu=True, add_after=query_feat)
+        # self attention (+ identity), norm1
+        D, H = self.embed_dims, sa.num_heads
+        pad = (-(3 * D + H)) % 4
+        in_w = torch.cat([att.in_proj_weight, sa.gen_tau.weight] + ([att.in_proj_weight.new_zeros(pad, D)] if pad else []), 0)
+        in_b = torch.cat([att.in_proj_bias, sa.gen_tau.bias] + ([att.in_proj_bias.new_zeros(pad)] if pad else []), 0)
+        qkvt = AG.linear(x, in_w, in_b)
+        mask = attn_mask.to(device=x.device, dtype=torch.uint8).contiguous() if attn_mask is not None else None
+        a = AG.SasaCore.apply(qkvt, query_bbox, mask, tuple(sa.pc_range), H, sa.attn_drop, seed)
+        x = AG.layer_norm(AG.linear(a, att.out_proj.weight, att.out_proj.bias, residual=x), self.norm1.weight, self.norm1.bias)
+        # adaptive spatio-temporal sampling
+        both = AG.linear(x, torch.cat([smp.sampling_offset.weight, smp.scale_weights.weight], 0),
+                         torch.cat([smp.sampling_offset.bias, smp.scale_weights.bias], 0))
+        cfg = (smp.num_frames, smp.num_groups, smp.num_points, smp.num_levels, tuple(smp.pc_range))
+        sampled = AG.Sampling.apply(query_bbox, both, feats, ctx, cfg, *orig_feats)
+        # adaptive mixing (+ identity), norm2
+        x = AG.layer_norm(AG.AdaptiveMixing.apply(sampled, x, mix.parameter_generator.weight, mix.parameter_generator.bias,
+                                                  mix.out_proj.weight, mix.out_proj.bias, mix.out_points),
+                          self.norm2.weight, self.norm2.bias)
+        # FFN (+ identity), norm3
+        f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]
+        h = AG.dropout(AG.linear(x, f0.weight, f0.bias, relu=True), self.ffn_drop, seed + 1)
+        if self.ffn_drop > 0:
+            # the torch add below is the `identity +` of mmcv's FFN around a dropped-out branch (autograd plumbing)
+            x = AG.layer_norm(x + AG.dropout(AG.linear(h, f1.weight, f1.bias), self.ffn_drop, seed + 2), self.norm3.weight, self.norm3.bias)
+        else:
+            x = AG.layer_norm(AG.linear(h, f1.weight, f1.bias, residual=x), self.norm3.weight, self.norm3.bias)
+        cb, rb = self.cls_branch, self.reg_branch
+        c = AG.layer_norm(AG.linear(x, cb[0].weight, cb[0].bias), cb[1].weight, cb[1].bias, relu=True)
+        c = AG.layer_norm(AG.linear(c, cb[3].weight, cb[3].bias), cb[4].weight, cb[4].bias, relu=True)
+        cls_score = AG.linear(c, cb[6].weight, cb[6].bias)
+        r = AG.linear(x, rb[0].weight, rb[0].bias, relu=True)
+        r = AG.linear(r, rb[2].weight, rb[2].bias, relu=True)
+        reg = AG.linear(r, rb[4].weight, rb[4].bias)
+        bbox_pred = AG.RefineBbox.apply(query_bbox, reg, ctx.vel_div)
+        return x, cls_score, bbox_pred
 
     def forward(self, query_bbox, query_feat, feats, attn_mask, ctx):
         pe = self.position_encoder
@@ -259,6 +309,24 @@ class FeaturePyramid:
 
     def sample(self, loc, w_bp, T, G):
         return ops.msmv_sampling_nhwc(self.levels, self.B, T, G, loc, w_bp, out_layout=ops.OUT_MIX)
+
+    # -- training: gradient wrt the feature maps ---------------------------------------------------------------------------
+    # One zero-initialised channels-last buffer per level, shared by the sampler backward of ALL decoder layers of a call
+    # (they accumulate into it with atomics) and handed to autograd once, as a permuted view in the caller's [B,TN,C,H,W]
+    # axis order: six per-layer 735 MB gradient tensors and their summation never exist.
+    def grad_buffers(self):
+        if getattr(self, '_grads', None) is None:
+            self._grads = [torch.zeros_like(l, dtype=torch.float32) for l in self.levels]
+        return self._grads
+
+    def take_feature_grads(self):
+        TN = self.T * N_VIEWS
+        g = [b.view(self.B, TN, b.shape[1], b.shape[2], self.GC).permute(0, 1, 4, 2, 3) for b in self._grads]
+        self._grads = None
+        return g
+
+    def sample_backward(self, loc, w_bp, gout, T, G, grad_levels):
+        return ops.msmv_sampling_nhwc_backward(self.levels, self.B, T, G, loc, w_bp, gout, grad_levels, grad_layout=ops.OUT_MIX)
 
 
 class _PinnedUpload:
@@ -351,11 +419,43 @@ class SparseBEVTransformerDecoder(_Base):
         feats = mlvl_feats if hasattr(mlvl_feats, 'levels') else FeaturePyramid(mlvl_feats)   # FeaturePyramid / cache.RingPyramid pass through
         query_bbox = query_bbox.float().contiguous()
         query_feat = query_feat.float().contiguous()
+        if torch.is_grad_enabled() and (query_bbox.requires_grad or query_feat.requires_grad or any(p.requires_grad for p in self.parameters())
+                                        or any(torch.is_tensor(f) and f.requires_grad for f in (mlvl_feats if isinstance(mlvl_feats, (list, tuple)) else ()))):
+            return self.forward_differentiable(query_bbox, query_feat, mlvl_feats, feats, attn_mask, ctx)
         if not (layerwise or DUMP.enabled):
             if self._runtime is None or self._runtime.gemm_mode != self.gemm_mode or self._runtime.overlap != self.overlap:
                 from .runtime import DecoderRuntime
                 self._runtime = DecoderRuntime(self, self.gemm_mode, self.overlap)
             return self._runtime.forward(query_bbox, query_feat, feats, ctx, attn_mask)
+        cls_scores, bbox_preds = [], []
+        with torch.no_grad():
+            return self._forward_layerwise(query_bbox, query_feat, feats, attn_mask, ctx)
+
+    def forward_differentiable(self, query_bbox, query_feat, mlvl_feats, feats, attn_mask, ctx):
+        """Training / fine-tuning path (grad enabled and something requires grad): every op a HIP forward + HIP backward
+        node; dropout only in train() mode.  Mirrors models/sparsebev_transformer.py:86-101 including the detach of the
+        refined boxes between layers (:93)."""
+        if hasattr(feats, 'frame_slots'):
+            raise NotImplementedError('the online frame ring is an inference cache; train on [B, T*6, C, H, W] feature lists')
+        if feats.levels[0].dtype != torch.float32:
+            raise NotImplementedError('training needs fp32 feature maps (bf16 storage is an inference format)')
+        orig = [f for f in mlvl_feats if torch.is_tensor(f)] if isinstance(mlvl_feats, (list, tuple)) else []
+        layer = self.decoder_layer
+        saved = (layer.self_attn.attn_drop, layer.ffn_drop)
+        if not self.training:
+            layer.self_attn.attn_drop, layer.ffn_drop = 0.0, 0.0
+        try:
+            cls_scores, bbox_preds = [], []
+            for i in range(self.num_layers):
+                query_feat, cls_score, bbox_pred = layer.forward_train(query_bbox, query_feat, feats, attn_mask, ctx, orig)
+                query_bbox = bbox_pred.detach()
+                cls_scores.append(cls_score)
+                bbox_preds.append(bbox_pred)
+        finally:
+            layer.self_attn.attn_drop, layer.ffn_drop = saved
+        return torch.stack(cls_scores), torch.stack(bbox_preds)
+
+    def _forward_layerwise(self, query_bbox, query_feat, feats, attn_mask, ctx):
         cls_scores, bbox_preds = [], []
         for i in range(self.num_layers):
             DUMP.stage_count = i
@@ -384,10 +484,9 @@ class SparseBEVTransformer(_Base):
         self.decoder.init_weights()
 
     def forward(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=False):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError('sparsebev_amd implements the inference forward of the decoder; the backward '
-                                      '(SURVEY.md section 8f) is not built yet -- call in eval() under torch.no_grad()')
+        """Differentiable like the reference's module: with grad enabled and any input / parameter requiring grad the decoder
+        runs its autograd path (HIP forward + HIP backward kernels, sparsebev_amd/autograd.py); otherwise the fused inference
+        runtime.  train() additionally switches the dropouts on (mmcv's attn_drop / ffn_drop = 0.1)."""
         VERSION.require_supported()
-        with torch.no_grad():
-            cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=layerwise)
-            return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)
+        cls_scores, bbox_preds = self.decoder(query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, layerwise=layerwise)
+        return torch.nan_to_num(cls_scores), torch.nan_to_num(bbox_preds)

@@ -38,3 +38,12 @@ def golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode_by_default():
+    """The parity tests exercise the inference path (the reference's val.py / timing.py run under no_grad); with grad
+    enabled the drop-in module takes its differentiable path, exactly like the reference's nn.Module.  Training tests
+    switch grad back on with ``torch.enable_grad()``."""
+    with torch.no_grad():
+        yield

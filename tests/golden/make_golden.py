@@ -310,12 +310,71 @@ def main_version():
     save('g10_sample_points_versions', query_bbox=bbox, offset=offset, pts_v1=out['v1.0.0'], pts_v017=out['v0.17.1'])
 
 
+
+sample_indices = S.grad_sample_indices
+
+
+def main_train():
+    """G11: gradients of the REFERENCE decoder (its own modules, autograd, activation checkpoints -- models/
+    sparsebev_transformer.py:231-234,313-317,383-387) in train() mode with the mmcv dropouts set to 0 (RNG streams cannot
+    be matched), for random cotangents on (cls_scores, bbox_preds): d/d query_feat, query_bbox, all 48 parameters and the
+    feature maps.  Big gradients are stored as a seeded subsample + norm + sum.  `python tests/golden/make_golden.py train`."""
+    import copy
+    tr, smp, wrap, utils = import_reference()
+    assert wrap.MSMV_CUDA is False
+    for tag, n_layers, B, Q, T, L, pyr in (('L2', 2, 2, 36, 2, 4, 'tiny'), ('L6', 6, 1, 36, 2, 4, 'tiny')):
+        params = S.make_params(11, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+        m = tr.SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=n_layers, num_levels=L, num_classes=10,
+                                    code_size=10, pc_range=S.PC_RANGE)
+        m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+        m.train()
+        layer = m.decoder.decoder_layer
+        layer.self_attn.attention.attn.dropout = 0.0
+        for mod in layer.ffn.modules():
+            if isinstance(mod, nn.Dropout):
+                mod.p = 0.0
+        ih, iw, sizes = S.PYRAMIDS[pyr]
+        metas = S.make_img_metas(B, T, ih, iw)
+        for b, mm in enumerate(metas):
+            mm['img_timestamp'] = [ts + 0.003 * ((i * 7 + b) % 6) for i, ts in enumerate(mm['img_timestamp'])]
+        bbox, feat = S.make_queries(B, Q, seed=111)
+        feats = S.make_features(B, T, sizes, seed=112)
+        g = torch.Generator().manual_seed(113)
+        cot_cls = torch.randn(n_layers, B, Q, 10, generator=g)
+        cot_box = torch.randn(n_layers, B, Q, 10, generator=g)
+        bbox_g, feat_g = bbox.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        feats_g = [f.clone().requires_grad_(True) for f in feats]
+        with torch.enable_grad():
+            cls, box = m(bbox_g, feat_g, list(feats_g), None, copy.deepcopy(metas))
+            loss = (cls * cot_cls).sum() + (box * cot_box).sum()
+            loss.backward()
+        arrays = dict(query_bbox=bbox, query_feat=feat, cot_cls=cot_cls, cot_box=cot_box, out_cls=cls, out_bbox=box,
+                      grad_query_bbox=bbox_g.grad, grad_query_feat=feat_g.grad,
+                      cfg=np.array([B, Q, T, L, n_layers]), pyramid=np.array(pyr), seeds=np.array([11, 111, 112, 113]),
+                      timestamps=np.array([mm['img_timestamp'] for mm in metas]),
+                      params_checksum=S.checksum(params), feats_checksum=S.checksum(feats))
+        named = [(k[len(PREFIX):], p.grad) for k, p in m.named_parameters()] + [('feat%d' % i, f.grad) for i, f in enumerate(feats_g)]
+        for name, gr in named:
+            assert gr is not None, name
+            idx = sample_indices(gr.numel())
+            key = 'g.' + name
+            arrays[key + '.norm'] = gr.double().norm().float()
+            arrays[key + '.sum'] = gr.double().sum().float()
+            arrays[key] = gr if idx is None else gr.reshape(-1)[idx]
+        print('  G11 %s: loss %.4f, |g query_feat| %.3e, |g pg_w| %.3e, |g feat0| %.3e' % (
+            tag, float(loss), float(feat_g.grad.norm()), float(dict(named)['mixing.parameter_generator.weight'].norm()), float(feats_g[0].grad.norm())))
+        save('g11_train_' + tag, **arrays)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'head':
         main_head()
     elif len(sys.argv) > 1 and sys.argv[1] == 'version':
         main_version()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'train':
+        main_train()
     else:
         main()
         main_head()
         main_version()
+        main_train()

@@ -1,0 +1,369 @@
+"""GPU parity of the decoder's BACKWARD kernels: every autograd.Function of
+sparsebev_amd.autograd against torch autograd in fp64 on the CPU for the same op, the whole drop-in module against
+fixture G11 = the REFERENCE decoder's own autograd gradients (tests/golden/make_golden.py::main_train), and the
+training-mode dropouts against a host re-statement of their counter-based masks."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from sparsebev_amd import _lib, autograd as AG, synthetic as S
+from sparsebev_amd.transformer import SparseBEVTransformer, FeaturePyramid, DecoderContext
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+PREFIX = 'decoder.decoder_layer.'
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize('M,N,K', [(900, 256, 256), (900, 256, 32768), (256, 32768, 900), (32768, 256, 900), (900, 32768, 256),
+                                   (37, 10, 256), (256, 3, 72), (130, 129, 33), (1, 5, 7), (3600, 256, 8192)])
+def test_gemm_any_all_layouts_vs_fp64(M, N, K):
+    """sbev_gemm_f32 for the four operand layouts, ragged M / N / K (zero-filled tiles), the element-wise staging path
+    (ld % 4 != 0) and the split-K plan (few tiles, long K)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    for ak in (False, True):
+        for bk in (False, True):
+            A = torch.randn((K, M) if ak else (M, K), generator=g)
+            Bm = torch.randn((K, N) if bk else (N, K), generator=g) / K ** 0.5
+            ref = (A.double().t() if ak else A.double()) @ (Bm.double() if bk else Bm.double().t())
+            out = AG.gemm(A.to(DEV), ak, A.shape[1], Bm.to(DEV), bk, Bm.shape[1], M, N, K)
+            assert (out.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item()), (ak, bk)
+    # accumulate into a strided destination
+    A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / K ** 0.5
+    C0 = torch.randn(M, N + 3, generator=g)
+    out = C0.to(DEV)
+    AG.gemm(A.to(DEV), False, K, Bm.to(DEV), True, N, M, N, K, out=out, ldc=N + 3, accumulate=True)
+    ref = C0.double()
+    ref[:, :N] += A.double() @ Bm.double()
+    assert (out.cpu().double() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@torch.enable_grad()
+@pytest.mark.parametrize('M,N,K,relu,res', [(900, 256, 256, True, False), (900, 256, 512, False, True), (37, 10, 256, False, False),
+                                             (900, 776, 256, False, False), (64, 32768, 256, False, False), (64, 256, 32768, False, True)])
+def test_linear_function_vs_torch(M, N, K, relu, res):
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    gy = torch.randn(M, N, generator=g)
+    dv = [t.to(DEV).requires_grad_(True) for t in (x, w, b)] + ([r.to(DEV).requires_grad_(True)] if res else [None])
+    y = AG.linear(dv[0], dv[1], dv[2], relu=relu, residual=dv[3])
+    y.backward(gy.to(DEV))
+    cv = [t.double().requires_grad_(True) for t in (x, w, b)] + ([r.double().requires_grad_(True)] if res else [None])
+    yc = F.linear(cv[0], cv[1], cv[2])
+    yc = yc.relu() if relu else yc
+    yc = yc + cv[3] if res else yc
+    yc.backward(gy.double())
+    assert rel(y, yc) < 1e-5
+    for d, c in zip(dv, cv):
+        if d is not None:
+            assert rel(d.grad, c.grad) < 2e-5
+
+
+@torch.enable_grad()
+@pytest.mark.parametrize('M,N,relu,add', [(900, 256, False, False), (900, 256, True, True), (37, 512, True, False), (3600, 256, False, True)])
+def test_layer_norm_function_vs_torch(M, N, relu, add):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g) * 2 + 0.3
+    w, b = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    a = torch.randn(M, N, generator=g) if add else None
+    gy = torch.randn(M, N, generator=g)
+    dv = [t.to(DEV).requires_grad_(True) for t in (x, w, b)] + ([a.to(DEV).requires_grad_(True)] if add else [None])
+    y = AG.layer_norm(dv[0], dv[1], dv[2], relu=relu, add_after=dv[3])
+    y.backward(gy.to(DEV))
+    cv = [t.double().requires_grad_(True) for t in (x, w, b)] + ([a.double().requires_grad_(True)] if add else [None])
+    yc = F.layer_norm(cv[0], [N], cv[1], cv[2])
+    yc = yc.relu() if relu else yc
+    yc = yc + cv[3] if add else yc
+    yc.backward(gy.double())
+    for d, c in zip(dv, cv):
+        if d is not None:
+            assert rel(d.grad, c.grad) < 2e-5
+
+
+@torch.enable_grad()
+def test_position_encoder_first_stage_function_vs_torch():
+    g = torch.Generator().manual_seed(5)
+    B, Q, D = 2, 450, 256
+    bbox = torch.rand(B, Q, 10, generator=g)
+    w, b = torch.randn(D, 3, generator=g), torch.randn(D, generator=g)
+    lw, lb = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    gy = torch.randn(B, Q, D, generator=g)
+    dv = [t.to(DEV).requires_grad_(True) for t in (bbox, w, b, lw, lb)]
+    y = AG.Linear3LnRelu.apply(*dv)
+    y.backward(gy.to(DEV))
+    cv = [t.double().requires_grad_(True) for t in (bbox, w, b, lw, lb)]
+    yc = F.layer_norm(F.linear(cv[0][..., :3], cv[1], cv[2]), [D], cv[3], cv[4]).relu()
+    yc.backward(gy.double())
+    assert rel(y, yc) < 1e-5
+    for d, c in zip(dv, cv):
+        assert rel(d.grad, c.grad) < 2e-5
+    assert dv[0].grad[..., 3:].abs().max() == 0
+
+
+def _mix32(z):
+    z = (z + np.uint64(0x9e3779b97f4a7c15))
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+    return ((z ^ (z >> np.uint64(31))) >> np.uint64(32)).astype(np.uint32)
+
+
+def _keep_mask(seed, p, shape_bhqq):
+    """Host re-statement of the kernels' counter-based dropout: keep(i) = mix32(seed * 0x100000001b3 + i) >= p * 2^32."""
+    n = int(np.prod(shape_bhqq))
+    with np.errstate(over='ignore'):
+        idx = np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x100000001b3)
+        keep = _mix32(idx) >= np.uint32(int(float(np.float32(p)) * 4294967296.0))
+    return torch.from_numpy(keep.reshape(shape_bhqq))
+
+
+def _sasa_ref(qkvt, bbox, mask, H, keep=None, p=0.0):
+    """fp64 dense restatement of the attention core on the packed q | k | v | tau rows."""
+    B, Q, _ = qkvt.shape
+    D = H * 32
+    q, k, v, tau = qkvt[..., :D], qkvt[..., D:2 * D], qkvt[..., 2 * D:3 * D], qkvt[..., 3 * D:3 * D + H]
+    q = q.reshape(B, Q, H, 32).transpose(1, 2) / 32 ** 0.5
+    k = k.reshape(B, Q, H, 32).transpose(1, 2)
+    v = v.reshape(B, Q, H, 32).transpose(1, 2)
+    lo = torch.tensor(S.PC_RANGE[:2], dtype=torch.float32)
+    span = torch.tensor([S.PC_RANGE[3] - S.PC_RANGE[0], S.PC_RANGE[4] - S.PC_RANGE[1]], dtype=torch.float32)
+    c = (bbox[..., :2] * span + lo).double()
+    dist = (c[:, :, None] - c[:, None]).norm(dim=-1)                        # [B,Q,Q]
+    s = q @ k.transpose(-1, -2) - dist[:, None] * tau.transpose(1, 2)[..., None]
+    if mask is not None:
+        s = s.masked_fill(mask[None, None], float('-inf'))
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep.double() / (1 - p)
+    return (pr @ v).transpose(1, 2).reshape(B, Q, D)
+
+
+@torch.enable_grad()
+@pytest.mark.parametrize('Q,use_mask,p', [(100, False, 0.0), (37, True, 0.0), (130, False, 0.1), (64, True, 0.25)])
+def test_sasa_core_function_vs_fp64(Q, use_mask, p):
+    g = torch.Generator().manual_seed(Q)
+    B, H = 2, 8
+    D = H * 32
+    qkvt = torch.randn(B, Q, 3 * D + H, generator=g) * 0.7
+    qkvt[..., 3 * D:] = torch.rand(B, Q, H, generator=g) * 0.2
+    bbox, _ = S.make_queries(B, 36, seed=Q)
+    bbox = bbox[:, :1].expand(B, Q, 10).clone()
+    bbox[..., :2] = torch.rand(B, Q, 2, generator=g)
+    mask = None
+    if use_mask:
+        mask = torch.zeros(Q, Q, dtype=torch.bool)
+        mask[:10, 10:] = True
+        mask[10:, :4] = True
+    gy = torch.randn(B, Q, D, generator=g)
+    seed = 987654321
+    keep = _keep_mask(seed, p, (B, H, Q, Q)) if p > 0 else None
+    qd = qkvt.to(DEV).requires_grad_(True)
+    md = mask.to(DEV).to(torch.uint8) if use_mask else None
+    y = AG.SasaCore.apply(qd, bbox.to(DEV), md, tuple(S.PC_RANGE), H, p, seed)
+    y.backward(gy.to(DEV))
+    qc = qkvt.double().requires_grad_(True)
+    yc = _sasa_ref(qc, bbox, mask, H, keep, p)
+    yc.backward(gy.double())
+    assert rel(y, yc) < 2e-5
+    assert rel(qd.grad, qc.grad) < 5e-5
+    if p > 0:                                            # the mask really drops ~p of the probabilities
+        assert abs(1 - keep.float().mean().item() - p) < 0.02
+
+
+@torch.enable_grad()
+@pytest.mark.parametrize('T', [2, 8])
+def test_adaptive_mixing_function_vs_oracle_autograd(T):
+    from oracle import sparsebev_oracle as O
+    g = torch.Generator().manual_seed(T)
+    B, Q, G, P, C = 1, 20, 4, 4, 64
+    params = S.make_params(31, embed_dims=256, num_frames=T, num_points=P, num_levels=4)
+    names = ['mixing.parameter_generator.weight', 'mixing.parameter_generator.bias', 'mixing.out_proj.weight', 'mixing.out_proj.bias']
+    x = torch.randn(B, Q, G, T * P, C, generator=g)
+    query = torch.randn(B, Q, 256, generator=g)
+    gy = torch.randn(B, Q, 256, generator=g)
+    dv = [t.to(DEV).requires_grad_(True) for t in [x, query] + [params[n] for n in names]]
+    y = AG.AdaptiveMixing.apply(*dv, 128)
+    y.backward(gy.to(DEV))
+    pc = {n: params[n].double().requires_grad_(True) for n in names}
+    xc, qc = x.double().requires_grad_(True), query.double().requires_grad_(True)
+    yc = O.adaptive_mixing(pc, xc, qc)
+    yc.backward(gy.double())
+    assert rel(y, yc) < 2e-5
+    for d, c in zip(dv, [xc, qc] + [pc[n] for n in names]):
+        assert rel(d.grad, c.grad) < 1e-4, (d.shape, rel(d.grad, c.grad))
+
+
+@torch.enable_grad()
+@pytest.mark.parametrize('T,L,pyr', [(2, 4, 'tiny'), (4, 5, 'tiny5')])
+def test_sampling_function_vs_oracle_autograd(T, L, pyr):
+    """sample points -> projection / view select -> gather, differentiated: grads wrt the box (centre, dims, yaw), the packed
+    offsets | level logits and the feature maps vs the oracle's torch ops under autograd (fp32 on the CPU)."""
+    from oracle import sparsebev_oracle as O
+    B, Q, G, P = 2, 36, 4, 4
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    g = torch.Generator().manual_seed(T * 10 + L)
+    bbox, _ = S.make_queries(B, Q, seed=7)
+    both = torch.randn(B, Q, G * P * (3 + L), generator=g) * 0.5
+    feats = S.make_features(B, T, sizes, seed=8)
+    metas = S.make_img_metas(B, T, ih, iw)
+    gy = torch.randn(B, Q, G, T * P, 64, generator=g)
+    dev_feats = [f.to(DEV).requires_grad_(True) for f in feats]
+    pyrd, ctx = FeaturePyramid(dev_feats), DecoderContext(metas, B, torch.device(DEV))
+    bd, sd = bbox.to(DEV).requires_grad_(True), both.to(DEV).requires_grad_(True)
+    out = AG.Sampling.apply(bd, sd, pyrd, ctx, (T, G, P, L, tuple(S.PC_RANGE)), *dev_feats)
+    out.backward(gy.to(DEV))
+    # oracle: the same chain in torch (grid_sample sampler = the reference's native path), autograd
+    bc, sc = bbox.clone().requires_grad_(True), both.clone().requires_grad_(True)
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    td = O.time_diff_from_metas(metas, B)
+    l2i = torch.from_numpy(np.asarray([m['lidar2img'] for m in metas]).astype(np.float32))
+    n_off = G * P * 3
+    off = sc[..., :n_off].reshape(B, Q, G * P, 3)
+    pts = O.make_sample_points(bc, off, S.PC_RANGE).reshape(B, Q, 1, G, P, 3).expand(B, Q, T, G, P, 3)
+    dist = (bc[..., 8:].detach()[:, :, None, :] * td[:, None, :, None])[:, :, :, None, None, :]
+    pts = torch.cat([pts[..., 0:2] - dist, pts[..., 2:3]], dim=-1)
+    sw = torch.softmax(sc[..., n_off:].reshape(B, Q, G, 1, P, L), -1).expand(B, Q, G, T, P, L)
+    fr = O.regroup_features(fc, channel_last=False)
+    ref, _ = O.sampling_4d(pts, fr, sw, l2i, ih, iw, O.msmv_sampling_gridsample)
+    ref.backward(gy)
+    assert rel(out, ref) < 1e-4
+    assert rel(bd.grad, bc.grad) < 2e-4 and bd.grad[..., 8:].abs().max() == 0
+    assert rel(sd.grad, sc.grad) < 2e-4
+    for d, c in zip(dev_feats, fc):
+        assert d.grad.shape == c.grad.shape and rel(d.grad, c.grad) < 2e-4
+
+
+@torch.enable_grad()
+def test_refine_bbox_function_vs_torch():
+    from oracle import sparsebev_oracle as O
+    g = torch.Generator().manual_seed(3)
+    B, Q = 2, 50
+    bbox = torch.rand(B, Q, 10, generator=g)
+    bbox[0, 0, 0], bbox[0, 1, 1] = 0.0, 1.0                   # clamp edges of inverse_sigmoid
+    reg = torch.randn(B, Q, 10, generator=g)
+    vd = torch.tensor([0.5, 1.0])
+    gy = torch.randn(B, Q, 10, generator=g)
+    bd, rd = bbox.to(DEV).requires_grad_(True), reg.to(DEV).requires_grad_(True)
+    y = AG.RefineBbox.apply(bd, rd, vd.to(DEV))
+    y.backward(gy.to(DEV))
+    bc, rc = bbox.double().requires_grad_(True), reg.double().requires_grad_(True)
+    xyz = torch.sigmoid(rc[..., :3] + O.inverse_sigmoid(bc[..., :3]))
+    yc = torch.cat([xyz, rc[..., 3:8], rc[..., 8:] / vd.double()[:, None, None]], -1)
+    yc.backward(gy.double())
+    assert rel(y, yc) < 1e-5 and rel(rd.grad, rc.grad) < 1e-5
+    inner = (bbox[..., :3] > 1e-4) & (bbox[..., :3] < 1 - 1e-4)
+    assert ((bd.grad[..., :3].cpu().double() - bc.grad[..., :3]).abs()[inner]).max() < 1e-4 * bc.grad.abs().max()
+
+
+def build(T, L, seed, num_layers):
+    params = S.make_params(seed, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=num_layers, num_levels=L, num_classes=10,
+                             code_size=10, pc_range=S.PC_RANGE)
+    m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+    return m.to(DEV)
+
+
+def _g11_run(tag):
+    sample_indices = S.grad_sample_indices
+    g = load_golden('g11_train_' + tag)
+    B, Q, T, L, n_layers = [int(v) for v in g['cfg']]
+    seeds = [int(v) for v in g['seeds']]
+    ih, iw, sizes = S.PYRAMIDS[str(g['pyramid'])]
+    model = build(T, L, seeds[0], n_layers).train()
+    model.decoder.decoder_layer.self_attn.attn_drop = 0.0          # the fixture was recorded with the mmcv dropouts at 0
+    model.decoder.decoder_layer.ffn_drop = 0.0
+    feats = [f.to(DEV).requires_grad_(True) for f in S.make_features(B, T, sizes, seed=seeds[2])]
+    metas = S.make_img_metas(B, T, ih, iw)
+    for b, m in enumerate(metas):
+        m['img_timestamp'] = [float(v) for v in g['timestamps'][b]]
+    bbox, feat = g['query_bbox'].to(DEV).requires_grad_(True), g['query_feat'].to(DEV).requires_grad_(True)
+    cls, box = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert cls.requires_grad and box.requires_grad
+    ((cls * g['cot_cls'].to(DEV)).sum() + (box * g['cot_box'].to(DEV)).sum()).backward()
+    got = {'query_bbox': bbox.grad, 'query_feat': feat.grad}
+    errs = {'out_cls': rel(cls, g['out_cls']), 'out_bbox': rel(box, g['out_bbox']),
+            'grad_query_bbox': rel(bbox.grad, g['grad_query_bbox']), 'grad_query_feat': rel(feat.grad, g['grad_query_feat'])}
+    named = [(k[len(PREFIX):], p.grad) for k, p in model.named_parameters()] + [('feat%d' % i, f.grad) for i, f in enumerate(feats)]
+    assert len(named) == 48 + L
+    for name, gr in named:
+        assert gr is not None, name
+        want = g['g.' + name]
+        idx = sample_indices(gr.numel())
+        have = gr.reshape(want.shape) if idx is None else gr.reshape(-1)[idx.to(DEV)]
+        errs[name] = rel(have, want)
+        errs[name + '.norm'] = abs(gr.double().norm().item() - float(g['g.' + name + '.norm'])) / max(float(g['g.' + name + '.norm']), 1e-12)
+    return errs, got
+
+
+@torch.enable_grad()
+def test_g11_two_layer_train_mode_gradients_match_the_reference_autograd():
+    """model.train() forward + backward of the drop-in module (2 layers, B = 2, T = 2) against the reference's own modules
+    differentiated by torch autograd: outputs, d/d query_feat, d/d query_bbox, all 48 parameters and the feature maps, to
+    1e-4 relative (max-abs error over max-abs value per tensor)."""
+    errs, got = _g11_run('L2')
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst[1] < 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    assert got['query_bbox'][..., 8:].abs().max() == 0          # velocity is detached (:288) and refine reads reg only
+
+
+@torch.enable_grad()
+def test_g11_six_layer_gradients_stay_close_to_the_reference():
+    """Six free-running layers: fp32 rounding noise grows ~5x per random-init layer between ANY two implementations (DESIGN
+    section 2), so the 6-layer gradients are bounded loosely; the strict check is the two-layer fixture above."""
+    errs, _ = _g11_run('L6')
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst[1] < 5e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+
+
+@torch.enable_grad()
+def test_eval_mode_with_grad_is_differentiable_and_matches_the_inference_runtime():
+    """Grad enabled + something requires grad -> the module is differentiable like the reference's (no silent detached
+    outputs); its forward values equal the fused inference runtime's to rounding; under no_grad the runtime runs."""
+    B, Q, T, L = 1, 36, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 5, 2).eval()
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=6)]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=7)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    cls, box = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert cls.grad_fn is not None
+    with torch.no_grad():
+        cls_i, box_i = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert cls_i.grad_fn is None
+    assert (cls - cls_i).abs().max() < 1e-4 and (box - box_i).abs().max() < 1e-4
+    cls.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@torch.enable_grad()
+def test_train_mode_dropout_is_active_seeded_and_unbiased():
+    B, Q, T, L = 1, 64, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 9, 1).train()
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=10)]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=11)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    torch.manual_seed(1)
+    a = model(bbox, feat, list(feats), None, copy.deepcopy(metas))[0]
+    torch.manual_seed(1)
+    b = model(bbox, feat, list(feats), None, copy.deepcopy(metas))[0]
+    c = model(bbox, feat, list(feats), None, copy.deepcopy(metas))[0]
+    assert torch.equal(a, b)                                   # same torch seed -> same masks
+    assert not torch.equal(a, c)                               # dropout is on in train()
+    model.eval()
+    d = model(bbox, feat, list(feats), None, copy.deepcopy(metas))[0]
+    assert (a - d).abs().max() > 1e-4 and (a - d).abs().mean() < 0.5
+    # the elementwise dropout kernel: keep rate and scaling
+    x = torch.ones(1 << 20, device=DEV)
+    y = AG.dropout(x, 0.1, 42)
+    assert abs((y == 0).float().mean().item() - 0.1) < 5e-3 and abs(y.mean().item() - 1.0) < 1e-2
+    assert torch.equal(y, AG.dropout(x, 0.1, 42)) and not torch.equal(y, AG.dropout(x, 0.1, 43))

@@ -191,6 +191,7 @@ def test_int64_offsets_beyond_2g_elements():
 
 
 @pytest.mark.parametrize('tag', ['L4_C8', 'L5_C64'])
+@torch.enable_grad()
 def test_g8_msmv_backward_vs_reference_autograd(tag):
     """grads of the HIP op vs the reference's native-PyTorch sampler differentiated by autograd."""
     g = load_golden('g8_msmv_bwd_' + tag)
@@ -206,6 +207,7 @@ def test_g8_msmv_backward_vs_reference_autograd(tag):
     assert loc.grad[..., 2].abs().max() == 0            # like the reference op: no gradient for the view index
 
 
+@torch.enable_grad()
 def test_msmv_backward_full_size_vs_oracle_sample():
     """Config-2-sized backward (115 200 points): spot-check against the torch oracle on one sample batch entry."""
     from oracle import sparsebev_oracle as O
@@ -223,6 +225,7 @@ def test_msmv_backward_full_size_vs_oracle_sample():
 
 
 @pytest.mark.parametrize('P,L,C', [(6, 4, 64), (1, 5, 64), (9, 2, 64), (5, 3, 24)])
+@torch.enable_grad()
 def test_msmv_backward_point_tails_and_both_kernels_vs_oracle(P, L, C):
     """Backward with point counts that are not multiples of the 4-point chunk (C = 64 fast kernel) and a channel count
     that takes the generic kernel; coordinates include out-of-map taps and exact grid points."""

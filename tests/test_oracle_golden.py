@@ -217,3 +217,35 @@ def test_g10_sample_points_both_box_conventions():
             assert (got - g[key]).abs().max() < 1e-5, name
     finally:
         O.VERSION_NAME = 'v1.0.0'
+
+
+@pytest.mark.parametrize('tag,tol', [('L2', 2e-4), ('L6', 5e-2)])
+def test_g11_oracle_autograd_matches_the_reference_gradients(tag, tol):
+    """The oracle is built from differentiable torch ops; its autograd gradients must reproduce fixture G11 = the reference
+    decoder's own train()-mode gradients (mmcv dropouts at 0).  This pins the oracle as the gradient checker the GPU
+    backward tests use (tests/test_gpu_backward.py)."""
+    from sparsebev_amd import synthetic as S
+    g = load_golden('g11_train_' + tag)
+    B, Q, T, L, n_layers = [int(v) for v in g['cfg']]
+    seeds = [int(v) for v in g['seeds']]
+    ih, iw, sizes = S.PYRAMIDS[str(g['pyramid'])]
+    params = {k: v.clone().requires_grad_(True) for k, v in S.make_params(seeds[0], embed_dims=256, num_frames=T, num_points=4, num_levels=L).items()}
+    feats = [f.requires_grad_(True) for f in S.make_features(B, T, sizes, seed=seeds[2])]
+    metas = S.make_img_metas(B, T, ih, iw)
+    for b, m in enumerate(metas):
+        m['img_timestamp'] = [float(v) for v in g['timestamps'][b]]
+    bbox, feat = g['query_bbox'].clone().requires_grad_(True), g['query_feat'].clone().requires_grad_(True)
+    with torch.enable_grad():
+        cls, box, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=n_layers)
+        ((cls * g['cot_cls']).sum() + (box * g['cot_box']).sum()).backward()
+
+    def rel(a, b):
+        return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12)).item()
+
+    errs = {'query_feat': rel(feat.grad, g['grad_query_feat']), 'query_bbox': rel(bbox.grad, g['grad_query_bbox'])}
+    for name, gr in list((k, v.grad) for k, v in params.items()) + [('feat%d' % i, f.grad) for i, f in enumerate(feats)]:
+        idx = S.grad_sample_indices(gr.numel())
+        have = gr.reshape(g['g.' + name].shape) if idx is None else gr.reshape(-1)[idx]
+        errs[name] = rel(have, g['g.' + name])
+    assert max(errs.values()) < tol, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    assert bbox.grad[..., 8:].abs().max() == 0

@@ -54,14 +54,14 @@ def test_zero_time_diff_is_replaced_by_one():
     assert float(ctx.vel_div[0]) == 1.0
 
 
-def test_product_refuses_cpu_features_and_training():
+def test_product_refuses_cpu_features_in_eval_and_in_training():
     m = SparseBEVTransformer(256, num_frames=1, pc_range=S.PC_RANGE).eval()
     feats = S.make_features(1, 1, S.PYRAMIDS['tiny'][2])
     with pytest.raises(RuntimeError, match='no CPU path'):
         FeaturePyramid(feats)
     bbox, feat = S.make_queries(1, 4)
     m.train()
-    with pytest.raises(NotImplementedError):
+    with torch.enable_grad(), pytest.raises(RuntimeError, match='no CPU path'):    # the training path has no CPU fallback either
         m(bbox, feat, feats, None, S.make_img_metas(1, 1, 256, 704))
     with pytest.raises(AssertionError):
         SparseBEVTransformer(256, init_cfg=dict(type='Xavier'))            # same guard as the reference (:19-20)

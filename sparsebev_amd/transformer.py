@@ -404,6 +404,9 @@ class SparseBEVTransformerDecoder(_Base):
                                     # classification branch aside): measured -3 % samples/s at c2 -- the big kernels fill every CU, and
                                     # the forked path cannot use the grouped branch launches
         self.gemm_mode = 0          # 0 = exact fp32 MFMA (default); 1 = opt-in 3 x bf16 split for the two big mixing GEMMs
+        self.value_forcing = None   # tests only: (bbox per layer, feat per layer) recorded from the reference; the differentiable path then
+                                    # evaluates layer i+1 AT those values (x + (x_ref - x).detach()) with the autograd graph intact, so that
+                                    # multi-layer gradients can be compared at 1e-4 although fp32 rounding noise grows ~5x per layer
         self.decoder_layer = SparseBEVTransformerDecoderLayer(embed_dims, num_frames, num_points, num_levels,
                                                               num_classes, code_size, pc_range=pc_range)
 
@@ -451,6 +454,10 @@ class SparseBEVTransformerDecoder(_Base):
                 query_bbox = bbox_pred.detach()
                 cls_scores.append(cls_score)
                 bbox_preds.append(bbox_pred)
+                if self.value_forcing is not None:      # tests only: evaluate the NEXT layer at recorded values, graph intact
+                    ref_bbox, ref_feat = self.value_forcing
+                    query_bbox = ref_bbox[i].to(query_bbox)
+                    query_feat = query_feat + (ref_feat[i].to(query_feat) - query_feat).detach()
         finally:
             layer.self_attn.attn_drop, layer.ffn_drop = saved
         return torch.stack(cls_scores), torch.stack(bbox_preds)

@@ -344,11 +344,15 @@ def main_train():
         cot_box = torch.randn(n_layers, B, Q, 10, generator=g)
         bbox_g, feat_g = bbox.clone().requires_grad_(True), feat.clone().requires_grad_(True)
         feats_g = [f.clone().requires_grad_(True) for f in feats]
+        per_layer = []          # the layer's query_feat output at every stage (value forcing in the tests, see test_gpu_backward.py)
+        hook = layer.register_forward_hook(lambda mod, inp, out: per_layer.append(out[0].detach().clone()))
         with torch.enable_grad():
             cls, box = m(bbox_g, feat_g, list(feats_g), None, copy.deepcopy(metas))
             loss = (cls * cot_cls).sum() + (box * cot_box).sum()
             loss.backward()
+        hook.remove()
         arrays = dict(query_bbox=bbox, query_feat=feat, cot_cls=cot_cls, cot_box=cot_box, out_cls=cls, out_bbox=box,
+                      out_feat=torch.stack(per_layer[:n_layers]),
                       grad_query_bbox=bbox_g.grad, grad_query_feat=feat_g.grad,
                       cfg=np.array([B, Q, T, L, n_layers]), pyramid=np.array(pyr), seeds=np.array([11, 111, 112, 113]),
                       timestamps=np.array([mm['img_timestamp'] for mm in metas]),

@@ -1,0 +1,56 @@
+"""Dev tool: time one TRAINING step of the decoder (forward + backward through all 6 layers, HIP kernels both ways) at a
+bench config, features requiring grad or frozen.  Not the headline metric (that is inference samples/s, bench.py)."""
+import argparse, copy, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sparsebev_amd import synthetic as S
+from sparsebev_amd.transformer import SparseBEVTransformer
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--q', type=int, default=900)
+ap.add_argument('--t', type=int, default=8)
+ap.add_argument('--b', type=int, default=1)
+ap.add_argument('--pyr', default='r50_704x256')
+ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--feat-grad', action='store_true')
+ap.add_argument('--dropout', action='store_true')
+a = ap.parse_args()
+dev = 'cuda:0'
+ih, iw, sizes = S.PYRAMIDS[a.pyr]
+m = SparseBEVTransformer(256, num_frames=a.t, num_points=4, num_layers=6, num_levels=len(sizes), pc_range=S.PC_RANGE)
+m.init_weights(); S.randomize_zero_init(m, std=0.02, seed=0)
+m = m.to(dev).train()
+if not a.dropout:
+    m.decoder.decoder_layer.self_attn.attn_drop = 0.0
+    m.decoder.decoder_layer.ffn_drop = 0.0
+feats = [f.requires_grad_(a.feat_grad) for f in S.make_features(a.b, a.t, sizes, seed=0, device=dev)]
+bbox, feat = [t.to(dev) for t in S.make_queries(a.b, a.q, seed=0)]
+feat.requires_grad_(True)
+metas = S.make_img_metas(a.b, a.t, ih, iw)
+
+def step():
+    for p in m.parameters():
+        p.grad = None
+    cls, box = m(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    (cls.sum() + box.sum()).backward()
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+with torch.no_grad():
+    m.eval()
+    for _ in range(3):
+        m(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    torch.cuda.synchronize()
+    di = (time.perf_counter() - t0) / a.steps
+print('train step (fwd+bwd, 6 layers, Q=%d T=%d B=%d, feat_grad=%s, dropout=%s): %.2f ms   inference step: %.2f ms   peak mem %.2f GB'
+      % (a.q, a.t, a.b, a.feat_grad, a.dropout, dt * 1e3, di * 1e3, torch.cuda.max_memory_allocated() / 1e9))

@@ -369,13 +369,17 @@ int sbev_gemm_f32(const float* A, int a_kmajor, int64_t lda, const float* B, int
                   float* workspace, sbev_stream_t stream);
 
 /* dZ = dY * (Y > 0) (Y = a ReLU's forward output, NULL: dZ = dY; dZ may be NULL or alias dY) and db[n] = sum_m dZ[m,n]
- * (NULL: skipped).  Rows have stride ld. */
+ * (NULL: skipped).  Rows have stride ld.  workspace: sbev_colsum_workspace(M, N) bytes (needed when db != NULL);
+ * column sums are added in a fixed order (bit-reproducible). */
+int64_t sbev_colsum_workspace(int64_t M, int N);
 int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
-                       sbev_stream_t stream);
+                       float* workspace, sbev_stream_t stream);
 
-/* LayerNorm(+ReLU) backward over the last dim (N % 4 == 0, N <= 1024): X is the LayerNorm INPUT; stats = [M,2] scratch. */
+/* LayerNorm(+ReLU) backward over the last dim (N % 4 == 0, N <= 1024): X is the LayerNorm INPUT;
+ * workspace: sbev_layer_norm_bwd_workspace(M, N) bytes. */
+int64_t sbev_layer_norm_bwd_workspace(int64_t M, int N);
 int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
-                        float* dX, float* dgamma, float* dbeta, float* stats, int64_t M, int N, sbev_stream_t stream);
+                        float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, sbev_stream_t stream);
 
 /* sbev_linear3_ln_relu_f32 that also stores the Linear's pre-LayerNorm output `pre` [M,N] (may be NULL). */
 int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const float* w, const float* b,

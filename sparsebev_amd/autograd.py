@@ -62,7 +62,9 @@ def _bias_relu_bwd(gy2, y2, want_db):
         return gy2, None
     gz = torch.empty_like(gy2) if y2 is not None else None
     db = torch.empty(N, device=gy2.device, dtype=torch.float32) if want_db else None
-    st = _lib.load().sbev_bias_relu_bwd(_p(gy2), _p(y2), _p(gz), _p(db), M, N, N, _stream())
+    lib = _lib.load()
+    ws = torch.empty(max(lib.sbev_colsum_workspace(M, N) // 4, 1), device=gy2.device, dtype=torch.float32) if want_db else None
+    st = lib.sbev_bias_relu_bwd(_p(gy2), _p(y2), _p(gz), _p(db), M, N, N, _p(ws), _stream())
     _lib.check(st, 'sbev_bias_relu_bwd')
     return (gz if gz is not None else gy2), db
 
@@ -116,7 +118,7 @@ class LayerNorm(torch.autograd.Function):
         M = x2.shape[0]
         gx = torch.empty_like(x2)
         dg, dbeta = torch.empty_like(g), torch.empty_like(b)
-        stats = torch.empty(max(M, 1), 2, device=x.device, dtype=torch.float32)
+        stats = torch.empty(max(_lib.load().sbev_layer_norm_bwd_workspace(M, N) // 4, 1), device=x.device, dtype=torch.float32)
         st = _lib.load().sbev_layer_norm_bwd(_p(gy2), _p(x2), _p(_c(g)), _p(_c(b)), _EPS, int(ctx.relu), _p(gx), _p(dg), _p(dbeta),
                                              _p(stats), M, N, _stream())
         _lib.check(st, 'sbev_layer_norm_bwd')
@@ -152,8 +154,8 @@ class Linear3LnRelu(torch.autograd.Function):
         gy2 = _c(gy).reshape(-1, N)
         gpre = torch.empty_like(pre)
         dg, dbeta = torch.empty_like(lnw), torch.empty_like(lnb)
-        stats = torch.empty(max(M, 1), 2, device=gy.device, dtype=torch.float32)
         lib = _lib.load()
+        stats = torch.empty(max(lib.sbev_layer_norm_bwd_workspace(M, N) // 4, 1), device=gy.device, dtype=torch.float32)
         _lib.check(lib.sbev_layer_norm_bwd(_p(gy2), _p(pre), _p(_c(lnw)), _p(_c(lnb)), _EPS, 1, _p(gpre), _p(dg), _p(dbeta), _p(stats),
                                            M, N, _stream()), 'sbev_layer_norm_bwd')
         _, db = _bias_relu_bwd(gpre, None, True)

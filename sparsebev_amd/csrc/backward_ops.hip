@@ -12,12 +12,15 @@ namespace {
 
 // ---- column sums (bias gradients) with an optional ReLU mask -------------------------------------------------------
 // dZ = dY * (Y > 0)  (Y = the forward OUTPUT of a ReLU; null -> dZ = dY);  db[n] = sum_m dZ[m, n].
-// Block = 64 columns x 4 row lanes, rows strided by 4, the four partial sums merged through LDS: deterministic.
+// Two deterministic passes: block (column block of 64, row chunk of 128 rows) = 64 columns x 4 row lanes writes one
+// partial row of sums, a second tiny kernel adds the chunks in order.  (One block per 64 columns over ALL rows was 4
+// workgroups for a 256-wide Linear: 73 us for 0.9 MB.)
+constexpr int ROW_CHUNK = 128;
 struct ColArgs {
     const float* dY;     // [M, ld]
     const float* Y;      // [M, ld] or null
     float* dZ;           // [M, ld] or null (may alias dY)
-    float* db;           // [N] or null
+    float* part;         // [chunks, N] or null (no column sums wanted)
     long long M, ld;
     int N;
 };
@@ -26,18 +29,32 @@ __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const ColArgs a) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const long long n = (long long)blockIdx.x * 64 + c;
+    const long long m0 = (long long)blockIdx.y * ROW_CHUNK, m1 = m0 + ROW_CHUNK < a.M ? m0 + ROW_CHUNK : a.M;
     float s = 0.f;
     if (n < a.N) {
-        for (long long m = rg; m < a.M; m += 4) {
+        for (long long m = m0 + rg; m < m1; m += 4) {
             float g = a.dY[m * a.ld + n];
             if (a.Y && !(a.Y[m * a.ld + n] > 0.f)) g = 0.f;
             if (a.dZ) a.dZ[m * a.ld + n] = g;
             s += g;
         }
     }
+    if (!a.part) return;
     red[rg][c] = s;
     __syncthreads();
-    if (rg == 0 && n < a.N && a.db) a.db[n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (rg == 0 && n < a.N) a.part[(long long)blockIdx.y * a.N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// out[k][n] = sum_chunks part[k][chunk][n]  for K stacked partial sets (K = 1: bias; K = 2: dgamma, dbeta)
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
+                                                        int chunks, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float* out = blockIdx.y == 0 ? out0 : out1;
+    const float* p = part + (long long)blockIdx.y * chunks * N;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += p[(long long)c * N + n];
+    out[n] = s;
 }
 
 // ---- LayerNorm backward ---------------------------------------------------------------------------------------------
@@ -51,7 +68,7 @@ struct LnBwdArgs {
     const float* gamma;  // [N]
     const float* beta;   // [N]      (only read when relu)
     float* dX;           // [M, N]
-    float* stats;        // [M, 2]   (mean, rstd)
+    float* stats;        // workspace: [M, 2] (mean, rstd) followed by [2][chunks][N] partial column sums
     float* dgamma;       // [N]
     float* dbeta;        // [N]
     long long M;
@@ -134,10 +151,12 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const LnBwdArgs a) {
     __shared__ float red[2][4][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const long long m0 = (long long)blockIdx.y * ROW_CHUNK, m1 = m0 + ROW_CHUNK < a.M ? m0 + ROW_CHUNK : a.M;
+    const int chunks = gridDim.y;
     float sg = 0.f, sb = 0.f;
     if (n < a.N) {
         const float w = a.gamma[n], bt = a.relu ? a.beta[n] : 0.f;
-        for (long long m = rg; m < a.M; m += 4) {
+        for (long long m = m0 + rg; m < m1; m += 4) {
             const float h = (a.X[m * a.N + n] - a.stats[m * 2]) * a.stats[m * 2 + 1];
             float g = a.dY[m * a.N + n];
             if (a.relu && !(h * w + bt > 0.f)) g = 0.f;
@@ -149,8 +168,9 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const LnBwdArgs a) {
     red[1][rg][c] = sb;
     __syncthreads();
     if (rg == 0 && n < a.N) {
-        a.dgamma[n] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        a.dbeta[n] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        float* part = a.stats + 2 * a.M;                   // [2][chunks][N] behind the row statistics
+        part[(long long)blockIdx.y * a.N + n] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        part[((long long)chunks + blockIdx.y) * a.N + n] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
     }
 }
 
@@ -361,29 +381,55 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 
 }  // namespace
 
+extern "C" int64_t sbev_colsum_workspace(int64_t M, int N) {
+    if (M < 0 || N < 0) return -1;
+    return ((M + ROW_CHUNK - 1) / ROW_CHUNK) * (int64_t)N * (int64_t)sizeof(float);
+}
+
 extern "C" int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
-                                  sbev_stream_t stream) {
+                                  float* workspace, sbev_stream_t stream) {
     SBEV_REQUIRE(M >= 0 && N >= 0 && ld >= N, "sbev_bias_relu_bwd: bad sizes");
     if (N == 0) return SBEV_OK;
-    SBEV_REQUIRE(dY != nullptr, "sbev_bias_relu_bwd: null grad");
-    ColArgs a{dY, Y, dZ, db, M, ld, N};
-    hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-    return sbev::check_launch("sbev_bias_relu_bwd");
+    SBEV_REQUIRE(dY != nullptr && (!db || workspace), "sbev_bias_relu_bwd: null grad / workspace");
+    const int chunks = (int)((M + ROW_CHUNK - 1) / ROW_CHUNK);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (chunks > 0) {
+        SBEV_REQUIRE(chunks <= 65535, "sbev_bias_relu_bwd: too many rows");
+        ColArgs a{dY, Y, dZ, db ? workspace : nullptr, M, ld, N};
+        hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, s, a);
+        int st = sbev::check_launch("sbev_bias_relu_bwd");
+        if (st != SBEV_OK) return st;
+    }
+    if (db) {
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((N + 255) / 256), 1), dim3(256), 0, s, workspace, db, db, chunks, N);
+        return sbev::check_launch("sbev_bias_relu_bwd (sum)");
+    }
+    return SBEV_OK;
+}
+
+extern "C" int64_t sbev_layer_norm_bwd_workspace(int64_t M, int N) {
+    if (M < 0 || N < 0) return -1;
+    return (2 * M + 2 * ((M + ROW_CHUNK - 1) / ROW_CHUNK) * (int64_t)N) * (int64_t)sizeof(float);
 }
 
 extern "C" int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
-                                   float* dX, float* dgamma, float* dbeta, float* stats, int64_t M, int N, sbev_stream_t stream) {
+                                   float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, sbev_stream_t stream) {
     SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024, "sbev_layer_norm_bwd: N=%d must be a multiple of 4 in 4..1024", N);
-    SBEV_REQUIRE(dY && X && gamma && dX && dgamma && dbeta && stats && (!relu || beta), "sbev_layer_norm_bwd: null pointer");
-    LnBwdArgs a{dY, X, gamma, beta, dX, stats, dgamma, dbeta, M, N, relu, eps};
+    SBEV_REQUIRE(dY && X && gamma && dX && dgamma && dbeta && workspace && (!relu || beta), "sbev_layer_norm_bwd: null pointer");
+    LnBwdArgs a{dY, X, gamma, beta, dX, workspace, dgamma, dbeta, M, N, relu, eps};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int chunks = (int)((M + ROW_CHUNK - 1) / ROW_CHUNK);
+    SBEV_REQUIRE(chunks <= 65535, "sbev_layer_norm_bwd: too many rows");
     if (M > 0) {
         hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, a);
         int st = sbev::check_launch("sbev_layer_norm_bwd (rows)");
         if (st != SBEV_OK) return st;
+        hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, s, a);
+        st = sbev::check_launch("sbev_layer_norm_bwd (columns)");
+        if (st != SBEV_OK) return st;
     }
-    hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, a);
-    return sbev::check_launch("sbev_layer_norm_bwd (columns)");
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, workspace + 2 * M, dgamma, dbeta, chunks, N);
+    return sbev::check_launch("sbev_layer_norm_bwd (sum)");
 }
 
 extern "C" int sbev_refine_bbox_bwd(const float* grad_out, const float* out, const float* query_bbox, const float* vel_div,

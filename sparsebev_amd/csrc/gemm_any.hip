@@ -189,10 +189,12 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 }
 
 int plan_splits(long long M, int N, long long K) {
+    // fewer tiles than CUs and a reduction long enough to cut: split K so that ~256 workgroups exist, each with at least
+    // two 32-wide K steps (a 256 x 256 weight gradient over K = B*Q = 900 rows is 4 tiles: 72 us on 4 CUs unsplit)
     const long long tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    if (tiles >= 128 || K < 4096) return 1;
+    if (tiles >= 128 || K < 256) return 1;
     long long s = 256 / tiles;
-    const long long max_s = K / 512;
+    const long long max_s = K / 64;
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
     return s < 2 ? 1 : (int)s;

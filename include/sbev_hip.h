@@ -352,6 +352,25 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
                               int64_t M, int N, int K, int64_t ldx, int relu, int splits, float* workspace,
                               sbev_stream_t stream);
 
+/*
+ * Gather + adaptive mixing in ONE launch: the workgroup of item (b*Q + q, g) samples its own x[T*P, 64] (the arithmetic of
+ * sbev_msmv_fwd / sbev_msmv_fwd_ring with out_layout SBEV_OUT_MIX, frames spread over its four waves) into LDS and runs
+ * sbev_adaptive_mixing_f32 on it -- bit-identical to the two launches, without the [B,Q,G,T*P,C] round trip through HBM.
+ * Replaces: sampling_4d's gather + the middle of AdaptiveMixing.inner_forward (models/sparsebev_sampling.py:122-128,
+ *           models/sparsebev_transformer.py:362-374).
+ * Shapes covered: sbev_sample_mix_supported(L, C, P, T, gdiv, G) != 0  (L in {4,5}, C = 64, P = 4, gdiv = G, T*P in
+ * {16, 32, 48, 64}); feats / strides / loc / weights as for sbev_msmv_fwd with B' = B*T*G; frame_slots NULL = dense
+ * pyramid, else the online ring (n_slots, see sbev_msmv_fwd_ring); params [B*Q, G, C*C + Pout*T*P]; y [B*Q, G, Pout, C].
+ */
+int sbev_sample_mix_supported(int L, int C, int P, int T, int gdiv, int G);
+int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                        int64_t B, int N, int Q, int T, int G, int P, int C,
+                        const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                        const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                        const float* params, float* y, int Pout, float eps, sbev_stream_t stream);
+/* sbev_decoder_forward uses the fused launch where supported (default 1); 0 restores sampler + mixing as two launches. */
+int sbev_decoder_fuse_sample_mix(int enable);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Training: backward passes of the decoder layer.
  * Replaces: torch autograd through SparseBEVTransformerDecoderLayer.forward and the activation-checkpointed
@@ -504,7 +523,7 @@ int64_t sbev_graph_num_nodes(const sbev_graph* graph);   /* kernel nodes recorde
 int sbev_graph_destroy(sbev_graph* graph);
 
 /* Bracket launches with HIP events on their stream -- `enable` is a bit mask of kinds: 1 = every sbev_msmv_fwd launch,
- * 2 = the parameter-generator GEMM, 4 = the out-projection GEMM, 0 = off -- and read back + clear the elapsed times in ms
+ * 2 = the parameter-generator GEMM, 4 = the out-projection GEMM, 8 = the fused gather + mixing launch, 0 = off -- and read back + clear the elapsed times in ms
  * (blocks until those launches finished).  Measurement aid for bench.py's roofline figures. */
 int sbev_profile_sampler(int enable);
 int sbev_profile_sampler_read(float* ms, int max_n);
@@ -512,7 +531,7 @@ int sbev_profile_sampler_read(float* ms, int max_n);
  * six sampler launches): bracket the launches of only every n-th sbev_decoder_forward call (n = 1: every call, the default).
  * Resets the call counter, so the first call after it is a bracketed one. */
 int sbev_profile_stride(int every_n_calls);
-/* Same for the other bracketed launches: kind 0 = sampler, 1 = parameter-generator GEMM, 2 = out-projection GEMM. */
+/* Same for the other bracketed launches: kind 0 = sampler, 1 = parameter-generator GEMM, 2 = out-projection GEMM, 3 = fused gather + mixing. */
 int sbev_profile_read(int kind, float* ms, int max_n);
 
 #ifdef __cplusplus

@@ -92,6 +92,12 @@ SIGNATURES = {
     'sbev_profile_read': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int]),
     'sbev_linear_splitk_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    'sbev_sample_mix_supported': (ctypes.c_int, [ctypes.c_int] * 6),
+    'sbev_sample_mix_f32': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,
+                                           _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
+    'sbev_decoder_fuse_sample_mix': (ctypes.c_int, [ctypes.c_int]),
     'sbev_gemm_f32_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
     'sbev_gemm_f32': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),

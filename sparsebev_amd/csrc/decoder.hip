@@ -6,6 +6,7 @@
 // provided workspace (size: sbev_decoder_workspace_bytes); nothing is allocated, nothing synchronises.
 // The launch sequence is static for a given config, which also makes it capturable into a hipGraph by the
 // caller (the stream may be in capture mode: no call in here is capture-illegal).
+#include <atomic>
 #include "sbev_common.hpp"
 
 #include <mutex>
@@ -57,6 +58,10 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.bytes = k.off;
     return b;
 }
+
+// gather + mixing in one launch (sbev_sample_mix_f32) where supported; sbev_decoder_fuse_sample_mix(0) restores the two
+// launches (A/B measurements; results are bit-identical)
+std::atomic<int> g_fuse_sample_mix{1};
 
 int validate(const sbev_decoder_config* c) {
     SBEV_REQUIRE(c != nullptr, "sbev_decoder: null config");
@@ -199,15 +204,25 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // adaptive spatio-temporal sampling                                     (:170)
         TRY(sbev_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
                                     c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
-        if (c.n_slots > 0)
-            TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
-                                   c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, c.frame_slots, c.n_slots, stream));
-        else
-            TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
-                              c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
+        // gather + adaptive mixing: ONE launch when the fused kernel covers the shape (the sampled features then never
+        // touch HBM), else the sampler followed by the mixing kernel (same arithmetic, bit-identical results)
+        const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
+                           sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0;
+        if (!fused) {
+            if (c.n_slots > 0)
+                TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                                       c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, c.frame_slots, c.n_slots, stream));
+            else
+                TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                                  c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
+        }
         // adaptive mixing + norm2 (join: the generator's output is needed now)  (:171)
         if (fork_pg) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_pg, 0), "hipStreamWaitEvent"));
-        TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
+        if (fused)
+            TRY(sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
+                                    c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, stream));
+        else
+            TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
         if (c.gemm_mode == SBEV_GEMM_BF16X3)
             TRY(sbev_linear_splitk_bf16x3(b.mixed, w->op_w2, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
                                           0, splits, b.slabs, stream));
@@ -325,6 +340,11 @@ extern "C" int sbev_profile_stride(int every_n_calls) {
     std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
     sbev::g_prof_stride = every_n_calls;
     sbev::g_prof_calls = 0;
+    return SBEV_OK;
+}
+
+extern "C" int sbev_decoder_fuse_sample_mix(int enable) {
+    g_fuse_sample_mix.store(enable ? 1 : 0, std::memory_order_relaxed);
     return SBEV_OK;
 }
 

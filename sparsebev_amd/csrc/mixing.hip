@@ -35,6 +35,34 @@ struct MixArgs {
     float eps;
 };
 
+#include "msmv_common.hpp"
+
+// 1: request the item's M / S parameters BEFORE the gather (their HBM latency hides under it, but 32 more live registers
+// push the fused kernel from 3 to 2 waves per SIMD); 0: request them after the gather
+#ifndef SBEV_SAMPLE_MIX_PREFETCH
+#define SBEV_SAMPLE_MIX_PREFETCH 0
+#endif
+
+// Fused sampler + mixing (SL > 0 instantiations of the kernel below): the workgroup of item (b*Q + q, g) first GATHERS its
+// own x[T*P, 64] -- wave w runs the sampler's per-chunk code (msmv_chunk.inc, one 4-point chunk per frame) for the frames
+// t = w, w + 4, ... of sample batch b' = (b*T + t)*G + g and leaves the rows in LDS -- so the sampled features
+// (29.5 MB per layer at config 2) are neither written to nor re-read from HBM, and one launch disappears.
+struct SampleMixArgs {
+    const float* x;       // unused (kept so that the kernel body reads the same member names)
+    const float* params;
+    float* y;
+    long long n_items;
+    int Pin;
+    float eps;
+    MsmvArgs s;           // sampler descriptors: s.loc [B*T*G, Q, P, 3], s.w [B*G*T, Q, P, L]; s.Q, s.T, s.G, s.P (== 4), s.N
+};
+template <int SL>
+struct MixArgsOf { typedef MixArgs type; };
+template <>
+struct MixArgsOf<4> { typedef SampleMixArgs type; };
+template <>
+struct MixArgsOf<5> { typedef SampleMixArgs type; };
+
 constexpr int C = 64, POUT = 128;
 constexpr int LDA = C + 4;    // A-operand rows (x): 16-B aligned rows, <= 2-way bank conflict on fragment reads
 constexpr int LDB = C + 16;   // B-operand rows (M, y1): row stride = 16 banks -> conflict-free fragment reads
@@ -73,8 +101,10 @@ __device__ __forceinline__ void block_mean_rstd(float s_w, float m2_w, float n_w
     rstd = rsqrtf(m2 / n + eps);
 }
 
-template <int RT, bool WIDE>   // RT = ceil(Pin / 16) row tiles of matmul 1; WIDE: Pin % 16 == 0 (b128 A reads in matmul 2)
-__global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
+// RT = ceil(Pin / 16) row tiles of matmul 1; WIDE: Pin % 16 == 0 (b128 A reads in matmul 2); L > 0: fused sampler with L
+// feature levels of storage type FT (WIDE only)
+template <int RT, bool WIDE, int L = 0, typename FT = float>
+__global__ __launch_bounds__(256) void adaptive_mixing_kernel(const typename MixArgsOf<L>::type a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
     const int lds_s = Pin + 4;                                  // S row stride
@@ -98,7 +128,7 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     // ---- stage x, M, S (coalesced float4) --------------------------------------------------------------
     const int fi = lane & 15, fk = lane >> 4;                   // fragment row/col index, k sub-index
     f32x4 xf[WIDE ? RT : 1][C / 16];                            // WIDE: A fragments of matmul 1, x[r*16 + fi][16 blk + 4 fk ..]
-    if (WIDE) {
+    if (WIDE && L == 0) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -114,12 +144,10 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     // WIDE: the B fragments of matmul 1 (this wave's 16 columns of M, 4 KiB) also go straight to registers -- matmul 1
     // then depends on no LDS staging and no barrier at all
     float mf[WIDE ? C / 16 : 1][4];
-    if (WIDE) {
-#pragma unroll
-        for (int blk = 0; blk < C / 16; ++blk)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mf[blk][j] = pg[(16 * blk + 4 * fk + j) * C + wave * 16 + fi];
-    }
+#define SBEV_LOAD_MF()                                                                                   \
+    _Pragma("unroll") for (int blk = 0; blk < C / 16; ++blk)                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) mf[blk][j] = pg[(16 * blk + 4 * fk + j) * C + wave * 16 + fi];
+    if (WIDE && (L == 0 || SBEV_SAMPLE_MIX_PREFETCH)) { SBEV_LOAD_MF() }
     for (int i = tid; i < (WIDE ? 0 : C * (C / 4)); i += 256) {
         const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
         *reinterpret_cast<float4*>(&Ms[r * LDB + c4]) = *reinterpret_cast<const float4*>(pg + r * C + c4);
@@ -128,15 +156,74 @@ __global__ __launch_bounds__(256) void adaptive_mixing_kernel(const MixArgs a) {
     // it to LDS behind matmul 1, in front of the LayerNorm-1 exchange whose barriers publish it -- its HBM latency hides
     // behind matmul 1 and the staging barrier only waits for M
     f32x4 sreg[WIDE ? 2 * RT : 1];
-    if (WIDE) {
-#pragma unroll
-        for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (tid + 256 * k) * 4);
-    }
+#define SBEV_LOAD_S() \
+    _Pragma("unroll") for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (tid + 256 * k) * 4);
+    if (WIDE && (L == 0 || SBEV_SAMPLE_MIX_PREFETCH)) { SBEV_LOAD_S() }
     for (int i = tid; i < (WIDE ? 0 : POUT * Pin / 4); i += 256) {
         const int r = (i * 4) / Pin, c4 = (i * 4) % Pin;
         *reinterpret_cast<float4*>(&Ss[r * lds_s + c4]) = *reinterpret_cast<const float4*>(sg + i * 4);
     }
     if (!WIDE) __syncthreads();
+    if constexpr (L > 0) {
+        // ---- fused gather: x rows t*4 + p of this (query, group) item, frames t = wave, wave + 4, ... -------------------
+        // (the M / S requests above are already in flight: their HBM latency hides under the gather)
+        float* Xg = Ss + POUT * lds_s;                          // [Pin][LDA], behind S; dead once xf is loaded
+        {
+            const MsmvArgs& m = a.s;
+            const int G = m.G, T = m.T, Q = m.Q;
+            const unsigned ubq = (unsigned)(item / G);
+            const int g = (int)(item - (long long)ubq * G);
+            const unsigned b = ubq / (unsigned)Q;
+            const int q = (int)(ubq - b * (unsigned)Q);
+            const int k = lane >> 4;
+            const int j4 = (lane & 15) * 4;
+            const float nm1 = (float)(m.N - 1);
+            auto fetch_lv = [&](int t) {
+                const long long it = ((long long)(b * (unsigned)T + t) * G + g) * Q + q;      // (b', q) with b' = (b*T + t)*G + g
+                float v = 0.f;
+                if (lane < 12) v = m.loc[it * 12 + lane];
+                if (lane >= 16 && lane < 16 + 4 * L) v = m.w[it * (4 * L) + (lane - 16)];
+                return v;
+            };
+            float lv_next = wave < T ? fetch_lv(wave) : 0.f;
+#pragma unroll 1
+            for (int t = wave; t < T; t += 4) {
+                const float lv = lv_next;
+                if (t + 4 < T) lv_next = fetch_lv(t + 4);
+                unsigned ubo = b * (unsigned)T + (unsigned)t;
+                if (m.ring_T) ubo = b * (unsigned)m.n_slots + (unsigned)m.slots[t];
+                const FT* base[L];
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    base[l] = reinterpret_cast<const FT*>(m.feat[l]) + (long long)ubo * m.stride_bo[l] + (long long)g * m.stride_g + j4;
+                const int npts = 4;
+                const bool chan_ok = true;
+                {
+                    const MsmvArgs& a = m;                      // the included chunk code names its argument block `a`
+#include "msmv_chunk.inc"
+                    float4 sv;
+                    sv.x = corner_reduce_scatter(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+                    sv.y = corner_reduce_scatter(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+                    sv.z = corner_reduce_scatter(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
+                    sv.w = corner_reduce_scatter(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
+                    *reinterpret_cast<float4*>(&Xg[(t * 4 + k) * LDA + j4]) = sv;       // row k of the wave = point k of frame t
+                }
+            }
+        }
+        if (!SBEV_SAMPLE_MIX_PREFETCH) {                        // M / S requested only now: the gather phase keeps its 3 waves per SIMD
+            __builtin_amdgcn_sched_barrier(0);
+            SBEV_LOAD_MF()
+            SBEV_LOAD_S()
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int blk = 0; blk < C / 16; ++blk)
+                xf[r][blk] = *reinterpret_cast<const f32x4*>(&Xg[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
+    }
+#undef SBEV_LOAD_MF
+#undef SBEV_LOAD_S
 
     const int cw = wave * 16;                                   // this wave's channel slab
 
@@ -289,6 +376,31 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
     return a.Pin % 16 == 0 ? launch_mix_w<RT, true>(a, s) : launch_mix_w<RT, false>(a, s);
 }
 
+template <int RT, int L, typename FT>
+int launch_sample_mix(const SampleMixArgs& a, hipStream_t s) {
+    const int Pin = a.Pin;
+    size_t floats = (size_t)POUT * (Pin + 4) + (size_t)Pin * LDA;        // S, then the gathered x behind it
+    const size_t out_floats = (size_t)POUT * LDY;
+    if (floats < out_floats) floats = out_floats;
+    const size_t bytes = (floats + 8) * sizeof(float);
+    auto k = adaptive_mixing_kernel<RT, true, L, FT>;
+    hipEvent_t e0, e1;
+    const bool prof = sbev::profile_begin(s, &e0, &e1, 3);
+    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(256), bytes, s, a);
+    if (prof) sbev::profile_end(s, e0, e1, 3);
+    return sbev::check_launch("sbev_sample_mix_f32");
+}
+
+template <int L, typename FT>
+int launch_sample_mix_rt(const SampleMixArgs& a, hipStream_t s) {
+    switch (a.Pin / 16) {
+        case 1: return launch_sample_mix<1, L, FT>(a, s);
+        case 2: return launch_sample_mix<2, L, FT>(a, s);
+        case 3: return launch_sample_mix<3, L, FT>(a, s);
+        default: return launch_sample_mix<4, L, FT>(a, s);
+    }
+}
+
 }  // namespace
 
 extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
@@ -312,4 +424,51 @@ extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, flo
         case 7: return launch_mix<7>(a, s);
         default: return launch_mix<8>(a, s);
     }
+}
+
+extern "C" int sbev_sample_mix_supported(int L, int C, int P, int T, int gdiv, int G) {
+    return (L == 4 || L == 5) && C == 64 && P == 4 && gdiv == G && T >= 1 && (T * P) % 16 == 0 && T * P <= 64;
+}
+
+extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                   int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                                   const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                   const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                   const float* params, float* y, int Pout, float eps, sbev_stream_t stream) {
+    SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_sample_mix_f32: null descriptor array");
+    SBEV_REQUIRE(sbev_sample_mix_supported(L, Cg, P, T, G, G), "sbev_sample_mix_f32: needs L in {4,5}, C = 64, P = 4, T*P in {16,32,48,64} (got L=%d C=%d P=%d T=%d)", L, Cg, P, T);
+    SBEV_REQUIRE(Pout == POUT, "sbev_sample_mix_f32: built for 128 out points");
+    SBEV_REQUIRE(B >= 0 && Q >= 0 && N >= 1 && G >= 1, "sbev_sample_mix_f32: bad sizes");
+    SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16, "sbev_sample_mix_f32: feat_dtype %d", feat_dtype);
+    SBEV_REQUIRE(stride_px % 4 == 0 && stride_g % 4 == 0, "sbev_sample_mix_f32: pixel/group strides must be multiples of 4 elements");
+    if (B == 0 || Q == 0) return SBEV_OK;
+    SBEV_REQUIRE(loc && weights && params && y, "sbev_sample_mix_f32: null pointer");
+    SBEV_REQUIRE(B * Q * G <= 0x7fffffffLL && B * (int64_t)T * G * Q <= 0x7fffffffLL, "sbev_sample_mix_f32: too many items");
+    SampleMixArgs a{};
+    a.params = params; a.y = y; a.n_items = B * Q * G; a.Pin = T * P; a.eps = eps;
+    MsmvArgs& m = a.s;
+    for (int l = 0; l < L; ++l) {
+        SBEV_REQUIRE(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_sample_mix_f32: level %d", l);
+        SBEV_REQUIRE(stride_bo[l] % 4 == 0 && stride_v[l] % 4 == 0 && stride_v[l] >= 0 && stride_px >= 0 &&
+                         (int64_t)(N - 1) * stride_v[l] + ((int64_t)hw[2 * l] * hw[2 * l + 1] - 1) * stride_px + Cg <= 0x7fffffffLL,
+                     "sbev_sample_mix_f32: level %d strides (multiples of 4; one slab must fit the 32-bit in-slab offset)", l);
+        m.feat[l] = feats[l];
+        m.H[l] = hw[2 * l]; m.W[l] = hw[2 * l + 1];
+        m.stride_bo[l] = stride_bo[l]; m.stride_v[l] = stride_v[l];
+    }
+    m.stride_g = stride_g; m.stride_px = stride_px;
+    m.loc = loc; m.w = weights; m.out = nullptr;
+    m.n_waves = B * T * G * Q;
+    m.N = N; m.C = Cg; m.Q = Q; m.P = P; m.gdiv = G; m.T = T; m.G = G;
+    if (frame_slots) {
+        SBEV_REQUIRE(T <= SBEV_MAX_FRAMES && n_slots >= T, "sbev_sample_mix_f32: ring needs T <= %d, n_slots >= T", SBEV_MAX_FRAMES);
+        m.ring_T = T; m.n_slots = n_slots;
+        for (int t = 0; t < T; ++t) {
+            SBEV_REQUIRE(frame_slots[t] >= 0 && frame_slots[t] < n_slots, "sbev_sample_mix_f32: frame_slots[%d] out of range", t);
+            m.slots[t] = frame_slots[t];
+        }
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (feat_dtype == SBEV_F32) return L == 4 ? launch_sample_mix_rt<4, float>(a, s) : launch_sample_mix_rt<5, float>(a, s);
+    return L == 4 ? launch_sample_mix_rt<4, unsigned short>(a, s) : launch_sample_mix_rt<5, unsigned short>(a, s);
 }

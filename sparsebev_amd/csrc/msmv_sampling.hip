@@ -23,68 +23,7 @@
 
 namespace {
 
-struct MsmvArgs {
-    const void* feat[SBEV_MAX_LEVELS];
-    int H[SBEV_MAX_LEVELS];
-    int W[SBEV_MAX_LEVELS];
-    long long stride_bo[SBEV_MAX_LEVELS];
-    long long stride_v[SBEV_MAX_LEVELS];
-    long long stride_g;
-    long long stride_px;
-    const float* loc;
-    const float* w;
-    float* out;
-    long long n_waves;  // B' * Q
-    int N, C, Q, P, gdiv, T, G;
-    // online frame ring (sbev_msmv_fwd_ring): logical frame t of a sample lives in physical slot slots[t] of n_slots
-    int ring_T, n_slots;
-    int slots[SBEV_MAX_FRAMES];
-};
-
-// A tap is kept in its storage form until it is consumed: 4 bf16 channels stay two registers while the 4 * L loads of a
-// chunk are in flight (converted tap by tap in phase 3), which is what decides the waves per SIMD of this latency-bound
-// kernel (c5, L = 5: 71.5 -> 59 us; L = 4 bf16: 39.9 -> 34.5 us).
-__device__ __forceinline__ float4 load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ uint2 load_raw(const unsigned short* p) { return *reinterpret_cast<const uint2*>(p); }
-__device__ __forceinline__ float4 widen(const float4 r) { return r; }
-__device__ __forceinline__ float4 widen(const uint2 r) {  // 4 x bf16 -> fp32 (exact)
-    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
-                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
-}
-
-// Reduce-scatter over the 4 corner groups (16-lane rows r = 0..3 of the wave) without LDS:
-// given one value per item i = 0..3 in every lane, returns in row r the sum over all 4 rows of item r.
-// permlane16_swap(x, y) exchanges the odd rows of x with the even rows of y, so x + y afterwards holds
-// [i0(r0+r1), i1(r0+r1), i0(r2+r3), i1(r2+r3)]; permlane32_swap(x, y) exchanges the upper half of x with
-// the lower half of y and finishes the sum.  3 swaps + 3 adds for 4 items (an all-reduce needs 8 + 8).
-__device__ __forceinline__ float pair16(float a, float b) {
-    auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
-}
-__device__ __forceinline__ float corner_reduce_scatter(float i0, float i1, float i2, float i3) {
-    const float u = pair16(i0, i1), v = pair16(i2, i3);
-    auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(v), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
-}
-
-// QPW > 1 (only for P <= 4, C <= 64: one chunk per query): a wave walks QPW consecutive (b', q) items and requests the
-// NEXT item's coordinates / level weights while it works on the current one, so each item costs one exposed memory round
-// trip (its feature taps) instead of two (coordinates, then taps).  PMC on the QPW = 1 kernel: 45 % of the wave cycles sit
-// in s_waitcnt, and bf16 features (half the bytes) ran no faster than fp32 -- latency-, not bandwidth-bound.
-#ifndef SBEV_MSMV_QPW
-#define SBEV_MSMV_QPW 2
-#endif
-// Waves per SIMD asked of the register allocator: with bf16 taps the 5-level kernel lands 2 registers above the 3-wave
-// budget (170 vs 168), which the allocator closes when told to (4 spilled registers; 59.2 -> 58.0 us at c5).  Not for
-// L = 4: 134 -> 128 registers for a 4th wave costs 8 spills and measured 40.0 vs 34.5 us.  fp32 is left alone.
-template <int L, typename FT>
-constexpr int msmv_min_waves() {
-#ifdef SBEV_MSMV_NO_BF16_WAVES
-    return 1;
-#else
-    return (sizeof(FT) == 2 && L >= 5) ? 3 : 1;
-#endif
-}
+#include "msmv_common.hpp"
 
 template <int L, typename FT, int OUT, int QPW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(msmv_min_waves<L, FT>()))) void msmv_fwd_kernel(const MsmvArgs a) {
@@ -148,81 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(msmv_min_wa
                 if (lane < npts * 3) lv = locq[p0 * 3 + lane];
                 if (lane >= 16 && lane < 16 + npts * L) lv = wq[p0 * L + (lane - 16)];
             }
-            // Phase 1 -- tap geometry, computed ONCE per wave with the lanes as (tap, corner) pairs instead of
-            // redundantly in all 64 lanes (gfx9 has no scalar float ALU, so "wave-uniform" math costs full VALU rate;
-            // the first version spent ~1500 VALU instructions per query there and was VALU-, not memory-bound):
-            // setup lane s handles tap s/4 = (point, level) and corner s%4 and produces one coefficient
-            // (corner weight x level weight, 0 outside the map) and one 32-bit element offset (bit 31 = "outside").
-            // 4*L*4 = 64 pairs for L = 4: exactly one pass; L = 5 takes a second pass for taps 16..19.
-            constexpr int NPASS = (4 * L * 4 + 63) / 64;
-            float s_coef[NPASS];
-            int s_off[NPASS];
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int t = ps * 16 + (lane >> 2);          // tap index = pp * L + l
-                const int sc = lane & 3, skh = sc >> 1, skw = sc & 1;
-                const int pp = t / L, l = t - pp * L;         // L is a compile-time constant
-                const bool t_ok = t < 4 * L && pp < npts;
-                const int ppc = min(pp, 3);
-                const float x = __shfl(lv, ppc * 3 + 0), y = __shfl(lv, ppc * 3 + 1), z = __shfl(lv, ppc * 3 + 2);
-                const float wl = __shfl(lv, 16 + min(t, 4 * L - 1));
-                int H = a.H[0], W = a.W[0], sv = (int)a.stride_v[0];
-#pragma unroll
-                for (int i = 1; i < L; ++i)
-                    if (l == i) { H = a.H[i]; W = a.W[i]; sv = (int)a.stride_v[i]; }
-                int view = (int)roundf(z * nm1);              // reference: round(loc.z * (num_views - 1))
-                view = min(max(view, 0), a.N - 1);            // (the reference reads out of bounds here; we clamp)
-                const float h_im = y * (float)(H - 1);        // align_corners = True
-                const float w_im = x * (float)(W - 1);
-                const bool lvl_ok = t_ok && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const float lh = h_im - hf, lw = w_im - wf;
-                // clamp before the int conversion so NaN / huge coordinates stay addressable
-                const int hc = (int)fminf(fmaxf(hf, -1.f), (float)H) + skh;
-                const int wc = (int)fminf(fmaxf(wf, -1.f), (float)W) + skw;
-                const bool inb = lvl_ok && hc >= 0 && hc <= H - 1 && wc >= 0 && wc <= W - 1;
-                const float cw = (skh ? lh : 1.f - lh) * (skw ? lw : 1.f - lw);
-                s_coef[ps] = inb ? cw * wl : 0.f;
-                const int hcc = min(max(hc, 0), H - 1), wcc = min(max(wc, 0), W - 1);
-                const int off = view * sv + (hcc * W + wcc) * (int)a.stride_px;      // < 2^31: inside one sample-batch slab
-                s_off[ps] = inb ? off : (off | (int)0x80000000);
-            }
-            // Phase 2 -- every lane (corner k, channel quad j) fetches the (coef, offset) of ITS corner of tap t with two
-            // ds_bpermute (the LDS crossbar: this is the "stage the query's coordinates once" step, without an LDS round
-            // trip through memory), and ALL 4*L tap loads are issued back to back; phase 3 consumes them.
-            float tcoef[4][L];
-            int toff[4][L];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    const int t = pp * L + l;
-                    const int src = ((t & 15) * 4 + k) * 4;   // byte address of setup lane (t%16)*4 + k
-                    tcoef[pp][l] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(s_coef[t / 16])));
-                    toff[pp][l] = __builtin_amdgcn_ds_bpermute(src, s_off[t / 16]);
-                }
-            decltype(load_raw(base[0])) tv[4][L];
-            __builtin_amdgcn_sched_barrier(0);     // pin the phases: hipcc otherwise re-interleaves loads, waits and math
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-                for (int l = 0; l < L; ++l) tv[pp][l] = load_raw(base[l] + (toff[pp][l] & 0x7fffffff));   // always a valid address
-            __builtin_amdgcn_sched_barrier(0);
-            float4 acc[4];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                acc[pp] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    float4 v = widen(tv[pp][l]);
-                    if (toff[pp][l] < 0 || !chan_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);   // outside the map: exactly 0
-                    const float coef = tcoef[pp][l];
-                    acc[pp].x = fmaf(coef, v.x, acc[pp].x);
-                    acc[pp].y = fmaf(coef, v.y, acc[pp].y);
-                    acc[pp].z = fmaf(coef, v.z, acc[pp].z);
-                    acc[pp].w = fmaf(coef, v.w, acc[pp].w);
-                }
-            }
+#include "msmv_chunk.inc"
             if (OUT == SBEV_OUT_REF) {
                 // out[b', q, c, p]: scatter by CHANNEL -- row k ends up with channel c0 + 4j + k of all 4 points
                 float r[4];

@@ -255,6 +255,41 @@ def msmv_sampling_ring(levels, B, T, G, frame_slots, n_slots, sampling_locations
     return out
 
 
+def sample_mix_supported(L, C, P, T, G):
+    return bool(_lib.load().sbev_sample_mix_supported(L, C, P, T, G, G))
+
+
+def sample_mix(levels, B, T, G, sampling_locations, scale_weights, params, out_points, frame_slots=None, n_slots=0):
+    """Gather + adaptive mixing in one launch (sbev_sample_mix_f32): levels as for msmv_sampling_nhwc (or the ring's
+    buffers with frame_slots / n_slots), params [B,Q,G*(C*C + out_points*T*P)] -> mixed [B,Q,G*out_points*C].
+    Bit-identical to msmv_sampling_nhwc(..., OUT_MIX) followed by the mixing kernel."""
+    feats = list(levels)
+    _need_device(sampling_locations, scale_weights, params, *feats)
+    _no_grad_only(sampling_locations, scale_weights, params, *feats)
+    N = N_VIEWS
+    Q, P = _check_sampling_args(feats, sampling_locations, scale_weights, B * T * G, 'sample_mix')
+    GC = feats[0].shape[-1]
+    C = GC // G
+    L = len(feats)
+    if not sample_mix_supported(L, C, P, T, G):
+        raise RuntimeError('sample_mix: shape not covered by the fused kernel (L=%d C=%d P=%d T=%d)' % (L, C, P, T))
+    hw = [(f.shape[1], f.shape[2]) for f in feats]
+    params = params.contiguous()
+    if params.dtype != torch.float32 or params.numel() != B * Q * G * (C * C + out_points * T * P):
+        raise RuntimeError('sample_mix: params must be fp32 [B, Q, G*(C*C + out_points*T*P)]')
+    y = torch.empty(B, Q, G * out_points * C, device=params.device, dtype=torch.float32)
+    c_feats = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    c_hw = (ctypes.c_int32 * (2 * L))(*[v for pair in hw for v in pair])
+    c_sbo = (ctypes.c_int64 * L)(*[N * h * w * GC for h, w in hw])
+    c_sv = (ctypes.c_int64 * L)(*[h * w * GC for h, w in hw])
+    c_slots = (ctypes.c_int32 * T)(*[int(v) for v in frame_slots]) if frame_slots is not None else None
+    st = _lib.load().sbev_sample_mix_f32(c_feats, c_hw, L, _feat_dtype(feats), B, N, Q, T, G, P, C, c_sbo, C, c_sv, GC,
+                                         _ptr(sampling_locations.contiguous()), _ptr(scale_weights.contiguous()), c_slots, n_slots,
+                                         _ptr(params), _ptr(y), out_points, 1e-5, _stream())
+    _lib.check(st, 'sbev_sample_mix_f32')
+    return y
+
+
 def project_select(sample_points, lidar2img, image_h, image_w, G, P, eps=1e-5, dump=False):
     """Front half of sampling_4d (models/sparsebev_sampling.py:49-114) on device, bit-exact camera-hit
     mask.  sample_points ``[B,Q,T,G*P,3]``, lidar2img ``[B,T*6,4,4]`` -> loc ``[B*T*G,Q,P,3]`` and, with

@@ -41,6 +41,9 @@ class DecoderRuntime:
     Re-binds automatically when a parameter is replaced or modified in place (``_version`` / ``data_ptr`` change)."""
 
     def __init__(self, decoder, gemm_mode=0, overlap=False):
+        import os
+        if os.environ.get('SBEV_NO_SAMPLE_MIX') == '1':
+            fuse_sample_mix(False)
         self.decoder = decoder
         self.gemm_mode = gemm_mode
         self.overlap = overlap
@@ -201,8 +204,15 @@ class DecoderGraph:
             pass
 
 
+def fuse_sample_mix(enable):
+    """Gather + adaptive mixing as one launch inside sbev_decoder_forward where the fused kernel covers the shape (default on;
+    results are bit-identical either way).  ``SBEV_NO_SAMPLE_MIX=1`` in the environment switches it off for A/B runs."""
+    _lib.check(_lib.load().sbev_decoder_fuse_sample_mix(int(bool(enable))), 'sbev_decoder_fuse_sample_mix')
+
+
 def profile_sampler(enable):
-    """enable: False / True (sampler launches only) or an int mask (1 sampler | 2 generator GEMM | 4 out-projection GEMM)."""
+    """enable: False / True (sampler launches only) or an int mask (1 sampler | 2 generator GEMM | 4 out-projection GEMM |
+    8 fused gather + mixing)."""
     _lib.load().sbev_profile_sampler(int(enable))
 
 
@@ -212,7 +222,8 @@ def profile_stride(every_n_calls):
 
 
 def read_kernel_ms(kind, max_n=4096):
-    """Elapsed ms of the bracketed launches of one kind (0 sampler, 1 generator GEMM, 2 out-projection GEMM)."""
+    """Elapsed ms of the bracketed launches of one kind (0 sampler, 1 generator GEMM, 2 out-projection GEMM, 3 fused gather +
+    mixing)."""
     buf = (ctypes.c_float * max_n)()
     n = _lib.load().sbev_profile_read(kind, buf, max_n)
     return [buf[i] for i in range(n)]

@@ -1,0 +1,94 @@
+"""The fused gather + adaptive-mixing launch (sbev_sample_mix_f32) against the two launches it replaces: the workgroup of
+a (query, group) item samples its own [T*P, 64] rows with the sampler's chunk code and mixes them, so results must be
+BIT-identical to msmv_sampling (OUT_MIX) followed by the mixing kernel -- dense and ring pyramids, fp32 and bf16 storage,
+4 and 5 levels -- and the decoder runtime must give identical outputs with the fusion on and off."""
+import copy
+import ctypes
+
+import pytest
+import torch
+
+from sparsebev_amd import _lib, ops, runtime as rt, synthetic as S
+from sparsebev_amd.transformer import SparseBEVTransformer
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+PREFIX = 'decoder.decoder_layer.'
+
+
+def mixing(x, params, out_points=128):
+    B, Q, G, Pin, C = x.shape
+    y = torch.empty(B, Q, G * out_points * C, device=x.device)
+    st = _lib.load().sbev_adaptive_mixing_f32(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(params.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                              B * Q, G, Pin, C, out_points, 1e-5, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    return y
+
+
+@pytest.mark.parametrize('B,Q,T,pyr,dtype', [(1, 900, 8, 'tiny', torch.float32), (2, 37, 4, 'tiny5', torch.float32),
+                                             (1, 100, 8, 'tiny5', torch.bfloat16), (3, 5, 16, 'tiny', torch.bfloat16),
+                                             (1, 64, 12, 'r50_704x256', torch.float32)])
+def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtype):
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    L, G, P, C = len(sizes), 4, 4, 64
+    g = torch.Generator(device=DEV).manual_seed(B * 100 + Q + T)
+    levels = [torch.randn(B * T * 6, h, w, G * C, generator=g, device=DEV).to(dtype) for h, w in sizes]
+    loc = torch.rand(B * T * G, Q, P, 3, generator=g, device=DEV) * 1.3 - 0.15          # incl. a border band and outside points
+    loc[..., 2] = torch.randint(0, 6, (B * T * G, Q, P), generator=g, device=DEV).float() / 5
+    w = torch.softmax(torch.randn(B * T * G, Q, P, L, generator=g, device=DEV), -1)
+    params = torch.randn(B, Q, G * (C * C + 128 * T * P), generator=g, device=DEV) * 0.3
+    assert ops.sample_mix_supported(L, C, P, T, G)
+    x = ops.msmv_sampling_nhwc(levels, B, T, G, loc, w, out_layout=ops.OUT_MIX)
+    want = mixing(x, params)
+    got = ops.sample_mix(levels, B, T, G, loc, w, params, 128)
+    assert torch.equal(got, want)
+    assert got.abs().max() > 0
+
+
+def test_fused_launch_on_the_frame_ring():
+    B, Q, T, n_slots, G, P, C = 2, 50, 4, 6, 4, 4, 64
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    L = len(sizes)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    levels = [torch.randn(B * n_slots * 6, h, w, G * C, generator=g, device=DEV) for h, w in sizes]
+    slots = [4, 0, 5, 2]
+    loc = torch.rand(B * T * G, Q, P, 3, generator=g, device=DEV)
+    loc[..., 2] = torch.randint(0, 6, (B * T * G, Q, P), generator=g, device=DEV).float() / 5
+    w = torch.softmax(torch.randn(B * T * G, Q, P, L, generator=g, device=DEV), -1)
+    params = torch.randn(B, Q, G * (C * C + 128 * T * P), generator=g, device=DEV) * 0.3
+    x = ops.msmv_sampling_ring(levels, B, T, G, slots, n_slots, loc, w)
+    got = ops.sample_mix(levels, B, T, G, loc, w, params, 128, frame_slots=slots, n_slots=n_slots)
+    assert torch.equal(got, mixing(x, params))
+
+
+def test_unsupported_shapes_are_refused_and_the_runtime_falls_back():
+    assert not ops.sample_mix_supported(4, 64, 8, 2, 4)        # P = 8
+    assert not ops.sample_mix_supported(4, 64, 4, 2, 4)        # T*P = 8: not a multiple of 16
+    assert not ops.sample_mix_supported(3, 64, 4, 8, 4)
+    levels = [torch.zeros(12, 4, 4, 256, device=DEV) for _ in range(4)]
+    with pytest.raises(RuntimeError):
+        ops.sample_mix(levels, 1, 2, 4, torch.zeros(8, 3, 4, 3, device=DEV), torch.zeros(8, 3, 4, 4, device=DEV),
+                       torch.zeros(1, 3, 4 * (4096 + 128 * 8), device=DEV), 128)
+
+
+@pytest.mark.parametrize('T,L,pyr', [(8, 4, 'tiny'), (4, 5, 'tiny5'), (2, 4, 'tiny')])
+def test_decoder_runtime_fused_equals_unfused(T, L, pyr):
+    B, Q = 2, 100
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    params = S.make_params(3, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=3, num_levels=L, pc_range=S.PC_RANGE)
+    m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=4)]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=5)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    try:
+        rt.fuse_sample_mix(True)
+        a = m(bbox, feat, list(feats), None, copy.deepcopy(metas))
+        rt.fuse_sample_mix(False)
+        b = m(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    finally:
+        rt.fuse_sample_mix(True)
+    lw = m(bbox, feat, list(feats), None, copy.deepcopy(metas), layerwise=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0], lw[0]) and torch.equal(a[1], lw[1])

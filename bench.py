@@ -149,6 +149,11 @@ def gpu_quick(config, device, steps=30, warmup=5):
     return round(steps * B / dt, 2), model
 
 
+def ops_sample_mix_supported(L, T):
+    from sparsebev_amd import ops
+    return os.environ.get('SBEV_NO_SAMPLE_MIX') != '1' and ops.sample_mix_supported(L, 64, 4, T, 4)
+
+
 def mfma_util():
     """MFMA-pipe utilisation per kernel from the committed PMC summary (tools/mfma_summary.py), {} when absent."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
@@ -272,11 +277,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP events around the sampler launches, on their stream, in every 5th step of the timed region: the two records
+    # HIP events around the gather launches, on their stream, in every 5th step of the timed region: the two records
     # around a launch leave ~5.6 us of idle stream each (kernel trace), i.e. bracketing all six launches of every step
-    # would cost `value` 2 %
+    # would cost `value` 2 %.  The decoder step runs the gather FUSED with the adaptive-mixing kernel where the fused
+    # launch covers the shape (kind 3); otherwise the stand-alone sampler (kind 0) is what the step launches.
+    fused_cfg = ops_sample_mix_supported(L, T)
     runtime.profile_stride(PROFILE_EVERY)
-    runtime.profile_sampler(True)
+    runtime.profile_sampler(8 if fused_cfg else 1)
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -287,13 +294,22 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sorted(runtime.read_sampler_ms())
+    fused_ms = sorted(runtime.read_kernel_ms(3)) if fused_cfg else []
+    kernel_ms = [] if fused_cfg else sorted(runtime.read_sampler_ms())
+    # a few extra steps outside the timed region: the two mixing GEMMs bracketed, and -- when the timed steps ran the fused
+    # launch -- the same decoder step with the sampler as its own launch (fusion off), so that the stand-alone sampling
+    # kernel of BASELINE.json's metric is timed in the decoder's cache state on the same inputs
     runtime.profile_stride(1)
-    runtime.profile_sampler(6)                   # a few extra steps (outside the timed region) with the two mixing GEMMs bracketed
+    runtime.profile_sampler(6 | (1 if fused_cfg else 0))
+    if fused_cfg:
+        runtime.fuse_sample_mix(False)
     for _ in range(min(10, args.steps)):
         step()
     torch.cuda.synchronize()
     gemm_ms = [sorted(runtime.read_kernel_ms(k)) for k in (1, 2)]
+    if fused_cfg:
+        kernel_ms = sorted(runtime.read_sampler_ms())
+        runtime.fuse_sample_mix(True)
     runtime.profile_sampler(False)
     checksum = float(cls.double().abs().sum().item() + box.double().abs().sum().item())
 
@@ -371,8 +387,25 @@ def main():
                          'cache_served_fraction': round(1.0 - traffic / alg_bytes, 4) if traffic else None,
                          'l2_hit_ratio_pmc': pmc.get('l2_hit_ratio') if pmc else None,
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
-                         'event_sampling': 'HIP events around the sampler launches of every %dth step of the timed region' % PROFILE_EVERY},
+                         'event_sampling': ('HIP events around the stand-alone sampler launches of %d extra decoder steps run with the fusion off right after '
+                                            'the timed region (inside it the gather runs fused with the mixing kernel: roofline_fused)' % min(10, args.steps))
+                                           if fused_ms else 'HIP events around the sampler launches of every %dth step of the timed region' % PROFILE_EVERY},
         }
+        if fused_ms:
+            # the launch the timed steps really run: gather + adaptive mixing in one kernel.  Algorithmic bytes = the sampler's
+            # gather reads (no [B,Q,G,T*P,C] write any more) + the item's dynamic parameters + its mixed output
+            f_avg = sum(fused_ms) / len(fused_ms)
+            items = B * Q * G_
+            f_alg = npts * (L * 4 * Cg_ * sf + 12 + 4 * L) + items * ((Cg_ * Cg_ + 128 * T * P_) * 4 + 128 * Cg_ * 4)
+            fp, fp_file = pmc_profile(args.config, 'adaptive_mixing_kernel')
+            f_traffic = fp['hbm_bytes_per_launch'] if fp else None
+            out['roofline_fused'] = {'kernel': 'adaptive_mixing_kernel<RT, true, L, FT> (gather + adaptive mixing, one launch)', 'bound': 'hbm',
+                                     'achieved': round(f_traffic / (f_avg * 1e-3) / 1e9, 1) if f_traffic else None, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                                     'frac': round(f_traffic / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if f_traffic else None,
+                                     'traffic': f_traffic, 'traffic_source': ('profiles/%s' % fp_file) if fp else 'no committed PMC profile for this config',
+                                     'achieved_algorithmic': round(f_alg / (f_avg * 1e-3) / 1e9, 1), 'algorithmic_bytes_per_launch': f_alg,
+                                     'launches': len(fused_ms), 'avg_us': round(f_avg * 1e3, 2),
+                                     'event_sampling': 'HIP events around the fused launches of every %dth step of the timed region' % PROFILE_EVERY}
         # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event
         # measurement, priced against the f32-input MFMA peak; PMC MFMA-pipe utilisation from profiles/ when present
         if args.gemm == 'f32' and all(gemm_ms):

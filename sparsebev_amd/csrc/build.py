@@ -25,7 +25,9 @@ UNITS = {
     'mixing_bwd.hip': [],
     'attention_bwd.hip': [],
     'backward_ops.hip': ['-ffp-contract=off'],   # re-runs project.hip's individually rounded projection to re-select the camera
-    'mixing.hip': [],
+    # no implicit FMA contraction: the fused gather + mixing instantiations and the plain mixing kernel must round identically
+    # (contraction decisions are made per instantiation by the backend; explicit fmaf / MFMA are unaffected)
+    'mixing.hip': ['-ffp-contract=off'],
     'attention.hip': [],
     'layout.hip': [],
     'head.hip': ['-ffp-contract=off'],   # __fmul_rn / __fadd_rn are plain * and + in HIP: keep them unfused

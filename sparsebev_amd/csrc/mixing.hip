@@ -103,8 +103,15 @@ __device__ __forceinline__ void block_mean_rstd(float s_w, float m2_w, float n_w
 
 // RT = ceil(Pin / 16) row tiles of matmul 1; WIDE: Pin % 16 == 0 (b128 A reads in matmul 2); L > 0: fused sampler with L
 // feature levels of storage type FT (WIDE only)
+#ifndef SBEV_SAMPLE_MIX_WAVES
+#define SBEV_SAMPLE_MIX_WAVES 3          // waves per SIMD asked of the register allocator for the fused instantiations: 184 -> 151 VGPRs, no
+                                         // spills, 318 -> 326 samples/s at config 2 (unfused 320; requesting M / S before the gather: 313..319)
+#endif
+template <int L>
+constexpr int mix_min_waves() { return L > 0 ? SBEV_SAMPLE_MIX_WAVES : 1; }
+
 template <int RT, bool WIDE, int L = 0, typename FT = float>
-__global__ __launch_bounds__(256) void adaptive_mixing_kernel(const typename MixArgsOf<L>::type a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_waves<L>()))) void adaptive_mixing_kernel(const typename MixArgsOf<L>::type a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
     const int lds_s = Pin + 4;                                  // S row stride

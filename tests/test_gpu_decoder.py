@@ -348,14 +348,15 @@ def test_profile_stride_brackets_every_nth_call_only():
     bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=53)]
     run = DecoderRuntime(model.decoder)
     ref = [t.clone() for t in run.forward(bbox, feat, pyr, ctx)]
-    rt.read_sampler_ms()                                       # drop anything an earlier test left behind
+    rt.read_kernel_ms(3)                                       # drop anything an earlier test left behind
+    rt.read_sampler_ms()
     try:
         rt.profile_stride(3)
-        rt.profile_sampler(True)
+        rt.profile_sampler(1 | 8)                              # the stand-alone sampler and the fused gather + mixing launch
         for _ in range(7):
             out = run.forward(bbox, feat, pyr, ctx)
         torch.cuda.synchronize()
-        ms = rt.read_sampler_ms()
+        ms = rt.read_sampler_ms() + rt.read_kernel_ms(3)       # this shape (T*P = 16) runs fused: kind 3; kind 0 stays empty
     finally:
         rt.profile_sampler(False)
         rt.profile_stride(1)

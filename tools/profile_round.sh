@@ -1,19 +1,28 @@
 #!/bin/bash
-# Round profile recipe (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats of the same command,
-# and the two separate PMC passes (FETCH_SIZE / WRITE_SIZE) that tools/pmc_summary.py turns into bytes per launch.
+# Round profile recipe (run on the GPU box through gpurun):  tools/profile_round.sh r2
+# bench line (default command), rocprofv3 kernel stats of the same workload (exact fp32 and the opt-in bf16x3 mode), the
+# MFMA-busy counter pass, the other configs' bench lines, one training step's kernel stats.  PMC byte counters per config:
+# tools/profile_pmc.sh.  Everything lands in gpurun_out/prof_<round>/; copy what is to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof
+ROUND=${1:-r2}
+OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
-tail -1 $OUT/bench_line.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py --no-cpu-baseline --no-alt --steps 20 > $OUT/kt.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o bench -- python $R/bench.py --no-cpu-baseline --no-alt --steps 20 --gemm bf16x3 > $OUT/kt3.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py --no-cpu-baseline --no-alt --steps 5 --warmup 2 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $R/bench.py --no-cpu-baseline --no-alt --steps 5 --warmup 2 > $OUT/pmc_write.log 2>&1
-find $OUT -name "*.csv" | head -20
-for c in c1 c3 c4; do python $R/bench.py --config $c --no-cpu-baseline --no-alt --steps 30 2>/dev/null | tail -1 | cut -c1-200; done
-python $R/bench.py --nhwc --no-cpu-baseline --no-alt --steps 50 2>/dev/null | tail -1 | cut -c1-200
-python $R/bench.py --online --no-cpu-baseline --no-alt --steps 50 2>/dev/null | tail -1 | cut -c1-200
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $R/bench.py --no-cpu-baseline --no-alt --steps 5 --warmup 2 > $OUT/pmc_mfma.log 2>&1
+tail -1 $OUT/bench_line.json | cut -c1-400
+Q="--no-cpu-baseline --no-alt --no-detector"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py $Q --steps 20 > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o bench -- python $R/bench.py $Q --steps 20 --gemm bf16x3 > $OUT/kt3.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 > $OUT/pmc_mfma.log 2>&1
+python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary.json | head -12
+rm -f $(find $OUT/pmc_mfma -name "*counter_collection.csv")
+for c in c1 c3 c4 c5; do python $R/bench.py --config $c $Q --steps 30 2>/dev/null | tail -1 > $OUT/bench_$c.json; cut -c1-220 $OUT/bench_$c.json; done
+python $R/bench.py --nhwc $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_nhwc.json; cut -c1-200 $OUT/bench_nhwc.json
+python $R/bench.py --online $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_online.json; cut -c1-200 $OUT/bench_online.json
+SBEV_NO_SAMPLE_MIX=1 python $R/bench.py $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_unfused.json; cut -c1-200 $OUT/bench_unfused.json
+python $R/tools/bench_train.py > $OUT/train.log 2>&1; tail -1 $OUT/train.log
+python $R/tools/bench_train.py --feat-grad --dropout >> $OUT/train.log 2>&1; tail -1 $OUT/train.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -o train -- python $R/tools/bench_train.py --steps 5 > $OUT/kt_train.log 2>&1
+find $OUT -name "*kernel_stats.csv"
+rm -f $(find $OUT -name "*kernel_trace.csv") $(find $OUT -name "*agent_info.csv")

@@ -281,7 +281,7 @@ def main():
     # around a launch leave ~5.6 us of idle stream each (kernel trace), i.e. bracketing all six launches of every step
     # would cost `value` 2 %.  The decoder step runs the gather FUSED with the adaptive-mixing kernel where the fused
     # launch covers the shape (kind 3); otherwise the stand-alone sampler (kind 0) is what the step launches.
-    fused_cfg = ops_sample_mix_supported(L, T)
+    fused_cfg = ops_sample_mix_supported(L, T) and not (L == 5 and fdtype == torch.float32)     # the runtime's own rule (csrc/decoder.hip)
     runtime.profile_stride(PROFILE_EVERY)
     runtime.profile_sampler(8 if fused_cfg else 1)
     shard.barrier()

@@ -8,7 +8,7 @@
 //     dV_j = sum_i Pd_ij dO_i        dPd_ij = dO_i . v_j        dS_ij = P_ij (keep_ij dPd_ij / (1-p) - D_i),  D_i = dO_i . O_i
 //     dq_i = sum_j dS_ij k_j / sqrt(d)     dk_j = sum_i dS_ij q_i / sqrt(d)     dtau_ih = -sum_j dS_ij dist_ij
 // (dist carries no gradient: calc_bbox_dists is @torch.no_grad, :236-248.)
-// Two deterministic passes, flash-attention style: a ROW kernel (thread = one query of one head; online softmax over key
+// Two deterministic passes, flash-attention style: a ROW kernel (lane = one query of one head, four waves share the keys; online softmax over key
 // tiles staged in LDS, then dq / dtau and the row's log-sum-exp + D_i) and a COLUMN kernel (thread = one key; loops over
 // query tiles, accumulates dk / dv).  No atomics.  The dropout keep decision is a hash of (seed, b, h, i, j), so forward
 // and both backward kernels regenerate the same mask.  1.3 GFLOP forward per layer-sample: plain VALU math is enough.
@@ -47,12 +47,23 @@ __device__ __forceinline__ bool keep_of(const SasaBwdArgs& a, unsigned thr, int 
     return mix32(a.seed * 0x100000001b3ull + idx) >= thr;
 }
 
-// grid = (ceil(Q / 64), H, B), 64 threads: thread = query row.  FWD: writes O (training forward with dropout);
-// !FWD: writes dq, dtau (and zeroes the padding columns), lse, dvec.
+constexpr int NW = 4;          // waves per workgroup: wave w walks key (row kernel) / query (column kernel) tiles w, w + 4, ...
+constexpr int ROWF = 2 * TILE * (HD + 1) + 2 * TILE;      // floats of one wave's private tile area: K | V | centres (row kernel)
+constexpr int COLF = 2 * TILE * (HD + 1) + 5 * TILE;      // Q | dO | (cx, cy, tau, lse, dvec) (column kernel)
+
+// grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 query rows: lane = query row, wave w owns the key tiles w, w + 4, ...
+// (its own LDS tile area: no workgroup barrier inside the loops -- a wave's DS operations execute in order), and the four
+// partial results of a row are merged through LDS: (max, sum) after pass 1, (dq | O, dtau) after pass 2.  With one wave
+// per 64 rows the kernel was 120 waves of two 900-key serial loops (0.99 ms per layer at config 2).
+// FWD: writes O (training forward with dropout); !FWD: writes dq, dtau (and zeroes the padding columns), lse, dvec.
 template <bool FWD>
-__global__ __launch_bounds__(64) void sasa_row_kernel(const SasaBwdArgs a) {
-    __shared__ float Ks[TILE][HD + 1], Vs[TILE][HD + 1], Cs[TILE][2];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) {
+    __shared__ float smem[NW * ROWF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float (*Ks)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * ROWF);
+    float (*Vs)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * ROWF + TILE * (HD + 1));
+    float (*Cs)[2] = reinterpret_cast<float (*)[2]>(smem + wave * ROWF + 2 * TILE * (HD + 1));
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = a.H * HD;
     const int i = blockIdx.x * 64 + lane;
@@ -77,8 +88,8 @@ __global__ __launch_bounds__(64) void sasa_row_kernel(const SasaBwdArgs a) {
     }
     float m = -INFINITY, l = 0.f, dtau = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
-        for (int k0 = 0; k0 < a.Q; k0 += TILE) {
-            __syncthreads();
+        for (int k0 = wave * TILE; k0 < a.Q; k0 += NW * TILE) {
+            __builtin_amdgcn_wave_barrier();                 // the wave is done reading its previous tile
             {
                 const int kj = min(k0 + lane, a.Q - 1);
                 const float* row = base + (long long)kj * a.ld + h * HD;
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(64) void sasa_row_kernel(const SasaBwdArgs a) {
                 Cs[lane][0] = a.bbox[((long long)b * a.Q + kj) * 10] * a.span[0] + a.lo[0];
                 Cs[lane][1] = a.bbox[((long long)b * a.Q + kj) * 10 + 1] * a.span[1] + a.lo[1];
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             const int nk = min(TILE, a.Q - k0);
             for (int jj = 0; jj < nk; ++jj) {
                 const int j = k0 + jj;
@@ -129,8 +140,39 @@ __global__ __launch_bounds__(64) void sasa_row_kernel(const SasaBwdArgs a) {
                 }
             }
         }
+        if (pass == 0) {
+            // merge the four waves' (max, sum) of every row: all waves end up with the row's global softmax statistics
+            __syncthreads();
+            float* mg = smem;                                // [NW][2][64]
+            mg[(wave * 2 + 0) * 64 + lane] = m;
+            mg[(wave * 2 + 1) * 64 + lane] = l;
+            __syncthreads();
+            float mm = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mm = fmaxf(mm, mg[(w * 2) * 64 + lane]);
+            float ll = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float mw = mg[(w * 2) * 64 + lane];
+                ll += mw == -INFINITY ? 0.f : mg[(w * 2 + 1) * 64 + lane] * __expf(mw - mm);
+            }
+            m = mm;
+            l = ll;
+            __syncthreads();                                 // the merge area aliases the tile areas
+        }
     }
-    if (!live) return;
+    // merge the partial accumulators (fixed order: deterministic); [NW][HD + 1][64] floats alias the tile areas
+    __syncthreads();
+    float* pr = smem;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) pr[(wave * (HD + 1) + d) * 64 + lane] = acc[d];
+    pr[(wave * (HD + 1) + HD) * 64 + lane] = dtau;
+    __syncthreads();
+    if (wave != 0 || !live) return;
+#pragma unroll
+    for (int d = 0; d < HD; ++d)
+        acc[d] = (pr[d * 64 + lane] + pr[((HD + 1) + d) * 64 + lane]) + (pr[(2 * (HD + 1) + d) * 64 + lane] + pr[(3 * (HD + 1) + d) * 64 + lane]);
+    dtau = (pr[HD * 64 + lane] + pr[((HD + 1) + HD) * 64 + lane]) + (pr[(2 * (HD + 1) + HD) * 64 + lane] + pr[(3 * (HD + 1) + HD) * 64 + lane]);
     if (FWD) {
 #pragma unroll
         for (int d = 0; d < HD; ++d) a.out[((long long)b * a.Q + i) * D + h * HD + d] = acc[d];
@@ -146,10 +188,15 @@ __global__ __launch_bounds__(64) void sasa_row_kernel(const SasaBwdArgs a) {
     }
 }
 
-// grid = (ceil(Q / 64), H, B), 64 threads: thread = key column j; writes dk_j, dv_j.
-__global__ __launch_bounds__(64) void sasa_col_kernel(const SasaBwdArgs a) {
-    __shared__ float Qs[TILE][HD + 1], Gs[TILE][HD + 1], Rs[TILE][5];   // Rs: cx, cy, tau, lse, dvec of the query
-    const int lane = threadIdx.x;
+// grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 keys: lane = key column j, wave w owns the query tiles w, w + 4, ...;
+// the four partial (dk_j, dv_j) are merged through LDS in a fixed order.
+__global__ __launch_bounds__(64 * NW) void sasa_col_kernel(const SasaBwdArgs a) {
+    __shared__ float smem[NW * COLF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float (*Qs)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * COLF);
+    float (*Gs)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * COLF + TILE * (HD + 1));
+    float (*Rs)[5] = reinterpret_cast<float (*)[5]>(smem + wave * COLF + 2 * TILE * (HD + 1));   // cx, cy, tau, lse, dvec of the query
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = a.H * HD;
     const int j = blockIdx.x * 64 + lane;
@@ -166,8 +213,8 @@ __global__ __launch_bounds__(64) void sasa_col_kernel(const SasaBwdArgs a) {
     }
     const float kx = a.bbox[((long long)b * a.Q + jc) * 10] * a.span[0] + a.lo[0];
     const float ky = a.bbox[((long long)b * a.Q + jc) * 10 + 1] * a.span[1] + a.lo[1];
-    for (int i0 = 0; i0 < a.Q; i0 += TILE) {
-        __syncthreads();
+    for (int i0 = wave * TILE; i0 < a.Q; i0 += NW * TILE) {
+        __builtin_amdgcn_wave_barrier();
         {
             const int qi = min(i0 + lane, a.Q - 1);
 #pragma unroll
@@ -181,7 +228,7 @@ __global__ __launch_bounds__(64) void sasa_col_kernel(const SasaBwdArgs a) {
             Rs[lane][3] = a.lse[((long long)b * a.H + h) * a.Q + qi];
             Rs[lane][4] = a.dvec[((long long)b * a.H + h) * a.Q + qi];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         const int ni = min(TILE, a.Q - i0);
         for (int ii = 0; ii < ni; ++ii) {
             const int i = i0 + ii;
@@ -205,12 +252,21 @@ __global__ __launch_bounds__(64) void sasa_col_kernel(const SasaBwdArgs a) {
             }
         }
     }
-    if (!live) return;
+    __syncthreads();
+    float* pr = smem;                              // [NW][2 * HD][64] floats = 64 KiB <= NW * COLF * 4
+    static_assert(NW * 2 * HD * 64 <= NW * COLF, "merge area must fit the tile areas");
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        pr[(wave * 2 * HD + d) * 64 + lane] = dk[d];
+        pr[(wave * 2 * HD + HD + d) * 64 + lane] = dv[d];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
     float* g = a.dqkvt + ((long long)b * a.Q + j) * a.ld;
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
-        g[D + h * HD + d] = dk[d];
-        g[2 * D + h * HD + d] = dv[d];
+        g[D + h * HD + d] = (pr[d * 64 + lane] + pr[(2 * HD + d) * 64 + lane]) + (pr[(4 * HD + d) * 64 + lane] + pr[(6 * HD + d) * 64 + lane]);
+        g[2 * D + h * HD + d] = (pr[(HD + d) * 64 + lane] + pr[(3 * HD + d) * 64 + lane]) + (pr[(5 * HD + d) * 64 + lane] + pr[(7 * HD + d) * 64 + lane]);
     }
 }
 
@@ -242,7 +298,7 @@ extern "C" int sbev_sasa_train_fwd_f32(const float* qkvt, int64_t ld, const floa
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(qkvt && query_bbox && pc_range && out, "sbev_sasa_train_fwd_f32: null pointer");
     a.out = out;
-    hipLaunchKernelGGL(sasa_row_kernel<true>, dim3((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B), dim3(64), 0,
+    hipLaunchKernelGGL(sasa_row_kernel<true>, dim3((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B), dim3(64 * NW), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_sasa_train_fwd_f32");
 }
@@ -261,9 +317,9 @@ extern "C" int sbev_sasa_bwd_f32(const float* qkvt, int64_t ld, const float* que
     a.dvec = workspace + (long long)B * H * Q;           // [B, H, Q]
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(sasa_row_kernel<false>, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(sasa_row_kernel<false>, grid, dim3(64 * NW), 0, s, a);
     st = sbev::check_launch("sbev_sasa_bwd_f32 (rows)");
     if (st != SBEV_OK) return st;
-    hipLaunchKernelGGL(sasa_col_kernel, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(sasa_col_kernel, grid, dim3(64 * NW), 0, s, a);
     return sbev::check_launch("sbev_sasa_bwd_f32 (columns)");
 }

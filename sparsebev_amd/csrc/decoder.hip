@@ -206,8 +206,10 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                                     c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
         // gather + adaptive mixing: ONE launch when the fused kernel covers the shape (the sampled features then never
         // touch HBM), else the sampler followed by the mixing kernel (same arithmetic, bit-identical results)
+        // (not for 5 fp32 levels: the fused instantiation needs 168 registers + spills for 3 waves per SIMD there and measured
+        // 272 vs 277 samples/s at config 4; 4 fp32 levels +1.6 % at config 2, 5 bf16 levels +4.3 % at config 5)
         const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                           sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0;
+                           sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
         if (!fused) {
             if (c.n_slots > 0)
                 TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,

@@ -300,16 +300,21 @@ def main():
     # launch -- the same decoder step with the sampler as its own launch (fusion off), so that the stand-alone sampling
     # kernel of BASELINE.json's metric is timed in the decoder's cache state on the same inputs
     runtime.profile_stride(1)
-    runtime.profile_sampler(6 | (1 if fused_cfg else 0))
-    if fused_cfg:
+    if fused_cfg:                                # (own phase: event records around the neighbouring GEMM launches would inflate it)
         runtime.fuse_sample_mix(False)
+        runtime.profile_stride(PROFILE_EVERY)
+        runtime.profile_sampler(1)
+        for _ in range(min(20, 2 * args.steps)):
+            step()
+        torch.cuda.synchronize()
+        kernel_ms = sorted(runtime.read_sampler_ms())
+        runtime.fuse_sample_mix(True)
+        runtime.profile_stride(1)
+    runtime.profile_sampler(6)
     for _ in range(min(10, args.steps)):
         step()
     torch.cuda.synchronize()
     gemm_ms = [sorted(runtime.read_kernel_ms(k)) for k in (1, 2)]
-    if fused_cfg:
-        kernel_ms = sorted(runtime.read_sampler_ms())
-        runtime.fuse_sample_mix(True)
     runtime.profile_sampler(False)
     checksum = float(cls.double().abs().sum().item() + box.double().abs().sum().item())
 
@@ -387,8 +392,8 @@ def main():
                          'cache_served_fraction': round(1.0 - traffic / alg_bytes, 4) if traffic else None,
                          'l2_hit_ratio_pmc': pmc.get('l2_hit_ratio') if pmc else None,
                          'launches': len(kernel_ms), 'avg_us': round(avg_ms * 1e3, 2),
-                         'event_sampling': ('HIP events around the stand-alone sampler launches of %d extra decoder steps run with the fusion off right after '
-                                            'the timed region (inside it the gather runs fused with the mixing kernel: roofline_fused)' % min(10, args.steps))
+                         'event_sampling': ('HIP events around the stand-alone sampler launches of every %dth of %d extra decoder steps run with the fusion off right after '
+                                            'the timed region (inside it the gather runs fused with the mixing kernel: roofline_fused)' % (PROFILE_EVERY, min(20, 2 * args.steps)))
                                            if fused_ms else 'HIP events around the sampler launches of every %dth step of the timed region' % PROFILE_EVERY},
         }
         if fused_ms:

@@ -84,17 +84,11 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     __syncthreads();
     // ---- y2 = S n1 : thread = channel c (lane) x rows o = wave, wave + 4, ...   (S[o][p] is wave-uniform)
     s = 0.f;
-    for (int o = wave; o < POUT; o += 16) {                    // 4 rows per pass: one LDS read of n1[p][c] feeds 4 FMAs
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;  // (the S operands are wave-uniform: scalar loads)
-        for (int p = 0; p < Pin; ++p) {
-            const float n = fmaxf(h1[p * LD + lane], 0.f);
-            acc0 += Sg[o * Pin + p] * n;
-            acc1 += Sg[(o + 4) * Pin + p] * n;
-            acc2 += Sg[(o + 8) * Pin + p] * n;
-            acc3 += Sg[(o + 12) * Pin + p] * n;
-        }
-        y2[o * LD + lane] = acc0; y2[(o + 4) * LD + lane] = acc1; y2[(o + 8) * LD + lane] = acc2; y2[(o + 12) * LD + lane] = acc3;
-        s += (acc0 + acc1) + (acc2 + acc3);
+    for (int o = wave; o < POUT; o += 4) {
+        float acc = 0.f;
+        for (int p = 0; p < Pin; ++p) acc += Sg[o * Pin + p] * fmaxf(h1[p * LD + lane], 0.f);
+        y2[o * LD + lane] = acc;
+        s += acc;
     }
     const float mean2 = block_sum(s, red, wave, lane) / n2cnt;
     s = 0.f;
@@ -130,41 +124,24 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     }
     // ---- dn1[p][c] = sum_o S[o][p] dy2[o][c];  g1 = dn1 * (h1 > 0)
     sg = 0.f; sgh = 0.f;
-    for (int p0 = wave; p0 < Pin; p0 += 16) {                  // up to 4 rows p per pass share every LDS read of dy2[o][c]
-        float accv[4] = {0.f, 0.f, 0.f, 0.f};
-        const int np = min(4, (Pin - p0 + 3) / 4);
-        for (int o = 0; o < POUT; ++o) {
-            const float dv = y2[o * LD + lane];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < np) accv[u] += Sg[o * Pin + p0 + 4 * u] * dv;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (u >= np) break;
-            const int p = p0 + 4 * u;
-            const float h = h1[p * LD + lane];
-            const float g = h > 0.f ? accv[u] : 0.f;
-            d1[p * LD + lane] = g;
-            sg += g;
-            sgh += g * h;
-        }
+    for (int p = wave; p < Pin; p += 4) {
+        float acc = 0.f;
+        for (int o = 0; o < POUT; ++o) acc += Sg[o * Pin + p] * y2[o * LD + lane];
+        const float h = h1[p * LD + lane];
+        const float g = h > 0.f ? acc : 0.f;
+        d1[p * LD + lane] = g;
+        sg += g;
+        sgh += g * h;
     }
     const float mg1 = block_sum(sg, red, wave, lane) / n1cnt;
     const float mgh1 = block_sum(sgh, red + 4, wave, lane) / n1cnt;
     for (int p = wave; p < Pin; p += 4) d1[p * LD + lane] = rstd1 * (d1[p * LD + lane] - mg1 - h1[p * LD + lane] * mgh1);
     __syncthreads();
     // ---- dM[ci][co] = sum_p x[p][ci] dy1[p][co] : thread = co (lane) x ci = wave, wave + 4, ...
-    for (int ci = wave; ci < C; ci += 16) {                    // 4 rows ci per pass share the read of dy1[p][co]
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-        for (int p = 0; p < Pin; ++p) {
-            const float dv = d1[p * LD + lane];
-            acc0 += xs[p * LD + ci] * dv;
-            acc1 += xs[p * LD + ci + 4] * dv;
-            acc2 += xs[p * LD + ci + 8] * dv;
-            acc3 += xs[p * LD + ci + 12] * dv;
-        }
-        gM[ci * C + lane] = acc0; gM[(ci + 4) * C + lane] = acc1; gM[(ci + 8) * C + lane] = acc2; gM[(ci + 12) * C + lane] = acc3;
+    for (int ci = wave; ci < C; ci += 4) {
+        float acc = 0.f;
+        for (int p = 0; p < Pin; ++p) acc += xs[p * LD + ci] * d1[p * LD + lane];
+        gM[ci * C + lane] = acc;
     }
     // ---- dx[p][ci] = sum_co dy1[p][co] M[ci][co] : thread = ci (lane), its M row in registers
 #pragma unroll

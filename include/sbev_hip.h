@@ -352,6 +352,10 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
                               int64_t M, int N, int K, int64_t ldx, int relu, int splits, float* workspace,
                               sbev_stream_t stream);
 
+/* dst[i] = (float)src[i] over a contiguous run; src_dtype: 0 fp32, 1 bf16, 2 fp16.  How the online frame ring takes
+ * channels-last frames (sparsebev_amd/cache.py); replaces the torch.cat of cached frames, models/sparsebev.py:297-303. */
+int sbev_copy_widen_f32(const void* src, int src_dtype, float* dst, int64_t n, sbev_stream_t stream);
+
 /*
  * Gather + adaptive mixing in ONE launch: the workgroup of item (b*Q + q, g) samples its own x[T*P, 64] (the arithmetic of
  * sbev_msmv_fwd / sbev_msmv_fwd_ring with out_layout SBEV_OUT_MIX, frames spread over its four waves) into LDS and runs

@@ -92,6 +92,7 @@ SIGNATURES = {
     'sbev_profile_read': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int]),
     'sbev_linear_splitk_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    'sbev_copy_widen_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int64, _vp]),
     'sbev_sample_mix_supported': (ctypes.c_int, [ctypes.c_int] * 6),
     'sbev_sample_mix_f32': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

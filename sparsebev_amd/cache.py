@@ -45,7 +45,13 @@ class FrameFeatureCache:
             if not f.is_cuda or f.shape[0] != self.B or f.shape[1] != N_VIEWS:
                 raise RuntimeError('frame features must be device tensors [B, 6, C, H, W]')
             if f.stride(2) == 1 and f[0].is_contiguous(memory_format=torch.channels_last):      # NHWC memory: zero relayout
-                buf[:, slot].copy_(f.permute(0, 1, 3, 4, 2))
+                code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}.get(f.dtype)
+                if code is None:
+                    raise RuntimeError('channels-last frame features must be fp32 / fp16 / bf16')
+                for b in range(self.B):          # f[b] is one contiguous [6, H, W, C] run in memory; so is buf[b, slot]
+                    st = lib.sbev_copy_widen_f32(ctypes.c_void_p(f[b].data_ptr()), code, ctypes.c_void_p(buf[b, slot].data_ptr()),
+                                                 buf[b, slot].numel(), stream)
+                    _lib.check(st, 'sbev_copy_widen_f32')
                 continue
             if f.dtype != torch.float32:
                 raise RuntimeError('NCHW frame features must be fp32 (channels-last inputs may be fp16 / bf16)')

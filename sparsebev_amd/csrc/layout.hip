@@ -70,6 +70,32 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const TrArgs a) {
 
 __global__ __launch_bounds__(256) void linear3_ln_relu_kernel(const PosArgs a) { lin3_rows(a, blockIdx.x); }
 
+// contiguous copy with widening to fp32 (channels-last frames handed to the online ring: fp32 / fp16 / bf16 storage), 4 elements per thread
+template <typename ST>
+__device__ __forceinline__ float widen1(ST v);
+template <>
+__device__ __forceinline__ float widen1<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float widen1<_Float16>(_Float16 v) { return (float)v; }
+template <>
+__device__ __forceinline__ float widen1<unsigned short>(unsigned short v) { return __uint_as_float((unsigned)v << 16); }   // bf16
+
+template <typename ST>
+__global__ __launch_bounds__(256) void copy_widen_kernel(const ST* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 o;
+        o.x = widen1<ST>(src[i]); o.y = widen1<ST>(src[i + 1]); o.z = widen1<ST>(src[i + 2]); o.w = widen1<ST>(src[i + 3]);
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+            *reinterpret_cast<float4*>(dst + i) = o;
+        } else {
+            dst[i] = o.x; dst[i + 1] = o.y; dst[i + 2] = o.z; dst[i + 3] = o.w;
+        }
+    } else {
+        for (long long j = i; j < n; ++j) dst[j] = widen1<ST>(src[j]);
+    }
+}
+
 }  // namespace
 
 extern "C" int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int channels, int hw,
@@ -110,4 +136,19 @@ extern "C" int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const fl
     PosArgs a{x, w, b, ln_w, ln_b, y, M, N, (int)ldx, eps, pre};
     hipLaunchKernelGGL(linear3_ln_relu_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_linear3_ln_relu_ex_f32");
+}
+
+// dst[i] = (float)src[i] for a contiguous run: src_dtype 0 = fp32, 1 = bf16 (enum sbev_dtype), 2 = fp16.  The online frame
+// ring's path for channels-last frames (cache.FrameFeatureCache.push): replaces a torch copy_ kernel on the product path.
+extern "C" int sbev_copy_widen_f32(const void* src, int src_dtype, float* dst, int64_t n, sbev_stream_t stream) {
+    SBEV_REQUIRE(n >= 0 && src_dtype >= 0 && src_dtype <= 2, "sbev_copy_widen_f32: bad arguments");
+    if (n == 0) return SBEV_OK;
+    SBEV_REQUIRE(src && dst, "sbev_copy_widen_f32: null pointer");
+    const long long blocks = (n / 4 + 255) / 256 + 1;
+    SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_copy_widen_f32: too many elements for one launch");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (src_dtype == 0) hipLaunchKernelGGL(copy_widen_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(src), dst, (long long)n);
+    else if (src_dtype == 1) hipLaunchKernelGGL(copy_widen_kernel<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const unsigned short*>(src), dst, (long long)n);
+    else hipLaunchKernelGGL(copy_widen_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const _Float16*>(src), dst, (long long)n);
+    return sbev::check_launch("sbev_copy_widen_f32");
 }

@@ -364,3 +364,24 @@ def test_profile_stride_brackets_every_nth_call_only():
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])       # bracketing changes no result
     with pytest.raises(Exception):
         rt.profile_stride(0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_ring_takes_channels_last_frames_through_the_widening_copy(dtype):
+    """FrameFeatureCache.push with channels-last memory (what a channels_last conv stack emits, fp32 / fp16 / bf16): the frame is
+    copied + widened straight into its slot by sbev_copy_widen_f32 (no relayout, no torch kernel) and must equal the values a
+    dense NCHW push of the widened tensor stores."""
+    from sparsebev_amd.cache import FrameFeatureCache
+    B, T = 2, 2
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    g = torch.Generator(device=DEV).manual_seed(7)
+    ring_cl, ring_ref = FrameFeatureCache(T), FrameFeatureCache(T)
+    for _ in range(3):
+        frame = [torch.randn(B, 6, 256, h, w, generator=g, device=DEV).to(dtype) for h, w in sizes]
+        cl = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in frame]        # NHWC memory, NCHW axes
+        assert cl[0].stride(2) == 1
+        ring_cl.push(cl)
+        ring_ref.push([f.float().contiguous() for f in frame])
+    assert ring_cl.order == ring_ref.order
+    for a, b in zip(ring_cl.buffers, ring_ref.buffers):
+        assert torch.equal(a, b)

@@ -119,3 +119,40 @@ def test_transformer_refuses_other_code_sizes():
     from sparsebev_amd import synthetic as S
     with pytest.raises(ValueError):
         SparseBEVTransformer(256, num_frames=2, num_levels=4, code_size=11, pc_range=S.PC_RANGE)
+
+
+def test_round2_entry_points_validate_without_gpu(lib):
+    """Argument validation of the training / fused entry points returns the documented status before any HIP call."""
+    one = ctypes.c_void_p(16)
+    pc = (ctypes.c_double * 6)(-51.2, -51.2, -5, 51.2, 51.2, 3)
+    # shape coverage table of the fused gather + mixing launch
+    assert lib.sbev_sample_mix_supported(4, 64, 4, 8, 4, 4) == 1 and lib.sbev_sample_mix_supported(5, 64, 4, 16, 4, 4) == 1
+    assert lib.sbev_sample_mix_supported(4, 64, 4, 2, 4, 4) == 0          # T*P = 8
+    assert lib.sbev_sample_mix_supported(4, 64, 8, 8, 4, 4) == 0          # P = 8
+    assert lib.sbev_sample_mix_supported(4, 32, 4, 8, 4, 4) == 0          # C = 32
+    assert lib.sbev_sample_mix_supported(4, 64, 4, 8, 1, 4) == 0          # reference layout (gdiv != G)
+    # generic GEMM: empty problems are fine, bad leading dimensions are refused
+    assert lib.sbev_gemm_f32(None, 0, 8, None, 1, 8, None, 8, 0, 8, 8, 0, None, None) == 0
+    assert lib.sbev_gemm_f32(one, 0, 4, one, 1, 8, one, 8, 4, 8, 8, 0, None, None) == -1 and b'leading dimension' in lib.sbev_last_error()
+    assert lib.sbev_gemm_f32_workspace(900, 256, 32768) > 0 and lib.sbev_gemm_f32_workspace(900, 32768, 256) == 0
+    assert lib.sbev_gemm_f32_workspace(-1, 4, 4) == -1
+    # workspaces
+    assert lib.sbev_colsum_workspace(900, 256) == 8 * 256 * 4 and lib.sbev_layer_norm_bwd_workspace(900, 256) == (1800 + 2 * 8 * 256) * 4
+    # mixing backward: same shape contract as the forward
+    assert lib.sbev_adaptive_mixing_bwd_f32(one, one, one, one, one, 4, 4, 32, 32, 128, 1e-5, None) == -1      # C != 64
+    assert lib.sbev_adaptive_mixing_bwd_f32(one, one, one, one, one, 4, 4, 30, 64, 128, 1e-5, None) == -1      # Pin % 4
+    assert lib.sbev_adaptive_mixing_bwd_f32(None, None, None, None, None, 0, 4, 32, 64, 128, 1e-5, None) == 0  # empty
+    # attention backward: head_dim and dropout range
+    assert lib.sbev_sasa_bwd_f32(one, 776, one, pc, None, one, one, one, one, 1, 8, 8, 64, 0.0, 0, None) == -1
+    assert lib.sbev_sasa_bwd_f32(one, 776, one, pc, None, one, one, one, one, 1, 8, 8, 32, 1.0, 0, None) == -1
+    assert lib.sbev_sasa_bwd_f32(None, 776, None, pc, None, None, None, None, None, 0, 8, 8, 32, 0.1, 0, None) == 0
+    # LayerNorm backward: width contract
+    assert lib.sbev_layer_norm_bwd(one, one, one, one, 1e-5, 0, one, one, one, one, 4, 6, None) == -1
+    # sampler backward: mixing-layout gradient needs B' = B*T*G
+    feats = (ctypes.c_void_p * 1)(16)
+    hw = (ctypes.c_int32 * 2)(4, 4)
+    s64 = (ctypes.c_int64 * 1)(6 * 16 * 64)
+    sv = (ctypes.c_int64 * 1)(16 * 64)
+    assert lib.sbev_msmv_bwd_ex(feats, None, hw, 1, 6, 6, 64, 3, 4, 1, s64, 0, sv, 64, one, one, one, 1, 4, 4, one, one, None) == -1
+    assert lib.sbev_dropout_f32(one, one, 16, 1, 1.0, None) == -1 and lib.sbev_dropout_f32(None, None, 0, 1, 0.5, None) == 0
+    assert lib.sbev_copy_widen_f32(one, 3, one, 4, None) == -1

@@ -400,9 +400,13 @@ def test_full_size_c2_one_layer_backward_vs_oracle_autograd():
     """BASELINE config 2 at full size (r50 704x256 pyramid, 900 queries, T = 8), one layer, forward + backward against the
     oracle's torch autograd on the CPU: the backward kernels at the workload's real shapes (M = 900 rows: ragged 128-row GEMM
     tiles, K = 900 reductions, the 64-way split-K of the generator's input gradient, 3 600 mixing items, 115 200 sample points).
-    Tensors downstream of the sampler (out-projection, FFN, norm3, both branches) must agree to 1e-4; the ones upstream of it
-    inherit the image-border discontinuity of the camera selection (a few of the 115 200 points) and are
-    bounded at 2e-2 with the median tensor at 1e-3."""
+    The gradient is discontinuous wherever the forward takes a decision -- the ReLU of the FFN's 460 800 hidden activations, the
+    LayerNorm+ReLU masks of adaptive mixing, the first-hit camera of the 115 200 sample points -- and the device's values are
+    ulps away from the CPU's, so at this size a handful of decisions flip: ONE flipped FFN activation moves its row of the
+    FFN weight gradient by ~1/sqrt(900) of the maximum (measured: 1.2e-2 on ffn.layers.0.0.weight with everything else at
+    1e-6).  Hence: the tensors with no decision between them and the loss (norm3, both branches) agree to 1e-4; every tensor
+    agrees NORM-wise to 5e-3 (a flipped row is one of 900); max-abs errors are bounded at 5e-2 with the median tensor at
+    1e-3.  The strict per-tensor 1e-4 statement is the two-layer fixture G11 (small enough to see no flip)."""
     from oracle import sparsebev_oracle as O
     B, Q, T, L = 1, 900, 8, 4
     ih, iw, sizes = S.PYRAMIDS['r50_704x256']
@@ -421,10 +425,16 @@ def test_full_size_c2_one_layer_backward_vs_oracle_autograd():
     c2, b2, _ = O.decoder(po, bbox, fo, feats, metas, S.PC_RANGE, num_layers=1)
     ((c2 * cc).sum() + (b2 * cb).sum()).backward()
     assert rel(cls, c2) < 1e-4 and rel(box, b2) < 1e-4
-    errs = {'query_feat': rel(fd.grad, fo.grad)}
-    for k, p in model.named_parameters():
-        errs[k[len(PREFIX):]] = rel(p.grad, po[k[len(PREFIX):]].grad)
-    down = {k: v for k, v in errs.items() if any(t in k for t in ('mixing.out_proj', 'ffn', 'norm3', 'cls_branch', 'reg_branch'))}
-    vals = sorted(errs.values())
-    assert max(down.values()) < 1e-4, sorted(down.items(), key=lambda kv: -kv[1])[:5]
-    assert vals[len(vals) // 2] < 1e-3 and vals[-1] < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    def rel_l2(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+    pairs = [('query_feat', fd.grad, fo.grad)] + [(k[len(PREFIX):], p.grad, po[k[len(PREFIX):]].grad) for k, p in model.named_parameters()]
+    l2 = {k: rel_l2(a, b) for k, a, b in pairs}
+    mx = {k: rel(a, b) for k, a, b in pairs}
+    branches = {k: v for k, v in mx.items() if 'cls_branch' in k or 'reg_branch' in k or 'norm3' in k}
+    report = sorted(((k, l2[k], mx[k]) for k in l2), key=lambda t: -t[1])[:8]
+    assert max(branches.values()) < 1e-4, report                 # no ReLU / camera decision between them and the loss that could flip
+    assert max(l2.values()) < 5e-3, report                       # norm-wise: a flipped row is one of 900
+    vals = sorted(mx.values())
+    assert vals[len(vals) // 2] < 1e-3 and vals[-1] < 5e-2, report

@@ -438,3 +438,39 @@ def test_full_size_c2_one_layer_backward_vs_oracle_autograd():
     assert max(l2.values()) < 2e-2, report                       # norm-wise: a flipped row / point is one of many (measured: 4.8e-3 worst)
     vals = sorted(mx.values())
     assert vals[len(vals) // 2] < 1e-2 and vals[-1] < 5e-2, report
+
+
+@torch.enable_grad()
+def test_training_refuses_inference_only_feature_formats_and_supports_the_dn_mask():
+    """bf16 storage and the online frame ring are inference formats: the differentiable path must refuse them loudly instead of
+    silently detaching; the query-denoising attention mask (models/sparsebev_transformer.py:224-225) trains."""
+    from sparsebev_amd.cache import FrameFeatureCache
+    B, Q, T, L = 1, 36, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 21, 1).train()
+    model.decoder.decoder_layer.self_attn.attn_drop = 0.0
+    model.decoder.decoder_layer.ffn_drop = 0.0
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=22)]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=23)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    with pytest.raises(NotImplementedError):
+        model(bbox, feat, [f.to(torch.bfloat16).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats], None, copy.deepcopy(metas))
+    ring = FrameFeatureCache(T)
+    for t in range(T):
+        ring.push([f[:, t * 6:(t + 1) * 6].contiguous() for f in feats])
+    with pytest.raises(NotImplementedError):
+        model(bbox, feat, ring.pyramid(), None, copy.deepcopy(metas))
+    mask = torch.zeros(Q, Q, dtype=torch.bool, device=DEV)
+    mask[:10, 10:] = True
+    mask[10:, :10] = True
+    fd = feat.clone().requires_grad_(True)
+    cls, box = model(bbox, fd, list(feats), mask, copy.deepcopy(metas))
+    (cls.sum() + box.sum()).backward()
+    assert torch.isfinite(fd.grad).all() and fd.grad.abs().max() > 0
+    # against the oracle's autograd with the same mask
+    from oracle import sparsebev_oracle as O
+    params = S.make_params(21, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    fo = feat.cpu().clone().requires_grad_(True)
+    c2, b2, _ = O.decoder(params, bbox.cpu(), fo, [f.cpu() for f in feats], metas, S.PC_RANGE, num_layers=1, pre_attn_mask=mask.cpu())
+    (c2.sum() + b2.sum()).backward()
+    assert rel(cls, c2) < 1e-4 and rel(fd.grad, fo.grad) < 1e-3

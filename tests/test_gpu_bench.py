@@ -38,6 +38,11 @@ def test_single_process_line_has_the_contract_fields():
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 2 and d['value'] > 0
     assert d['roofline']['bound'] == 'hbm' and d['roofline']['achieved'] > 0 and 0 < d['roofline']['frac']
     assert abs(d['value'] - 1e3 / d['ms_per_step']) < 0.01 * d['value']          # bs 1: samples/s = 1 / step time
+    # roofline.traffic is measured in the run (bench.py re-runs itself under rocprofv3 --pmc) when rocprofv3 is on the box
+    import shutil
+    if shutil.which('rocprofv3'):
+        assert d['roofline']['traffic_source'].startswith('measured in this run'), d['roofline']['traffic_source']
+        assert 1.5e8 < d['roofline']['traffic'] < 3.5e8 and d['roofline']['frac'] <= 1.0
 
 
 def test_two_ranks_as_the_driver_launches_them():

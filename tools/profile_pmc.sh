@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 for CFG in "$@"; do
   OUT=$R/gpurun_out/pmc_$CFG
   mkdir -p $OUT
-  CMD="python $R/bench.py --config $CFG --no-cpu-baseline --no-alt --no-detector --steps 4 --warmup 2"
+  CMD="python $R/bench.py --config $CFG --no-cpu-baseline --no-alt --no-detector --no-live-pmc --steps 4 --warmup 2"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/tcc -o bench -- $CMD > $OUT/tcc.log 2>&1

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 tail -1 $OUT/bench_line.json | cut -c1-400
-Q="--no-cpu-baseline --no-alt --no-detector"
+Q="--no-cpu-baseline --no-alt --no-detector --no-live-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py $Q --steps 20 > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o bench -- python $R/bench.py $Q --steps 20 --gemm bf16x3 > $OUT/kt3.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 > $OUT/pmc_mfma.log 2>&1

@@ -287,6 +287,8 @@ def main():
     torch.set_grad_enabled(False)     # inference benchmark, like the reference's timing.py / val.py (with grad enabled the
                                       # module takes its differentiable path, as the reference's nn.Module would)
     rank, world, device = init_distributed(args.gpus)
+    if world > 1:
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))      # N host processes share the box: no 256-thread pools each
     cfg = CONFIGS[args.config]
     pyr, Q, T, B, fdtype = cfg
     ih, iw, sizes = S.PYRAMIDS[pyr]

@@ -46,11 +46,45 @@ def gemm(A, a_kmajor, lda, B, b_kmajor, ldb, M, N, K, out=None, ldc=None, accumu
     return out
 
 
+_WT_CACHE = {}
+
+
+def _transposed(w):
+    """W^T [K, N] of a Linear weight [N, K], made by the tiled-transpose kernel (layout.hip) and cached until the weight is
+    modified in place (an optimizer step bumps ``_version``): with it grad_x = grad_y . W is the FORWARD product
+    ``linear(grad_y, W^T)`` and runs on the tuned forward kernels -- the small-tile kernel for the 256-wide layers (6.6 us
+    instead of a 128 x 128-tile split-K launch + slab sum: 33 us), the strip kernel for grad_mixed (K = 256 -> 32 768 columns),
+    the register-tile split-K kernel for the generator's input gradient (K = 32 768).  Costs one 2 x 33.5 MB transpose per
+    big weight and optimizer step (12 us each)."""
+    # cached for leaf tensors only (parameters), matched by OBJECT identity -- the entry keeps the tensor alive, so a recycled
+    # address or id can never alias a stale entry; temporaries (the packed q | k | v | tau weight) are transposed each time
+    key = id(w)
+    cacheable = w.is_leaf
+    if cacheable:
+        hit = _WT_CACHE.get(key)
+        if hit is not None and hit[0] is w and hit[1] == w._version and hit[2].device == w.device:
+            return hit[2]
+    N, K = w.shape
+    wt = torch.empty(K, N, device=w.device, dtype=torch.float32)
+    st = _lib.load().sbev_nchw_to_nhwc_f32(_p(_c(w.detach())), _p(wt), 1, N, K, _stream())      # [1, R = N, S = K] -> [1, S, R]
+    _lib.check(st, 'sbev_nchw_to_nhwc_f32 (weight transpose)')
+    if cacheable:
+        if len(_WT_CACHE) > 128:
+            _WT_CACHE.clear()
+        _WT_CACHE[key] = (w, w._version, wt)
+    return wt
+
+
 def _linear_grads(gy2, x2, w, need_x, need_w):
     """gy2 [M,N], x2 [M,K], w [N,K] -> (grad_x [M,K] | None, grad_w [N,K] | None)"""
     M, N = gy2.shape
     K = w.shape[1]
-    gx = gemm(gy2, False, N, w, True, K, M, K, N) if need_x else None          # grad_y . W
+    gx = None
+    if need_x:
+        if N % 4 == 0 and K % 4 == 0:
+            gx = dense.linear(gy2, _transposed(w), None)                        # grad_y . W as a forward Linear with W^T
+        else:
+            gx = gemm(gy2, False, N, w, True, K, M, K, N)                       # 10-wide heads: the layout-generic kernel
     gw = gemm(gy2, True, N, x2, True, K, N, K, M) if need_w else None           # grad_y^T . x
     return gx, gw
 
@@ -247,9 +281,8 @@ class AdaptiveMixing(torch.autograd.Function):
         # parameter generator backward; `query +` residual passes gy through
         _, gb_pg = _bias_relu_bwd(gparams, None, True)
         _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
-        gq = gy2.clone()                                                                  # the `query +` residual ...
-        gemm(gparams, False, NP, _c(pg_w), True, D, BQ, D, NP, out=gq, ldc=D, accumulate=True)   # ... + grad_params . W_pg
-        gq = gq.reshape(query.shape)
+        # grad_query = grad_y (the `query +` residual) + grad_params . W_pg: the forward split-K Linear with W_pg^T, residual fused
+        gq = dense.linear(gparams, _transposed(pg_w), None, residual=gy2).reshape(query.shape)
         return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None
 
 

@@ -269,9 +269,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const ProjBwdArgs a) {
 }
 
 // ---- sample-point generation + level softmax backward (models/sparsebev_transformer.py:270-311) ---------------------
-// One thread per (b, q): walks the query's G*P points (summing each point's gradient over the T warped copies, which
-// share the un-warped point), emits the offset / logit gradients per point and accumulates the 8 box gradients (centre,
-// log-dims, sin, cos) in registers.  B*Q threads is little parallelism, but the whole op reads 1.4 MB at config 2.
+// Per query: each of its G*P points sums its gradient over the T warped copies (which share the un-warped point) and emits
+// its offset / logit gradients; the 8 box gradients (centre, log-dims, sin, cos) are summed over the points.
 // Velocity is detached in the reference (:288) -> no gradient to columns 8, 9.
 struct FrontBwdArgs {
     const float* bbox;      // [B,Q,10]
@@ -289,10 +288,15 @@ struct FrontBwdArgs {
     float rot_sign;
 };
 
+// one wave per (b, q), lane = sample point gp (G*P <= 64): per-point work in parallel, the 8 box gradients reduced over the
+// wave with DPP sums (one THREAD per query walking its 16 points x T frames serially took 139 us at config 2)
 __global__ __launch_bounds__(256) void front_bwd_kernel(const FrontBwdArgs a) {
-    const long long bq = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long bq = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bq >= (long long)a.B * a.Q) return;
     const int GP = a.G * a.P;
+    const int gp = lane;
+    const bool act = gp < GP;
     const int b = (int)((unsigned)bq / (unsigned)a.Q), q = (int)((unsigned)bq - (unsigned)b * (unsigned)a.Q);
     const float* bb = a.bbox + bq * 10;
     float gb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(const FrontBwdArgs a) {
         const float cs = cosf(yaw), sn_raw = sinf(yaw), sn = a.rot_sign * sn_raw;
         const float ew = expf(bb[3]), el = expf(bb[4]), eh = expf(bb[5]);
         float g_yaw = 0.f;
-        for (int gp = 0; gp < GP; ++gp) {
+        if (act) {
             float gx = 0.f, gy = 0.f, gz = 0.f;
             for (int t = 0; t < a.T; ++t) {
                 const float* gpt = a.gpts + ((bq * a.T + t) * GP + gp) * 3;
@@ -314,51 +318,53 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(const FrontBwdArgs a) {
             const float g_dx = gx * cs + gy * sn, g_dy = -gx * sn + gy * cs;
             float* go = a.goffset + bq * a.ld_g + gp * 3;
             go[0] = g_dx * ew; go[1] = g_dy * el; go[2] = gz * eh;
-            gb[0] += gx; gb[1] += gy; gb[2] += gz;
-            gb[3] += g_dx * dx; gb[4] += g_dy * dy; gb[5] += gz * dz;
+            gb[0] = gx; gb[1] = gy; gb[2] = gz;
+            gb[3] = g_dx * dx; gb[4] = g_dy * dy; gb[5] = gz * dz;
             const float g_cs = gx * dx + gy * dy, g_sn = -gx * dy + gy * dx;
-            g_yaw += g_cs * (-sn_raw) + g_sn * a.rot_sign * cs;
+            g_yaw = g_cs * (-sn_raw) + g_sn * a.rot_sign * cs;
         }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) gb[d] = sbev::wave_sum_dpp(gb[d]);
+        g_yaw = sbev::wave_sum_dpp(g_yaw);
         const float r2 = s * s + c * c;
         gb[6] = g_yaw * c / r2;
         gb[7] = -g_yaw * s / r2;
         gb[0] *= a.pc_span[0]; gb[1] *= a.pc_span[1]; gb[2] *= a.pc_span[2];
-    } else {
-        for (int i = 0; i < GP * 3; ++i) a.goffset[bq * a.ld_g + i] = 0.f;
+    } else if (act) {
+        for (int i = 0; i < 3; ++i) a.goffset[bq * a.ld_g + gp * 3 + i] = 0.f;
     }
-    if (a.gbbox) {
+    if (a.gbbox && lane == 0) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) a.gbbox[bq * 10 + d] = gb[d];
         a.gbbox[bq * 10 + 8] = 0.f;
         a.gbbox[bq * 10 + 9] = 0.f;
     }
-    for (int gp = 0; gp < GP; ++gp) {
-        float* gl = a.glogits + bq * a.ld_g + gp * a.L;
-        if (!a.gw_bp) {
-            for (int l = 0; l < a.L; ++l) gl[l] = 0.f;
-            continue;
-        }
-        const int g = gp / a.P, p = gp - g * a.P;
-        const float* lg = a.logits + bq * a.ld_logit + gp * a.L;
-        float mx = lg[0];
-        for (int l = 1; l < a.L; ++l) mx = fmaxf(mx, lg[l]);
-        float e[SBEV_MAX_LEVELS], gs[SBEV_MAX_LEVELS];
-        float sum = 0.f;
-        for (int l = 0; l < a.L; ++l) {
-            e[l] = expf(lg[l] - mx);
-            sum += e[l];
-            gs[l] = 0.f;
-        }
-        // the softmax of (g, p) was replicated into the T weight rows r = (b*G + g)*T + t' (forward kernel): sum their grads
-        for (int tp = 0; tp < a.T; ++tp) {
-            const long long row = ((long long)b * a.G + g) * a.T + tp;
-            const float* gw = a.gw_bp + ((row * a.Q + q) * a.P + p) * a.L;
-            for (int l = 0; l < a.L; ++l) gs[l] += gw[l];
-        }
-        float dot = 0.f;
-        for (int l = 0; l < a.L; ++l) dot += (e[l] / sum) * gs[l];
-        for (int l = 0; l < a.L; ++l) gl[l] = (e[l] / sum) * (gs[l] - dot);
+    if (!act) return;
+    float* gl = a.glogits + bq * a.ld_g + gp * a.L;
+    if (!a.gw_bp) {
+        for (int l = 0; l < a.L; ++l) gl[l] = 0.f;
+        return;
     }
+    const int g = gp / a.P, p = gp - g * a.P;
+    const float* lg = a.logits + bq * a.ld_logit + gp * a.L;
+    float mx = lg[0];
+    for (int l = 1; l < a.L; ++l) mx = fmaxf(mx, lg[l]);
+    float e[SBEV_MAX_LEVELS], gs[SBEV_MAX_LEVELS];
+    float sum = 0.f;
+    for (int l = 0; l < a.L; ++l) {
+        e[l] = expf(lg[l] - mx);
+        sum += e[l];
+        gs[l] = 0.f;
+    }
+    // the softmax of (g, p) was replicated into the T weight rows r = (b*G + g)*T + t' (forward kernel): sum their grads
+    for (int tp = 0; tp < a.T; ++tp) {
+        const long long row = ((long long)b * a.G + g) * a.T + tp;
+        const float* gw = a.gw_bp + ((row * a.Q + q) * a.P + p) * a.L;
+        for (int l = 0; l < a.L; ++l) gs[l] += gw[l];
+    }
+    float dot = 0.f;
+    for (int l = 0; l < a.L; ++l) dot += (e[l] / sum) * gs[l];
+    for (int l = 0; l < a.L; ++l) gl[l] = (e[l] / sum) * (gs[l] - dot);
 }
 
 // ---- dropout (training only; mmcv MultiheadAttention / FFN: models/sparsebev_transformer.py:125,202) ----------------
@@ -470,8 +476,9 @@ extern "C" int sbev_sampling_front_bwd(const float* query_bbox, const float* off
     for (int d = 0; d < 3; ++d) a.pc_span[d] = (float)(pc_range[3 + d] - pc_range[d]);
     a.B = B; a.Q = Q; a.T = T; a.G = G; a.P = P; a.L = L;
     a.rot_sign = sbev::box_convention() == SBEV_BOX_V0_17_1 ? -1.f : 1.f;
+    SBEV_REQUIRE(G * P <= 64, "sbev_sampling_front_bwd: G*P = %d sample points per query exceed one wave", G * P);
     const long long n = (long long)B * Q;
-    hipLaunchKernelGGL(front_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(front_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_sampling_front_bwd");
 }
 

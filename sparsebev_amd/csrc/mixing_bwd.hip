@@ -75,11 +75,15 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     f32x4 acc1[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s4 = 0; s4 < C / 4; ++s4) {
-        const float bq = Mg[(4 * s4 + fk) * C + cw + fi];
+    // operands that come from global memory are requested as ONE batch of independent loads per product (a load inside the
+    // MFMA chain made every MFMA wait for its own L2 round trip: 47 us per workgroup for 4 us of matrix-core work)
+    float mB[C / 4];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc1[r] = MFMA16(xs[(r * 16 + fi) * LD + 4 * s4 + fk], bq, acc1[r]);
+    for (int s4 = 0; s4 < C / 4; ++s4) mB[s4] = Mg[(4 * s4 + fk) * C + cw + fi];
+#pragma unroll
+    for (int s4 = 0; s4 < C / 4; ++s4) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc1[r] = MFMA16(xs[(r * 16 + fi) * LD + 4 * s4 + fk], mB[s4], acc1[r]);
     }
     float s = 0.f;
 #pragma unroll
@@ -108,10 +112,21 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     f32x4 acc2[POUT / 16];
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s4 = 0; s4 < Pin / 4; ++s4) {
-        const float bq = fmaxf(h1[(4 * s4 + fk) * LD + cw + fi], 0.f);
+    {
+        float sA[POUT / 16], sN[POUT / 16];
 #pragma unroll
-        for (int r = 0; r < POUT / 16; ++r) acc2[r] = MFMA16(Sg[(r * 16 + fi) * Pin + 4 * s4 + fk], bq, acc2[r]);
+        for (int r = 0; r < POUT / 16; ++r) sA[r] = Sg[(r * 16 + fi) * Pin + fk];
+        for (int s4 = 0; s4 < Pin / 4; ++s4) {
+            if (s4 + 1 < Pin / 4) {
+#pragma unroll
+                for (int r = 0; r < POUT / 16; ++r) sN[r] = Sg[(r * 16 + fi) * Pin + 4 * (s4 + 1) + fk];      // next step's operands in flight
+            }
+            const float bq = fmaxf(h1[(4 * s4 + fk) * LD + cw + fi], 0.f);
+#pragma unroll
+            for (int r = 0; r < POUT / 16; ++r) acc2[r] = MFMA16(sA[r], bq, acc2[r]);
+#pragma unroll
+            for (int r = 0; r < POUT / 16; ++r) sA[r] = sN[r];
+        }
     }
     s = 0.f;
 #pragma unroll
@@ -171,13 +186,23 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     f32x4 acc4[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc4[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int s4 = 0; s4 < POUT / 4; ++s4) {
-        const float bq = y2[(4 * s4 + fk) * LD + cw + fi];
+    {
+        constexpr int AHEAD = 8;                                  // steps of S^T operands requested together
+        float tA[AHEAD][RT];
+        for (int s0 = 0; s0 < POUT / 4; s0 += AHEAD) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const int p = r * 16 + fi;
-            acc4[r] = MFMA16(p < Pin ? Sg[(4 * s4 + fk) * Pin + p] : 0.f, bq, acc4[r]);
+            for (int u = 0; u < AHEAD; ++u)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const int p = r * 16 + fi;
+                    tA[u][r] = p < Pin ? Sg[(4 * (s0 + u) + fk) * Pin + p] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < AHEAD; ++u) {
+                const float bq = y2[(4 * (s0 + u) + fk) * LD + cw + fi];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc4[r] = MFMA16(tA[u][r], bq, acc4[r]);
+            }
         }
     }
     sg = 0.f; sgh = 0.f;
@@ -223,11 +248,13 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
         f32x4 acc[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s4 = 0; s4 < C / 4; ++s4) {
-            const float bq = Mg[(cw + fi) * C + 4 * s4 + fk];                // B[k = co][j = ci] = M[ci][co]
+        float mT[C / 4];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = MFMA16(d1[(r * 16 + fi) * LD + 4 * s4 + fk], bq, acc[r]);
+        for (int s4 = 0; s4 < C / 4; ++s4) mT[s4] = Mg[(cw + fi) * C + 4 * s4 + fk];    // B[k = co][j = ci] = M[ci][co]
+#pragma unroll
+        for (int s4 = 0; s4 < C / 4; ++s4) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = MFMA16(d1[(r * 16 + fi) * LD + 4 * s4 + fk], mT[s4], acc[r]);
         }
 #pragma unroll
         for (int r = 0; r < RT; ++r)

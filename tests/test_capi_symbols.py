@@ -137,7 +137,7 @@ def test_round2_entry_points_validate_without_gpu(lib):
     assert lib.sbev_gemm_f32_workspace(900, 256, 32768) > 0 and lib.sbev_gemm_f32_workspace(900, 32768, 256) == 0
     assert lib.sbev_gemm_f32_workspace(-1, 4, 4) == -1
     # workspaces
-    assert lib.sbev_colsum_workspace(900, 256) == 8 * 256 * 4 and lib.sbev_layer_norm_bwd_workspace(900, 256) == (1800 + 2 * 8 * 256) * 4
+    assert lib.sbev_colsum_workspace(900, 256) == 29 * 256 * 4 and lib.sbev_layer_norm_bwd_workspace(900, 256) == (1800 + 2 * 29 * 256) * 4
     # mixing backward: same shape contract as the forward
     assert lib.sbev_adaptive_mixing_bwd_f32(one, one, one, one, one, 4, 4, 32, 32, 128, 1e-5, None) == -1      # C != 64
     assert lib.sbev_adaptive_mixing_bwd_f32(one, one, one, one, one, 4, 4, 30, 64, 128, 1e-5, None) == -1      # Pin % 4

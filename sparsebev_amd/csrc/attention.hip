@@ -30,7 +30,7 @@ constexpr int NQ = 2;         // query row groups (16 rows each) per workgroup
 constexpr int KS = 4;         // key splits per workgroup: wave (ks, qg) walks key tiles ks, ks+KS, ... of row group qg
 constexpr int NWAVES = NQ * KS;
 constexpr int LDK = HD + 4;   // K tile row stride (B operand of QK^T is read along d: rows = keys)
-constexpr int LDV = HD + 16;  // V tile row stride (B operand of PV is read along keys: stride = 16 banks)
+constexpr int LDV = KT + 4;    // V tile is staged TRANSPOSED, [dim][key]: the B operand of PV is then one 16-byte read along the keys
 constexpr int LDP = KT + 4;   // P patch row stride
 
 struct AttnArgs {
@@ -68,7 +68,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <bool MASK>
 __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) float Ks[KS * KT * LDK];
-    __shared__ __attribute__((aligned(16))) float Vs[KS * KT * LDV];
+    __shared__ __attribute__((aligned(16))) float Vs[KS * HD * LDV];
     __shared__ __attribute__((aligned(16))) float Cs[KS * KT * 2];
     __shared__ __attribute__((aligned(16))) float Ps[NWAVES * 16 * LDP];
 
@@ -85,11 +85,18 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
     const int q0 = qt * 16 * NQ + qg * 16;                   // this wave's first query row
 
     // Q fragments (A operand: row = fi, k = 4s + fk), pre-scaled like torch's MHA (q * head_dim^-0.5)
-    float qf[HD / 4];
+    // k order of every MFMA chain below: lane group fk owns k = 16 blk + 4 fk + j (j = 0..3) -- any k <-> (step, lane group)
+    // bijection is valid as long as A and B agree -- so that an operand row is ONE 16-byte LDS read per 4 MFMAs (the kernel
+    // is LDS-latency-bound: 80 ds_read_b32 per key tile and wave before, 20 ds_read_b128 now)
+    f32x4 qf[HD / 16];
     {
         const int qi = min(q0 + fi, a.Q - 1);
 #pragma unroll
-        for (int s = 0; s < HD / 4; ++s) qf[s] = base[(long long)qi * a.ld + h * HD + 4 * s + fk] * a.scale;
+        for (int blk = 0; blk < HD / 16; ++blk) {
+            qf[blk] = *reinterpret_cast<const f32x4*>(base + (long long)qi * a.ld + h * HD + 16 * blk + 4 * fk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[blk][j] *= a.scale;
+        }
     }
     // per-lane rows of the C layout: row r = fk*4 + e  ->  query q0 + r
     float cx[4], cy[4], tau[4];
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
     o_acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float* Pw = Ps + wave * 16 * LDP;
     const float* Kw = Ks + ks * KT * LDK;
-    const float* Vw = Vs + ks * KT * LDV;
+    const float* Vw = Vs + ks * HD * LDV;
     const float* Cw = Cs + ks * KT * 2;
 
     // K/V staging: the workgroup fetches KS tiles (KS*64 keys) per iteration; thread -> SLOTS x (key row, float4
@@ -140,7 +147,9 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             const int i = tid + j * 64 * NWAVES;
             const int r = i / (HD / 4), c4 = (i % (HD / 4)) * 4;      // r in [0, KS*KT): tile r / KT, row r % KT
             *reinterpret_cast<f32x4*>(&Ks[r * LDK + c4]) = rk[j];
-            *reinterpret_cast<f32x4*>(&Vs[r * LDV + c4]) = rv[j];
+            float* vt = Vs + (r / KT) * HD * LDV + (r % KT);        // [tile][dim][key]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vt[(c4 + e) * LDV] = rv[j][e];
         }
         if (tid < KS * KT) { Cs[2 * tid] = rc.x * a.span[0] + a.lo[0]; Cs[2 * tid + 1] = rc.y * a.span[1] + a.lo[1]; }
     };
@@ -161,8 +170,11 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             for (int c = 0; c < KT / 16; ++c) {
                 s_acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < HD / 4; ++s)
-                    s_acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], Kw[(c * 16 + fi) * LDK + 4 * s + fk], s_acc[c], 0, 0, 0);
+                for (int blk = 0; blk < HD / 16; ++blk) {
+                    const f32x4 kb = *reinterpret_cast<const f32x4*>(&Kw[(c * 16 + fi) * LDK + 16 * blk + 4 * fk]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s_acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[blk][j], kb[j], s_acc[c], 0, 0, 0);
+                }
             }
             // + distance bias, masks; tile row max.  C layout: column (key) = fi, row (query) = fk*4 + e
             float tmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -215,10 +227,15 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             __builtin_amdgcn_wave_barrier();
             // O += P V : 2 column tiles of 16 dims, K = 64 keys
 #pragma unroll
-            for (int s = 0; s < KT / 4; ++s) {
-                const float pa = Pw[fi * LDP + 4 * s + fk];
-                o_acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vw[(4 * s + fk) * LDV + fi], o_acc[0], 0, 0, 0);
-                o_acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, Vw[(4 * s + fk) * LDV + 16 + fi], o_acc[1], 0, 0, 0);
+            for (int blk = 0; blk < KT / 16; ++blk) {
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(&Pw[fi * LDP + 16 * blk + 4 * fk]);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Vw[fi * LDV + 16 * blk + 4 * fk]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Vw[(16 + fi) * LDV + 16 * blk + 4 * fk]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o_acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j], v0[j], o_acc[0], 0, 0, 0);
+                    o_acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[j], v1[j], o_acc[1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                                       // every wave is done with these K/V/centre tiles

@@ -55,7 +55,7 @@ def pmc_profile(config, kernel='msmv_fwd_kernel'):
     return best
 
 
-def live_pmc(config, timeout=240):
+def live_pmc(config, timeout=90):
     """HBM-side byte counters of THIS run's kernels, measured now: bench.py re-runs itself for a few steps under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes -- the two do not fit one; --kernel-trace only beside
     them) on the same box and parses the counter CSVs exactly like tools/pmc_summary.py (KiB units, FETCH_SIZE x2 on gfx950).
@@ -66,6 +66,8 @@ def live_pmc(config, timeout=240):
     import tempfile
     if os.environ.get('SBEV_BENCH_CHILD') == '1' or shutil.which('rocprofv3') is None:
         return None
+    if any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTX', 'ROCTRACER')) or k == 'HSA_TOOLS_LIB' for k in os.environ):
+        return None          # this process is itself being profiled: no nested profiler (committed profile instead)
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import pmc_summary
     tmp = tempfile.mkdtemp(prefix='sbev_pmc_', dir='/tmp')

@@ -474,3 +474,56 @@ def test_training_refuses_inference_only_feature_formats_and_supports_the_dn_mas
     c2, b2, _ = O.decoder(params, bbox.cpu(), fo, [f.cpu() for f in feats], metas, S.PC_RANGE, num_layers=1, pre_attn_mask=mask.cpu())
     (c2.sum() + b2.sum()).backward()
     assert rel(cls, c2) < 1e-4 and rel(fd.grad, fo.grad) < 1e-3
+
+
+@torch.enable_grad()
+def test_a_few_optimizer_steps_follow_the_oracle_trajectory_and_reduce_the_loss():
+    """The module TRAINS: 12 Adam steps on a synthetic regression target (queries and decoder parameters learn; dropouts off for
+    determinism) through the HIP forward + backward, beside the same 12 steps of the CPU oracle under torch autograd from the same
+    initial state.  The loss must fall, and the two loss trajectories must agree closely early on (they drift apart slowly, as
+    any two fp32 implementations of a non-smooth network do)."""
+    from oracle import sparsebev_oracle as O
+    B, Q, T, L, n_layers, steps = 1, 36, 2, 4, 2, 12
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    params0 = S.make_params(301, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    feats = S.make_features(B, T, sizes, seed=302)
+    bbox0, feat0 = S.make_queries(B, Q, seed=303)
+    metas = S.make_img_metas(B, T, ih, iw)
+    g = torch.Generator().manual_seed(304)
+    tgt_cls, tgt_box = torch.randn(n_layers, B, Q, 10, generator=g) * 0.5, torch.rand(n_layers, B, Q, 10, generator=g)
+
+    def loss_of(cls, box, tc, tb):
+        return ((cls - tc) ** 2).mean() + ((box - tb) ** 2).mean()
+
+    # HIP path
+    model = build(T, L, 301, n_layers).train()
+    model.decoder.decoder_layer.self_attn.attn_drop = 0.0
+    model.decoder.decoder_layer.ffn_drop = 0.0
+    qf = feat0.to(DEV).requires_grad_(True)
+    dev_feats = [f.to(DEV) for f in feats]
+    opt = torch.optim.Adam(list(model.parameters()) + [qf], lr=2e-4)
+    hip_losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        cls, box = model(bbox0.to(DEV), qf, list(dev_feats), None, copy.deepcopy(metas))
+        loss = loss_of(cls, box, tgt_cls.to(DEV), tgt_box.to(DEV))
+        loss.backward()
+        opt.step()
+        hip_losses.append(loss.item())
+    # oracle path, same recipe on the CPU
+    po = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
+    qo = feat0.clone().requires_grad_(True)
+    opt_o = torch.optim.Adam(list(po.values()) + [qo], lr=2e-4)
+    ref_losses = []
+    for _ in range(steps):
+        opt_o.zero_grad(set_to_none=True)
+        c2, b2, _ = O.decoder(po, bbox0, qo, feats, metas, S.PC_RANGE, num_layers=n_layers)
+        loss = loss_of(c2, b2, tgt_cls, tgt_box)
+        loss.backward()
+        opt_o.step()
+        ref_losses.append(loss.item())
+    assert hip_losses[-1] < 0.9 * hip_losses[0], hip_losses
+    assert abs(hip_losses[0] - ref_losses[0]) < 1e-4 * ref_losses[0]
+    for a, b in zip(hip_losses[:4], ref_losses[:4]):
+        assert abs(a - b) < 2e-3 * b, (hip_losses, ref_losses)
+    assert abs(hip_losses[-1] - ref_losses[-1]) < 5e-2 * ref_losses[-1], (hip_losses, ref_losses)

@@ -240,20 +240,39 @@ class SasaCore(torch.autograd.Function):
 
 
 class AdaptiveMixing(torch.autograd.Function):
-    """AdaptiveMixing.inner_forward (models/sparsebev_transformer.py:351-381) as ONE node that keeps only its inputs: the
-    dynamic parameters [B*Q, 32768] and the mixed activations [B*Q, 32768] are recomputed in backward -- the reference's
-    checkpoint policy (:383-387) -- so 29.5 MB instead of 265 MB per layer stay alive at config 2."""
+    """AdaptiveMixing.inner_forward (models/sparsebev_transformer.py:351-381) as ONE autograd node.
+
+    ``recompute=True`` keeps only the node's inputs and re-runs the generator GEMM and the mixing kernel in backward -- the
+    reference's activation-checkpoint policy (:383-387): 29.5 MB instead of 265 MB alive per layer at config 2.
+    ``recompute=False`` (the decoder's default on this hardware: 6 layers x 236 MB = 1.4 GB of 288 GB) also keeps the dynamic
+    parameters [B*Q, 32768] and the mixed activations [B*Q, 32768] and saves the two re-runs (183 us per layer)."""
 
     @staticmethod
-    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points):
-        y = dense.adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points)       # = query + out_proj(mix)
-        ctx.save_for_backward(x, query, pg_w, pg_b, op_w, op_b)
-        ctx.out_points = out_points
+    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points, recompute):
+        B, Q, G, Pin, C = x.shape
+        D = query.shape[-1]
+        BQ = B * Q
+        ctx.out_points, ctx.recompute = out_points, bool(recompute)
+        if recompute:
+            y = dense.adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points)       # = query + out_proj(mix)
+            ctx.save_for_backward(x, query, pg_w, pg_b, op_w, op_b)
+            return y
+        x = _c(x)
+        params = dense.linear(_c(query).reshape(BQ, D), pg_w, pg_b)
+        mixed = torch.empty(BQ, G * out_points * C, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, out_points, _EPS, _stream()),
+                   'sbev_adaptive_mixing_f32')
+        y = dense.linear(mixed, op_w, op_b, residual=query).reshape(query.shape)
+        ctx.save_for_backward(x, query, pg_w, pg_b, op_w, op_b, params, mixed)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, query, pg_w, pg_b, op_w, op_b = ctx.saved_tensors
+        if ctx.recompute:
+            x, query, pg_w, pg_b, op_w, op_b = ctx.saved_tensors
+            params = mixed = None
+        else:
+            x, query, pg_w, pg_b, op_w, op_b, params, mixed = ctx.saved_tensors
         B, Q, G, Pin, C = x.shape
         D = query.shape[-1]
         BQ = B * Q
@@ -261,13 +280,11 @@ class AdaptiveMixing(torch.autograd.Function):
         x = _c(x)
         q2 = _c(query).reshape(BQ, D)
         gy2 = _c(gy).reshape(BQ, D)
-        # recompute: dynamic parameters and mixed activations (the two forward launches)
-        params = dense.linear(q2, pg_w, pg_b)                                            # [BQ, G*(C*C + Pout*Pin)]
-        NP = params.shape[1]
-        NM = G * ctx.out_points * C
-        mixed = torch.empty(BQ, NM, device=x.device, dtype=torch.float32)
-        _lib.check(lib.sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, ctx.out_points, _EPS, _stream()),
-                   'sbev_adaptive_mixing_f32')
+        if params is None:        # recompute: dynamic parameters and mixed activations (the two forward launches)
+            params = dense.linear(q2, pg_w, pg_b)                                        # [BQ, G*(C*C + Pout*Pin)]
+            mixed = torch.empty(BQ, G * ctx.out_points * C, device=x.device, dtype=torch.float32)
+            _lib.check(lib.sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, ctx.out_points, _EPS, _stream()),
+                       'sbev_adaptive_mixing_f32')
         # out-projection backward
         _, gb_op = _bias_relu_bwd(gy2, None, True)
         gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, True)
@@ -278,12 +295,12 @@ class AdaptiveMixing(torch.autograd.Function):
         _lib.check(lib.sbev_adaptive_mixing_bwd_f32(_p(x), _p(params), _p(gmixed), _p(gx), _p(gparams), BQ, G, Pin, C, ctx.out_points,
                                                     _EPS, _stream()), 'sbev_adaptive_mixing_bwd_f32')
         del gmixed, params
-        # parameter generator backward; `query +` residual passes gy through
+        # parameter generator backward
         _, gb_pg = _bias_relu_bwd(gparams, None, True)
         _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
         # grad_query = grad_y (the `query +` residual) + grad_params . W_pg: the forward split-K Linear with W_pg^T, residual fused
         gq = dense.linear(gparams, _transposed(pg_w), None, residual=gy2).reshape(query.shape)
-        return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None
+        return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None
 
 
 class Sampling(torch.autograd.Function):

@@ -179,6 +179,9 @@ class SparseBEVTransformerDecoderLayer(_Base):
         self.mixing = AdaptiveMixing(in_dim=D, in_points=num_points * num_frames, n_groups=N_GROUPS, out_points=OUT_POINTS)
         self.ffn = _FFNParams(D, FFN_CHANNELS)
         self.ffn_drop = 0.1                  # mmcv FFN(ffn_drop=0.1): active in train() only
+        self.recompute_mixing = False        # training: keep the dynamic parameters / mixed activations (236 MB per layer and sample at
+                                             # T = 8) instead of re-running generator GEMM + mixing in backward like the reference's
+                                             # checkpoint (:383-387); True trades 183 us per layer for that memory
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(D), nn.LayerNorm(D), nn.LayerNorm(D)
         cls = []
         for _ in range(num_cls_fcs):
@@ -225,7 +228,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
         sampled = AG.Sampling.apply(query_bbox, both, feats, ctx, cfg, *orig_feats)
         # adaptive mixing (+ identity), norm2
         x = AG.layer_norm(AG.AdaptiveMixing.apply(sampled, x, mix.parameter_generator.weight, mix.parameter_generator.bias,
-                                                  mix.out_proj.weight, mix.out_proj.bias, mix.out_points),
+                                                  mix.out_proj.weight, mix.out_proj.bias, mix.out_points, self.recompute_mixing),
                           self.norm2.weight, self.norm2.bias)
         # FFN (+ identity), norm3
         f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]

@@ -191,7 +191,7 @@ def test_adaptive_mixing_function_vs_oracle_autograd(T):
     query = torch.randn(B, Q, 256, generator=g)
     gy = torch.randn(B, Q, 256, generator=g)
     dv = [t.to(DEV).requires_grad_(True) for t in [x, query] + [params[n] for n in names]]
-    y = AG.AdaptiveMixing.apply(*dv, 128)
+    y = AG.AdaptiveMixing.apply(*dv, 128, T == 8)            # T = 8: the recompute variant, T = 2: activations kept
     y.backward(gy.to(DEV))
     pc = {n: params[n].double().requires_grad_(True) for n in names}
     xc, qc = x.double().requires_grad_(True), query.double().requires_grad_(True)

@@ -14,12 +14,14 @@ ap.add_argument('--pyr', default='r50_704x256')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--feat-grad', action='store_true')
 ap.add_argument('--dropout', action='store_true')
+ap.add_argument('--recompute', action='store_true', help='re-run generator GEMM + mixing in backward (the reference\'s checkpoint policy) instead of keeping 236 MB per layer')
 a = ap.parse_args()
 dev = 'cuda:0'
 ih, iw, sizes = S.PYRAMIDS[a.pyr]
 m = SparseBEVTransformer(256, num_frames=a.t, num_points=4, num_layers=6, num_levels=len(sizes), pc_range=S.PC_RANGE)
 m.init_weights(); S.randomize_zero_init(m, std=0.02, seed=0)
 m = m.to(dev).train()
+m.decoder.decoder_layer.recompute_mixing = a.recompute
 if not a.dropout:
     m.decoder.decoder_layer.self_attn.attn_drop = 0.0
     m.decoder.decoder_layer.ffn_drop = 0.0
@@ -52,5 +54,5 @@ with torch.no_grad():
         m(bbox, feat, list(feats), None, copy.deepcopy(metas))
     torch.cuda.synchronize()
     di = (time.perf_counter() - t0) / a.steps
-print('train step (fwd+bwd, 6 layers, Q=%d T=%d B=%d, feat_grad=%s, dropout=%s): %.2f ms   inference step: %.2f ms   peak mem %.2f GB'
-      % (a.q, a.t, a.b, a.feat_grad, a.dropout, dt * 1e3, di * 1e3, torch.cuda.max_memory_allocated() / 1e9))
+print('train step (fwd+bwd, 6 layers, Q=%d T=%d B=%d, feat_grad=%s, dropout=%s, recompute=%s): %.2f ms   inference step: %.2f ms   peak mem %.2f GB'
+      % (a.q, a.t, a.b, a.feat_grad, a.dropout, a.recompute, dt * 1e3, di * 1e3, torch.cuda.max_memory_allocated() / 1e9))

@@ -48,8 +48,9 @@ __device__ __forceinline__ bool keep_of(const SasaBwdArgs& a, unsigned thr, int 
 }
 
 constexpr int NW = 4;          // waves per workgroup: wave w walks key (row kernel) / query (column kernel) tiles w, w + 4, ...
-constexpr int ROWF = 2 * TILE * (HD + 1) + 2 * TILE;      // floats of one wave's private tile area: K | V | centres (row kernel)
-constexpr int COLF = 2 * TILE * (HD + 1) + 5 * TILE;      // Q | dO | (cx, cy, tau, lse, dvec) (column kernel)
+constexpr int LDT = HD + 4;        // staged rows: 36 floats = 16-byte aligned, so a row is read as 8 broadcast ds_read_b128 (was 32 b32)
+constexpr int ROWF = 2 * TILE * LDT + 2 * TILE;      // floats of one wave's private tile area: K | V | centres (row kernel)
+constexpr int COLF = 2 * TILE * LDT + 5 * TILE;      // Q | dO | (cx, cy, tau, lse, dvec) (column kernel)
 
 // grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 query rows: lane = query row, wave w owns the key tiles w, w + 4, ...
 // (its own LDS tile area: no workgroup barrier inside the loops -- a wave's DS operations execute in order), and the four
@@ -58,12 +59,12 @@ constexpr int COLF = 2 * TILE * (HD + 1) + 5 * TILE;      // Q | dO | (cx, cy, t
 // FWD: writes O (training forward with dropout); !FWD: writes dq, dtau (and zeroes the padding columns), lse, dvec.
 template <bool FWD>
 __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) {
-    __shared__ float smem[NW * ROWF];
+    __shared__ __attribute__((aligned(16))) float smem[NW * ROWF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float (*Ks)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * ROWF);
-    float (*Vs)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * ROWF + TILE * (HD + 1));
-    float (*Cs)[2] = reinterpret_cast<float (*)[2]>(smem + wave * ROWF + 2 * TILE * (HD + 1));
+    float (*Ks)[LDT] = reinterpret_cast<float (*)[LDT]>(smem + wave * ROWF);
+    float (*Vs)[LDT] = reinterpret_cast<float (*)[LDT]>(smem + wave * ROWF + TILE * LDT);
+    float (*Cs)[2] = reinterpret_cast<float (*)[2]>(smem + wave * ROWF + 2 * TILE * LDT);
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = a.H * HD;
     const int i = blockIdx.x * 64 + lane;
@@ -94,9 +95,9 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
                 const int kj = min(k0 + lane, a.Q - 1);
                 const float* row = base + (long long)kj * a.ld + h * HD;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) {
-                    Ks[lane][d] = row[D + d];
-                    Vs[lane][d] = row[2 * D + d];
+                for (int d4 = 0; d4 < HD / 4; ++d4) {
+                    *reinterpret_cast<float4*>(&Ks[lane][4 * d4]) = *reinterpret_cast<const float4*>(row + D + 4 * d4);
+                    *reinterpret_cast<float4*>(&Vs[lane][4 * d4]) = *reinterpret_cast<const float4*>(row + 2 * D + 4 * d4);
                 }
                 Cs[lane][0] = a.bbox[((long long)b * a.Q + kj) * 10] * a.span[0] + a.lo[0];
                 Cs[lane][1] = a.bbox[((long long)b * a.Q + kj) * 10 + 1] * a.span[1] + a.lo[1];
@@ -108,7 +109,10 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
                 if (a.mask && a.mask[(long long)ic * a.Q + j]) continue;
                 float s = 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) s += q[d] * Ks[jj][d];
+                for (int d4 = 0; d4 < HD / 4; ++d4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(&Ks[jj][4 * d4]);
+                    s += q[4 * d4] * k4.x; s += q[4 * d4 + 1] * k4.y; s += q[4 * d4 + 2] * k4.z; s += q[4 * d4 + 3] * k4.w;
+                }
                 const float dx = cx - Cs[jj][0], dy = cy - Cs[jj][1];
                 const float dist = sqrtf(dx * dx + dy * dy);
                 s -= dist * tau;
@@ -123,18 +127,27 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
                         if (keep) {
                             const float pd = p * a.inv_keep;
 #pragma unroll
-                            for (int d = 0; d < HD; ++d) acc[d] += pd * Vs[jj][d];
+                            for (int d4 = 0; d4 < HD / 4; ++d4) {
+                                const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * d4]);
+                                acc[4 * d4] += pd * v4.x; acc[4 * d4 + 1] += pd * v4.y; acc[4 * d4 + 2] += pd * v4.z; acc[4 * d4 + 3] += pd * v4.w;
+                            }
                         }
                     } else {
                         float dp = 0.f;
                         if (keep) {
 #pragma unroll
-                            for (int d = 0; d < HD; ++d) dp += go[d] * Vs[jj][d];
+                            for (int d4 = 0; d4 < HD / 4; ++d4) {
+                                const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * d4]);
+                                dp += go[4 * d4] * v4.x; dp += go[4 * d4 + 1] * v4.y; dp += go[4 * d4 + 2] * v4.z; dp += go[4 * d4 + 3] * v4.w;
+                            }
                             dp *= a.inv_keep;
                         }
                         const float ds = p * (dp - dsum);
 #pragma unroll
-                        for (int d = 0; d < HD; ++d) acc[d] += ds * Ks[jj][d];
+                        for (int d4 = 0; d4 < HD / 4; ++d4) {
+                            const float4 k4 = *reinterpret_cast<const float4*>(&Ks[jj][4 * d4]);
+                            acc[4 * d4] += ds * k4.x; acc[4 * d4 + 1] += ds * k4.y; acc[4 * d4 + 2] += ds * k4.z; acc[4 * d4 + 3] += ds * k4.w;
+                        }
                         dtau -= ds * dist;
                     }
                 }
@@ -191,12 +204,12 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
 // grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 keys: lane = key column j, wave w owns the query tiles w, w + 4, ...;
 // the four partial (dk_j, dv_j) are merged through LDS in a fixed order.
 __global__ __launch_bounds__(64 * NW) void sasa_col_kernel(const SasaBwdArgs a) {
-    __shared__ float smem[NW * COLF];
+    __shared__ __attribute__((aligned(16))) float smem[NW * COLF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float (*Qs)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * COLF);
-    float (*Gs)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem + wave * COLF + TILE * (HD + 1));
-    float (*Rs)[5] = reinterpret_cast<float (*)[5]>(smem + wave * COLF + 2 * TILE * (HD + 1));   // cx, cy, tau, lse, dvec of the query
+    float (*Qs)[LDT] = reinterpret_cast<float (*)[LDT]>(smem + wave * COLF);
+    float (*Gs)[LDT] = reinterpret_cast<float (*)[LDT]>(smem + wave * COLF + TILE * LDT);
+    float (*Rs)[5] = reinterpret_cast<float (*)[5]>(smem + wave * COLF + 2 * TILE * LDT);   // cx, cy, tau, lse, dvec of the query
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = a.H * HD;
     const int j = blockIdx.x * 64 + lane;
@@ -218,9 +231,11 @@ __global__ __launch_bounds__(64 * NW) void sasa_col_kernel(const SasaBwdArgs a) 
         {
             const int qi = min(i0 + lane, a.Q - 1);
 #pragma unroll
-            for (int d = 0; d < HD; ++d) {
-                Qs[lane][d] = base[(long long)qi * a.ld + h * HD + d] * a.scale;
-                Gs[lane][d] = a.dO[((long long)b * a.Q + qi) * D + h * HD + d];
+            for (int d4 = 0; d4 < HD / 4; ++d4) {
+                float4 qv = *reinterpret_cast<const float4*>(base + (long long)qi * a.ld + h * HD + 4 * d4);
+                qv.x *= a.scale; qv.y *= a.scale; qv.z *= a.scale; qv.w *= a.scale;
+                *reinterpret_cast<float4*>(&Qs[lane][4 * d4]) = qv;
+                *reinterpret_cast<float4*>(&Gs[lane][4 * d4]) = *reinterpret_cast<const float4*>(a.dO + ((long long)b * a.Q + qi) * D + h * HD + 4 * d4);
             }
             Rs[lane][0] = a.bbox[((long long)b * a.Q + qi) * 10] * a.span[0] + a.lo[0];
             Rs[lane][1] = a.bbox[((long long)b * a.Q + qi) * 10 + 1] * a.span[1] + a.lo[1];
@@ -234,10 +249,13 @@ __global__ __launch_bounds__(64 * NW) void sasa_col_kernel(const SasaBwdArgs a) 
             const int i = i0 + ii;
             if (a.mask && a.mask[(long long)i * a.Q + jc]) continue;
             float s = 0.f, dp = 0.f;
+            float4 q4[HD / 4], g4[HD / 4];
 #pragma unroll
-            for (int d = 0; d < HD; ++d) {
-                s += Qs[ii][d] * k[d];
-                dp += Gs[ii][d] * v[d];
+            for (int d4 = 0; d4 < HD / 4; ++d4) {
+                q4[d4] = *reinterpret_cast<const float4*>(&Qs[ii][4 * d4]);
+                g4[d4] = *reinterpret_cast<const float4*>(&Gs[ii][4 * d4]);
+                s += q4[d4].x * k[4 * d4]; s += q4[d4].y * k[4 * d4 + 1]; s += q4[d4].z * k[4 * d4 + 2]; s += q4[d4].w * k[4 * d4 + 3];
+                dp += g4[d4].x * v[4 * d4]; dp += g4[d4].y * v[4 * d4 + 1]; dp += g4[d4].z * v[4 * d4 + 2]; dp += g4[d4].w * v[4 * d4 + 3];
             }
             const float dx = Rs[ii][0] - kx, dy = Rs[ii][1] - ky;
             s -= sqrtf(dx * dx + dy * dy) * Rs[ii][2];
@@ -246,9 +264,9 @@ __global__ __launch_bounds__(64 * NW) void sasa_col_kernel(const SasaBwdArgs a) 
             const float pd = keep ? p * a.inv_keep : 0.f;
             const float ds = p * ((keep ? dp * a.inv_keep : 0.f) - Rs[ii][4]);
 #pragma unroll
-            for (int d = 0; d < HD; ++d) {
-                dv[d] += pd * Gs[ii][d];
-                dk[d] += ds * Qs[ii][d];          // Qs is pre-scaled by 1/sqrt(d)
+            for (int d4 = 0; d4 < HD / 4; ++d4) {                              // (Qs is pre-scaled by 1/sqrt(d))
+                dv[4 * d4] += pd * g4[d4].x; dv[4 * d4 + 1] += pd * g4[d4].y; dv[4 * d4 + 2] += pd * g4[d4].z; dv[4 * d4 + 3] += pd * g4[d4].w;
+                dk[4 * d4] += ds * q4[d4].x; dk[4 * d4 + 1] += ds * q4[d4].y; dk[4 * d4 + 2] += ds * q4[d4].z; dk[4 * d4 + 3] += ds * q4[d4].w;
             }
         }
     }
@@ -274,7 +292,7 @@ int fill(SasaBwdArgs& a, const float* qkvt, int64_t ld, const float* bbox, const
          int B, int Q, int H, int head_dim, float p_drop, uint64_t seed, const char* who) {
     SBEV_REQUIRE(B >= 0 && Q >= 0 && H >= 1, "%s: bad sizes", who);
     SBEV_REQUIRE(head_dim == HD, "%s: built for head_dim 32 (got %d)", who, head_dim);
-    SBEV_REQUIRE(ld >= 3 * H * HD + H, "%s: row stride %lld must be >= 3*H*32 + H", who, (long long)ld);
+    SBEV_REQUIRE(ld >= 3 * H * HD + H && ld % 4 == 0 && (((uintptr_t)qkvt) & 15) == 0, "%s: row stride %lld must be >= 3*H*32 + H and a multiple of 4, qkvt 16-byte aligned", who, (long long)ld);
     SBEV_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "%s: need 0 <= attn_drop < 1", who);
     SBEV_REQUIRE((int64_t)Q * Q * H * (B > 0 ? B : 1) >= 0, "%s: overflow", who);
     a.qkvt = qkvt; a.bbox = bbox; a.mask = mask;

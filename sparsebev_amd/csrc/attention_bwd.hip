@@ -12,6 +12,7 @@
 // tiles staged in LDS, then dq / dtau and the row's log-sum-exp + D_i) and a COLUMN kernel (thread = one key; loops over
 // query tiles, accumulates dk / dv).  No atomics.  The dropout keep decision is a hash of (seed, b, h, i, j), so forward
 // and both backward kernels regenerate the same mask.  1.3 GFLOP forward per layer-sample: plain VALU math is enough.
+#include <cstdlib>
 #include "sbev_common.hpp"
 
 namespace {
@@ -330,10 +331,17 @@ extern "C" int sbev_sasa_bwd_f32(const float* qkvt, int64_t ld, const float* que
     if (st != SBEV_OK) return st;
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(qkvt && query_bbox && pc_range && out && grad_out && grad_qkvt && workspace, "sbev_sasa_bwd_f32: null pointer");
-    a.O = out; a.dO = grad_out; a.dqkvt = grad_qkvt;
-    a.lse = workspace;                                   // [B, H, Q]
-    a.dvec = workspace + (long long)B * H * Q;           // [B, H, Q]
+    // the matrix-core kernels (attention_bwd_mfma.hip); SBEV_SASA_BWD_VALU=1 keeps the plain-VALU pair below for A/B runs
+    static const bool valu = std::getenv("SBEV_SASA_BWD_VALU") != nullptr;
+    float* lse = workspace;                              // [B, H, Q]
+    float* dvec = workspace + (long long)B * H * Q;      // [B, H, Q]
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!valu)
+        return sbev::launch_sasa_bwd_mfma(qkvt, ld, query_bbox, a.lo, a.span, mask, out, grad_out, grad_qkvt, lse, dvec, B, Q, H,
+                                          a.scale, attn_drop, seed, s);
+    a.O = out; a.dO = grad_out; a.dqkvt = grad_qkvt;
+    a.lse = lse;
+    a.dvec = dvec;
     const dim3 grid((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL(sasa_row_kernel<false>, grid, dim3(64 * NW), 0, s, a);
     st = sbev::check_launch("sbev_sasa_bwd_f32 (rows)");

@@ -24,6 +24,7 @@ UNITS = {
     'gemm_any.hip': [],                  # layout-generic GEMM: grad_x / grad_W of every Linear (training)
     'mixing_bwd.hip': [],
     'attention_bwd.hip': [],
+    'attention_bwd_mfma.hip': [],
     'backward_ops.hip': ['-ffp-contract=off'],   # re-runs project.hip's individually rounded projection to re-select the camera
     # no implicit FMA contraction: the fused gather + mixing instantiations and the plain mixing kernel must round identically
     # (contraction decisions are made per instantiation by the backend; explicit fmaf / MFMA are unaffected)

@@ -8,11 +8,11 @@
 //     dV_j = sum_i Pd_ij dO_i        dPd_ij = dO_i . v_j        dS_ij = P_ij (keep_ij dPd_ij / (1-p) - D_i),  D_i = dO_i . O_i
 //     dq_i = sum_j dS_ij k_j / sqrt(d)     dk_j = sum_i dS_ij q_i / sqrt(d)     dtau_ih = -sum_j dS_ij dist_ij
 // (dist carries no gradient: calc_bbox_dists is @torch.no_grad, :236-248.)
-// Two deterministic passes, flash-attention style: a ROW kernel (lane = one query of one head, four waves share the keys; online softmax over key
-// tiles staged in LDS, then dq / dtau and the row's log-sum-exp + D_i) and a COLUMN kernel (thread = one key; loops over
-// query tiles, accumulates dk / dv).  No atomics.  The dropout keep decision is a hash of (seed, b, h, i, j), so forward
-// and both backward kernels regenerate the same mask.  1.3 GFLOP forward per layer-sample: plain VALU math is enough.
-#include <cstdlib>
+// The backward runs on the matrix cores (attention_bwd_mfma.hip: a ROW kernel for dq / dtau / log-sum-exp / D_i and a COLUMN
+// kernel for dk / dv, flash-attention style, no atomics).  This file keeps the C entry points and the TRAINING FORWARD with
+// attention dropout (only taken when attn_drop > 0: plain VALU math, lane = one query of one head, four waves sharing the
+// keys; the inference forward is attention.hip).  The dropout keep decision is a hash of (seed, b, h, i, j), so the forward
+// and both backward kernels regenerate the same mask.
 #include "sbev_common.hpp"
 
 namespace {
@@ -25,12 +25,7 @@ struct SasaBwdArgs {
     const float* bbox;          // [B, Q, 10]
     float lo[2], span[2];
     const unsigned char* mask;  // [Q, Q] or null
-    const float* O;             // [B, Q, D]    forward output (backward only)
-    const float* dO;            // [B, Q, D]
-    float* out;                 // forward mode: O [B, Q, D]
-    float* dqkvt;               // [B, Q, ld]
-    float* lse;                 // [B, H, Q]
-    float* dvec;                // [B, H, Q]
+    float* out;                 // [B, Q, D]
     int B, Q, H, ld;
     float scale;
     float p_drop, inv_keep;
@@ -48,18 +43,15 @@ __device__ __forceinline__ bool keep_of(const SasaBwdArgs& a, unsigned thr, int 
     return mix32(a.seed * 0x100000001b3ull + idx) >= thr;
 }
 
-constexpr int NW = 4;          // waves per workgroup: wave w walks key (row kernel) / query (column kernel) tiles w, w + 4, ...
-constexpr int LDT = HD + 4;        // staged rows: 36 floats = 16-byte aligned, so a row is read as 8 broadcast ds_read_b128 (was 32 b32)
-constexpr int ROWF = 2 * TILE * LDT + 2 * TILE;      // floats of one wave's private tile area: K | V | centres (row kernel)
-constexpr int COLF = 2 * TILE * LDT + 5 * TILE;      // Q | dO | (cx, cy, tau, lse, dvec) (column kernel)
+constexpr int NW = 4;              // waves per workgroup: wave w walks the key tiles w, w + 4, ...
+constexpr int LDT = HD + 4;        // staged rows: 36 floats = 16-byte aligned, so a row is read as 8 broadcast ds_read_b128
+constexpr int ROWF = 2 * TILE * LDT + 2 * TILE;      // floats of one wave's private tile area: K | V | centres
 
-// grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 query rows: lane = query row, wave w owns the key tiles w, w + 4, ...
-// (its own LDS tile area: no workgroup barrier inside the loops -- a wave's DS operations execute in order), and the four
-// partial results of a row are merged through LDS: (max, sum) after pass 1, (dq | O, dtau) after pass 2.  With one wave
-// per 64 rows the kernel was 120 waves of two 900-key serial loops (0.99 ms per layer at config 2).
-// FWD: writes O (training forward with dropout); !FWD: writes dq, dtau (and zeroes the padding columns), lse, dvec.
-template <bool FWD>
-__global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) {
+// Training forward with attention dropout.  grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 query rows: lane = query
+// row, wave w owns the key tiles w, w + 4, ... (its own LDS tile area: no workgroup barrier inside the loops -- a wave's DS
+// operations execute in order), and the four partial results of a row are merged through LDS: (max, sum) after pass 1, the
+// partial outputs after pass 2.
+__global__ __launch_bounds__(64 * NW) void sasa_dropout_fwd_kernel(const SasaBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[NW * ROWF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -73,22 +65,16 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
     const int ic = live ? i : a.Q - 1;
     const float* base = a.qkvt + (long long)b * a.Q * a.ld;
     const unsigned thr = (unsigned)((double)a.p_drop * 4294967296.0);
-    float q[HD], go[HD], acc[HD];
+    float q[HD], acc[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
         q[d] = base[(long long)ic * a.ld + h * HD + d] * a.scale;
-        go[d] = FWD ? 0.f : a.dO[((long long)b * a.Q + ic) * D + h * HD + d];
         acc[d] = 0.f;
     }
     const float cx = a.bbox[((long long)b * a.Q + ic) * 10] * a.span[0] + a.lo[0];
     const float cy = a.bbox[((long long)b * a.Q + ic) * 10 + 1] * a.span[1] + a.lo[1];
     const float tau = base[(long long)ic * a.ld + 3 * D + h];
-    float dsum = 0.f;
-    if (!FWD) {
-#pragma unroll
-        for (int d = 0; d < HD; ++d) dsum += go[d] * a.O[((long long)b * a.Q + ic) * D + h * HD + d];
-    }
-    float m = -INFINITY, l = 0.f, dtau = 0.f;
+    float m = -INFINITY, l = 0.f;
     for (int pass = 0; pass < 2; ++pass) {
         for (int k0 = wave * TILE; k0 < a.Q; k0 += NW * TILE) {
             __builtin_amdgcn_wave_barrier();                 // the wave is done reading its previous tile
@@ -115,41 +101,17 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
                     s += q[4 * d4] * k4.x; s += q[4 * d4 + 1] * k4.y; s += q[4 * d4 + 2] * k4.z; s += q[4 * d4 + 3] * k4.w;
                 }
                 const float dx = cx - Cs[jj][0], dy = cy - Cs[jj][1];
-                const float dist = sqrtf(dx * dx + dy * dy);
-                s -= dist * tau;
+                s -= sqrtf(dx * dx + dy * dy) * tau;
                 if (pass == 0) {
                     const float mn = fmaxf(m, s);
                     l = l * __expf(m - mn) + __expf(s - mn);
                     m = mn;
-                } else {
-                    const float p = __expf(s - m) / l;
-                    const bool keep = a.p_drop > 0.f ? keep_of(a, thr, b, h, ic, j) : true;
-                    if (FWD) {
-                        if (keep) {
-                            const float pd = p * a.inv_keep;
+                } else if (a.p_drop <= 0.f || keep_of(a, thr, b, h, ic, j)) {
+                    const float pd = __expf(s - m) / l * a.inv_keep;
 #pragma unroll
-                            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                                const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * d4]);
-                                acc[4 * d4] += pd * v4.x; acc[4 * d4 + 1] += pd * v4.y; acc[4 * d4 + 2] += pd * v4.z; acc[4 * d4 + 3] += pd * v4.w;
-                            }
-                        }
-                    } else {
-                        float dp = 0.f;
-                        if (keep) {
-#pragma unroll
-                            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                                const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * d4]);
-                                dp += go[4 * d4] * v4.x; dp += go[4 * d4 + 1] * v4.y; dp += go[4 * d4 + 2] * v4.z; dp += go[4 * d4 + 3] * v4.w;
-                            }
-                            dp *= a.inv_keep;
-                        }
-                        const float ds = p * (dp - dsum);
-#pragma unroll
-                        for (int d4 = 0; d4 < HD / 4; ++d4) {
-                            const float4 k4 = *reinterpret_cast<const float4*>(&Ks[jj][4 * d4]);
-                            acc[4 * d4] += ds * k4.x; acc[4 * d4 + 1] += ds * k4.y; acc[4 * d4 + 2] += ds * k4.z; acc[4 * d4 + 3] += ds * k4.w;
-                        }
-                        dtau -= ds * dist;
+                    for (int d4 = 0; d4 < HD / 4; ++d4) {
+                        const float4 v4 = *reinterpret_cast<const float4*>(&Vs[jj][4 * d4]);
+                        acc[4 * d4] += pd * v4.x; acc[4 * d4 + 1] += pd * v4.y; acc[4 * d4 + 2] += pd * v4.z; acc[4 * d4 + 3] += pd * v4.w;
                     }
                 }
             }
@@ -175,118 +137,17 @@ __global__ __launch_bounds__(64 * NW) void sasa_row_kernel(const SasaBwdArgs a) 
             __syncthreads();                                 // the merge area aliases the tile areas
         }
     }
-    // merge the partial accumulators (fixed order: deterministic); [NW][HD + 1][64] floats alias the tile areas
+    // merge the partial outputs (fixed order: deterministic); [NW][HD][64] floats alias the tile areas
     __syncthreads();
     float* pr = smem;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) pr[(wave * (HD + 1) + d) * 64 + lane] = acc[d];
-    pr[(wave * (HD + 1) + HD) * 64 + lane] = dtau;
+    for (int d = 0; d < HD; ++d) pr[(wave * HD + d) * 64 + lane] = acc[d];
     __syncthreads();
     if (wave != 0 || !live) return;
 #pragma unroll
     for (int d = 0; d < HD; ++d)
-        acc[d] = (pr[d * 64 + lane] + pr[((HD + 1) + d) * 64 + lane]) + (pr[(2 * (HD + 1) + d) * 64 + lane] + pr[(3 * (HD + 1) + d) * 64 + lane]);
-    dtau = (pr[HD * 64 + lane] + pr[((HD + 1) + HD) * 64 + lane]) + (pr[(2 * (HD + 1) + HD) * 64 + lane] + pr[(3 * (HD + 1) + HD) * 64 + lane]);
-    if (FWD) {
-#pragma unroll
-        for (int d = 0; d < HD; ++d) a.out[((long long)b * a.Q + i) * D + h * HD + d] = acc[d];
-    } else {
-        float* g = a.dqkvt + ((long long)b * a.Q + i) * a.ld;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) g[h * HD + d] = acc[d] * a.scale;
-        g[3 * D + h] = dtau;
-        if (h == 0)
-            for (int c = 3 * D + a.H; c < a.ld; ++c) g[c] = 0.f;
-        a.lse[((long long)b * a.H + h) * a.Q + i] = m + __logf(l);
-        a.dvec[((long long)b * a.H + h) * a.Q + i] = dsum;
-    }
-}
-
-// grid = (ceil(Q / 64), H, B), 256 threads = 4 waves x 64 keys: lane = key column j, wave w owns the query tiles w, w + 4, ...;
-// the four partial (dk_j, dv_j) are merged through LDS in a fixed order.
-__global__ __launch_bounds__(64 * NW) void sasa_col_kernel(const SasaBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[NW * COLF];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float (*Qs)[LDT] = reinterpret_cast<float (*)[LDT]>(smem + wave * COLF);
-    float (*Gs)[LDT] = reinterpret_cast<float (*)[LDT]>(smem + wave * COLF + TILE * LDT);
-    float (*Rs)[5] = reinterpret_cast<float (*)[5]>(smem + wave * COLF + 2 * TILE * LDT);   // cx, cy, tau, lse, dvec of the query
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int D = a.H * HD;
-    const int j = blockIdx.x * 64 + lane;
-    const bool live = j < a.Q;
-    const int jc = live ? j : a.Q - 1;
-    const float* base = a.qkvt + (long long)b * a.Q * a.ld;
-    const unsigned thr = (unsigned)((double)a.p_drop * 4294967296.0);
-    float k[HD], v[HD], dk[HD], dv[HD];
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        k[d] = base[(long long)jc * a.ld + D + h * HD + d];
-        v[d] = base[(long long)jc * a.ld + 2 * D + h * HD + d];
-        dk[d] = dv[d] = 0.f;
-    }
-    const float kx = a.bbox[((long long)b * a.Q + jc) * 10] * a.span[0] + a.lo[0];
-    const float ky = a.bbox[((long long)b * a.Q + jc) * 10 + 1] * a.span[1] + a.lo[1];
-    for (int i0 = wave * TILE; i0 < a.Q; i0 += NW * TILE) {
-        __builtin_amdgcn_wave_barrier();
-        {
-            const int qi = min(i0 + lane, a.Q - 1);
-#pragma unroll
-            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                float4 qv = *reinterpret_cast<const float4*>(base + (long long)qi * a.ld + h * HD + 4 * d4);
-                qv.x *= a.scale; qv.y *= a.scale; qv.z *= a.scale; qv.w *= a.scale;
-                *reinterpret_cast<float4*>(&Qs[lane][4 * d4]) = qv;
-                *reinterpret_cast<float4*>(&Gs[lane][4 * d4]) = *reinterpret_cast<const float4*>(a.dO + ((long long)b * a.Q + qi) * D + h * HD + 4 * d4);
-            }
-            Rs[lane][0] = a.bbox[((long long)b * a.Q + qi) * 10] * a.span[0] + a.lo[0];
-            Rs[lane][1] = a.bbox[((long long)b * a.Q + qi) * 10 + 1] * a.span[1] + a.lo[1];
-            Rs[lane][2] = base[(long long)qi * a.ld + 3 * D + h];
-            Rs[lane][3] = a.lse[((long long)b * a.H + h) * a.Q + qi];
-            Rs[lane][4] = a.dvec[((long long)b * a.H + h) * a.Q + qi];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int ni = min(TILE, a.Q - i0);
-        for (int ii = 0; ii < ni; ++ii) {
-            const int i = i0 + ii;
-            if (a.mask && a.mask[(long long)i * a.Q + jc]) continue;
-            float s = 0.f, dp = 0.f;
-            float4 q4[HD / 4], g4[HD / 4];
-#pragma unroll
-            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                q4[d4] = *reinterpret_cast<const float4*>(&Qs[ii][4 * d4]);
-                g4[d4] = *reinterpret_cast<const float4*>(&Gs[ii][4 * d4]);
-                s += q4[d4].x * k[4 * d4]; s += q4[d4].y * k[4 * d4 + 1]; s += q4[d4].z * k[4 * d4 + 2]; s += q4[d4].w * k[4 * d4 + 3];
-                dp += g4[d4].x * v[4 * d4]; dp += g4[d4].y * v[4 * d4 + 1]; dp += g4[d4].z * v[4 * d4 + 2]; dp += g4[d4].w * v[4 * d4 + 3];
-            }
-            const float dx = Rs[ii][0] - kx, dy = Rs[ii][1] - ky;
-            s -= sqrtf(dx * dx + dy * dy) * Rs[ii][2];
-            const float p = __expf(s - Rs[ii][3]);
-            const bool keep = a.p_drop > 0.f ? keep_of(a, thr, b, h, i, jc) : true;
-            const float pd = keep ? p * a.inv_keep : 0.f;
-            const float ds = p * ((keep ? dp * a.inv_keep : 0.f) - Rs[ii][4]);
-#pragma unroll
-            for (int d4 = 0; d4 < HD / 4; ++d4) {                              // (Qs is pre-scaled by 1/sqrt(d))
-                dv[4 * d4] += pd * g4[d4].x; dv[4 * d4 + 1] += pd * g4[d4].y; dv[4 * d4 + 2] += pd * g4[d4].z; dv[4 * d4 + 3] += pd * g4[d4].w;
-                dk[4 * d4] += ds * q4[d4].x; dk[4 * d4 + 1] += ds * q4[d4].y; dk[4 * d4 + 2] += ds * q4[d4].z; dk[4 * d4 + 3] += ds * q4[d4].w;
-            }
-        }
-    }
-    __syncthreads();
-    float* pr = smem;                              // [NW][2 * HD][64] floats = 64 KiB <= NW * COLF * 4
-    static_assert(NW * 2 * HD * 64 <= NW * COLF, "merge area must fit the tile areas");
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        pr[(wave * 2 * HD + d) * 64 + lane] = dk[d];
-        pr[(wave * 2 * HD + HD + d) * 64 + lane] = dv[d];
-    }
-    __syncthreads();
-    if (wave != 0 || !live) return;
-    float* g = a.dqkvt + ((long long)b * a.Q + j) * a.ld;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        g[D + h * HD + d] = (pr[d * 64 + lane] + pr[(2 * HD + d) * 64 + lane]) + (pr[(4 * HD + d) * 64 + lane] + pr[(6 * HD + d) * 64 + lane]);
-        g[2 * D + h * HD + d] = (pr[(HD + d) * 64 + lane] + pr[(3 * HD + d) * 64 + lane]) + (pr[(5 * HD + d) * 64 + lane] + pr[(7 * HD + d) * 64 + lane]);
-    }
+        a.out[((long long)b * a.Q + i) * D + h * HD + d] =
+            (pr[d * 64 + lane] + pr[(HD + d) * 64 + lane]) + (pr[(2 * HD + d) * 64 + lane] + pr[(3 * HD + d) * 64 + lane]);
 }
 
 int fill(SasaBwdArgs& a, const float* qkvt, int64_t ld, const float* bbox, const double* pc_range, const uint8_t* mask,
@@ -317,7 +178,7 @@ extern "C" int sbev_sasa_train_fwd_f32(const float* qkvt, int64_t ld, const floa
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(qkvt && query_bbox && pc_range && out, "sbev_sasa_train_fwd_f32: null pointer");
     a.out = out;
-    hipLaunchKernelGGL(sasa_row_kernel<true>, dim3((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B), dim3(64 * NW), 0,
+    hipLaunchKernelGGL(sasa_dropout_fwd_kernel, dim3((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B), dim3(64 * NW), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_sasa_train_fwd_f32");
 }
@@ -331,21 +192,8 @@ extern "C" int sbev_sasa_bwd_f32(const float* qkvt, int64_t ld, const float* que
     if (st != SBEV_OK) return st;
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(qkvt && query_bbox && pc_range && out && grad_out && grad_qkvt && workspace, "sbev_sasa_bwd_f32: null pointer");
-    // the matrix-core kernels (attention_bwd_mfma.hip); SBEV_SASA_BWD_VALU=1 keeps the plain-VALU pair below for A/B runs
-    static const bool valu = std::getenv("SBEV_SASA_BWD_VALU") != nullptr;
     float* lse = workspace;                              // [B, H, Q]
     float* dvec = workspace + (long long)B * H * Q;      // [B, H, Q]
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (!valu)
-        return sbev::launch_sasa_bwd_mfma(qkvt, ld, query_bbox, a.lo, a.span, mask, out, grad_out, grad_qkvt, lse, dvec, B, Q, H,
-                                          a.scale, attn_drop, seed, s);
-    a.O = out; a.dO = grad_out; a.dqkvt = grad_qkvt;
-    a.lse = lse;
-    a.dvec = dvec;
-    const dim3 grid((unsigned)((Q + 63) / 64), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL(sasa_row_kernel<false>, grid, dim3(64 * NW), 0, s, a);
-    st = sbev::check_launch("sbev_sasa_bwd_f32 (rows)");
-    if (st != SBEV_OK) return st;
-    hipLaunchKernelGGL(sasa_col_kernel, grid, dim3(64 * NW), 0, s, a);
-    return sbev::check_launch("sbev_sasa_bwd_f32 (columns)");
+    return sbev::launch_sasa_bwd_mfma(qkvt, ld, query_bbox, a.lo, a.span, mask, out, grad_out, grad_qkvt, lse, dvec, B, Q, H,
+                                      a.scale, attn_drop, seed, reinterpret_cast<hipStream_t>(stream));
 }

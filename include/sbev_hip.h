@@ -491,7 +491,22 @@ typedef struct sbev_decoder_weights {
     const float *norm1_g, *norm1_b, *norm2_g, *norm2_b, *norm3_g, *norm3_b;
     const float *cls0_w, *cls0_b, *cls1_g, *cls1_b, *cls3_w, *cls3_b, *cls4_g, *cls4_b, *cls6_w, *cls6_b;  /* cls_branch.* */
     const float *reg0_w, *reg0_b, *reg2_w, *reg2_b, *reg4_w, *reg4_b;                                        /* reg_branch.* */
+    const float *chain_pack;   /* sbev_decoder_chain_pack image of the small Linears' weights, or NULL (op-by-op launches) */
 } sbev_decoder_weights;
+
+/*
+ * Row chains.  Every op of a decoder layer except the self attention, the sampler and the two big mixing GEMMs is
+ * row-local (position_encoder, attention in/out projections, norm1-3, sampling Linear, ffn, cls_branch, reg_branch,
+ * refine_bbox: models/sparsebev_transformer.py:166-183), so with `chain_pack` set sbev_decoder_forward runs them as three
+ * launches per layer with the rows in LDS (7 launches per layer instead of 17).  The kernels stream the weights in a
+ * lane-ordered layout: sbev_decoder_chain_pack writes that image (sbev_decoder_chain_pack_floats floats, 16-byte aligned,
+ * 0 = config not covered: needs embed_dims 256, ffn 512, code_size 10) from the weight pointers of `weights`; re-pack when
+ * the weights change.  Results agree with the op-by-op launches to fp32 round-off (different summation order), not bit for bit.
+ * sbev_decoder_row_chain(0) makes sbev_decoder_forward ignore chain_pack (default 1).
+ */
+int64_t sbev_decoder_chain_pack_floats(const sbev_decoder_config* cfg);
+int sbev_decoder_chain_pack(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights, float* out, sbev_stream_t stream);
+int sbev_decoder_row_chain(int enable);
 
 /* Bytes of scratch sbev_decoder_forward needs for this config (-1 on an invalid config). */
 int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg);

@@ -33,6 +33,7 @@ UNITS = {
     'layout.hip': [],
     'head.hip': ['-ffp-contract=off'],   # __fmul_rn / __fadd_rn are plain * and + in HIP: keep them unfused
     'decoder.hip': [],
+    'row_chain.hip': [],                 # the row-local op chains of a layer (4x4x1 MFMA with A broadcast)
     # bit-exact projection: no FMA contraction anywhere in this file
     'project.hip': ['-ffp-contract=off'],
 }

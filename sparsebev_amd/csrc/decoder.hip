@@ -63,6 +63,10 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
 // launches (A/B measurements; results are bit-identical)
 std::atomic<int> g_fuse_sample_mix{1};
 
+// the row-local op chains of a layer as three launches (row_chain.hip) when the caller supplied packed weights
+// (sbev_decoder_weights.chain_pack); sbev_decoder_row_chain(0) restores the op-by-op launches (A/B measurements)
+std::atomic<int> g_row_chain{1};
+
 int validate(const sbev_decoder_config* c) {
     SBEV_REQUIRE(c != nullptr, "sbev_decoder: null config");
     SBEV_REQUIRE(c->B >= 1 && c->Q >= 1 && c->T >= 1 && c->N >= 1 && c->G >= 1 && c->P >= 1, "sbev_decoder: bad sizes");
@@ -168,9 +172,47 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const float* bbox = query_bbox;
     const float* feat = query_feat;
     bool pe0_done = false;             // the previous layer's tail already ran this layer's first position-encoder stage
+    // Row chains (row_chain.hip): 7 launches per layer instead of 17 -- everything between the out-projection GEMM and the self
+    // attention, and between the self attention and the sampler, is row-local and runs with the rows in LDS.
+    const bool chain = g_row_chain.load(std::memory_order_relaxed) != 0 && w->chain_pack != nullptr && !fork && sbev::row_chain_supported(c) &&
+                       sbev::row_chain_pays(BQ);
+    if (chain) TRY(sbev::launch_chain_front(c, *w, query_bbox, query_feat, b.x, b.qkvt, eps, s_main));
     for (int layer = 0; layer < c.num_layers; ++layer) {
         float* cls_l = cls_out + (int64_t)layer * BQ * c.num_classes;
         float* box_l = bbox_out + (int64_t)layer * BQ * c.code_size;
+        if (chain) {
+            TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
+            TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, b.so, eps, s_main));
+            if (c.gemm_mode == SBEV_GEMM_BF16X3)
+                TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, stream));
+            else
+                TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
+            TRY(sbev_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
+                                        c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
+            const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
+                               sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
+            if (fused) {
+                TRY(sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
+                                        c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, stream));
+            } else {
+                if (c.n_slots > 0)
+                    TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                                           c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, c.frame_slots, c.n_slots, stream));
+                else
+                    TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
+                                      c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
+                TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
+            }
+            int used = 0;
+            if (c.gemm_mode == SBEV_GEMM_BF16X3)
+                TRY(sbev::launch_splitk_slabs_bf16x3(b.mixed, w->op_w2, BQ, D, mixN, mixN, splits, b.slabs, &used, s_main));
+            else
+                TRY(sbev::launch_splitk_slabs(b.mixed, w->op_w, BQ, D, mixN, mixN, mixN, splits, b.slabs, &used, s_main));
+            TRY(sbev::launch_chain_tail(c, *w, b.slabs, used, b.x1, bbox, c.T > 1 ? vel_div : nullptr, b.x3, cls_l, box_l,
+                                        layer + 1 < c.num_layers, b.x, b.qkvt, eps, s_main));
+            bbox = box_l;
+            continue;
+        }
         // position encoder -> x = feat + pos                                   (sparsebev_transformer.py:166-167)
         if (!pe0_done) TRY(sbev_linear3_ln_relu_f32(bbox, layer == 0 ? 10 : c.code_size, w->pe0_w, w->pe0_b, w->pe1_g, w->pe1_b, eps, b.t0, BQ, D, stream));
         pe0_done = false;
@@ -342,6 +384,11 @@ extern "C" int sbev_profile_stride(int every_n_calls) {
     std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
     sbev::g_prof_stride = every_n_calls;
     sbev::g_prof_calls = 0;
+    return SBEV_OK;
+}
+
+extern "C" int sbev_decoder_row_chain(int enable) {
+    g_row_chain.store(enable != 0, std::memory_order_relaxed);
     return SBEV_OK;
 }
 

@@ -693,36 +693,46 @@ extern "C" int64_t sbev_linear_splitk_workspace(int64_t M, int N, int splits) {
     return (int64_t)sizeof(float) * M * N * (splits > 0 ? splits : 0);
 }
 
-extern "C" int sbev_linear_splitk_f32(const float* X, const float* W, const float* bias, const float* residual,
-                                      const float* ln_w, const float* ln_b, float ln_eps, float* Y,
-                                      int64_t M, int N, int K, int64_t ldx, int64_t ldw, int relu,
-                                      int splits, float* workspace, sbev_stream_t stream) {
+namespace sbev {
+// the GEMM half of sbev_linear_splitk_f32: *used partial slabs [used, M, N] in `workspace`, no reduction (the row-chain
+// tail kernel of the decoder sums them in its prologue)
+int launch_splitk_slabs(const float* X, const float* W, int64_t M, int N, int K, int64_t ldx, int64_t ldw, int splits,
+                        float* workspace, int* used, hipStream_t s) {
+    if (regtile_ok(M, N, K) && splits <= K / 32) return launch_splitk_regtile(X, W, workspace, M, N, K, ldx, ldw, splits, used, s);
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    *used = (K + kps - 1) / kps;
+    GemmArgs a{X, W, nullptr, nullptr, workspace, M, N, K, ldx, ldw, (long long)N, kps, 0};
+    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (K % BK != 0)
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, true>), dim3((unsigned)tiles, 1, (unsigned)*used), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, false>), dim3((unsigned)tiles, 1, (unsigned)*used), dim3(256), 0, s, a);
+    return check_launch("sbev_linear_splitk_f32 (gemm)");
+}
+}  // namespace sbev
+
+static int check_splitk_args(const float* X, const float* W, const void* Y, const float* workspace, int64_t M, int N, int K,
+                             int64_t ldx, int64_t ldw, int splits) {
     SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024 && K >= 1, "sbev_linear_splitk_f32: need N %% 4 == 0, N <= 1024 (N=%d)", N);
     SBEV_REQUIRE(splits >= 1 && splits <= 1024, "sbev_linear_splitk_f32: splits=%d", splits);
     if (M == 0) return SBEV_OK;
     SBEV_REQUIRE(X && W && Y && workspace, "sbev_linear_splitk_f32: null pointer");
     SBEV_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && ldx >= K && ldw >= K, "sbev_linear_splitk_f32: leading dimensions");
     SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)W | (uintptr_t)workspace) & 15) == 0, "sbev_linear_splitk_f32: 16-byte alignment");
+    return SBEV_OK;
+}
+
+extern "C" int sbev_linear_splitk_f32(const float* X, const float* W, const float* bias, const float* residual,
+                                      const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                      int64_t M, int N, int K, int64_t ldx, int64_t ldw, int relu,
+                                      int splits, float* workspace, sbev_stream_t stream) {
+    int st = check_splitk_args(X, W, Y, workspace, M, N, K, ldx, ldw, splits);
+    if (st != SBEV_OK || M == 0) return st;
     SBEV_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), "sbev_linear_splitk_f32: ln_w and ln_b go together");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int used;
-    if (regtile_ok(M, N, K) && splits <= K / 32) {
-        int st = sbev::launch_splitk_regtile(X, W, workspace, M, N, K, ldx, ldw, splits, &used, s);     // gemm_regtile.hip
-        if (st != SBEV_OK) return st;
-        ReduceArgs r{workspace, bias, residual, ln_w, ln_b, nullptr, Y, M, N, used, relu, ln_eps};
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, r);
-        return sbev::check_launch("sbev_linear_splitk_f32 (reduce)");
-    }
-    int kps = (K + splits - 1) / splits;
-    kps = (kps + BK - 1) / BK * BK;
-    used = (K + kps - 1) / kps;
-    GemmArgs a{X, W, nullptr, nullptr, workspace, M, N, K, ldx, ldw, (long long)N, kps, 0};
-    const long long tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    if (K % BK != 0)
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, true>), dim3((unsigned)tiles, 1, (unsigned)used), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<true, 2, 2, false>), dim3((unsigned)tiles, 1, (unsigned)used), dim3(256), 0, s, a);
-    int st = sbev::check_launch("sbev_linear_splitk_f32 (gemm)");
+    st = sbev::launch_splitk_slabs(X, W, M, N, K, ldx, ldw, splits, workspace, &used, s);
     if (st != SBEV_OK) return st;
     ReduceArgs r{workspace, bias, residual, ln_w, ln_b, nullptr, Y, M, N, used, relu, ln_eps};
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, r);

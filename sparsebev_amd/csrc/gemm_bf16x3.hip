@@ -257,6 +257,23 @@ extern "C" int sbev_linear_bf16x3(const float* X, const uint16_t* W2, const floa
     return sbev::check_launch("sbev_linear_bf16x3");
 }
 
+namespace sbev {
+// the GEMM half of sbev_linear_splitk_bf16x3: *used partial slabs [used, M, N], not reduced
+int launch_splitk_slabs_bf16x3(const float* X, const uint16_t* W2, int64_t M, int N, int K, int64_t ldx, int splits,
+                               float* workspace, int* used, hipStream_t s) {
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    *used = (K + kps - 1) / kps;
+    G3Args a{X, W2, nullptr, nullptr, workspace, M, N, K, ldx, (long long)N, kps, 0};
+    const long long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    auto k = gemm_bf16x3_kernel<true>;
+    int st = set_lds(reinterpret_cast<const void*>(k));
+    if (st != SBEV_OK) return st;
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles, 1, (unsigned)*used), dim3(256), 2 * STAGE, s, a);
+    return check_launch("sbev_linear_splitk_bf16x3 (gemm)");
+}
+}  // namespace sbev
+
 extern "C" int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* bias, const float* residual,
                                          const float* ln_w, const float* ln_b, float ln_eps, float* Y,
                                          int64_t M, int N, int K, int64_t ldx, int relu, int splits, float* workspace,
@@ -265,16 +282,8 @@ extern "C" int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, con
     SBEV_REQUIRE(splits >= 1 && splits <= 1024, "sbev_linear_splitk_bf16x3: splits=%d", splits);
     if (M == 0) return SBEV_OK;
     SBEV_REQUIRE(X && W2 && Y && workspace && ldx % 4 == 0 && ldx >= K, "sbev_linear_splitk_bf16x3: bad pointers");
-    int kps = (K + splits - 1) / splits;
-    kps = (kps + BK - 1) / BK * BK;
-    const int used = (K + kps - 1) / kps;
-    G3Args a{X, W2, nullptr, nullptr, workspace, M, N, K, ldx, (long long)N, kps, 0};
-    const long long tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    auto k = gemm_bf16x3_kernel<true>;
-    int st = set_lds(reinterpret_cast<const void*>(k));
-    if (st != SBEV_OK) return st;
-    hipLaunchKernelGGL(k, dim3((unsigned)tiles, 1, (unsigned)used), dim3(256), 2 * STAGE, reinterpret_cast<hipStream_t>(stream), a);
-    st = sbev::check_launch("sbev_linear_splitk_bf16x3 (gemm)");
+    int used;
+    int st = sbev::launch_splitk_slabs_bf16x3(X, W2, M, N, K, ldx, splits, workspace, &used, reinterpret_cast<hipStream_t>(stream));
     if (st != SBEV_OK) return st;
     // the slab reducer (bias + residual + LayerNorm) is shared with the exact path
     return sbev_splitk_reduce_f32(workspace, used, bias, residual, ln_w, ln_b, ln_eps, Y, M, N, relu, stream);

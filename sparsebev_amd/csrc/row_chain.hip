@@ -1,0 +1,759 @@
+// Row chains of the decoder layer: every op between the big mixing GEMMs and the self attention is ROW-LOCAL (a Linear, a
+// LayerNorm, a ReLU, refine_bbox: query i's output depends on query i only), so a workgroup that owns R = 4 queries can run
+// the whole chain with the activations in LDS instead of one full-chip launch per op (sparsebev_transformer.py:166-183 are
+// 17 small ops per layer; the per-op launches cost 5-10 us each for < 1 us of arithmetic).  Two chains per layer:
+//   TAIL (+ FRONT of the next layer): split-K slabs of mixing.out_proj -> + bias + residual -> norm2 -> ffn -> norm3 ->
+//       cls_branch / reg_branch -> refine_bbox  [-> position_encoder -> x = feat + pos -> attention in-projection]
+//   ATTN: attention out-projection + residual -> norm1 -> sampling_offset / scale_weights Linear
+//
+// GEMM engine (M = 4 rows, so neither a 16- nor a 32-row MFMA tile fits): v_mfma_f32_4x4x1_16b_f32 with the A-matrix
+// BROADCAST modifier (cbsz = 4, abid = k): the 16 blocks of the instruction are 16 groups of 4 output COLUMNS (lane = one
+// of 64 columns), all multiplied by the same 4 rows of block `abid` of the A register -- A holds 16 k-values x 4 rows (one
+// ds_read_b32 per 16 k), B is the lane's own weight column, D is 4 rows x 64 columns in 4 VGPRs.  Exact fp32 (fmaf chain)
+// at the full f32 MFMA rate, no operand duplication.  The weights are streamed from L2 (every workgroup reads every
+// weight: that stream, ~64 B/clk/CU, is the bound), so they are PRE-PACKED (sbev_decoder_chain_pack) in the order the lanes
+// consume them: a wave-load is one contiguous 1 KB line group, and a 32-deep register ring per wave keeps 32 KB in flight --
+// the loads of the NEXT unit are issued while the current one multiplies (weights do not depend on activations).
+// Work split: 8 waves; a unit (one or two independent Linears reading LDS rows) is cut into items of 64 columns x 128 k;
+// item i goes to wave i % 8 in round i / 8 and leaves its partial sums in LDS slot i; the unit's epilogue (wave = row)
+// adds the k-halves in a fixed order, + bias, ReLU / residual / LayerNorm, and writes the next unit's input rows.
+#include "sbev_common.hpp"
+#include <cstdlib>
+
+namespace {
+
+constexpr int R = 4;                 // rows (queries) per workgroup
+constexpr int NWAVE = 8;
+constexpr int DM = 256, FF = 512;    // embed_dims, ffn width (host-checked)
+constexpr int LDX = DM + 8;          // LDS row strides: == 8 (mod 32) so the A read (4 rows x 16 k per 32 lanes) is conflict-free
+constexpr int LDH = FF + 8;
+constexpr int ITEM_FLOATS = 64 * 128;   // one item's packed weights (32 KB)
+constexpr int MAX_SLOTS = 16;
+
+// LDS map (float offsets)
+constexpr int OFF_X2 = 0;                    // x2 (norm2 output) / x (attention input rows) / att rows
+constexpr int OFF_X3 = OFF_X2 + R * LDX;     // x3 = the layer's output rows (next layer's query_feat) / x1
+constexpr int OFF_H = OFF_X3 + R * LDX;      // ffn hidden rows; dead after ffn.layers.1, then:
+constexpr int OFF_C = OFF_H;                 //   classification-branch rows / position-encoder rows
+constexpr int OFF_R = OFF_H + R * LDX;       //   regression-branch rows
+constexpr int OFF_P = OFF_H + 2 * R * LDX;   // partial sums [MAX_SLOTS][R][64]     (2 R LDX >= R LDH)
+constexpr int LDS_FLOATS = OFF_P + MAX_SLOTS * R * 64;
+static_assert(2 * R * LDX >= R * LDH, "branch rows alias the ffn hidden rows");
+
+// The small vectors (biases, LayerNorm weights, the 3 -> 256 position-encoder weight) live behind the packed matrices in the
+// chain_pack image, grouped per chain, and are copied into LDS at kernel start (one contiguous copy; every epilogue would
+// otherwise pay a cold global load).  Float offsets inside the LDS parameter block:
+constexpr int PV_OP_B = 0, PV_N2G = 256, PV_N2B = 512, PV_FFN0_B = 768, PV_FFN1_B = 1280, PV_N3G = 1536, PV_N3B = 1792,
+              PV_CLS0_B = 2048, PV_CLS1G = 2304, PV_CLS1B = 2560, PV_CLS3_B = 2816, PV_CLS4G = 3072, PV_CLS4B = 3328,
+              PV_CLS6_B = 3584, PV_REG0_B = 3648, PV_REG2_B = 3904, PV_REG4_B = 4160, PV_TAIL_END = 4224;
+constexpr int PV_PE0_W = PV_TAIL_END, PV_PE0_B = PV_PE0_W + 768, PV_PE1G = PV_PE0_B + 256, PV_PE1B = PV_PE1G + 256,
+              PV_PE3_B = PV_PE1B + 256, PV_PE4G = PV_PE3_B + 256, PV_PE4B = PV_PE4G + 256, PV_QKV_B = PV_PE4B + 256, PV_QKV_PAD = 832,
+              PV_FRONT_END = PV_QKV_B + PV_QKV_PAD;
+// attention chain (its own launch: offsets from the block start again)
+constexpr int PV_AOUT_B = 0, PV_N1G = 256, PV_N1B = 512, PV_SAMP_B = 768, PV_ATTN_END = 1024;
+constexpr int PV_IMAGE_FLOATS = PV_FRONT_END + PV_ATTN_END;      // in the image: [tail | front | attention]
+
+enum Epi { EPI_FFN0, EPI_FFN1, EPI_BR1, EPI_BR2, EPI_OUT, EPI_PE3, EPI_QKV, EPI_AOUT, EPI_SAMP };
+enum Pre { PRE_SLABS, PRE_FRONT, PRE_ATT };
+
+struct Lin {
+    const float* wp;     // packed weights of this Linear
+    int in_off, ld;      // LDS rows it reads
+    int KH;              // K / 128
+    int items;           // 64-column groups x KH
+};
+struct Unit {
+    Lin a, b;            // b.items == 0: one Linear
+    int epi;
+    int col0;            // EPI_QKV: first output column of this unit
+};
+
+#ifdef SBEV_CHAIN_TRACE
+#define SBEV_TRACE(i) if (blockIdx.x == 7 && lane == 0) a.trace[wave * 64 + (i)] = (long long)__builtin_readcyclecounter();
+#else
+#define SBEV_TRACE(i)
+#endif
+
+struct ChainArgs {
+#ifdef SBEV_CHAIN_TRACE
+    long long* trace;
+#endif
+    Unit units[8];
+    int n_units, pre, front;     // front: EPI_OUT continues with the next layer's position encoder
+    const float* warm;           // the launch's packed weights: one contiguous span of the chain_pack image ...
+    int warm_lines;              // ... of this many 128-byte lines (L2 warm-up, see warm_l2)
+    const float* vec;            // the launch's small vectors in the image -> LDS parameter block [vec_off, vec_off + vec_n)
+    int vec_off, vec_n;
+    long long M;                 // rows (B * Q)
+    int Q;
+    const float* slabs; int splits;      // PRE_SLABS: [splits, M, 256]
+    const float* x1;             // [M, 256] residual of mixing.out_proj
+    float* x3;                   // [M, 256] the layer's output rows
+    const float* bbox;           // [M, 10] this layer's query boxes
+    const float* vel_div;        // [B] or null
+    float* cls_out;              // [M, num_classes]
+    float* box_out;              // [M, 10]
+    int num_classes;
+    const float* feat;           // PRE_FRONT: [M, 256] query_feat
+    float* x;                    // [M, 256]
+    float* qkvt; int attn_in_rows;
+    const float* att;            // PRE_ATT: [M, 256]
+    float* x1_out;               // [M, 256]
+    float* so; int soN;
+    float eps;
+};
+
+// ---- the weight stream --------------------------------------------------------------------------------------------------
+// A wave's items (in program order) form one stream of 4 KB chunks (64 columns x 16 k, 4 wave-loads of 1 KB).  The chunks
+// go global -> LDS directly (global_load_lds_dwordx4) into a private 3-slot ring per wave; a chunk is read into registers
+// and its slot refilled at once, so THREE chunks (12 KB per wave, 96 KB per CU) are in flight while one multiplies, also
+// across item / unit boundaries (weights do not depend on activations).  The loads are issued
+// and waited for by hand (inline asm, counted s_waitcnt vmcnt): hipcc waits vmcnt(0) before every LDS read that follows a
+// compiler-visible LDS-DMA load, which would serialise the stream.  Vector-memory loads return in order, so "at most 4
+// outstanding" means everything older than the newest chunk has landed; compiler-issued loads / stores in between only
+// make these waits (and the compiler's own) more conservative.
+constexpr int RING_SLOTS = 3;
+constexpr int CHUNK_FLOATS = 1024;
+constexpr int OFF_RING = LDS_FLOATS;                                      // [NWAVE][RING_SLOTS][CHUNK_FLOATS]
+constexpr int OFF_DUMP = OFF_RING + NWAVE * RING_SLOTS * CHUNK_FLOATS;     // [NWAVE][64] sink of the warm-up loads
+constexpr int OFF_PARAM = OFF_DUMP + NWAVE * 64;                           // the launch's small vectors (PV_* offsets)
+constexpr int LDS_TOTAL_FLOATS = OFF_PARAM + PV_FRONT_END;
+static_assert(LDS_TOTAL_FLOATS * 4 <= 160 * 1024, "LDS budget of one CU");
+
+// L2 warm-up.  The L2 is cold for the weights at every launch (a whole layer of GEMM / gather traffic went through it), and
+// the workgroups of an XCD stream the same lines in near lock-step, so each line's HBM / Infinity-Cache miss latency would be
+// seen by all of them, every round.  Instead the workgroups of an XCD (workgroup i runs on XCD i % 8) split the launch's
+// weight span between them and touch one dword per 128-byte line of their slice up front, while the prologue runs; the
+// loads go to an LDS sink (no register to keep alive) and are older than every chunk load, so the counted waits stay valid.
+__device__ __forceinline__ void warm_l2(const ChainArgs& a, int wave, int lane) {
+    const int per_xcd = ((int)gridDim.x + 7) / 8;
+    const int parts = per_xcd < 32 ? per_xcd : 32;
+    const int part = ((int)blockIdx.x / 8) % parts;
+    const int n = (a.warm_lines + parts - 1) / parts;
+    const int l0 = part * n;
+    const int l1 = min(a.warm_lines, l0 + n);
+    const unsigned dump = (unsigned)(OFF_DUMP + wave * 64) * 4u;
+    for (int l = l0 + wave * 64; l < l1; l += NWAVE * 64) {
+        const int line = min(l + lane, l1 - 1);
+        const unsigned voff = (unsigned)line * 128u;
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dword %1, %2\n\t"
+            :
+            : "s"(dump), "v"(voff), "s"(a.warm)
+            : "memory");
+    }
+}
+
+struct Walk {            // position of a wave in its item stream
+    int u, it, step;
+};
+
+__device__ __forceinline__ int unit_items(const ChainArgs& a, int u) { return a.units[u].a.items + a.units[u].b.items; }
+
+// first item of this wave at or after (u, it)
+__device__ __forceinline__ void walk_settle(const ChainArgs& a, Walk& w, int wave) {
+    while (w.u < a.n_units && w.it >= unit_items(a, w.u)) {
+        ++w.u;
+        w.it = wave;
+    }
+}
+
+__device__ __forceinline__ const float* item_weights(const Unit& un, int it) {
+    const bool second = it >= un.a.items;
+    const Lin& l = second ? un.b : un.a;
+    return l.wp + (long long)(it - (second ? un.a.items : 0)) * ITEM_FLOATS;
+}
+
+__device__ __forceinline__ void issue_chunk(const float* g, unsigned lds_byte, unsigned voff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        :
+        : "s"(lds_byte), "v"(voff), "s"(g)
+        : "memory");
+}
+
+struct Stream {
+    Walk iw;             // item of the next chunk to issue
+    const float* g;      // its weights (next chunk)
+    int issued, used;    // chunk counters
+    int islot, uslot;    // issued % RING_SLOTS, used % RING_SLOTS
+    unsigned ring_byte;  // LDS byte address of this wave's ring
+    unsigned voff;       // lane * 16
+};
+
+__device__ __forceinline__ void stream_seek(const ChainArgs& a, Stream& st, int wave) {
+    walk_settle(a, st.iw, wave);
+    st.iw.step = 0;
+    if (st.iw.u < a.n_units) st.g = item_weights(a.units[st.iw.u], st.iw.it);
+}
+
+__device__ __forceinline__ void stream_issue(const ChainArgs& a, Stream& st, int wave) {
+    if (st.iw.u >= a.n_units) return;
+    issue_chunk(st.g + st.iw.step * CHUNK_FLOATS, st.ring_byte + (unsigned)st.islot * (CHUNK_FLOATS * 4), st.voff);
+    ++st.issued;
+    st.islot = st.islot == RING_SLOTS - 1 ? 0 : st.islot + 1;
+    if (++st.iw.step == 8) {
+        st.iw.it += NWAVE;
+        stream_seek(a, st, wave);
+    }
+}
+
+#define SBEV_MF(KK, BV) acc[(KK) & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, BV, acc[(KK) & 1], 4, KK, 0);
+#define SBEV_MSTEP(m, q) SBEV_MF(4 * (m) + 0, q.x) SBEV_MF(4 * (m) + 1, q.y) SBEV_MF(4 * (m) + 2, q.z) SBEV_MF(4 * (m) + 3, q.w)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one item (64 columns x 128 k) of Linear `l`: 8 chunks from the ring; partial sums -> P[slot]
+__device__ __forceinline__ void mma_item(const ChainArgs& a, Stream& st, const Lin& l, int j, float* smem, int pslot, int lane, int wave) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int kh = j % l.KH;
+    const float* arow = smem + l.in_off + kh * 128 + (lane & 3) * l.ld + (lane >> 2);
+    const float* ring = smem + OFF_RING + wave * (RING_SLOTS * CHUNK_FLOATS) + lane * 4;
+    for (int s = 0; s < 8; ++s) {
+        const int ahead = st.issued - st.used;             // chunks in flight incl. this one
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float av = arow[s * 16];
+        const float* slot = ring + st.uslot * CHUNK_FLOATS;
+        const float4 q0 = *reinterpret_cast<const float4*>(slot);
+        const float4 q1 = *reinterpret_cast<const float4*>(slot + 256);
+        const float4 q2 = *reinterpret_cast<const float4*>(slot + 512);
+        const float4 q3 = *reinterpret_cast<const float4*>(slot + 768);
+        // the chunk is in registers: its slot is refilled right away (three chunks in flight while this one multiplies)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++st.used;
+        st.uslot = st.uslot == RING_SLOTS - 1 ? 0 : st.uslot + 1;
+        stream_issue(a, st, wave);
+        __builtin_amdgcn_sched_barrier(0);
+        SBEV_MSTEP(0, q0) SBEV_MSTEP(1, q1) SBEV_MSTEP(2, q2) SBEV_MSTEP(3, q3)
+    }
+    const f32x4 t = acc[0] + acc[1];
+    float* p = smem + OFF_P + pslot * (R * 64) + lane;
+    p[0] = t.x; p[64] = t.y; p[128] = t.z; p[192] = t.w;
+}
+
+__device__ __forceinline__ float wsum(float v) { return sbev::wave_sum_dpp(v); }
+
+// LayerNorm over 256 columns held as 4 per lane (column = lane + 64 c)
+__device__ __forceinline__ void ln4(float (&v)[4], const float* g, const float* b, float eps, bool relu, int lane) {
+    const float mean = wsum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / DM);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const float d = v[c] - mean; q += d * d; }
+    const float rstd = rsqrtf(wsum(q) * (1.f / DM) + eps);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float o = (v[c] - mean) * rstd * g[lane + 64 * c] + b[lane + 64 * c];
+        v[c] = relu ? fmaxf(o, 0.f) : o;
+    }
+}
+
+// partial sums of 4 column groups (cg0 .. cg0 + 3) of a Linear whose items start at slot `base`: k-halves added in order, + bias.
+// KH is 2 (K = 256) or 4 (K = 512): specialised so that all LDS reads are in flight before the first add.
+template <int KH>
+__device__ __forceinline__ void gather4_t(float (&v)[4], const float* P, int base, int cg0, int row, int lane, const float* bias, int bias0) {
+    float t[4][KH];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) t[c][kh] = P[(base + (cg0 + c) * KH + kh) * (R * 64) + row * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) s += t[c][kh];
+        v[c] = s + bias[bias0 + lane + 64 * c];
+    }
+}
+__device__ __forceinline__ void gather4(float (&v)[4], const float* P, int base, int KH, int cg0, int row, int lane, const float* bias,
+                                        int bias0) {
+    if (KH == 2) gather4_t<2>(v, P, base, cg0, row, lane, bias, bias0);
+    else gather4_t<4>(v, P, base, cg0, row, lane, bias, bias0);
+}
+
+__device__ __forceinline__ void store_rows(float* smem, int off, int ld, int row, int lane, const float (&v)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) smem[off + row * ld + lane + 64 * c] = v[c];
+}
+
+// position_encoder[0..2]: Linear(3 -> 256) + LayerNorm + ReLU of one row (sparsebev_transformer.py:116-119), into LDS
+__device__ __forceinline__ void pe0_row(const ChainArgs& a, float* smem, int row, int lane, float x0, float x1, float x2) {
+    const float* pv = smem + OFF_PARAM;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = lane + 64 * c;
+        const float* w = pv + PV_PE0_W + n * 3;
+        v[c] = ((x0 * w[0] + x1 * w[1]) + x2 * w[2]) + pv[PV_PE0_B + n];
+    }
+    ln4(v, pv + PV_PE1G, pv + PV_PE1B, a.eps, true, lane);
+    store_rows(smem, OFF_C, LDX, row, lane, v);
+}
+
+// PRE: how the input rows are produced (compile-time: the three chains are three instantiations)
+template <int PRE>
+__global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // LDS_TOTAL_FLOATS (dynamic: > 64 KB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long row0 = (long long)blockIdx.x * R;
+    float* P = smem + OFF_P;
+
+    // the weight stream starts before anything else: two chunks in flight
+    SBEV_TRACE(0)
+    warm_l2(a, wave, lane);
+    Stream st;
+    st.iw = Walk{0, wave, 0};
+    st.issued = st.used = st.islot = st.uslot = 0;
+    st.ring_byte = (unsigned)(OFF_RING + wave * (RING_SLOTS * CHUNK_FLOATS)) * 4u;
+    st.voff = (unsigned)lane * 16u;
+    st.g = nullptr;
+    stream_seek(a, st, wave);
+    stream_issue(a, st, wave);
+    stream_issue(a, st, wave);
+    stream_issue(a, st, wave);
+
+    // ---- prologue: every global load of it is issued before the first wait (one memory latency, not one per phase) -----
+    const float* pv = smem + OFF_PARAM;
+    constexpr int PASSES = (PV_FRONT_END / 4 + 64 * NWAVE - 1) / (64 * NWAVE);
+    float4 pq[PASSES];                                   // the launch's small vectors, on their way to LDS
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+        const int i4 = (int)threadIdx.x + j * 64 * NWAVE;
+        pq[j] = *reinterpret_cast<const float4*>(a.vec + 4 * min(i4, a.vec_n / 4 - 1));
+    }
+    const int prow = wave;                               // waves 0 .. R-1 own one input row each
+    const long long pg = row0 + prow;
+    const bool plive = wave < R && pg < a.M;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), r4 = t;
+    float v0[4] = {0.f, 0.f, 0.f, 0.f};
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    if (PRE == PRE_SLABS) {
+        // mixing.out_proj: sum of the split-K slabs (16 independent loads in flight, added in slab order); lane = 4 columns
+        if (plive) {
+            r4 = *reinterpret_cast<const float4*>(a.x1 + pg * DM + lane * 4);
+            for (int z0 = 0; z0 < a.splits; z0 += 16) {
+                float4 q[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    q[j] = *reinterpret_cast<const float4*>(a.slabs + ((long long)min(z0 + j, a.splits - 1) * a.M + pg) * DM + lane * 4);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) asm volatile("" ::"v"(q[j].x), "v"(q[j].y), "v"(q[j].z), "v"(q[j].w));   // all 16 issued first
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float m = z0 + j < a.splits ? 1.f : 0.f;        // (a select, not a branch: hipcc sinks the loads into branches)
+                    t.x += q[j].x * m; t.y += q[j].y * m; t.z += q[j].z * m; t.w += q[j].w * m;
+                }
+            }
+        }
+    } else if (plive) {
+        const float* src = PRE == PRE_FRONT ? a.feat : a.att;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v0[c] = src[pg * DM + lane + 64 * c];
+        if (PRE == PRE_FRONT) { bx = a.bbox[pg * 10]; by = a.bbox[pg * 10 + 1]; bz = a.bbox[pg * 10 + 2]; }
+    }
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) asm volatile("" ::"v"(pq[j].x), "v"(pq[j].y), "v"(pq[j].z), "v"(pq[j].w));   // keeps the loads up there
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+        const int i4 = (int)threadIdx.x + j * 64 * NWAVE;
+        if (i4 < a.vec_n / 4) *reinterpret_cast<float4*>(smem + OFF_PARAM + a.vec_off + 4 * i4) = pq[j];
+    }
+    __syncthreads();
+    if (wave < R) {
+        if (PRE == PRE_SLABS) {
+            // + bias + residual x1 -> norm2 (sparsebev_transformer.py:171)
+            const float4 b4 = *reinterpret_cast<const float4*>(pv + PV_OP_B + lane * 4);
+            if (plive) { t.x = (t.x + b4.x) + r4.x; t.y = (t.y + b4.y) + r4.y; t.z = (t.z + b4.z) + r4.z; t.w = (t.w + b4.w) + r4.w; }
+            const float mean = wsum((t.x + t.y) + (t.z + t.w)) * (1.f / DM);
+            const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+            const float rstd = rsqrtf(wsum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / DM) + a.eps);
+            const float4 g4 = *reinterpret_cast<const float4*>(pv + PV_N2G + lane * 4);
+            const float4 n4 = *reinterpret_cast<const float4*>(pv + PV_N2B + lane * 4);
+            *reinterpret_cast<float4*>(smem + OFF_X2 + prow * LDX + lane * 4) =
+                make_float4(dx * rstd * g4.x + n4.x, dy * rstd * g4.y + n4.y, dz * rstd * g4.z + n4.z, dw * rstd * g4.w + n4.w);
+        } else {
+            store_rows(smem, PRE == PRE_FRONT ? OFF_X3 : OFF_X2, LDX, prow, lane, v0);
+            if (PRE == PRE_FRONT) pe0_row(a, smem, prow, lane, bx, by, bz);
+        }
+    }
+    __syncthreads();
+
+    SBEV_TRACE(1)
+    for (int u = 0; u < a.n_units; ++u) {
+        const Unit& un = a.units[u];
+        const int items = un.a.items + un.b.items;
+        for (int it = wave; it < items; it += NWAVE) {
+            const bool second = it >= un.a.items;
+            mma_item(a, st, second ? un.b : un.a, it - (second ? un.a.items : 0), smem, it, lane, wave);
+        }
+        SBEV_TRACE(2 + 4 * u)
+        __syncthreads();
+        SBEV_TRACE(3 + 4 * u)
+        // ---- epilogue: task = (row, side); wave-local row ops ----------------------------------------------------------
+        for (int task = wave; task < 2 * R; task += NWAVE) {
+            const int row = task % R, side = task / R;
+            const long long g = row0 + row;
+            const bool live = g < a.M;
+            float v[4];
+            switch (un.epi) {
+            case EPI_FFN0: {     // relu(x2 W0^T + b0): side = column half
+                gather4(v, P, 0, un.a.KH, side * 4, row, lane, pv + PV_FFN0_B, side * 256);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) smem[OFF_H + row * LDH + side * 256 + lane + 64 * c] = fmaxf(v[c], 0.f);
+            } break;
+            case EPI_FFN1: {     // + x2 -> norm3 -> x3
+                if (side) break;
+                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_FFN1_B, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += smem[OFF_X2 + row * LDX + lane + 64 * c];
+                ln4(v, pv + PV_N3G, pv + PV_N3B, a.eps, false, lane);
+                store_rows(smem, OFF_X3, LDX, row, lane, v);
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a.x3[g * DM + lane + 64 * c] = v[c];
+                }
+            } break;
+            case EPI_BR1:        // cls_branch[0..2] | reg_branch[0..1]
+            case EPI_BR2: {      // cls_branch[3..5] | reg_branch[2..3]
+                const bool first = un.epi == EPI_BR1;
+                if (side == 0) {
+                    gather4(v, P, 0, un.a.KH, 0, row, lane, pv + (first ? PV_CLS0_B : PV_CLS3_B), 0);
+                    ln4(v, pv + (first ? PV_CLS1G : PV_CLS4G), pv + (first ? PV_CLS1B : PV_CLS4B), a.eps, true, lane);
+                    store_rows(smem, OFF_C, LDX, row, lane, v);
+                } else {
+                    gather4(v, P, un.a.items, un.b.KH, 0, row, lane, pv + (first ? PV_REG0_B : PV_REG2_B), 0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                    store_rows(smem, OFF_R, LDX, row, lane, v);
+                }
+            } break;
+            case EPI_OUT: {      // cls_branch[6] -> scores | reg_branch[4] -> refine_bbox (:174-183) [-> next position encoder]
+                if (side == 0) {
+                    if (lane < a.num_classes) {
+                        float s = 0.f;
+                        for (int kh = 0; kh < un.a.KH; ++kh) s += P[kh * (R * 64) + row * 64 + lane];
+                        if (live) a.cls_out[g * a.num_classes + lane] = s + pv[PV_CLS6_B + lane];
+                    }
+                } else {
+                    float o = 0.f;
+                    if (lane < 10) {
+                        float s = 0.f;
+                        for (int kh = 0; kh < un.b.KH; ++kh) s += P[(un.a.items + kh) * (R * 64) + row * 64 + lane];
+                        const float r = s + pv[PV_REG4_B + lane];
+                        const long long gi = live ? g : 0;
+                        if (lane < 3) {
+                            float p = a.bbox[gi * 10 + lane];
+                            p = fminf(fmaxf(p, 0.f), 1.f);
+                            const float logit = logf(fmaxf(p, 1e-5f) / fmaxf(1.f - p, 1e-5f));
+                            o = 1.f / (1.f + expf(-(r + logit)));
+                        } else {
+                            o = r;
+                            if (lane >= 8 && a.vel_div) o = r / a.vel_div[(unsigned)gi / (unsigned)a.Q];
+                        }
+                        if (live) a.box_out[g * 10 + lane] = o;
+                    }
+                    if (a.front) {
+                        const int ob = (int)__float_as_uint(o);
+                        const float x0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(ob, 0));
+                        const float x1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(ob, 1));
+                        const float x2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(ob, 2));
+                        pe0_row(a, smem, row, lane, x0, x1, x2);
+                    }
+                }
+            } break;
+            case EPI_PE3: {      // position_encoder[3..5] + query_feat -> x (:166-167)
+                if (side) break;
+                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_PE3_B, 0);
+                ln4(v, pv + PV_PE4G, pv + PV_PE4B, a.eps, true, lane);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += smem[OFF_X3 + row * LDX + lane + 64 * c];
+                store_rows(smem, OFF_X2, LDX, row, lane, v);
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a.x[g * DM + lane + 64 * c] = v[c];
+                }
+            } break;
+            case EPI_QKV: {      // attention in-projection + gen_tau rows -> qkvt
+                const int ncg = un.a.items / un.a.KH;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int cg = side * 4 + c;
+                    const int n = un.col0 + cg * 64 + lane;
+                    if (cg < ncg && n < a.attn_in_rows) {
+                        float s = 0.f;
+                        for (int kh = 0; kh < un.a.KH; ++kh) s += P[(cg * un.a.KH + kh) * (R * 64) + row * 64 + lane];
+                        if (live) a.qkvt[g * a.attn_in_rows + n] = s + pv[PV_QKV_B + n];
+                    }
+                }
+            } break;
+            case EPI_AOUT: {     // attention out-projection + x -> norm1 -> x1 (:169)
+                if (side) break;
+                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_AOUT_B, 0);
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] += a.x[g * DM + lane + 64 * c];
+                }
+                ln4(v, pv + PV_N1G, pv + PV_N1B, a.eps, false, lane);
+                store_rows(smem, OFF_X3, LDX, row, lane, v);
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a.x1_out[g * DM + lane + 64 * c] = v[c];
+                }
+            } break;
+            case EPI_SAMP: {     // sampling_offset | scale_weights Linear -> so
+                if (side) break;
+                const int ncg = un.a.items / un.a.KH;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int n = c * 64 + lane;
+                    if (c < ncg && n < a.soN) {
+                        float s = 0.f;
+                        for (int kh = 0; kh < un.a.KH; ++kh) s += P[(c * un.a.KH + kh) * (R * 64) + row * 64 + lane];
+                        if (live) a.so[g * a.soN + n] = s + pv[PV_SAMP_B + n];
+                    }
+                }
+            } break;
+            }
+        }
+        SBEV_TRACE(4 + 4 * u)
+        __syncthreads();
+        SBEV_TRACE(5 + 4 * u)
+    }
+}
+
+// weights [N, K] row-major (ld) -> the order the lanes consume them: [ceil(N/64)][K/16][4][64 lanes][4 floats],
+// lane = column within the group, (step, m, e) -> k = 16 step + 4 m + e; rows past N are zero
+__global__ void pack_kernel(const float* W, long long ld, int N, int K, float* out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one float4 each
+    const long long total = (long long)((N + 63) / 64) * K * 16;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const long long t = i >> 6;
+    const int m = (int)(t & 3);
+    const long long t2 = t >> 2;
+    const int steps = K / 16;
+    const int s = (int)(t2 % steps);
+    const int cg = (int)(t2 / steps);
+    const int n = cg * 64 + lane;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) v = *reinterpret_cast<const float4*>(W + (long long)n * ld + 16 * s + 4 * m);
+    reinterpret_cast<float4*>(out)[i] = v;
+}
+
+__global__ void copy_pad_kernel(const float* src, int n, float* dst, int slot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < slot) dst[i] = i < n ? src[i] : 0.f;
+}
+
+long long packed_floats(int N, int K) { return (long long)((N + 63) / 64) * 64 * K; }
+
+struct PackMap {     // float offsets into the chain_pack blob
+    long long ffn0, ffn1, cls0, reg0, cls3, reg2, cls6, reg4, pe3, attn_in, attn_out, samp, vec, total;
+};
+PackMap pack_map(const sbev_decoder_config& c) {
+    PackMap m{};
+    long long o = 0;
+    auto put = [&](long long& slot, int N, int K) { slot = o; o += packed_floats(N, K); };
+    put(m.ffn0, c.ffn, c.D); put(m.ffn1, c.D, c.ffn);
+    put(m.cls0, c.D, c.D); put(m.reg0, c.D, c.D); put(m.cls3, c.D, c.D); put(m.reg2, c.D, c.D);
+    put(m.cls6, c.num_classes, c.D); put(m.reg4, c.code_size, c.D);
+    put(m.pe3, c.D, c.D); put(m.attn_in, c.attn_in_rows, c.D);
+    put(m.attn_out, c.D, c.D); put(m.samp, c.G * c.P * (3 + c.L), c.D);
+    m.vec = o;                     // the small vectors: [tail | front | attention], PV_* offsets
+    m.total = o + PV_IMAGE_FLOATS;
+    return m;
+}
+
+Lin lin(const float* wp, int in_off, int ld, int N, int K, int cg0 = 0, int ncg = -1) {
+    const int KH = K / 128;
+    const int all = (N + 63) / 64;
+    if (ncg < 0) ncg = all - cg0;
+    return Lin{wp + (long long)cg0 * KH * ITEM_FLOATS, in_off, ld, KH, ncg * KH};
+}
+const Lin kNone{nullptr, 0, LDX, 1, 0};
+
+}  // namespace
+
+namespace sbev {
+
+bool row_chain_supported(const sbev_decoder_config& c) {
+    return c.D == DM && c.ffn == FF && c.code_size == 10 && c.num_classes >= 1 && c.num_classes <= 64 &&
+           c.attn_in_rows <= PV_QKV_PAD && c.G * c.P * (3 + c.L) <= 256 && (long long)c.B * c.Q < 0x7fffffffLL;
+}
+
+// One workgroup per 4 rows streams every weight: that pays while the launch is a single wave of workgroups (<= 256 CUs).
+// Measured (samples/s with / without the chains): config 2 (900 rows) 350 / 328, config 5 387 / 358; config 3 (3200 rows)
+// 747 / 755, config 4 (3600 rows) 271 / 272 -- larger batches keep the op-by-op launches, whose tiles amortise the weights.
+bool row_chain_pays(long long rows) { return rows <= 256 * R; }
+
+static void fill_common(ChainArgs& a, const sbev_decoder_config& c, float eps) {
+    a.M = (long long)c.B * c.Q;
+    a.Q = c.Q;
+    a.eps = eps;
+    a.num_classes = c.num_classes;
+    a.attn_in_rows = c.attn_in_rows;
+    a.soN = c.G * c.P * (3 + c.L);
+}
+
+static int add_front(ChainArgs& a, int n, const sbev_decoder_config& c, const float* pk, const PackMap& m) {
+    a.units[n++] = Unit{lin(pk + m.pe3, OFF_C, LDX, c.D, c.D), kNone, EPI_PE3, 0};
+    const int ncg = (c.attn_in_rows + 63) / 64;
+    for (int cg0 = 0; cg0 < ncg; cg0 += 8)
+        a.units[n++] = Unit{lin(pk + m.attn_in, OFF_X2, LDX, c.attn_in_rows, c.D, cg0, ncg - cg0 < 8 ? ncg - cg0 : 8), kNone, EPI_QKV, cg0 * 64};
+    return n;
+}
+
+template <int PRE>
+static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_FLOATS * 4);
+    if (attr != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, LDS_TOTAL_FLOATS * 4, hipGetErrorString(attr));
+        return SBEV_ELAUNCH;
+    }
+    static const bool no_warm = getenv("SBEV_CHAIN_NO_WARM") != nullptr;       // A/B switch
+    ChainArgs b = a;
+    if (no_warm) b.warm_lines = 0;
+#ifdef SBEV_CHAIN_TRACE
+    static long long* tr = nullptr;
+    static int calls = 0;
+    if (!tr) { (void)hipMalloc(&tr, 64 * 8 * 8 * 64); (void)hipMemset(tr, 0, 64 * 8 * 8 * 64); }
+    b.trace = tr + (calls % 64) * 512;
+#endif
+    hipLaunchKernelGGL(row_chain_kernel<PRE>, dim3((unsigned)((a.M + R - 1) / R)), dim3(64 * NWAVE), LDS_TOTAL_FLOATS * 4, s, b);
+#ifdef SBEV_CHAIN_TRACE
+    if (++calls == 13) {        // the first step's 13 launches
+        (void)hipDeviceSynchronize();
+        static long long h[64 * 512];
+        (void)hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost);
+        for (int c = 0; c < 13; ++c) {
+            const long long* t = h + c * 512;
+            printf("launch %d:", c);
+            for (int w = 0; w < 8; w += 7) {
+                printf(" [w%d]", w);
+                for (int i = 1; i < 2 + 4 * 8 && t[w * 64 + i]; ++i) printf(" %lld", t[w * 64 + i] - t[w * 64]);
+            }
+            printf("\n");
+        }
+    }
+#endif
+    return check_launch(what);
+}
+
+static int launch(const ChainArgs& a, hipStream_t s, const char* what) {
+    return a.pre == PRE_SLABS ? launch_t<PRE_SLABS>(a, s, what) : a.pre == PRE_FRONT ? launch_t<PRE_FRONT>(a, s, what) : launch_t<PRE_ATT>(a, s, what);
+}
+
+// position encoder + attention in-projection of the FIRST layer (the later layers' run at the end of the previous tail)
+int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* bbox, const float* feat, float* x,
+                       float* qkvt, float eps, hipStream_t s) {
+    const PackMap m = pack_map(c);
+    ChainArgs a{};
+    fill_common(a, c, eps);
+    a.pre = PRE_FRONT;
+    a.bbox = bbox; a.feat = feat; a.x = x; a.qkvt = qkvt;
+    a.n_units = add_front(a, 0, c, w.chain_pack, m);
+    a.warm = w.chain_pack + m.pe3;
+    a.warm_lines = (int)((m.attn_out - m.pe3) / 32);
+    a.vec = w.chain_pack + m.vec + PV_TAIL_END; a.vec_off = PV_TAIL_END; a.vec_n = PV_FRONT_END - PV_TAIL_END;
+    return launch(a, s, "row chain (front)");
+}
+
+// attention out-projection + residual + norm1 -> x1, sampling Linear -> so
+int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
+                      float* so, float eps, hipStream_t s) {
+    const PackMap m = pack_map(c);
+    ChainArgs a{};
+    fill_common(a, c, eps);
+    a.pre = PRE_ATT;
+    a.att = att; a.x = const_cast<float*>(x); a.x1_out = x1; a.so = so;
+    a.units[0] = Unit{lin(w.chain_pack + m.attn_out, OFF_X2, LDX, c.D, c.D), kNone, EPI_AOUT, 0};
+    a.units[1] = Unit{lin(w.chain_pack + m.samp, OFF_X3, LDX, a.soN, c.D), kNone, EPI_SAMP, 0};
+    a.n_units = 2;
+    a.warm = w.chain_pack + m.attn_out;
+    a.warm_lines = (int)((m.vec - m.attn_out) / 32);
+    a.vec = w.chain_pack + m.vec + PV_FRONT_END; a.vec_off = 0; a.vec_n = PV_ATTN_END;
+    return launch(a, s, "row chain (attention)");
+}
+
+// out_proj slabs -> norm2 -> ffn -> norm3 -> branches -> refine_bbox [-> the next layer's position encoder + in-projection]
+int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* slabs, int splits, const float* x1,
+                      const float* bbox, const float* vel_div, float* x3, float* cls_out, float* box_out, int with_front, float* x,
+                      float* qkvt, float eps, hipStream_t s) {
+    const PackMap m = pack_map(c);
+    const float* pk = w.chain_pack;
+    ChainArgs a{};
+    fill_common(a, c, eps);
+    a.pre = PRE_SLABS;
+    a.slabs = slabs; a.splits = splits; a.x1 = x1; a.bbox = bbox; a.vel_div = vel_div;
+    a.x3 = x3; a.cls_out = cls_out; a.box_out = box_out; a.front = with_front; a.x = x; a.qkvt = qkvt;
+    int n = 0;
+    a.units[n++] = Unit{lin(pk + m.ffn0, OFF_X2, LDX, c.ffn, c.D), kNone, EPI_FFN0, 0};
+    a.units[n++] = Unit{lin(pk + m.ffn1, OFF_H, LDH, c.D, c.ffn), kNone, EPI_FFN1, 0};
+    a.units[n++] = Unit{lin(pk + m.cls0, OFF_X3, LDX, c.D, c.D), lin(pk + m.reg0, OFF_X3, LDX, c.D, c.D), EPI_BR1, 0};
+    a.units[n++] = Unit{lin(pk + m.cls3, OFF_C, LDX, c.D, c.D), lin(pk + m.reg2, OFF_R, LDX, c.D, c.D), EPI_BR2, 0};
+    a.units[n++] = Unit{lin(pk + m.cls6, OFF_C, LDX, c.num_classes, c.D), lin(pk + m.reg4, OFF_R, LDX, c.code_size, c.D), EPI_OUT, 0};
+    if (with_front) n = add_front(a, n, c, pk, m);
+    a.n_units = n;
+    a.warm = pk + m.ffn0;
+    a.warm_lines = (int)(((with_front ? m.attn_out : m.pe3) - m.ffn0) / 32);
+    a.vec = pk + m.vec; a.vec_off = 0; a.vec_n = with_front ? PV_FRONT_END : PV_TAIL_END;
+    return launch(a, s, "row chain (tail)");
+}
+
+}  // namespace sbev
+
+extern "C" int64_t sbev_decoder_chain_pack_floats(const sbev_decoder_config* cfg) {
+    if (!cfg || !sbev::row_chain_supported(*cfg)) return 0;
+    return pack_map(*cfg).total;
+}
+
+extern "C" int sbev_decoder_chain_pack(const sbev_decoder_config* cfg, const sbev_decoder_weights* w, float* out, sbev_stream_t stream) {
+    SBEV_REQUIRE(cfg && w && out, "sbev_decoder_chain_pack: null pointer");
+    SBEV_REQUIRE(sbev::row_chain_supported(*cfg), "sbev_decoder_chain_pack: config not covered by the row-chain kernels (embed_dims 256, ffn 512, code_size 10)");
+    SBEV_REQUIRE((((uintptr_t)out) & 15) == 0, "sbev_decoder_chain_pack: output must be 16-byte aligned");
+    const sbev_decoder_config& c = *cfg;
+    const PackMap m = pack_map(c);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    struct Job { const float* W; long long off; int N, K; };
+    const Job jobs[12] = {{w->ffn0_w, m.ffn0, c.ffn, c.D}, {w->ffn1_w, m.ffn1, c.D, c.ffn}, {w->cls0_w, m.cls0, c.D, c.D},
+                          {w->reg0_w, m.reg0, c.D, c.D}, {w->cls3_w, m.cls3, c.D, c.D}, {w->reg2_w, m.reg2, c.D, c.D},
+                          {w->cls6_w, m.cls6, c.num_classes, c.D}, {w->reg4_w, m.reg4, c.code_size, c.D}, {w->pe3_w, m.pe3, c.D, c.D},
+                          {w->attn_in_w, m.attn_in, c.attn_in_rows, c.D}, {w->attn_out_w, m.attn_out, c.D, c.D},
+                          {w->samp_w, m.samp, c.G * c.P * (3 + c.L), c.D}};
+    for (const Job& j : jobs) {
+        SBEV_REQUIRE(j.W && (((uintptr_t)j.W) & 15) == 0, "sbev_decoder_chain_pack: null / unaligned weight");
+        const long long n4 = (long long)((j.N + 63) / 64) * j.K * 16;
+        hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, j.W, (long long)j.K, j.N, j.K, out + j.off);
+    }
+    // the small vectors, zero-padded to their slots
+    float* pv = out + m.vec;
+    struct Vec { const float* p; int off, n, slot; };
+    const int soN = c.G * c.P * (3 + c.L);
+    const Vec vecs[] = {
+        {w->op_b, PV_OP_B, c.D, 256}, {w->norm2_g, PV_N2G, c.D, 256}, {w->norm2_b, PV_N2B, c.D, 256}, {w->ffn0_b, PV_FFN0_B, c.ffn, 512},
+        {w->ffn1_b, PV_FFN1_B, c.D, 256}, {w->norm3_g, PV_N3G, c.D, 256}, {w->norm3_b, PV_N3B, c.D, 256},
+        {w->cls0_b, PV_CLS0_B, c.D, 256}, {w->cls1_g, PV_CLS1G, c.D, 256}, {w->cls1_b, PV_CLS1B, c.D, 256},
+        {w->cls3_b, PV_CLS3_B, c.D, 256}, {w->cls4_g, PV_CLS4G, c.D, 256}, {w->cls4_b, PV_CLS4B, c.D, 256},
+        {w->cls6_b, PV_CLS6_B, c.num_classes, 64}, {w->reg0_b, PV_REG0_B, c.D, 256}, {w->reg2_b, PV_REG2_B, c.D, 256},
+        {w->reg4_b, PV_REG4_B, c.code_size, 64},
+        {w->pe0_w, PV_PE0_W, 3 * c.D, 768}, {w->pe0_b, PV_PE0_B, c.D, 256}, {w->pe1_g, PV_PE1G, c.D, 256}, {w->pe1_b, PV_PE1B, c.D, 256},
+        {w->pe3_b, PV_PE3_B, c.D, 256}, {w->pe4_g, PV_PE4G, c.D, 256}, {w->pe4_b, PV_PE4B, c.D, 256},
+        {w->attn_in_b, PV_QKV_B, c.attn_in_rows, PV_QKV_PAD},
+        {w->attn_out_b, PV_FRONT_END + PV_AOUT_B, c.D, 256}, {w->norm1_g, PV_FRONT_END + PV_N1G, c.D, 256},
+        {w->norm1_b, PV_FRONT_END + PV_N1B, c.D, 256}, {w->samp_b, PV_FRONT_END + PV_SAMP_B, soN, 256}};
+    for (const Vec& v : vecs) {
+        SBEV_REQUIRE(v.p, "sbev_decoder_chain_pack: null bias / LayerNorm pointer");
+        hipLaunchKernelGGL(copy_pad_kernel, dim3((unsigned)((v.slot + 255) / 256)), dim3(256), 0, s, v.p, v.n, pv + v.off, v.slot);
+    }
+    return sbev::check_launch("sbev_decoder_chain_pack");
+}

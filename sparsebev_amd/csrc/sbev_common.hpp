@@ -38,6 +38,24 @@ int launch_splitk_regtile(const float* X, const float* W, float* slabs, int64_t 
 
 int regtile_plan(int64_t M, int N, int K);
 
+// gemm.hip: the GEMM half of sbev_linear_splitk_f32 (*used partial slabs [used, M, N], not reduced)
+int launch_splitk_slabs(const float* X, const float* W, int64_t M, int N, int K, int64_t ldx, int64_t ldw, int splits,
+                        float* workspace, int* used, hipStream_t s);
+
+int launch_splitk_slabs_bf16x3(const float* X, const uint16_t* W2, int64_t M, int N, int K, int64_t ldx, int splits,
+                               float* workspace, int* used, hipStream_t s);
+
+// row_chain.hip: the row-local op chains of a decoder layer as single launches (weights pre-packed: sbev_decoder_chain_pack)
+bool row_chain_supported(const sbev_decoder_config& c);
+bool row_chain_pays(long long rows);
+int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* bbox, const float* feat, float* x,
+                       float* qkvt, float eps, hipStream_t s);
+int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
+                      float* so, float eps, hipStream_t s);
+int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* slabs, int splits, const float* x1,
+                      const float* bbox, const float* vel_div, float* x3, float* cls_out, float* box_out, int with_front, float* x,
+                      float* qkvt, float eps, hipStream_t s);
+
 // gemm.hip: pairs of independent small ops of a decoder layer's tail in ONE launch (see pair_kernel)
 bool small_linear_shape(int64_t M, int N, int K);
 int launch_ln_and_linear(const float* X, const float* ln_w, const float* ln_b, float eps, int ln_relu, float* Yln, int64_t M, int N,

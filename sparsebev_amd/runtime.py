@@ -25,7 +25,7 @@ _WEIGHT_FIELDS = ['pe0_w', 'pe0_b', 'pe1_g', 'pe1_b', 'pe3_w', 'pe3_b', 'pe4_g',
                   'pg_w', 'pg_b', 'op_w', 'op_b', 'pg_w2', 'op_w2', 'ffn0_w', 'ffn0_b', 'ffn1_w', 'ffn1_b',
                   'norm1_g', 'norm1_b', 'norm2_g', 'norm2_b', 'norm3_g', 'norm3_b',
                   'cls0_w', 'cls0_b', 'cls1_g', 'cls1_b', 'cls3_w', 'cls3_b', 'cls4_g', 'cls4_b', 'cls6_w', 'cls6_b',
-                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b']
+                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b', 'chain_pack']
 
 
 class DecoderWeights(ctypes.Structure):
@@ -44,6 +44,8 @@ class DecoderRuntime:
         import os
         if os.environ.get('SBEV_NO_SAMPLE_MIX') == '1':
             fuse_sample_mix(False)
+        if os.environ.get('SBEV_NO_ROW_CHAIN') == '1':
+            row_chain(False)
         self.decoder = decoder
         self.gemm_mode = gemm_mode
         self.overlap = overlap
@@ -100,6 +102,21 @@ class DecoderRuntime:
         w = DecoderWeights()
         for k in _WEIGHT_FIELDS:
             setattr(w, k, keep[k].data_ptr() if k in keep else None)
+        # lane-ordered image of the small Linears' weights for the row-chain kernels (csrc/row_chain.hip), where they cover
+        # the layer's shape; re-made with every re-bind
+        lib = _lib.load()
+        cfg = DecoderConfig()
+        cfg.B = cfg.Q = 1
+        cfg.T, cfg.N, cfg.G, cfg.P, cfg.L = smp.num_frames, 6, smp.num_groups, smp.num_points, smp.num_levels
+        cfg.D, cfg.H, cfg.ffn = D, H, ffn[0][0].weight.shape[0]
+        cfg.num_classes, cfg.code_size, cfg.attn_in_rows = layer.num_classes, layer.code_size, attn_in_w.shape[0]
+        n_pack = lib.sbev_decoder_chain_pack_floats(ctypes.byref(cfg))
+        if n_pack > 0:
+            pack = torch.empty(n_pack, device=attn_in_w.device, dtype=torch.float32)
+            _lib.check(lib.sbev_decoder_chain_pack(ctypes.byref(cfg), ctypes.byref(w), _ptr(pack),
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'sbev_decoder_chain_pack')
+            keep['chain_pack'] = pack
+            w.chain_pack = pack.data_ptr()
         self._keep, self._weights = keep, w
         self._attn_in_rows = attn_in_w.shape[0]
 
@@ -208,6 +225,13 @@ def fuse_sample_mix(enable):
     """Gather + adaptive mixing as one launch inside sbev_decoder_forward where the fused kernel covers the shape (default on;
     results are bit-identical either way).  ``SBEV_NO_SAMPLE_MIX=1`` in the environment switches it off for A/B runs."""
     _lib.check(_lib.load().sbev_decoder_fuse_sample_mix(int(bool(enable))), 'sbev_decoder_fuse_sample_mix')
+
+
+def row_chain(enable):
+    """The row-local op chains of a layer (position encoder, attention projections, norms, ffn, branches, refine_bbox) as three
+    launches with the rows in LDS instead of one launch per op (default on where the kernels cover the layer's shape; results
+    agree to fp32 round-off, not bit for bit).  ``SBEV_NO_ROW_CHAIN=1`` in the environment switches it off for A/B runs."""
+    _lib.check(_lib.load().sbev_decoder_row_chain(int(bool(enable))), 'sbev_decoder_row_chain')
 
 
 def profile_sampler(enable):

@@ -40,6 +40,27 @@ def has_gpu():
     return torch.cuda.is_available()
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def op_by_op_runtime():
+    """sbev_decoder_forward with one launch per op (row chains off): exactly the launches of the layer-by-layer Python
+    path, so the two agree bit for bit; the row-chain kernels (csrc/row_chain.hip) sum in another order and agree to
+    fp32 round-off (tests/test_gpu_chain.py)."""
+    from sparsebev_amd import runtime
+    runtime.row_chain(False)
+    try:
+        yield
+    finally:
+        runtime.row_chain(True)
+
+
+def runtime_op_by_op(model, *args, **kw):
+    with op_by_op_runtime():
+        return model(*args, **kw)
+
+
 @pytest.fixture(autouse=True)
 def _inference_mode_by_default():
     """The parity tests exercise the inference path (the reference's val.py / timing.py run under no_grad); with grad

@@ -156,3 +156,25 @@ def test_round2_entry_points_validate_without_gpu(lib):
     assert lib.sbev_msmv_bwd_ex(feats, None, hw, 1, 6, 6, 64, 3, 4, 1, s64, 0, sv, 64, one, one, one, 1, 4, 4, one, one, None) == -1
     assert lib.sbev_dropout_f32(one, one, 16, 1, 1.0, None) == -1 and lib.sbev_dropout_f32(None, None, 0, 1, 0.5, None) == 0
     assert lib.sbev_copy_widen_f32(one, 3, one, 4, None) == -1
+
+
+def test_chain_pack_size_is_a_pure_host_function(lib):
+    """sbev_decoder_chain_pack_floats: the size of the lane-ordered weight image of the row-chain kernels for the
+    reference's layer shape, 0 for shapes the kernels do not cover; the pack call validates its arguments on the host."""
+    from sparsebev_amd.runtime import DecoderConfig, DecoderWeights
+    cfg = DecoderConfig()
+    cfg.B = cfg.Q = 1
+    cfg.T, cfg.N, cfg.G, cfg.P, cfg.L = 8, 6, 4, 4, 4
+    cfg.D, cfg.H, cfg.ffn, cfg.num_classes, cfg.code_size, cfg.attn_in_rows = 256, 8, 512, 10, 10, 776
+    n = lib.sbev_decoder_chain_pack_floats(ctypes.byref(cfg))
+    mats = (512 * 256 + 256 * 512 + 5 * 256 * 256 + 2 * 64 * 256      # ffn, cls0 / reg0 / cls3 / reg2 / pe3, cls6 / reg4 (64-column groups)
+            + 832 * 256 + 256 * 256 + 128 * 256)                        # attn_in (776 -> 13 groups), attn_out, sampling (112 -> 2 groups)
+    assert n > mats and (n - mats) % 64 == 0 and n - mats < 16384         # + the small vectors
+    cfg.ffn = 1024
+    assert lib.sbev_decoder_chain_pack_floats(ctypes.byref(cfg)) == 0
+    cfg.ffn, cfg.code_size = 512, 8
+    assert lib.sbev_decoder_chain_pack_floats(ctypes.byref(cfg)) == 0
+    w = DecoderWeights()
+    assert lib.sbev_decoder_chain_pack(ctypes.byref(cfg), ctypes.byref(w), None, None) == -1                  # SBEV_EINVAL
+    assert b'sbev_decoder_chain_pack' in lib.sbev_last_error()
+    assert lib.sbev_decoder_row_chain(1) == 0

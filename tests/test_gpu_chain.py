@@ -1,0 +1,157 @@
+"""The row-chain kernels (csrc/row_chain.hip: position encoder, attention projections, norms, ffn, branches, refine_bbox of a
+layer as three launches with the rows in LDS) against the op-by-op launches they replace -- which the other decoder tests
+pin to the reference recordings / the oracle -- and the lane-ordered weight image against a numpy restatement of its
+layout.  The chains add the k-halves of a Linear in another order than the small-tile GEMM: agreement is fp32 round-off
+(a few 1e-6 on O(1) outputs after one layer), not bit for bit; free-running layers amplify it ~7x per layer like any
+rounding difference, so deeper layers are bounded loosely here and tightly layer by layer."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import op_by_op_runtime
+from sparsebev_amd import runtime, synthetic as S
+from sparsebev_amd.transformer import SparseBEVTransformer, FeaturePyramid, DecoderContext
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+PREFIX = 'decoder.decoder_layer.'
+
+
+def build(T, L, seed, num_layers):
+    params = S.make_params(seed, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=num_layers, num_levels=L, num_classes=10, code_size=10,
+                             pc_range=S.PC_RANGE)
+    m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+    return m.to(DEV).eval(), params
+
+
+def inputs(B, Q, T, pyr, seed):
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=seed)]
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=seed + 1)]
+    return feats, bbox, feat, S.make_img_metas(B, T, ih, iw), len(sizes)
+
+
+def both(model, bbox, feat, feats, metas, mask=None):
+    fl = (lambda: feats) if hasattr(feats, 'levels') else (lambda: list(feats))
+    a = model(bbox, feat, fl(), mask, copy.deepcopy(metas))
+    with op_by_op_runtime():
+        b = model(bbox, feat, fl(), mask, copy.deepcopy(metas))
+    return a, b
+
+
+def packed_reference(W):
+    """[N, K] -> [ceil(N/64)][K/16][4][64 lanes][4]: lane = column of the group, (step, m, e) -> k = 16 step + 4 m + e."""
+    N, K = W.shape
+    out = np.zeros(((N + 63) // 64, K // 16, 4, 64, 4), np.float32)
+    for cg in range(out.shape[0]):
+        rows = W[cg * 64:(cg + 1) * 64]
+        out[cg, :, :, :rows.shape[0], :] = rows.reshape(rows.shape[0], K // 16, 4, 4).transpose(1, 2, 0, 3)
+    return out.reshape(-1)
+
+
+def test_weight_image_layout():
+    model, _ = build(8, 4, 3, 1)
+    feats, bbox, feat, metas, _ = inputs(1, 16, 8, 'tiny', 5)
+    model(bbox, feat, feats, None, metas)                         # binds the runtime
+    keep = model.decoder._runtime._keep
+    image = keep['chain_pack'].cpu().numpy()
+    order = ['ffn0_w', 'ffn1_w', 'cls0_w', 'reg0_w', 'cls3_w', 'reg2_w', 'cls6_w', 'reg4_w', 'pe3_w', 'attn_in_w', 'attn_out_w', 'samp_w']
+    off = 0
+    for name in order:
+        want = packed_reference(keep[name].cpu().numpy())
+        assert np.array_equal(image[off:off + want.size], want), name
+        off += want.size
+    # the small vectors behind the matrices: [tail | front | attention] blocks, zero-padded slots
+    vec = image[off:]
+    assert np.array_equal(vec[:256], keep['op_b'].cpu().numpy())
+    assert np.array_equal(vec[768:1280], keep['ffn0_b'].cpu().numpy())
+    assert np.array_equal(vec[3584:3594], keep['cls6_b'].cpu().numpy()) and not vec[3594:3648].any()
+    assert np.array_equal(vec[4224:4224 + 768], keep['pe0_w'].cpu().numpy().reshape(-1))
+
+
+@pytest.mark.parametrize('B,Q,T,pyr,layers', [(1, 49, 2, 'tiny', 1), (2, 49, 2, 'tiny', 3), (1, 900, 8, 'tiny', 2), (1, 100, 1, 'tiny5', 2),
+                                              (1, 1024, 4, 'tiny', 2), (1, 9, 4, 'tiny', 6)])
+def test_row_chains_equal_op_by_op_to_roundoff(B, Q, T, pyr, layers):
+    """98 rows (a partial 4-row tile), 1024 rows (the largest launch that takes the chains), T = 1 (no velocity division),
+    5 levels, 1 .. 6 layers (front-only, attention, tail, tail + next front launches)."""
+    feats, bbox, feat, metas, L = inputs(B, Q, T, pyr, 11)
+    model, _ = build(T, L, 12, layers)
+    a, b = both(model, bbox, feat, feats, metas)
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    for l in range(layers):
+        tol = 2e-5 if l == 0 else 3e-4 if l == 1 else 0.2
+        assert (a[0][l] - b[0][l]).abs().max() < tol, (l, (a[0][l] - b[0][l]).abs().max().item())
+        assert (a[1][l] - b[1][l]).abs().max() < tol, l
+    # run-to-run bit determinism, and rows do not depend on which workgroup / tile position computes them
+    a2 = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+
+
+def test_row_chains_every_layer_from_the_same_inputs():
+    """Layer by layer at the config-2 query count: every layer's chain launches from the op-by-op path's own inputs, so
+    each comparison is one layer deep (2e-5), including the tail + next-front launch whose output (x, qkvt) only the NEXT
+    layer shows: a 2-layer run whose layer 0 input is layer l's op-by-op state."""
+    B, Q, T = 1, 900, 8
+    feats, bbox, feat, metas, L = inputs(B, Q, T, 'tiny', 21)
+    model6, _ = build(T, L, 22, 6)
+    model2, _ = build(T, L, 22, 2)
+    layer = model6.decoder.decoder_layer
+    pyr, ctx = FeaturePyramid(feats), DecoderContext(metas, B, torch.device(DEV))
+    qb, qf = bbox, feat
+    for l in range(5):
+        a, b = both(model2, qb, qf, pyr, metas)
+        assert (a[0][0] - b[0][0]).abs().max() < 2e-5 and (a[1][0] - b[1][0]).abs().max() < 2e-5, l
+        assert (a[0][1] - b[0][1]).abs().max() < 3e-4 and (a[1][1] - b[1][1]).abs().max() < 3e-4, l
+        qf, _, qb = layer(qb, qf, pyr, None, ctx)               # the op-by-op layer's outputs feed the next comparison
+
+
+def test_row_chains_with_denoising_mask_and_bf16x3_gemms():
+    B, Q, T = 1, 64, 2
+    feats, bbox, feat, metas, L = inputs(B, Q, T, 'tiny', 31)
+    model, _ = build(T, L, 32, 2)
+    mask = torch.zeros(Q, Q, dtype=torch.bool)
+    mask[:48, 48:] = True
+    mask[48:, :48] = True
+    a, b = both(model, bbox, feat, feats, metas, mask.to(DEV))
+    assert (a[0][0] - b[0][0]).abs().max() < 2e-5 and (a[0][1] - b[0][1]).abs().max() < 3e-4
+    model.decoder.gemm_mode = runtime.GEMM_BF16X3
+    a, b = both(model, bbox, feat, feats, metas)
+    assert (a[0][0] - b[0][0]).abs().max() < 2e-5 and (a[1][0] - b[1][0]).abs().max() < 2e-5
+
+
+def test_weight_image_follows_parameter_updates():
+    """the image is re-packed when a parameter changes in place (optimizer step, load_state_dict)"""
+    feats, bbox, feat, metas, L = inputs(1, 49, 2, 'tiny', 41)
+    model, _ = build(2, L, 42, 1)
+    a0, _ = both(model, bbox, feat, feats, metas)
+    with torch.no_grad():
+        model.decoder.decoder_layer.ffn.layers[1].bias.add_(0.5)
+        model.decoder.decoder_layer.cls_branch[6].weight.mul_(2.0)
+    a1, b1 = both(model, bbox, feat, feats, metas)
+    assert (a1[0] - a0[0]).abs().max() > 1e-2
+    assert (a1[0] - b1[0]).abs().max() < 2e-5 and (a1[1] - b1[1]).abs().max() < 2e-5
+
+
+def test_large_batches_keep_the_op_by_op_launches():
+    """above 1024 rows one workgroup per 4 rows no longer pays (csrc/row_chain.hip: row_chain_pays): same launches either way"""
+    feats, bbox, feat, metas, L = inputs(3, 400, 2, 'tiny', 51)
+    model, _ = build(2, L, 52, 2)
+    a, b = both(model, bbox, feat, feats, metas)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_two_layer_chain_against_the_oracle():
+    from oracle import sparsebev_oracle as O
+    B, Q, T = 1, 36, 2
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    feats = S.make_features(B, T, sizes, seed=61)
+    bbox, feat = S.make_queries(B, Q, seed=62)
+    metas = S.make_img_metas(B, T, ih, iw)
+    model, params = build(T, len(sizes), 63, 2)
+    cls, box = model(bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
+    ref_cls, ref_box, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=2, sampler=O.msmv_sampling_kernel_semantics)
+    assert (cls[0].cpu() - ref_cls[0]).abs().max() < 1e-4 and (box[0].cpu() - ref_box[0]).abs().max() < 1e-4
+    assert (cls[1].cpu() - ref_cls[1]).abs().max() < 2e-3 and (box[1].cpu() - ref_box[1]).abs().max() < 2e-3   # free-running layer 2

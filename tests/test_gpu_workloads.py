@@ -11,6 +11,7 @@ import copy
 import pytest
 import torch
 
+from conftest import runtime_op_by_op
 from sparsebev_amd import synthetic as S
 from sparsebev_amd.transformer import SparseBEVTransformer
 
@@ -70,10 +71,12 @@ def test_one_layer_at_full_workload_shape_vs_oracle(name):
     cls, box = model(bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas))
     assert cls.shape == (1, B, Q, 10) and box.shape == (1, B, Q, 10)
     lw_cls, lw_box = model(bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas), layerwise=True)
-    assert torch.equal(cls, lw_cls) and torch.equal(box, lw_box)
+    rt_cls, rt_box = runtime_op_by_op(model, bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas))
+    assert torch.equal(rt_cls, lw_cls) and torch.equal(rt_box, lw_box)
     ref_cls, ref_box, _ = oracle_per_sample(params, bbox, feat, feats, metas)
-    assert (cls.cpu() - ref_cls).abs().max() < TOL
+    assert (cls.cpu() - ref_cls).abs().max() < TOL                   # (c2 / c5: through the row-chain kernels)
     assert (box.cpu() - ref_box).abs().max() < TOL
+    assert (lw_cls.cpu() - ref_cls).abs().max() < TOL and (lw_box.cpu() - ref_box).abs().max() < TOL
 
 
 def test_c2_six_layers_teacher_forced_vs_oracle():
@@ -90,10 +93,11 @@ def test_c2_six_layers_teacher_forced_vs_oracle():
     worst = 0.0
     with torch.no_grad():
         for i, (qb, qf) in enumerate(ins):
-            cls, box = model(qb.to(DEV), qf.to(DEV), pyr, None, copy.deepcopy(metas))            # C++ runtime, 1 layer
+            cls, box = model(qb.to(DEV), qf.to(DEV), pyr, None, copy.deepcopy(metas))            # C++ runtime, 1 layer (row chains)
+            rt = runtime_op_by_op(model, qb.to(DEV), qf.to(DEV), pyr, None, copy.deepcopy(metas))
             x, c, bb = layer(qb.to(DEV), qf.to(DEV), pyr, None, ctx)                            # same kernels, op by op
-            assert torch.equal(cls[0], c) and torch.equal(box[0], bb)
-            for got, want in ((x, ref_x[i]), (c, ref_cls[i]), (bb, ref_box[i])):
+            assert torch.equal(rt[0][0], c) and torch.equal(rt[1][0], bb)
+            for got, want in ((x, ref_x[i]), (c, ref_cls[i]), (bb, ref_box[i]), (cls[0], ref_cls[i]), (box[0], ref_box[i])):
                 err = (got.cpu() - want).abs().max().item()
                 worst = max(worst, err)
                 assert err < TOL, (i, err)
@@ -117,7 +121,8 @@ def test_full_workload_six_layer_properties(name):
     assert cls.shape == (6, B, Q, 10) and torch.isfinite(cls).all() and torch.isfinite(box).all()
     assert torch.equal(cls, cls2) and torch.equal(box, box2)
     lw_cls, lw_box = model(qb, qf, list(feats), None, copy.deepcopy(metas), layerwise=True)
-    assert torch.equal(cls, lw_cls) and torch.equal(box, lw_box)
+    rt_cls, rt_box = runtime_op_by_op(model, qb, qf, list(feats), None, copy.deepcopy(metas))
+    assert torch.equal(rt_cls, lw_cls) and torch.equal(rt_box, lw_box)
     if B > 1:
         b = B - 1
         one = model(qb[b:b + 1].contiguous(), qf[b:b + 1].contiguous(), [f[b:b + 1].contiguous() for f in feats], None,

@@ -172,7 +172,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const float* bbox = query_bbox;
     const float* feat = query_feat;
     bool pe0_done = false;             // the previous layer's tail already ran this layer's first position-encoder stage
-    // Row chains (row_chain.hip): 7 launches per layer instead of 17 -- everything between the out-projection GEMM and the self
+    // Row chains (row_chain.hip): 6 launches per layer instead of 17 -- everything between the out-projection GEMM and the self
     // attention, and between the self attention and the sampler, is row-local and runs with the rows in LDS.
     const bool chain = g_row_chain.load(std::memory_order_relaxed) != 0 && w->chain_pack != nullptr && !fork && sbev::row_chain_supported(c) &&
                        sbev::row_chain_pays(BQ);
@@ -182,13 +182,11 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         float* box_l = bbox_out + (int64_t)layer * BQ * c.code_size;
         if (chain) {
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
-            TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, b.so, eps, s_main));
+            TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main));
             if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, stream));
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
-            TRY(sbev_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
-                                        c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
                                sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
             if (fused) {

@@ -6,6 +6,7 @@
 // matmul on CPU is ((m0*x + m1*y) + m2*z) + m3 with separate roundings, and the camera-hit mask has to
 // match it bit for bit ("Bit-exact hit mask"; models/sparsebev_sampling.py:49-79).
 #include "sbev_common.hpp"
+#include "sample_point.hpp"
 
 namespace {
 
@@ -142,27 +143,15 @@ __global__ __launch_bounds__(256) void sampling_front_kernel(const FrontArgs a) 
     }
 }
 
-struct FusedArgs {
-    const float* bbox;      // [B,Q,10]
-    const float* offset;    // [B*Q, ld_off]
-    const float* logits;    // [B*Q, ld_logit]
-    long long ld_off, ld_logit;
-    const float* time_diff; // [B,T]
-    const float* l2i;       // [B,T*N,4,4]
-    float* loc_bp;          // [B*T*G,Q,P,3]
-    float* w_bp;            // [B*G*T,Q,P,L]
-    float pc_lo[3], pc_span[3];
-    int B, Q, T, N, G, P, L;
-    float image_h, image_w, eps;
-    float rot_sign;         // see FrontArgs
-};
+using FusedArgs = sbev_ops::SamplePointArgs;      // sample_point.hpp (shared with the row-chain kernel)
 
 // sampling_front_kernel + project_select_kernel in one launch (the decoder runtime's path): one thread per
-// (b, t, q, gp) rebuilds its 3-D sample point from the box and the offset (the same expressions, in the same
-// -ffp-contract=off translation unit, so the point -- and therefore the hit mask -- is bit-identical to the
-// two-kernel path) and projects it; the [B,Q,T,GP,3] point tensor never exists.  Every thread also writes the level
-// softmax of its (g, p) into row t of group g's T weight rows.
-__global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) {
+// (b, t, q, gp) rebuilds its 3-D sample point from the box and the offset (the same expressions, individually rounded,
+// so the point -- and therefore the hit mask -- is bit-identical to the two-kernel path) and projects it; the
+// [B,Q,T,GP,3] point tensor never exists.  Every thread also writes the level softmax of its (g, p) into row t of
+// group g's T weight rows.
+__global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a, const float* offset, const float* logits,
+                                                             long long ld_off, long long ld_logit) {
     const int GP = a.G * a.P;
     const long long total = (long long)a.B * a.T * a.Q * GP;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,58 +165,7 @@ __global__ __launch_bounds__(256) void sample_project_kernel(const FusedArgs a) 
     const int b = (int)(r2 / (unsigned)a.T);
     const int t = (int)(r2 - (unsigned)b * (unsigned)a.T);
     const long long bq = (long long)b * a.Q + q;
-    const float* bb = a.bbox + bq * 10;
-    const int g = gp / a.P, p = gp - g * a.P;
-
-    const float cx = bb[0] * a.pc_span[0] + a.pc_lo[0];
-    const float cy = bb[1] * a.pc_span[1] + a.pc_lo[1];
-    const float cz = bb[2] * a.pc_span[2] + a.pc_lo[2];
-    const float yaw = atan2f(bb[6], bb[7]);
-    const float cs = cosf(yaw), sn = a.rot_sign * sinf(yaw);
-    const float* of = a.offset + bq * a.ld_off + gp * 3;
-    const float dx = expf(bb[3]) * of[0], dy = expf(bb[4]) * of[1], dz = expf(bb[5]) * of[2];
-    const float px = cx + (dx * cs + dy * (-sn));
-    const float py = cy + (dx * sn + dy * cs);
-    const float pz = cz + dz;
-    const float td = a.time_diff[b * a.T + t];
-    const float x = px - bb[8] * td, y = py - bb[9] * td, z = pz;
-
-    int view = 0;
-    bool found = false;
-    float su = 0.f, sv = 0.f;
-    for (int n = 0; n < a.N; ++n) {
-        const float* m = a.l2i + (((long long)b * a.T + t) * a.N + n) * 16;
-        const float uh = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[0], x), __fmul_rn(m[1], y)), __fmul_rn(m[2], z)), m[3]);
-        const float vh = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[4], x), __fmul_rn(m[5], y)), __fmul_rn(m[6], z)), m[7]);
-        const float hm = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[8], x), __fmul_rn(m[9], y)), __fmul_rn(m[10], z)), m[11]);
-        const float hn = fmaxf(hm, a.eps);
-        const float u = __fdiv_rn(__fdiv_rn(uh, hn), a.image_w);
-        const float v = __fdiv_rn(__fdiv_rn(vh, hn), a.image_h);
-        const bool valid = (hm > a.eps) && (v > 0.f) && (v < 1.f) && (u > 0.f) && (u < 1.f);
-        if (n == 0 || (valid && !found)) { su = u; sv = v; view = n; }
-        found = found || valid;
-    }
-    float* o = a.loc_bp + (((((long long)b * a.T + t) * a.G + g) * a.Q + q) * a.P + p) * 3;
-    o[0] = su;
-    o[1] = sv;
-    o[2] = __fdiv_rn((float)view, (float)(a.N - 1));
-
-    // level softmax of (g, p): every frame's thread recomputes it (L expf) and writes ITS row t of group g's T weight
-    // rows, instead of the t == 0 threads writing all T rows (their 56 workgroups were the kernel's tail)
-    {
-        const float* lg = a.logits + bq * a.ld_logit + gp * a.L;
-        float mx = lg[0];
-        for (int l = 1; l < a.L; ++l) mx = fmaxf(mx, lg[l]);
-        float e[SBEV_MAX_LEVELS];
-        float sum = 0.f;
-        for (int l = 0; l < a.L; ++l) {
-            e[l] = expf(lg[l] - mx);
-            sum += e[l];
-        }
-        const long long row = ((long long)b * a.G + g) * a.T + t;
-        float* ow = a.w_bp + ((row * a.Q + q) * a.P + p) * a.L;
-        for (int l = 0; l < a.L; ++l) ow[l] = e[l] / sum;
-    }
+    sbev_ops::sample_point(a, b, t, q, gp, a.bbox + bq * 10, offset + bq * ld_off + gp * 3, logits + bq * ld_logit + gp * a.L);
 }
 
 }  // namespace
@@ -290,19 +228,12 @@ extern "C" int sbev_sample_and_project(const float* query_bbox, const float* off
     SBEV_REQUIRE(query_bbox && offset && scale_logits && time_diff && lidar2img && pc_range && loc_bp && weights_bp,
                  "sbev_sample_and_project: null pointer");
     SBEV_REQUIRE(ld_offset >= (int64_t)G * P * 3 && ld_logits >= (int64_t)G * P * L, "sbev_sample_and_project: row strides smaller than the rows");
-    FusedArgs a{};
-    a.bbox = query_bbox; a.offset = offset; a.logits = scale_logits; a.ld_off = ld_offset; a.ld_logit = ld_logits;
-    a.time_diff = time_diff; a.l2i = lidar2img; a.loc_bp = loc_bp; a.w_bp = weights_bp;
-    for (int i = 0; i < 3; ++i) {
-        a.pc_lo[i] = (float)pc_range[i];
-        a.pc_span[i] = (float)(pc_range[3 + i] - pc_range[i]);
-    }
-    a.B = B; a.Q = Q; a.T = T; a.N = N; a.G = G; a.P = P; a.L = L;
-    a.image_h = image_h; a.image_w = image_w; a.eps = eps;
-    a.rot_sign = sbev::box_convention() == SBEV_BOX_V0_17_1 ? -1.f : 1.f;
+    const FusedArgs a = sbev_ops::sample_point_args(query_bbox, time_diff, lidar2img, pc_range, B, Q, T, N, G, P, L, image_h, image_w,
+                                                    eps, loc_bp, weights_bp);
     const long long total = (long long)B * T * Q * G * P;
     const long long blocks = (total + 255) / 256;
     SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_sample_and_project: too many points");
-    hipLaunchKernelGGL(sample_project_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(sample_project_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, offset,
+                       scale_logits, (long long)ld_offset, (long long)ld_logits);
     return sbev::check_launch("sbev_sample_and_project");
 }

@@ -18,6 +18,7 @@
 // item i goes to wave i % 8 in round i / 8 and leaves its partial sums in LDS slot i; the unit's epilogue (wave = row)
 // adds the k-halves in a fixed order, + bias, ReLU / residual / LayerNorm, and writes the next unit's input rows.
 #include "sbev_common.hpp"
+#include "sample_point.hpp"
 #include <cstdlib>
 
 namespace {
@@ -99,7 +100,8 @@ struct ChainArgs {
     float* qkvt; int attn_in_rows;
     const float* att;            // PRE_ATT: [M, 256]
     float* x1_out;               // [M, 256]
-    float* so; int soN;
+    float* so; int soN;          // so: null when the sample points are projected in here (proj.loc_bp set)
+    sbev_ops::SamplePointArgs proj;
     float eps;
 };
 
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                     for (int c = 0; c < 4; ++c) a.x1_out[g * DM + lane + 64 * c] = v[c];
                 }
             } break;
-            case EPI_SAMP: {     // sampling_offset | scale_weights Linear -> so
+            case EPI_SAMP: {     // sampling_offset | scale_weights Linear -> so (kept in LDS for the projection below)
                 if (side) break;
                 const int ncg = un.a.items / un.a.KH;
 #pragma unroll
@@ -518,7 +520,9 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                     if (c < ncg && n < a.soN) {
                         float s = 0.f;
                         for (int kh = 0; kh < un.a.KH; ++kh) s += P[(c * un.a.KH + kh) * (R * 64) + row * 64 + lane];
-                        if (live) a.so[g * a.soN + n] = s + pv[PV_SAMP_B + n];
+                        s += pv[PV_SAMP_B + n];
+                        smem[OFF_H + row * 256 + n] = s;
+                        if (live && a.so) a.so[g * a.soN + n] = s;
                     }
                 }
             } break;
@@ -527,6 +531,23 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         SBEV_TRACE(4 + 4 * u)
         __syncthreads();
         SBEV_TRACE(5 + 4 * u)
+    }
+    if (PRE == PRE_ATT && a.proj.loc_bp) {
+        // adaptive spatio-temporal sampling, projection and camera selection of the rows' sample points (sample_point.hpp: the
+        // same function as sample_project_kernel): thread = (frame t, group g, row, point p) -> 48-byte runs of loc_bp
+        const int GP = a.proj.G * a.proj.P;
+        for (int i = threadIdx.x; i < R * a.proj.T * GP; i += 64 * NWAVE) {
+            const int p = i % a.proj.P;
+            const int row = (i / a.proj.P) % R;
+            const int tg = i / (a.proj.P * R);
+            const int gq = tg % a.proj.G, t = tg / a.proj.G;
+            const long long g = row0 + row;
+            if (g >= a.M) continue;
+            const int b = (int)((unsigned)g / (unsigned)a.Q), q = (int)((unsigned)g - (unsigned)b * (unsigned)a.Q);
+            const int gp = gq * a.proj.P + p;
+            const float* so = smem + OFF_H + row * 256;
+            sbev_ops::sample_point(a.proj, b, t, q, gp, a.proj.bbox + g * 10, so + gp * 3, so + GP * 3 + gp * a.proj.L);
+        }
     }
 }
 
@@ -668,14 +689,17 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
     return launch(a, s, "row chain (front)");
 }
 
-// attention out-projection + residual + norm1 -> x1, sampling Linear -> so
+// attention out-projection + residual + norm1 -> x1, sampling Linear -> sample points -> projection (loc, level weights)
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
-                      float* so, float eps, hipStream_t s) {
+                      const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
+                      hipStream_t s) {
     const PackMap m = pack_map(c);
     ChainArgs a{};
     fill_common(a, c, eps);
     a.pre = PRE_ATT;
-    a.att = att; a.x = const_cast<float*>(x); a.x1_out = x1; a.so = so;
+    a.att = att; a.x = const_cast<float*>(x); a.x1_out = x1; a.so = nullptr;
+    a.proj = sbev_ops::sample_point_args(bbox, time_diff, lidar2img, c.pc_range, c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w,
+                                         c.eps_homo, loc_bp, w_bp);
     a.units[0] = Unit{lin(w.chain_pack + m.attn_out, OFF_X2, LDX, c.D, c.D), kNone, EPI_AOUT, 0};
     a.units[1] = Unit{lin(w.chain_pack + m.samp, OFF_X3, LDX, a.soN, c.D), kNone, EPI_SAMP, 0};
     a.n_units = 2;

@@ -431,6 +431,7 @@ def main():
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
                                    '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
+                       'launches_per_layer': 6 if (B * Q <= 1024 and os.environ.get('SBEV_NO_ROW_CHAIN') != '1') else 17,
                        'checksum': checksum_sum},
             # per-rank spread (weak scaling: every rank runs the same per-GPU batch): slowest / fastest rank's own rate
             'per_rank_samples_per_s': {'min': round(args.steps * B / elapsed_max, 3), 'max': round(args.steps * B / elapsed_min, 3)},

@@ -498,7 +498,7 @@ typedef struct sbev_decoder_weights {
  * Row chains.  Every op of a decoder layer except the self attention, the sampler and the two big mixing GEMMs is
  * row-local (position_encoder, attention in/out projections, norm1-3, sampling Linear, ffn, cls_branch, reg_branch,
  * refine_bbox: models/sparsebev_transformer.py:166-183), so with `chain_pack` set sbev_decoder_forward runs them as three
- * launches per layer with the rows in LDS (7 launches per layer instead of 17).  The kernels stream the weights in a
+ * launches per layer with the rows in LDS (6 launches per layer instead of 17; the sample-point projection runs inside too).  The kernels stream the weights in a
  * lane-ordered layout: sbev_decoder_chain_pack writes that image (sbev_decoder_chain_pack_floats floats, 16-byte aligned,
  * 0 = config not covered: needs embed_dims 256, ffn 512, code_size 10) from the weight pointers of `weights`; re-pack when
  * the weights change.  Results agree with the op-by-op launches to fp32 round-off (different summation order), not bit for bit.

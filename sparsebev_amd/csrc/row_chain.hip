@@ -1,22 +1,24 @@
 // Row chains of the decoder layer: every op between the big mixing GEMMs and the self attention is ROW-LOCAL (a Linear, a
-// LayerNorm, a ReLU, refine_bbox: query i's output depends on query i only), so a workgroup that owns R = 4 queries can run
-// the whole chain with the activations in LDS instead of one full-chip launch per op (sparsebev_transformer.py:166-183 are
-// 17 small ops per layer; the per-op launches cost 5-10 us each for < 1 us of arithmetic).  Two chains per layer:
+// LayerNorm, a ReLU, refine_bbox, the sample points and their projection: query i's output depends on query i only), so a
+// workgroup that owns R = 4 queries runs the whole chain with the activations in LDS instead of one full-chip launch per op
+// (sparsebev_transformer.py:166-183 are 14 such ops per layer; the per-op launches cost 5-10 us each for < 1 us of arithmetic).
 //   TAIL (+ FRONT of the next layer): split-K slabs of mixing.out_proj -> + bias + residual -> norm2 -> ffn -> norm3 ->
 //       cls_branch / reg_branch -> refine_bbox  [-> position_encoder -> x = feat + pos -> attention in-projection]
-//   ATTN: attention out-projection + residual -> norm1 -> sampling_offset / scale_weights Linear
+//   ATT: attention out-projection + residual -> norm1 -> sampling_offset / scale_weights Linear -> sample points ->
+//       projection into the T*6 cameras, first-hit selection, level softmax (sample_point.hpp)
+//   FRONT: position_encoder + in-projection of layer 0
 //
 // GEMM engine (M = 4 rows, so neither a 16- nor a 32-row MFMA tile fits): v_mfma_f32_4x4x1_16b_f32 with the A-matrix
 // BROADCAST modifier (cbsz = 4, abid = k): the 16 blocks of the instruction are 16 groups of 4 output COLUMNS (lane = one
 // of 64 columns), all multiplied by the same 4 rows of block `abid` of the A register -- A holds 16 k-values x 4 rows (one
 // ds_read_b32 per 16 k), B is the lane's own weight column, D is 4 rows x 64 columns in 4 VGPRs.  Exact fp32 (fmaf chain)
-// at the full f32 MFMA rate, no operand duplication.  The weights are streamed from L2 (every workgroup reads every
-// weight: that stream, ~64 B/clk/CU, is the bound), so they are PRE-PACKED (sbev_decoder_chain_pack) in the order the lanes
-// consume them: a wave-load is one contiguous 1 KB line group, and a 32-deep register ring per wave keeps 32 KB in flight --
-// the loads of the NEXT unit are issued while the current one multiplies (weights do not depend on activations).
+// at the full f32 MFMA rate (8.6-9.8 cycles per instruction measured), no operand duplication.  The weights are streamed
+// from L2 (every workgroup reads every weight: that stream, ~50 B/clk/CU through global_load_lds_dwordx4, is the bound), so
+// they are PRE-PACKED (sbev_decoder_chain_pack) in the order the lanes consume them: a wave-load is 1 KB of contiguous memory.
 // Work split: 8 waves; a unit (one or two independent Linears reading LDS rows) is cut into items of 64 columns x 128 k;
 // item i goes to wave i % 8 in round i / 8 and leaves its partial sums in LDS slot i; the unit's epilogue (wave = row)
 // adds the k-halves in a fixed order, + bias, ReLU / residual / LayerNorm, and writes the next unit's input rows.
+// Results equal the op-by-op launches to fp32 round-off (other summation order), not bit for bit; DESIGN.md section 4.
 #include "sbev_common.hpp"
 #include "sample_point.hpp"
 #include <cstdlib>

@@ -170,6 +170,8 @@ __device__ __forceinline__ const float* item_weights(const Unit& un, int it) {
     return l.wp + (long long)(it - (second ? un.a.items : 0)) * ITEM_FLOATS;
 }
 
+// (M0 carries the LDS destination of an LDS-DMA load and is written inside the asm block; hipcc does not use M0 anywhere else
+// in these kernels -- LDS instructions need no M0 on gfx9+, there is no dynamic register indexing -- checked in the ISA.)
 __device__ __forceinline__ void issue_chunk(const float* g, unsigned lds_byte, unsigned voff) {
     asm volatile(
         "s_mov_b32 m0, %0\n\t"
@@ -635,10 +637,18 @@ static int add_front(ChainArgs& a, int n, const sbev_decoder_config& c, const fl
     return n;
 }
 
+// the kernels use 159 KB of dynamic LDS: raised once per instantiation (also from sbev_decoder_chain_pack, so that the first
+// launch may already be inside a stream capture)
 template <int PRE>
-static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
+static hipError_t lds_attr() {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_FLOATS * 4);
+    return attr;
+}
+
+template <int PRE>
+static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
+    const hipError_t attr = lds_attr<PRE>();
     if (attr != hipSuccess) {
         set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, LDS_TOTAL_FLOATS * 4, hipGetErrorString(attr));
         return SBEV_ELAUNCH;
@@ -670,6 +680,10 @@ static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
     }
 #endif
     return check_launch(what);
+}
+
+bool chain_lds_ready() {
+    return lds_attr<PRE_SLABS>() == hipSuccess && lds_attr<PRE_FRONT>() == hipSuccess && lds_attr<PRE_ATT>() == hipSuccess;
 }
 
 static int launch(const ChainArgs& a, hipStream_t s, const char* what) {
@@ -750,6 +764,7 @@ extern "C" int sbev_decoder_chain_pack(const sbev_decoder_config* cfg, const sbe
     const sbev_decoder_config& c = *cfg;
     const PackMap m = pack_map(c);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    SBEV_REQUIRE(sbev::chain_lds_ready(), "sbev_decoder_chain_pack: the device refuses %d bytes of LDS per workgroup", LDS_TOTAL_FLOATS * 4);
     struct Job { const float* W; long long off; int N, K; };
     const Job jobs[12] = {{w->ffn0_w, m.ffn0, c.ffn, c.D}, {w->ffn1_w, m.ffn1, c.D, c.ffn}, {w->cls0_w, m.cls0, c.D, c.D},
                           {w->reg0_w, m.reg0, c.D, c.D}, {w->cls3_w, m.cls3, c.D, c.D}, {w->reg2_w, m.reg2, c.D, c.D},

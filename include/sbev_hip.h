@@ -347,6 +347,11 @@ int sbev_splitk_reduce_f32(const float* slabs, int splits, const float* bias, co
 int sbev_split_bf16x3_weights(const float* W, uint16_t* W2, int64_t N, int K, sbev_stream_t stream);
 int sbev_linear_bf16x3(const float* X, const uint16_t* W2, const float* bias, const float* residual, float* Y,
                        int64_t M, int N, int K, int64_t ldx, int64_t ldy, int relu, sbev_stream_t stream);
+/* The parameter generator's shape (K = 256, N % 128 == 0, N >= 1024; sbev_linear_bf16x3_strip_ok) with the activation split
+ * ONCE by the caller (X2 = sbev_split_bf16x3_weights(X [M, 256])): W-stationary strips in registers, X2 streamed from L2. */
+int sbev_linear_bf16x3_strip_ok(int64_t M, int N, int K);
+int sbev_linear_bf16x3_strip(const uint16_t* X2, const uint16_t* W2, const float* bias, float* Y, int64_t M, int N, int K,
+                             int64_t ldy, int relu, sbev_stream_t stream);
 int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* bias, const float* residual,
                               const float* ln_w, const float* ln_b, float ln_eps, float* Y,
                               int64_t M, int N, int K, int64_t ldx, int relu, int splits, float* workspace,

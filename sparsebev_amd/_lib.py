@@ -65,6 +65,9 @@ SIGNATURES = {
     'sbev_splitk_reduce_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_split_bf16x3_weights': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_linear_bf16x3_strip_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sbev_linear_bf16x3_strip': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                ctypes.c_int, _vp]),
     'sbev_linear_bf16x3': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp]),
     'sbev_linear_splitk_bf16x3': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,

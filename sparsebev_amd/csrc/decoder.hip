@@ -27,7 +27,7 @@ struct Carver {
 
 struct Buffers {
     float *t0, *t1, *x, *x1, *x2, *x3, *qkvt, *att, *so, *wbp, *loc, *sampled, *params, *mixed, *slabs,
-        *h, *c0, *c1, *r0, *r1, *reg, *bbox;
+        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s;
     size_t bytes;
 };
 
@@ -55,6 +55,7 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.c0 = k.take(BQ * D); b.c1 = k.take(BQ * D); b.r0 = k.take(BQ * D); b.r1 = k.take(BQ * D);
     b.reg = k.take(BQ * c.code_size);
     b.bbox = k.take(BQ * 10);
+    b.x1s = k.take(BQ * D);        // x1 as (hi, lo) bf16 pairs: the generator's operand in gemm_mode bf16x3 (same byte count)
     b.bytes = k.off;
     return b;
 }
@@ -169,6 +170,16 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     auto next_ev = [&]() { return ax.ev[(evi++) & 7]; };
     hipEvent_t ev_cls = nullptr;
 
+    // parameter generator in the 3 x bf16 mode: x1 is split once per layer and streamed past W-stationary strips
+    const bool pg_strip = c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, pgN, D) != 0;
+    auto generator_bf16x3 = [&](sbev_stream_t st) -> int {
+        if (!pg_strip) return sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, st);
+        uint16_t* x2 = reinterpret_cast<uint16_t*>(b.x1s);
+        int e = sbev_split_bf16x3_weights(b.x1, x2, BQ, D, st);
+        if (e != SBEV_OK) return e;
+        return sbev_linear_bf16x3_strip(x2, w->pg_w2, w->pg_b, b.params, BQ, pgN, D, pgN, 0, st);
+    };
+
     const float* bbox = query_bbox;
     const float* feat = query_feat;
     bool pe0_done = false;             // the previous layer's tail already ran this layer's first position-encoder stage
@@ -184,7 +195,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main));
             if (c.gemm_mode == SBEV_GEMM_BF16X3)
-                TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, stream));
+                TRY(generator_bf16x3(stream));
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
@@ -234,7 +245,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
         }
         if (c.gemm_mode == SBEV_GEMM_BF16X3)
-            TRY(sbev_linear_bf16x3(b.x1, w->pg_w2, w->pg_b, nullptr, b.params, BQ, pgN, D, D, pgN, 0, fork_pg ? s_aux : stream));
+            TRY(generator_bf16x3(fork_pg ? s_aux : stream));
         else
             TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, fork_pg ? s_aux : stream));
         if (fork_pg) {

@@ -207,6 +207,128 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const G3Args a) {
     }
 }
 
+
+// ---- W-stationary strip kernel for the parameter generator ([M, 256] x [N >= 16384, 256]^T), bf16x3 -----------------------
+// The tile kernel above re-splits the same X rows in every one of the 256 column tiles and, with K = 256, spends its 8 K-steps
+// mostly in prologue / epilogue (83 us for 45 GFLOP of bf16 MFMA: 20 % of the 2.5 PF peak; round-1 review item 8).  Same
+// decomposition as gemm.hip's exact strip kernel instead: a WAVE owns a 64-column strip of W -- its (hi, lo) bf16 images, 256
+// registers, at one wave per SIMD -- for half of all 16-row fragments, and the X rows stream past it straight from L2, already
+// split ONCE per layer (sbev_split_bf16x3_weights on the [M, 256] activation: the same [row][K/8][hi 8 | lo 8] image as the
+// weights, so a lane's operand for one MFMA is one 16-byte load).  v_mfma_f32_16x16x32_bf16 with W as the row operand: a lane
+// ends up with 4 consecutive output columns of one row (float4 stores).  Per fragment and wave 8 k-steps x 4 column blocks x 3
+// products = 96 MFMAs of 16 cycles against 256 x 32 cycles in the exact kernel; the floor is the 118 MB output write.
+#define SBEV_ONE_WAVE_PER_EU __attribute__((amdgpu_waves_per_eu(1, 1)))
+#ifdef SBEV_EXP_NOSTORE          // experiments (never in the product build): drop the stores / keep the X rows L1-resident
+#define SBEV_EXP_STORE_COND && a.M < 0
+#else
+#define SBEV_EXP_STORE_COND
+#endif
+#ifdef SBEV_EXP_NOLOAD
+#define SBEV_EXP_ROW(r) ((r) & 15)
+#else
+#define SBEV_EXP_ROW(r) (r)
+#endif
+struct StripArgs {
+    const unsigned short* X2;    // [M, 32, 2, 8] bf16 (K = 256)
+    const unsigned short* W2;    // [N, 32, 2, 8]
+    const float* bias;           // [N] or null
+    float* Y;                    // [M, ldy]
+    int M;
+    long long ldy;
+};
+
+template <bool RELU>
+__global__ __launch_bounds__(256) SBEV_ONE_WAVE_PER_EU void gemm_bf16x3_strip_kernel(const StripArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fk = lane >> 4;
+    const long long n0 = (long long)blockIdx.x * 128 + (wave >> 1) * 64;
+    const int half = wave & 1;
+
+    // k order of an MFMA: lane group fk owns k = 32 s + 8 fk + (0..7) = block 4 s + fk of the row's image, for both operands
+    bf16x8 wh[8][4], wl[8][4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+            const unsigned short* p = a.W2 + ((n0 + cf * 16 + fi) * 32 + 4 * s + fk) * 16;
+            wh[s][cf] = *reinterpret_cast<const bf16x8*>(p);
+            wl[s][cf] = *reinterpret_cast<const bf16x8*>(p + 8);
+        }
+    // the bias (the accumulators' start value) waits in LDS: 16 registers less at a budget of 512
+    __shared__ __attribute__((aligned(16))) float bias_s[4][64];
+    bias_s[wave][lane] = a.bias ? a.bias[n0 + lane] : 0.f;
+    __builtin_amdgcn_wave_barrier();
+
+    const int M = a.M;
+    const int last = ((M + 15) >> 4) - 1;
+    bf16x8 xah[8], xal[8], xbh[8], xbl[8];
+#define SBEV_LOAD_X3(dh, dl, f)                                                                     \
+    {                                                                                               \
+        int row_ = SBEV_EXP_ROW(16 * (f) + fi);                                                     \
+        row_ = row_ < M ? row_ : M - 1;                                                             \
+        const unsigned short* p_ = a.X2 + ((long long)row_ * 32 + fk) * 16;                         \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                             \
+            dh[s] = *reinterpret_cast<const bf16x8*>(p_ + s * 64);                                  \
+            dl[s] = *reinterpret_cast<const bf16x8*>(p_ + s * 64 + 8);                              \
+        }                                                                                           \
+    }
+    // small terms first (lo.hi, hi.lo), then hi.hi; the four column blocks rotate so that no MFMA waits for its predecessor
+#define SBEV_STRIP3(sh, sl)                                                                         \
+    {                                                                                               \
+        _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) acc[cf] = *reinterpret_cast<const f32x4*>(&bias_s[wave][cf * 16 + 4 * fk]); \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                             \
+            _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s][cf], sh[s], acc[cf], 0, 0, 0); \
+            _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s][cf], sl[s], acc[cf], 0, 0, 0); \
+            _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s][cf], sh[s], acc[cf], 0, 0, 0); \
+        }                                                                                           \
+    }
+#define SBEV_STORE3(f)                                                                              \
+    {                                                                                               \
+        const int row_ = 16 * (f) + fi;                                                             \
+        if (row_ < M SBEV_EXP_STORE_COND) {                                                         \
+            float* y_ = a.Y + (long long)row_ * a.ldy + n0 + 4 * fk;                                \
+            _Pragma("unroll") for (int cf = 0; cf < 4; ++cf) {                                      \
+                f32x4 v_ = acc[cf];                                                                 \
+                if (RELU) { v_[0] = fmaxf(v_[0], 0.f); v_[1] = fmaxf(v_[1], 0.f); v_[2] = fmaxf(v_[2], 0.f); v_[3] = fmaxf(v_[3], 0.f); } \
+                *reinterpret_cast<f32x4*>(y_ + cf * 16) = v_;                                       \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    // fragments alternate between the two waves of a strip; two register sets used alternately, the next fragment's rows
+    // requested before each MFMA block, the stores of fragment f issued at the top of block f + 1 (gemm.hip's strip kernel)
+    f32x4 acc[4];
+    int f = half ^ ((wave >> 1) & 1);
+    if (f > last) return;
+    int fprev = f;
+    SBEV_LOAD_X3(xah, xal, f);
+    { const int fn = f + 2 <= last ? f + 2 : last; SBEV_LOAD_X3(xbh, xbl, fn); }
+    __builtin_amdgcn_sched_barrier(0);
+    SBEV_STRIP3(xah, xal);
+    f += 2;
+    while (f <= last) {
+        __builtin_amdgcn_sched_barrier(0);
+        { const int fn = f + 2 <= last ? f + 2 : last; SBEV_LOAD_X3(xah, xal, fn); }
+        SBEV_STORE3(fprev);
+        __builtin_amdgcn_sched_barrier(0);
+        SBEV_STRIP3(xbh, xbl);
+        fprev = f;
+        f += 2;
+        if (f > last) break;
+        __builtin_amdgcn_sched_barrier(0);
+        { const int fn = f + 2 <= last ? f + 2 : last; SBEV_LOAD_X3(xbh, xbl, fn); }
+        SBEV_STORE3(fprev);
+        __builtin_amdgcn_sched_barrier(0);
+        SBEV_STRIP3(xah, xal);
+        fprev = f;
+        f += 2;
+    }
+    SBEV_STORE3(fprev);
+#undef SBEV_STORE3
+#undef SBEV_LOAD_X3
+#undef SBEV_STRIP3
+}
+
 // W [N,K] fp32 -> [N, K/8, 2, 8] bf16: one thread per 8-k block
 __global__ void split_weights_kernel(const float* w, unsigned short* out, long long n_blocks) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,6 +377,27 @@ extern "C" int sbev_linear_bf16x3(const float* X, const uint16_t* W2, const floa
     if (st != SBEV_OK) return st;
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), 2 * STAGE, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_linear_bf16x3");
+}
+
+
+// The strip kernel's shape: the parameter generator of adaptive mixing (K = 256, wide N), any M.
+extern "C" int sbev_linear_bf16x3_strip_ok(int64_t M, int N, int K) { return M >= 1 && M < 0x7fffffffLL / 16 && K == 256 && N >= 1024 && N % 128 == 0; }
+
+// Y = X W^T + bias with X ALREADY split (X2 = sbev_split_bf16x3_weights image of the [M, 256] activation)
+extern "C" int sbev_linear_bf16x3_strip(const uint16_t* X2, const uint16_t* W2, const float* bias, float* Y, int64_t M, int N, int K,
+                                        int64_t ldy, int relu, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && sbev_linear_bf16x3_strip_ok(M > 0 ? M : 1, N, K), "sbev_linear_bf16x3_strip: needs K = 256 and N %% 128 == 0, N >= 1024 (N=%d K=%d)", N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X2 && W2 && Y && ldy >= N && ldy % 4 == 0, "sbev_linear_bf16x3_strip: bad pointers / leading dimension");
+    SBEV_REQUIRE((((uintptr_t)X2 | (uintptr_t)W2 | (uintptr_t)Y) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0), "sbev_linear_bf16x3_strip: 16-byte alignment");
+    StripArgs a{X2, W2, bias, Y, (int)M, (long long)ldy};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+    if (relu) hipLaunchKernelGGL(gemm_bf16x3_strip_kernel<true>, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_bf16x3_strip_kernel<false>, dim3((unsigned)(N / 128)), dim3(256), 0, s, a);
+    if (prof) sbev::profile_end(s, e0, e1, 1);
+    return sbev::check_launch("sbev_linear_bf16x3_strip");
 }
 
 namespace sbev {

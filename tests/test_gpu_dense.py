@@ -285,3 +285,36 @@ def test_layer_norm_prologue_falls_back_outside_the_small_tile_shapes():
     xn, y = dense.ln_linear(x, lw, lb, w, b)
     xn_ref = dense.layer_norm(x, lw, lb)
     assert torch.equal(xn, xn_ref) and torch.equal(y, dense.linear(xn_ref, w, b))
+
+
+@pytest.mark.parametrize('M,N,relu', [(900, 32768, 0), (3600, 20480, 0), (1, 1024, 1), (33, 2048, 1), (100, 18432, 0)])
+def test_bf16x3_strip_generator_kernel(M, N, relu):
+    """sbev_linear_bf16x3_strip (W-stationary strips, the activation split once): the same three bf16 products as the tile
+    kernel in another summation order -- fp32-class accuracy against fp64 and agreement with the tile kernel to round-off."""
+    import ctypes
+    from sparsebev_amd import _lib
+    lib = _lib.load()
+    K = 256
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.sbev_linear_bf16x3_strip_ok(M, N, K) == 1 and lib.sbev_linear_bf16x3_strip_ok(M, N, 512) == 0
+    w2 = torch.empty(N, 2 * K, device=DEV, dtype=torch.int16)
+    x2 = torch.empty(M, 2 * K, device=DEV, dtype=torch.int16)
+    assert lib.sbev_split_bf16x3_weights(p(w), p(w2), N, K, st) == 0 and lib.sbev_split_bf16x3_weights(p(x), p(x2), M, K, st) == 0
+    y = torch.full((M, N), float('nan'), device=DEV)
+    assert lib.sbev_linear_bf16x3_strip(p(x2), p(w2), p(b), p(y), M, N, K, N, relu, st) == 0, lib.sbev_last_error()
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    d = (y.double() - ref).abs()
+    assert d.pow(2).mean().sqrt().item() < 6e-6 and d.max().item() < 6e-5
+    tile = _bf16x3(x, w, b)
+    if relu:
+        tile = tile.clamp_min(0)
+    assert (y - tile).abs().max().item() < 2e-5
+    # refuses other shapes with the documented status
+    assert lib.sbev_linear_bf16x3_strip(p(x2), p(w2), p(b), p(y), M, N, 512, N, relu, st) == -1

@@ -248,8 +248,16 @@ __device__ __forceinline__ void mma_item(const ChainArgs& a, Stream& st, const L
 
 __device__ __forceinline__ float wsum(float v) { return sbev::wave_sum_dpp(v); }
 
-// LayerNorm over 256 columns held as 4 per lane (column = lane + 64 c)
-__device__ __forceinline__ void ln4(float (&v)[4], const float* g, const float* b, float eps, bool relu, int lane) {
+// LayerNorm over 256 columns held as 4 per lane (column = lane + 64 c).  The weights are fetched (LDS) by LnW's constructor,
+// i.e. where the caller declares it -- before the partial sums are gathered, so that their latency is not at the end of the chain.
+struct LnW {
+    float g[4], b[4];
+    __device__ __forceinline__ LnW(const float* gp, const float* bp, int lane) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { g[c] = gp[lane + 64 * c]; b[c] = bp[lane + 64 * c]; }
+    }
+};
+__device__ __forceinline__ void ln4(float (&v)[4], const LnW& w, float eps, bool relu) {
     const float mean = wsum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / DM);
     float q = 0.f;
 #pragma unroll
@@ -257,7 +265,7 @@ __device__ __forceinline__ void ln4(float (&v)[4], const float* g, const float* 
     const float rstd = rsqrtf(wsum(q) * (1.f / DM) + eps);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float o = (v[c] - mean) * rstd * g[lane + 64 * c] + b[lane + 64 * c];
+        float o = (v[c] - mean) * rstd * w.g[c] + w.b[c];
         v[c] = relu ? fmaxf(o, 0.f) : o;
     }
 }
@@ -293,6 +301,7 @@ __device__ __forceinline__ void store_rows(float* smem, int off, int ld, int row
 // position_encoder[0..2]: Linear(3 -> 256) + LayerNorm + ReLU of one row (sparsebev_transformer.py:116-119), into LDS
 __device__ __forceinline__ void pe0_row(const ChainArgs& a, float* smem, int row, int lane, float x0, float x1, float x2) {
     const float* pv = smem + OFF_PARAM;
+    const LnW lw(pv + PV_PE1G, pv + PV_PE1B, lane);
     float v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -300,7 +309,7 @@ __device__ __forceinline__ void pe0_row(const ChainArgs& a, float* smem, int row
         const float* w = pv + PV_PE0_W + n * 3;
         v[c] = ((x0 * w[0] + x1 * w[1]) + x2 * w[2]) + pv[PV_PE0_B + n];
     }
-    ln4(v, pv + PV_PE1G, pv + PV_PE1B, a.eps, true, lane);
+    ln4(v, lw, a.eps, true);
     store_rows(smem, OFF_C, LDX, row, lane, v);
 }
 
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
     const long long pg = row0 + prow;
     const bool plive = wave < R && pg < a.M;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f), r4 = t;
-    float v0[4] = {0.f, 0.f, 0.f, 0.f};
+    float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
     float bx = 0.f, by = 0.f, bz = 0.f;
     if (PRE == PRE_SLABS) {
         // mixing.out_proj: sum of the split-K slabs (16 independent loads in flight, added in slab order); lane = 4 columns
@@ -365,6 +374,10 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
 #pragma unroll
         for (int c = 0; c < 4; ++c) v0[c] = src[pg * DM + lane + 64 * c];
         if (PRE == PRE_FRONT) { bx = a.bbox[pg * 10]; by = a.bbox[pg * 10 + 1]; bz = a.bbox[pg * 10 + 2]; }
+        if (PRE == PRE_ATT) {        // the residual of the out-projection: x rows, kept in LDS until the first epilogue
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v1[c] = a.x[pg * DM + lane + 64 * c];
+        }
     }
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) asm volatile("" ::"v"(pq[j].x), "v"(pq[j].y), "v"(pq[j].z), "v"(pq[j].w));   // keeps the loads up there
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                 make_float4(dx * rstd * g4.x + n4.x, dy * rstd * g4.y + n4.y, dz * rstd * g4.z + n4.z, dw * rstd * g4.w + n4.w);
         } else {
             store_rows(smem, PRE == PRE_FRONT ? OFF_X3 : OFF_X2, LDX, prow, lane, v0);
+            if (PRE == PRE_ATT) store_rows(smem, OFF_R, LDX, prow, lane, v1);
             if (PRE == PRE_FRONT) pe0_row(a, smem, prow, lane, bx, by, bz);
         }
     }
@@ -418,10 +432,14 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             } break;
             case EPI_FFN1: {     // + x2 -> norm3 -> x3
                 if (side) break;
+                const LnW lw(pv + PV_N3G, pv + PV_N3B, lane);
+                float res[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) res[c] = smem[OFF_X2 + row * LDX + lane + 64 * c];
                 gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_FFN1_B, 0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] += smem[OFF_X2 + row * LDX + lane + 64 * c];
-                ln4(v, pv + PV_N3G, pv + PV_N3B, a.eps, false, lane);
+                for (int c = 0; c < 4; ++c) v[c] += res[c];
+                ln4(v, lw, a.eps, false);
                 store_rows(smem, OFF_X3, LDX, row, lane, v);
                 if (live) {
 #pragma unroll
@@ -432,8 +450,9 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             case EPI_BR2: {      // cls_branch[3..5] | reg_branch[2..3]
                 const bool first = un.epi == EPI_BR1;
                 if (side == 0) {
+                    const LnW lw(pv + (first ? PV_CLS1G : PV_CLS4G), pv + (first ? PV_CLS1B : PV_CLS4B), lane);
                     gather4(v, P, 0, un.a.KH, 0, row, lane, pv + (first ? PV_CLS0_B : PV_CLS3_B), 0);
-                    ln4(v, pv + (first ? PV_CLS1G : PV_CLS4G), pv + (first ? PV_CLS1B : PV_CLS4B), a.eps, true, lane);
+                    ln4(v, lw, a.eps, true);
                     store_rows(smem, OFF_C, LDX, row, lane, v);
                 } else {
                     gather4(v, P, un.a.items, un.b.KH, 0, row, lane, pv + (first ? PV_REG0_B : PV_REG2_B), 0);
@@ -478,10 +497,14 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             } break;
             case EPI_PE3: {      // position_encoder[3..5] + query_feat -> x (:166-167)
                 if (side) break;
-                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_PE3_B, 0);
-                ln4(v, pv + PV_PE4G, pv + PV_PE4B, a.eps, true, lane);
+                const LnW lw(pv + PV_PE4G, pv + PV_PE4B, lane);
+                float res[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] += smem[OFF_X3 + row * LDX + lane + 64 * c];
+                for (int c = 0; c < 4; ++c) res[c] = smem[OFF_X3 + row * LDX + lane + 64 * c];
+                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_PE3_B, 0);
+                ln4(v, lw, a.eps, true);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += res[c];
                 store_rows(smem, OFF_X2, LDX, row, lane, v);
                 if (live) {
 #pragma unroll
@@ -503,12 +526,14 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             } break;
             case EPI_AOUT: {     // attention out-projection + x -> norm1 -> x1 (:169)
                 if (side) break;
-                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_AOUT_B, 0);
-                if (live) {
+                const LnW lw(pv + PV_N1G, pv + PV_N1B, lane);
+                float res[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] += a.x[g * DM + lane + 64 * c];
-                }
-                ln4(v, pv + PV_N1G, pv + PV_N1B, a.eps, false, lane);
+                for (int c = 0; c < 4; ++c) res[c] = smem[OFF_R + row * LDX + lane + 64 * c];     // x rows, staged by the prologue
+                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_AOUT_B, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += res[c];
+                ln4(v, lw, a.eps, false);
                 store_rows(smem, OFF_X3, LDX, row, lane, v);
                 if (live) {
 #pragma unroll

@@ -155,3 +155,31 @@ def test_two_layer_chain_against_the_oracle():
     ref_cls, ref_box, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=2, sampler=O.msmv_sampling_kernel_semantics)
     assert (cls[0].cpu() - ref_cls[0]).abs().max() < 1e-4 and (box[0].cpu() - ref_box[0]).abs().max() < 1e-4
     assert (cls[1].cpu() - ref_cls[1]).abs().max() < 2e-3 and (box[1].cpu() - ref_box[1]).abs().max() < 2e-3   # free-running layer 2
+
+
+@pytest.mark.parametrize('tag', ['c1', 'c2small', 'L5'])
+def test_row_chains_against_the_reference_recordings(tag):
+    """Fixture G7 (the reference decoder's own per-layer inputs and outputs): every layer through the chain kernels from the
+    REFERENCE's inputs of that layer -- 1-layer runs (front, attention chain, tail) and 2-layer runs (tail + the next layer's
+    front in one launch: its x / qkvt only show in layer 2) -- against the reference's recorded outputs at 1e-4."""
+    from conftest import load_golden
+    g = load_golden('g7_decoder_' + tag)
+    B, Q, T, L = [int(v) for v in g['cfg']]
+    seeds = [int(v) for v in g['seeds']]
+    ih, iw, sizes = S.PYRAMIDS[str(g['pyramid'])]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=seeds[2])]
+    metas = S.make_img_metas(B, T, ih, iw)
+    for b, m in enumerate(metas):
+        m['img_timestamp'] = [float(v) for v in g['timestamps'][b]]
+    model1, _ = build(T, L, seeds[0], 1)
+    model2, _ = build(T, L, seeds[0], 2)
+    assert model1.decoder._runtime is None
+    n = g['out_cls'].shape[0]
+    ins = [(g['query_bbox'], g['query_feat'])] + [(g['out_bbox'][i - 1], g['out_feat'][i - 1]) for i in range(1, n)]
+    for i, (qb, qf) in enumerate(ins):
+        c1, b1 = model1(qb.to(DEV), qf.to(DEV), list(feats), None, copy.deepcopy(metas))
+        assert (c1[0].cpu() - g['out_cls'][i]).abs().max() < 1e-4 and (b1[0].cpu() - g['out_bbox'][i]).abs().max() < 1e-4, i
+        if i + 1 < n:
+            c2, b2 = model2(qb.to(DEV), qf.to(DEV), list(feats), None, copy.deepcopy(metas))
+            assert (c2[1].cpu() - g['out_cls'][i + 1]).abs().max() < 1e-4 and (b2[1].cpu() - g['out_bbox'][i + 1]).abs().max() < 1e-4, i
+    assert 'chain_pack' in model1.decoder._runtime._keep                       # the chains did run

@@ -21,6 +21,7 @@
 // Results equal the op-by-op launches to fp32 round-off (other summation order), not bit for bit; DESIGN.md section 4.
 #include "sbev_common.hpp"
 #include "sample_point.hpp"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -666,9 +667,15 @@ static int add_front(ChainArgs& a, int n, const sbev_decoder_config& c, const fl
 // launch may already be inside a stream capture)
 template <int PRE>
 static hipError_t lds_attr() {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_FLOATS * 4);
-    return attr;
+    static std::atomic<unsigned long long> done{0};      // bit d: raised on device d (a process may drive several devices)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_FLOATS * 4);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 template <int PRE>

@@ -282,8 +282,9 @@ def main():
     ap.add_argument('--detector', action='store_true', help='force the detector figure for other configs too: also report a LABELLED detector-level samples/s: stock-PyTorch ResNet-50 + FPN stand-in (tools/backbone_standin.py, fp16) on the 6 new images -> frame ring -> SparseBEVHead -> NMS-free decode (online mode, like the reference FPS)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
     ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
-    ap.add_argument('--gemm', default='f32', choices=['f32', 'bf16x3'],
-                    help='f32 = exact f32-input MFMA (default); bf16x3 = opt-in 3 x bf16 split of the two big mixing GEMMs')
+    ap.add_argument('--gemm', default='f32', choices=sorted(runtime.GEMM_MODES),
+                    help='the two big mixing GEMMs: f32 = exact f32-input MFMA (default); bf16x6 = fp32-class split on the bf16 matrix core '
+                         '(hi + mid + lo images, 6 products); bf16x3s / bf16x3 = 3 products (2^-16 class; new / round-2 kernels)')
     args = ap.parse_args()
 
     torch.set_grad_enabled(False)     # inference benchmark, like the reference's timing.py / val.py (with grad enabled the
@@ -297,7 +298,7 @@ def main():
     L = len(sizes)
 
     model = build_model(T, L, device)
-    model.decoder.gemm_mode = 1 if args.gemm == 'bf16x3' else 0
+    model.decoder.gemm_mode = args.gemm
     model.decoder.overlap = args.overlap
     shard = SampleShard(rank, world)
     # per-rank synthetic inputs (seed = rank), generated on the device and left resident
@@ -374,19 +375,33 @@ def main():
     # mixing GEMMs; reported next to -- never instead of -- the exact-fp32 `value`
     alt = None
     if world == 1 and args.gemm == 'f32' and not args.no_alt:
-        model.decoder.gemm_mode = 1
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            cls3, box3 = step()
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t1
-        model.decoder.gemm_mode = 0
-        alt = {'gemm': '3 x bf16 split products, f32 accumulate (sbev_linear_bf16x3), mixing generator + out-proj only',
-               'value': round(args.steps * B / dt3, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt3 / args.steps, 4),
-               'max_abs_dev_vs_exact_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
+        alt = {}
+        for mode, what in (('bf16x6', 'fp32-class: hi + mid + lo bf16 images, 6 products, f32 accumulate (csrc/gemm_bf16s.hip), mixing generator + out-proj only'),
+                           ('bf16x3s', '3 x bf16 split products (2^-16 class) on the gemm_bf16s.hip kernels'),
+                           ('bf16x3', '3 x bf16 split products, f32 accumulate (sbev_linear_bf16x3, round-2 kernels)')):
+            model.decoder.gemm_mode = mode
+            try:
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    cls3, box3 = step()
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t1
+                runtime.profile_sampler(6)
+                for _ in range(min(5, args.steps)):
+                    step()
+                torch.cuda.synchronize()
+                g_ms = [runtime.read_kernel_ms(k) for k in (1, 2)]
+                runtime.profile_sampler(False)
+                alt[mode] = {'gemm': what, 'value': round(args.steps * B / dt3, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt3 / args.steps, 4),
+                             'generator_us': round(1e3 * sum(g_ms[0]) / max(len(g_ms[0]), 1), 2), 'out_proj_us': round(1e3 * sum(g_ms[1]) / max(len(g_ms[1]), 1), 2),
+                             'max_abs_dev_vs_exact_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
+            except Exception as e:      # noqa: BLE001  (a secondary figure must never take the metric line down)
+                alt[mode] = {'error': repr(e)[:300]}
+            finally:
+                model.decoder.gemm_mode = 'f32'
 
     detector = None
     if world == 1 and (args.detector or (args.config == 'c2' and not args.no_detector and not args.online)):
@@ -426,7 +441,7 @@ def main():
             'ms_per_step': round(1e3 * elapsed_max / args.steps, 4),
             'host_issue_ms_per_step': round(1e3 * host_issue / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + (' (mixing GEMMs: 3xbf16 split, f32 accumulate)' if args.gemm == 'bf16x3' else ''),
+            'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + ('' if args.gemm == 'f32' else ' (mixing GEMMs: %s split on the bf16 matrix core, f32 accumulate)' % args.gemm),
             'data': 'synthetic',
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
                                    '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
@@ -486,7 +501,7 @@ def main():
                 for name, key, fl, ms in (('gemm_nt_f32_strip_kernel (mixing parameter generator)', 'gemm_nt_f32_strip_kernel<false>', flops, gemm_ms[0]),
                                           ('gemm_nt_f32_regtile_kernel (mixing out-projection, split-K)', 'gemm_nt_f32_regtile_kernel', flops2, gemm_ms[1]))]
         if alt is not None:
-            out['alt_bf16x3'] = alt
+            out['alt_gemm'] = alt
         if detector is not None:
             out['detector_standin'] = detector
         if world == 1 and not args.no_cpu_baseline:

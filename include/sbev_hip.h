@@ -40,7 +40,12 @@ enum sbev_status {
 };
 
 enum sbev_dtype { SBEV_F32 = 0, SBEV_BF16 = 1 };
-enum sbev_gemm_mode { SBEV_GEMM_F32 = 0 /* exact: f32-input MFMA */, SBEV_GEMM_BF16X3 = 1 /* opt-in 3 x bf16 split */ };
+enum sbev_gemm_mode {
+    SBEV_GEMM_F32 = 0,      /* exact: f32-input MFMA */
+    SBEV_GEMM_BF16X3 = 1,   /* opt-in 3 x bf16 split (rounds 1-2 kernels, gemm_bf16x3.hip) */
+    SBEV_GEMM_BF16X6 = 2,   /* fp32-class: hi + mid + lo bf16 images, 6 products, fp32 accumulate (gemm_bf16s.hip) */
+    SBEV_GEMM_BF16X3S = 3   /* 3 x bf16 split on the gemm_bf16s.hip kernels */
+};
 
 /* Output layouts of the sampler. */
 enum sbev_out_layout {
@@ -357,6 +362,36 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
                               int64_t M, int N, int K, int64_t ldx, int relu, int splits, float* workspace,
                               sbev_stream_t stream);
 
+/*
+ * Split-bf16 Linears on the bf16 matrix core, round 3 (gemm_bf16s.hip).  nimg = 3 ("bf16x6"): every fp32 operand is the exact
+ * sum of three RNE bf16 images (hi + mid + lo) and Y accumulates, in fp32 on v_mfma_f32_32x32x16_bf16, the six image products of
+ * weight >= 2^-16 (hh, hm, mh, mm, hl, lh); the dropped ones are <= 2^-23 |a b| per product, i.e. below what an fp32 fma chain
+ * rounds away per step -- fp32-class, not bit-equal to fp32 math.  nimg = 2 ("bf16x3"): hi + lo, three products, 2^-16 class.
+ * Replaces: torch.nn.Linear of AdaptiveMixing.parameter_generator / out_proj (models/sparsebev_transformer.py:358,378).
+ *
+ *   sbev_split_bf16s_rows   X [rows, ldx] fp32 -> out [nimg][rows][K] bf16 row-major planes (sbev_bf16s_image_elems elements);
+ *                           the generator's two operands (W once per weight update, X once per call).  K % 8 == 0.
+ *   sbev_pack_bf16s_frags   W [N, ldw] fp32 -> out [N/32][K/16][nimg][64][8] bf16, the MFMA operand order (same element count);
+ *                           the out-projection's weight.  N % 32 == 0, K % 16 == 0.
+ *   sbev_linear_bf16s_gen   Y [M, ldy] = X W^T + bias (ReLU optional) from split planes Xs / Ws.  N % 256 == 0, K % 32 == 0,
+ *                           K <= 4096 (sbev_linear_bf16s_gen_ok).
+ *   sbev_linear_splitk_bf16s  Y = LayerNorm?(relu?(X W^T + bias) + residual) for N == 256, K % 32 == 0 (sbev_linear_bf16s_out_ok):
+ *                           X stays fp32 [M, ldx] and is split inside the kernel; workspace = sbev_linear_bf16s_out_plan(M, N, K)
+ *                           partial slabs [plan, M, 256] fp32, summed in a fixed order (bit-reproducible) by sbev_splitk_reduce_f32.
+ */
+int64_t sbev_bf16s_image_elems(int64_t rows, int K, int nimg);
+int sbev_split_bf16s_rows(const float* X, int64_t ldx, uint16_t* out, int64_t rows, int K, int nimg, sbev_stream_t stream);
+int sbev_pack_bf16s_frags(const float* W, int64_t ldw, uint16_t* out, int N, int K, int nimg, sbev_stream_t stream);
+int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K);
+int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K,
+                          int64_t ldy, int relu, int nimg, sbev_stream_t stream);
+int sbev_linear_bf16s_out_ok(int64_t M, int N, int K);
+int sbev_linear_bf16s_out_plan(int64_t M, int N, int K);
+int sbev_linear_splitk_bf16s(const float* X, const uint16_t* Wp, const float* bias, const float* residual,
+                             const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                             int64_t M, int N, int K, int64_t ldx, int relu, int nimg, float* workspace,
+                             sbev_stream_t stream);
+
 /* dst[i] = (float)src[i] over a contiguous run; src_dtype: 0 fp32, 1 bf16, 2 fp16.  How the online frame ring takes
  * channels-last frames (sparsebev_amd/cache.py); replaces the torch.cat of cached frames, models/sparsebev.py:297-303. */
 int sbev_copy_widen_f32(const void* src, int src_dtype, float* dst, int64_t n, sbev_stream_t stream);
@@ -497,6 +532,8 @@ typedef struct sbev_decoder_weights {
     const float *cls0_w, *cls0_b, *cls1_g, *cls1_b, *cls3_w, *cls3_b, *cls4_g, *cls4_b, *cls6_w, *cls6_b;  /* cls_branch.* */
     const float *reg0_w, *reg0_b, *reg2_w, *reg2_b, *reg4_w, *reg4_b;                                        /* reg_branch.* */
     const float *chain_pack;   /* sbev_decoder_chain_pack image of the small Linears' weights, or NULL (op-by-op launches) */
+    const uint16_t *pg_ws;     /* gemm_mode 2 / 3: sbev_split_bf16s_rows planes of pg_w (3 / 2 images); else NULL */
+    const uint16_t *op_wp;     /* gemm_mode 2 / 3: sbev_pack_bf16s_frags image of op_w (3 / 2 images); else NULL */
 } sbev_decoder_weights;
 
 /*

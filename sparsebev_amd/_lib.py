@@ -72,6 +72,16 @@ SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp]),
     'sbev_linear_splitk_bf16x3': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'sbev_bf16s_image_elems': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sbev_split_bf16s_rows': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_pack_bf16s_frags': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_linear_bf16s_gen_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sbev_linear_bf16s_gen': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_linear_bf16s_out_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sbev_linear_bf16s_out_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    'sbev_linear_splitk_bf16s': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'sbev_msmv_bwd': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _c_i32p, ctypes.c_int,
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64,

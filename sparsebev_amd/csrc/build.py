@@ -21,6 +21,7 @@ UNITS = {
     # VGPR-form MFMAs: the kernel fits 256 VGPRs, AGPR-form costs 144 accumulator copies per loop iteration
     'gemm_regtile.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
     'gemm_bf16x3.hip': [],
+    'gemm_bf16s.hip': [],                # split-bf16 (bf16x6 / bf16x3) Linears, 8-wave workgroups on v_mfma_f32_32x32x16_bf16
     'gemm_any.hip': [],                  # layout-generic GEMM: grad_x / grad_W of every Linear (training)
     'mixing_bwd.hip': [],
     'attention_bwd.hip': [],
@@ -53,22 +54,41 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def header_deps():
+    """Everything a translation unit can textually include: *.hpp and the *.inc fragments of this directory (msmv_chunk.inc is
+    included by both msmv_sampling.hip and mixing.hip), the public header and this build recipe."""
+    deps = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith(('.hpp', '.inc'))]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'sbev_hip.h'))
+    deps.append(os.path.abspath(__file__))
+    return deps
+
+
+def object_path(src):
+    return os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
+
+
+def stale_units():
+    """Translation units whose object is missing or older than its source or any header / include fragment."""
+    headers = header_deps()
+    return [src for src in UNITS if _stale(object_path(src), [os.path.join(HERE, src)] + headers)]
+
+
+def build(force=False, verbose=False, jobs=None):
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.hpp')]
-    headers.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'sbev_hip.h'))
-    headers.append(os.path.abspath(__file__))
-    objs = []
-    for src, extra in UNITS.items():
-        s = os.path.join(HERE, src)
-        o = os.path.join(OBJ_DIR, src.replace('.hip', '.o'))
-        objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
-            if verbose:
-                print(' '.join(cmd))
-            subprocess.check_call(cmd)
+    todo = list(UNITS) if force else stale_units()
+    cmds = []
+    for src in todo:
+        cmd = [hipcc] + COMMON + UNITS[src] + ['-c', os.path.join(HERE, src), '-o', object_path(src)]
+        if verbose:
+            print(' '.join(cmd))
+        cmds.append(cmd)
+    if cmds:      # the units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        n = jobs or min(len(cmds), os.cpu_count() or 1, 16)
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            list(pool.map(subprocess.check_call, cmds))
+    objs = [object_path(src) for src in UNITS]
     if force or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

@@ -50,12 +50,17 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.sampled = k.take(BQ * c.G * Pin * Cg);
     b.params = k.take(BQ * pgN);
     b.mixed = k.take(BQ * mixN);
-    b.slabs = k.take((size_t)out_proj_splits(BQ, c.D, (int)mixN) * BQ * D);
+    {   // split-K slabs of the out-projection: the larger of the exact and the split-bf16 plans (the mode is a per-call choice)
+        int sl = out_proj_splits(BQ, c.D, (int)mixN);
+        const int sl2 = sbev_linear_bf16s_out_plan((int64_t)BQ, c.D, (int)mixN);
+        sl = sl2 > sl ? sl2 : sl;
+        b.slabs = k.take((size_t)sl * BQ * D);
+    }
     b.h = k.take(BQ * c.ffn);
     b.c0 = k.take(BQ * D); b.c1 = k.take(BQ * D); b.r0 = k.take(BQ * D); b.r1 = k.take(BQ * D);
     b.reg = k.take(BQ * c.code_size);
     b.bbox = k.take(BQ * 10);
-    b.x1s = k.take(BQ * D);        // x1 as (hi, lo) bf16 pairs: the generator's operand in gemm_mode bf16x3 (same byte count)
+    b.x1s = k.take(2 * BQ * D);    // x1 as bf16 images: the generator's operand in the split-bf16 modes (2 or 3 images of 2 bytes)
     b.bytes = k.off;
     return b;
 }
@@ -78,7 +83,7 @@ int validate(const sbev_decoder_config* c) {
     // every box kernel (sasa, sampling_front, refine, linear3) reads query_bbox rows with a stride of 10 floats
     SBEV_REQUIRE(c->code_size == 10, "sbev_decoder: code_size %d (the box kernels are built for the 10-wide box code)", c->code_size);
     SBEV_REQUIRE(c->num_layers >= 1 && c->num_classes >= 1 && c->ffn % 4 == 0, "sbev_decoder: head sizes");
-    SBEV_REQUIRE(c->gemm_mode == SBEV_GEMM_F32 || c->gemm_mode == SBEV_GEMM_BF16X3, "sbev_decoder: gemm_mode %d", c->gemm_mode);
+    SBEV_REQUIRE(c->gemm_mode >= SBEV_GEMM_F32 && c->gemm_mode <= SBEV_GEMM_BF16X3S, "sbev_decoder: gemm_mode %d", c->gemm_mode);
     return SBEV_OK;
 }
 
@@ -140,6 +145,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const sbev::ProfCallScope prof_scope;     // with sbev_profile_stride(n): only every n-th call's launches are bracketed
     SBEV_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sbev_decoder_forward: workspace must be 256-byte aligned");
     SBEV_REQUIRE(cfg->gemm_mode != SBEV_GEMM_BF16X3 || (w->pg_w2 && w->op_w2), "sbev_decoder_forward: gemm_mode bf16x3 needs pg_w2 / op_w2");
+    const int nimg = cfg->gemm_mode == SBEV_GEMM_BF16X6 ? 3 : cfg->gemm_mode == SBEV_GEMM_BF16X3S ? 2 : 0;   // split-bf16 kernels (gemm_bf16s.hip)
+    SBEV_REQUIRE(nimg == 0 || (w->pg_ws && w->op_wp), "sbev_decoder_forward: gemm_mode %d needs pg_ws / op_wp", cfg->gemm_mode);
     const Buffers b = carve(c, workspace);
     SBEV_REQUIRE((int64_t)b.bytes <= workspace_bytes, "sbev_decoder_forward: workspace too small (%lld < %zu)", (long long)workspace_bytes, b.bytes);
 
@@ -180,6 +187,16 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         return sbev_linear_bf16x3_strip(x2, w->pg_w2, w->pg_b, b.params, BQ, pgN, D, pgN, 0, st);
     };
 
+    SBEV_REQUIRE(nimg == 0 || (sbev_linear_bf16s_gen_ok(BQ, pgN, D) && sbev_linear_bf16s_out_ok(BQ, D, mixN)),
+                 "sbev_decoder_forward: gemm_mode %d does not cover this shape (rows %lld, generator %d x %d, out-projection %d x %d)",
+                 cfg->gemm_mode, (long long)BQ, pgN, D, D, mixN);
+    auto generator_bf16s = [&](sbev_stream_t st) -> int {      // x1 -> bf16 planes (once per layer) -> Y = X W^T + b
+        uint16_t* xs = reinterpret_cast<uint16_t*>(b.x1s);
+        int e = sbev_split_bf16s_rows(b.x1, D, xs, BQ, D, nimg, st);
+        if (e != SBEV_OK) return e;
+        return sbev_linear_bf16s_gen(xs, w->pg_ws, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg, st);
+    };
+
     const float* bbox = query_bbox;
     const float* feat = query_feat;
     bool pe0_done = false;             // the previous layer's tail already ran this layer's first position-encoder stage
@@ -194,7 +211,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         if (chain) {
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main));
-            if (c.gemm_mode == SBEV_GEMM_BF16X3)
+            if (nimg)
+                TRY(generator_bf16s(stream));
+            else if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(generator_bf16x3(stream));
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
@@ -213,7 +232,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                 TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
             }
             int used = 0;
-            if (c.gemm_mode == SBEV_GEMM_BF16X3)
+            if (nimg)
+                TRY(sbev::launch_splitk_slabs_bf16s(b.mixed, w->op_wp, BQ, mixN, mixN, nimg, b.slabs, &used, s_main));
+            else if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(sbev::launch_splitk_slabs_bf16x3(b.mixed, w->op_w2, BQ, D, mixN, mixN, splits, b.slabs, &used, s_main));
             else
                 TRY(sbev::launch_splitk_slabs(b.mixed, w->op_w, BQ, D, mixN, mixN, mixN, splits, b.slabs, &used, s_main));
@@ -244,7 +265,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
             TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
         }
-        if (c.gemm_mode == SBEV_GEMM_BF16X3)
+        if (nimg)
+            TRY(generator_bf16s(fork_pg ? s_aux : stream));
+        else if (c.gemm_mode == SBEV_GEMM_BF16X3)
             TRY(generator_bf16x3(fork_pg ? s_aux : stream));
         else
             TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, fork_pg ? s_aux : stream));
@@ -276,7 +299,10 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                                     c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, stream));
         else
             TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
-        if (c.gemm_mode == SBEV_GEMM_BF16X3)
+        if (nimg)
+            TRY(sbev_linear_splitk_bf16s(b.mixed, w->op_wp, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
+                                         0, nimg, b.slabs, stream));
+        else if (c.gemm_mode == SBEV_GEMM_BF16X3)
             TRY(sbev_linear_splitk_bf16x3(b.mixed, w->op_w2, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
                                           0, splits, b.slabs, stream));
         else

@@ -1,0 +1,565 @@
+// Split-bf16 Linears for the two 15-GFLOP GEMMs of adaptive mixing on the bf16 matrix core (round 3):
+//   NIMG = 3  "bf16x6": x = hi + mid + lo (three RNE bf16 images, 8 + 8 + 8 significand bits = an exact split of an fp32
+//             value), Y = sum of the SIX image products whose weight is >= 2^-16 (hh, hm, mh, mm, hl, lh), fp32 accumulation
+//             on v_mfma_f32_32x32x16_bf16.  Dropped: ml, lm, ll <= 2^-23 |a b| per product -- below the rounding an fp32 fma
+//             chain commits per step, so the result is fp32-class ("not narrower than fp32": tests/test_gpu_bf16s.py compares
+//             both against fp64).  6 x 15.1 GFLOP at the 2.5 PF bf16 peak = 36 us, against a 96 us floor on the f32 MFMA.
+//   NIMG = 2  "bf16x3": hi + lo, three products (2^-16 class), the opt-in fast mode of rounds 1-2 on the same kernels.
+// Replaces nothing in the reference (torch.nn.Linear, models/sparsebev_transformer.py:358,378); same semantics as
+// sbev_linear_f32 / sbev_linear_splitk_f32.
+//
+// Why these kernels and not gemm_bf16x3.hip's: a 16-byte-per-lane VGPR write-back (global load or ds_read_b128) costs the issuing
+// wave ~85 matrix-pipe cycles when it is alone on its SIMD and 23-38 with a partner wave, so the
+// one-wave-per-SIMD register-stationary strips that win for 32-cycle-per-16x16x4 f32 MFMAs are load-issue-bound at bf16 rates
+// (72 us for 45 GFLOP = 25 % of peak).  Here every workgroup is 8 waves = two per SIMD, operands are read as whole 1-KiB
+// fragments, and a wave owns a 64 x 64 output tile so that one fragment read feeds 2 (x3) ... 6 (x6) MFMAs of 32 cycles.
+//
+//   generator  Y[M, N] = X[M, K] W[N, K]^T + b   (K = 256, N = 32768 ...):  workgroup tile <= 128 rows x 256 columns, K slabs of
+//              32 through a double-buffered LDS stage filled by global_load_lds_dwordx4 (both operands pre-split into row-major
+//              bf16 planes: X once per layer by sbev_split_bf16s_rows, W once per weight update), 16-B chunks XOR-swizzled on
+//              the SOURCE address so that the lane-linear LDS image is conflict-free for ds_read_b128 fragments.  Row tiles
+//              are 3 or 4 fragments of 32 rows, balanced (900 rows = 5 x 4 + 3 x 3 fragments: 3 % padding instead of 12 %).
+//   out-proj   slabs[S, M, 256] = X[M, K] W[256, K]^T over S K-chunks (K = 32768): workgroup = 64 rows x all 256 columns x one
+//              chunk, its two wave quartets take the two halves of the chunk and fold through LDS (S slabs instead of 2 S).
+//              X (fp32, the mixing kernel's output) is split in the kernel -- each element exactly once -- into an LDS stage;
+//              W fragments come pre-packed in MFMA order (sbev_pack_bf16s_frags: 1 KiB per (32 columns, 16 k, image)), straight
+//              from L2 into registers (no sharing between waves to exploit: every wave owns its own 64 columns).
+#include <cstdlib>
+#include "sbev_common.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- the split ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+// 8 floats -> NIMG x (8 bf16): image i = RNE_bf16(remainder), remainder -= image (exact: the difference of an fp32 value and its
+// bf16 rounding is representable).  hi + mid + lo reproduces every finite normal fp32 value bit for bit.
+template <int NIMG>
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4* out) {
+    float r[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img) {
+        unsigned p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = pack_bf16(r[2 * i], r[2 * i + 1]);
+        out[img] = (u32x4){p[0], p[1], p[2], p[3]};
+        if (img + 1 < NIMG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[2 * i] -= __uint_as_float(p[i] << 16);
+                r[2 * i + 1] -= __uint_as_float(p[i] & 0xffff0000u);
+            }
+        }
+    }
+}
+
+// products in the order they are accumulated (small terms first inside a k-step): image of X, image of W
+//   x3: (h,l) (l,h) (h,h)                 x6: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+template <int NIMG>
+struct Prods {
+    static constexpr int N = NIMG == 2 ? 3 : 6;
+    __host__ __device__ static constexpr int ia(int p) { return NIMG == 2 ? (p == 1 ? 1 : 0) : (p == 1 ? 2 : (p == 2 || p == 4) ? 1 : 0); }
+    __host__ __device__ static constexpr int ib(int p) { return NIMG == 2 ? (p == 0 ? 1 : 0) : (p == 0 ? 2 : (p == 2 || p == 3) ? 1 : 0); }
+};
+
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned nb) {
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous range of logical ids (bijective for any nb)
+    const unsigned full = nb >> 3, rem = nb & 7, x = b & 7;
+    return x * full + (x < rem ? x : rem) + (b >> 3);
+}
+
+// ---- row-major bf16 planes [NIMG][rows][K] of an fp32 matrix [rows, ldx] --------------------------------------------------------
+template <int NIMG>
+__global__ void split_rows_kernel(const float* x, long long ldx, unsigned short* out, long long rows, int K) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 8 k
+    const int kb = K / 8;
+    if (i >= rows * kb) return;
+    const long long r = i / kb;
+    const int c = (int)(i - r * kb);
+    const float* p = x + r * ldx + c * 8;
+    u32x4 im[NIMG];
+    split8<NIMG>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), im);
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img)
+        *reinterpret_cast<u32x4*>(out + ((long long)img * rows + r) * K + c * 8) = im[img];
+}
+
+// ---- MFMA-ordered fragments [N/32][K/16][NIMG][64 lanes][8 bf16] of W [N, ldw]: lane l holds row 32 nf + (l & 31), k = 16 ks +
+// 8 (l >> 5) + 0..7, i.e. exactly its operand of one v_mfma_f32_32x32x16_bf16 -----------------------------------------------------
+template <int NIMG>
+__global__ void pack_frags_kernel(const float* w, long long ldw, unsigned short* out, int N, int K) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KS = K / 16;
+    if (i >= (long long)(N / 32) * KS * 64) return;
+    const int lane = (int)(i & 63);
+    const long long f = i >> 6;
+    const int ks = (int)(f % KS);
+    const int nf = (int)(f / KS);
+    const float* p = w + (long long)(nf * 32 + (lane & 31)) * ldw + ks * 16 + (lane >> 5) * 8;
+    u32x4 im[NIMG];
+    split8<NIMG>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), im);
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img)
+        *reinterpret_cast<u32x4*>(out + ((f * NIMG + img) * 64 + lane) * 8) = im[img];
+}
+
+// ---- LDS-DMA: 1 KiB per wave-instruction, LDS destination = M0 + 16 lane (lane-linear), source = sbase + voff per lane ----------
+// (M0 is written inside the asm block; hipcc uses M0 nowhere else in these kernels -- no LDS instruction needs it on gfx9+,
+// there is no dynamic register indexing; checked in the ISA, as for row_chain.hip.)
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_byte) {
+    // wave-uniform by construction; readfirstlane makes them SGPRs whatever the divergence analysis concluded
+    lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte);
+    const unsigned long long sb = (unsigned long long)sbase;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
+    sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        :
+        : "s"(lds_byte), "v"(voff), "s"(sbase)
+        : "memory");
+}
+
+// ==== generator-shaped GEMM ======================================================================================================
+struct GenArgs {
+    const unsigned short* Xs;    // [NIMG][M][K] bf16 planes
+    const unsigned short* Ws;    // [NIMG][N][K]
+    const float* bias;           // [N] or null
+    float* Y;                    // [M, ldy]
+    int M, N, K;
+    long long ldy;
+    int relu;
+    int ntm, base, rem;          // row tiles: the first `rem` have base + 1 fragments of 32 rows, the others `base`
+};
+
+constexpr int G_ROWS = 128, G_COLS = 256;
+constexpr int G_AIMG = G_ROWS * 64, G_BIMG = G_COLS * 64;        // bytes of one image of one stage (32 k = 64 B per row)
+
+template <int NIMG>
+__global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
+    constexpr int STAGE = NIMG * (G_AIMG + G_BIMG);
+    constexpr int NLOAD = 3 * NIMG;                                  // wave-loads per wave and slab (NIMG * 24 / 8 waves)
+    typedef Prods<NIMG> PR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                         // waves w and w + 4 (one SIMD) own the two row halves
+    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int ct = (int)(logical / (unsigned)a.ntm), rt = (int)(logical % (unsigned)a.ntm);
+    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
+    const int nf = a.base + (rt < a.rem ? 1 : 0);
+    const int m0 = f0 * 32, n0 = ct * G_COLS;
+    int nfa = nf - 2 * wr;                                           // this wave's row fragments: 0, 1 or 2
+    nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
+    const int M = a.M, K = a.K;
+
+    // --- the slab loads of this wave: load q = wave * NLOAD + j is a (image, 16-row block) of A or B -------------------------
+    const unsigned char* gbase[NLOAD];
+    unsigned voff[NLOAD], ldst[NLOAD];
+    const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);      // source chunk of LDS slot lane & 3 in row lrow
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+        const int q = wave * NLOAD + j;
+        if (q < NIMG * 8) {
+            const int img = q >> 3, blk = q & 7;
+            int row = m0 + blk * 16 + lrow;
+            row = row < M ? row : M - 1;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs + (long long)img * M * K);
+            voff[j] = (unsigned)row * (unsigned)K * 2u + (unsigned)lchunk * 16u;
+            ldst[j] = (unsigned)(img * G_AIMG + blk * 1024);
+        } else {
+            const int q2 = q - NIMG * 8;
+            const int img = q2 >> 4, blk = q2 & 15;
+            const int row = n0 + blk * 16 + lrow;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws + (long long)img * a.N * K);
+            voff[j] = (unsigned)row * (unsigned)K * 2u + (unsigned)lchunk * 16u;
+            ldst[j] = (unsigned)(NIMG * G_AIMG + img * G_BIMG + blk * 1024);
+        }
+    }
+    auto issue = [&](int s, int st) {
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j) glds16(gbase[j] + (long long)s * 64, voff[j], (unsigned)(st * STAGE) + ldst[j]);
+    };
+
+    // --- accumulators start from the bias: D rows = W rows (output columns), D columns = X rows ----------------------------------
+    f32x16 acc[2][2];
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + (wc * 2 + fb) * 32 + 8 * g + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][fb][4 * g + e] = acc[1][fb][4 * g + e] = bv[e];
+        }
+
+    // fragment read offsets: row (tile row l31) * 64 B + swizzled chunk of k-step j
+    const unsigned swz = (unsigned)((lane >> 2) & 3);
+    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
+    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
+
+    const int ns = K / 32;
+    issue(0, 0);
+    for (int s = 0; s < ns; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of slab s has landed ...
+        __syncthreads();                                     // ... everybody's has, and nobody reads the other stage any more
+        if (s + 1 < ns) issue(s + 1, (s + 1) & 1);
+        const unsigned char* A = lds + (s & 1) * STAGE + (wr * 2) * 32 * 64;
+        const unsigned char* B = lds + (s & 1) * STAGE + NIMG * G_AIMG + (wc * 2) * 32 * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned fo = j ? fo1 : fo0;
+            bf16x8 xf[2][NIMG], wf[2][NIMG];
+#pragma unroll
+            for (int img = 0; img < NIMG; ++img) {
+                wf[0][img] = *reinterpret_cast<const bf16x8*>(B + img * G_BIMG + fo);
+                wf[1][img] = *reinterpret_cast<const bf16x8*>(B + img * G_BIMG + 32 * 64 + fo);
+                xf[0][img] = *reinterpret_cast<const bf16x8*>(A + img * G_AIMG + fo);
+                xf[1][img] = *reinterpret_cast<const bf16x8*>(A + img * G_AIMG + 32 * 64 + fo);
+            }
+            if (nfa == 2) {
+#pragma unroll
+                for (int p = 0; p < PR::N; ++p)
+#pragma unroll
+                    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                        for (int fb = 0; fb < 2; ++fb)
+                            acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb], 0, 0, 0);
+            } else if (nfa == 1) {
+#pragma unroll
+                for (int p = 0; p < PR::N; ++p)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb)
+                        acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb], 0, 0, 0);
+            }
+        }
+    }
+
+    // --- epilogue: a lane holds 4 consecutive output columns of one row per 4 accumulator registers -> 16-byte stores --------------
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa) {
+        const int row = m0 + (wr * 2 + fa) * 32 + l31;
+        if (fa < nfa && row < M) {
+            float* y = a.Y + (long long)row * a.ldy + n0 + wc * 64 + 4 * lh;
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    *reinterpret_cast<f32x4*>(y + fb * 32 + 8 * g) = v;
+                }
+        }
+    }
+}
+
+// ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
+struct OutArgs {
+    const float* X;              // [M, ldx] fp32
+    const unsigned short* Wp;    // [8][K/16][NIMG][64][8] bf16 fragments
+    float* P;                    // [S, M, 256] partial slabs
+    int M, K;
+    long long ldx;
+    int nrt, S;                  // row tiles of 64 rows, K chunks
+};
+
+constexpr int O_IMG = 64 * 64;                  // bytes of one image of one half's stage (64 rows x 32 k)
+
+template <int NIMG>
+__global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int HSTAGE = NIMG * O_IMG;        // one half's stage
+    typedef Prods<NIMG> PR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wc = wave & 3;  // K half of the chunk, 64-column quarter
+    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
+    const int M = a.M;
+    const int m0 = rt * 64;
+    int nfa = (M - m0 + 31) / 32;               // row fragments of this tile: 1 or 2
+    nfa = nfa > 2 ? 2 : nfa;
+    // slabs (32 k) of this chunk, split between the two halves
+    const int nslab = a.K / 32;
+    const int c0 = (int)((long long)nslab * chunk / a.S), c1 = (int)((long long)nslab * (chunk + 1) / a.S);
+    const int n_all = c1 - c0, n0h = (n_all + 1) / 2;
+    const int sb = half == 0 ? c0 : c0 + n0h;            // first slab of this half
+    const int nh = half == 0 ? n0h : n_all - n0h;        // its slabs (the other half may have one more)
+    const int nit = n0h;
+
+    // --- X staging: thread t' of a half loads 8 floats of row t' >> 2, splits them, writes NIMG 16-byte chunks ------------------
+    const int th = tid & 255;
+    const int srow = th >> 2, skq = th & 3;
+    int grow = m0 + srow;
+    grow = grow < M ? grow : M - 1;
+    const float* xp = a.X + (long long)grow * a.ldx + skq * 8;
+    const unsigned wofs = (unsigned)(srow * 64 + ((skq ^ ((srow >> 2) & 3)) * 16));
+    unsigned char* hst = lds + half * (2 * HSTAGE);      // this half's two stages
+    const int last_slab = nh > 0 ? sb + nh - 1 : c1 - 1;
+    auto loadx = [&](int i, f32x4& v0, f32x4& v1) {      // slab i of this half (clamped: a dummy past the end)
+        int sl = sb + i;
+        sl = sl < last_slab ? sl : last_slab;
+        const float* p = xp + (long long)sl * 32;
+        v0 = *reinterpret_cast<const f32x4*>(p);
+        v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    };
+    auto stagex = [&](int st, const f32x4 v0, const f32x4 v1) {
+        u32x4 im[NIMG];
+        split8<NIMG>(v0, v1, im);
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) *reinterpret_cast<u32x4*>(hst + st * HSTAGE + img * O_IMG + wofs) = im[img];
+    };
+
+    // --- W fragments of this wave's two 32-column blocks, one k-step at a time ---------------------------------------------------
+    const int KS = a.K / 16;
+    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
+    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
+    const int last_ks = 2 * last_slab + 1;
+    auto loadw = [&](int kk, bf16x8 (&w)[2][NIMG]) {     // k-step kk of this half (clamped)
+        int ks = 2 * sb + kk;
+        ks = ks < last_ks ? ks : last_ks;
+        const long long o = (long long)ks * NIMG * 64 * 8;
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) {
+            w[0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
+            w[1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned swz = (unsigned)((lane >> 2) & 3);
+    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
+    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
+
+    auto kstep = [&](int st, int j, const bf16x8 (&w)[2][NIMG]) {
+        const unsigned char* A = hst + st * HSTAGE + (j ? fo1 : fo0);
+        bf16x8 xf[2][NIMG];
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) {
+            xf[0][img] = *reinterpret_cast<const bf16x8*>(A + img * O_IMG);
+            xf[1][img] = *reinterpret_cast<const bf16x8*>(A + img * O_IMG + 32 * 64);
+        }
+        if (nfa == 2) {
+#pragma unroll
+            for (int p = 0; p < PR::N; ++p)
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb)
+                        acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PR::N; ++p)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+                    acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb], 0, 0, 0);
+        }
+    };
+
+    // --- pipeline: X two slabs ahead in registers / one ahead in LDS, W one k-step ahead in registers ---------------------------
+    f32x4 x0, x1;
+    bf16x8 wA[2][NIMG], wB[2][NIMG];
+    loadx(0, x0, x1);
+    loadw(0, wA);
+    stagex(0, x0, x1);
+    loadx(1, x0, x1);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();                       // slab `it` is staged; nobody reads the other stage any more
+        if (it + 1 < nit) stagex((it + 1) & 1, x0, x1);
+        loadx(it + 2, x0, x1);
+        loadw(2 * it + 1, wB);
+        if (it < nh) kstep(it & 1, 0, wA);
+        loadw(2 * it + 2, wA);
+        if (it < nh) kstep(it & 1, 1, wB);
+    }
+
+    // --- fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab ----------------------------------------
+    __syncthreads();
+    f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * 16) * 64 + lane;       // [wc][fa][fb][g][lane] float4
+    if (half == 1) {
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+    }
+    __syncthreads();
+    if (half == 1) return;
+    float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
+#pragma unroll
+    for (int fa = 0; fa < 2; ++fa) {
+        const int row = m0 + fa * 32 + l31;
+        if (fa < nfa && row < M) {
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
+                    const f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
+                    *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
+                }
+        }
+    }
+}
+
+template <typename Kern>
+int reserve_lds(Kern k, int bytes, const char* what) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        sbev::set_error("%s: cannot reserve %d B of LDS: %s", what, bytes, hipGetErrorString(e));
+        return SBEV_ELAUNCH;
+    }
+    return SBEV_OK;
+}
+
+// K chunks of the out-projection: fill the 256 CUs with (64-row tile x chunk) workgroups in whole rounds, at least 8 slabs each
+int out_chunks(long long M, int K) {
+    const long long nrt = (M + 63) / 64;
+    const int max_s = K / 32 / 8 < 1 ? 1 : K / 32 / 8;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 64 && s <= max_s; ++s) {
+        const long long wgs = nrt * s;
+        const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int64_t sbev_bf16s_image_elems(int64_t rows, int K, int nimg) { return rows * K * nimg; }
+
+extern "C" int sbev_split_bf16s_rows(const float* X, int64_t ldx, uint16_t* out, int64_t rows, int K, int nimg, sbev_stream_t stream) {
+    SBEV_REQUIRE(rows >= 0 && K >= 8 && K % 8 == 0 && (nimg == 2 || nimg == 3), "sbev_split_bf16s_rows: K=%d (multiple of 8), nimg=%d (2 or 3)", K, nimg);
+    if (rows == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && out && ldx >= K && ldx % 4 == 0 && (((uintptr_t)X | (uintptr_t)out) & 15) == 0, "sbev_split_bf16s_rows: null / unaligned pointer or bad ldx");
+    const long long n = rows * (K / 8);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (nimg == 3) hipLaunchKernelGGL(split_rows_kernel<3>, grid, dim3(256), 0, s, X, (long long)ldx, out, (long long)rows, K);
+    else hipLaunchKernelGGL(split_rows_kernel<2>, grid, dim3(256), 0, s, X, (long long)ldx, out, (long long)rows, K);
+    return sbev::check_launch("sbev_split_bf16s_rows");
+}
+
+extern "C" int sbev_pack_bf16s_frags(const float* W, int64_t ldw, uint16_t* out, int N, int K, int nimg, sbev_stream_t stream) {
+    SBEV_REQUIRE(N >= 32 && N % 32 == 0 && K >= 16 && K % 16 == 0 && (nimg == 2 || nimg == 3), "sbev_pack_bf16s_frags: N=%d (multiple of 32), K=%d (multiple of 16), nimg=%d", N, K, nimg);
+    SBEV_REQUIRE(W && out && ldw >= K && ldw % 4 == 0 && (((uintptr_t)W | (uintptr_t)out) & 15) == 0, "sbev_pack_bf16s_frags: null / unaligned pointer or bad ldw");
+    const long long n = (long long)(N / 32) * (K / 16) * 64;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (nimg == 3) hipLaunchKernelGGL(pack_frags_kernel<3>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K);
+    else hipLaunchKernelGGL(pack_frags_kernel<2>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K);
+    return sbev::check_launch("sbev_pack_bf16s_frags");
+}
+
+extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {
+    return M >= 1 && M <= 0x7fffffffLL / 1024 && N >= 256 && N % 256 == 0 && K >= 32 && K % 32 == 0 && K <= 4096 &&
+           (long long)N * K * 2 < 0x7fffffffLL && M * K * 2 < 0x7fffffffLL;
+}
+
+extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K,
+                                     int64_t ldy, int relu, int nimg, sbev_stream_t stream) {
+    SBEV_REQUIRE(nimg == 2 || nimg == 3, "sbev_linear_bf16s_gen: nimg=%d (2 = bf16x3, 3 = bf16x6)", nimg);
+    SBEV_REQUIRE(M >= 0 && sbev_linear_bf16s_gen_ok(M > 0 ? M : 1, N, K), "sbev_linear_bf16s_gen: needs N %% 256 == 0, K %% 32 == 0, K <= 4096 (M=%lld N=%d K=%d)", (long long)M, N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(Xs && Ws && Y && ldy >= N && ldy % 4 == 0, "sbev_linear_bf16s_gen: bad pointers / leading dimension");
+    SBEV_REQUIRE((((uintptr_t)Xs | (uintptr_t)Ws | (uintptr_t)Y) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0), "sbev_linear_bf16s_gen: 16-byte alignment");
+    const int nfrag = (int)((M + 31) / 32);
+    const int ntm = (nfrag + 3) / 4;
+    GenArgs a{Xs, Ws, bias, Y, (int)M, N, K, (long long)ldy, relu, ntm, nfrag / ntm, nfrag % ntm};
+    const long long tiles = (long long)ntm * (N / G_COLS);
+    SBEV_REQUIRE(tiles <= 0x7fffffffLL, "sbev_linear_bf16s_gen: too many tiles");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    int st;
+    if (nimg == 3) {
+        constexpr int LDS = 2 * 3 * (G_AIMG + G_BIMG);
+        st = reserve_lds(gemm_bf16s_gen_kernel<3>, LDS, "sbev_linear_bf16s_gen");
+        if (st != SBEV_OK) return st;
+        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+        hipLaunchKernelGGL(gemm_bf16s_gen_kernel<3>, dim3((unsigned)tiles), dim3(512), LDS, s, a);
+        if (prof) sbev::profile_end(s, e0, e1, 1);
+    } else {
+        constexpr int LDS = 2 * 2 * (G_AIMG + G_BIMG);
+        st = reserve_lds(gemm_bf16s_gen_kernel<2>, LDS, "sbev_linear_bf16s_gen");
+        if (st != SBEV_OK) return st;
+        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+        hipLaunchKernelGGL(gemm_bf16s_gen_kernel<2>, dim3((unsigned)tiles), dim3(512), LDS, s, a);
+        if (prof) sbev::profile_end(s, e0, e1, 1);
+    }
+    return sbev::check_launch("sbev_linear_bf16s_gen");
+}
+
+extern "C" int sbev_linear_bf16s_out_ok(int64_t M, int N, int K) {
+    return M >= 1 && M <= 0x7fffffffLL / 512 && N == 256 && K >= 256 && K % 32 == 0;
+}
+
+extern "C" int sbev_linear_bf16s_out_plan(int64_t M, int N, int K) {
+    if (!sbev_linear_bf16s_out_ok(M, N, K)) return 0;
+    return out_chunks(M, K);
+}
+
+namespace sbev {
+// the GEMM half: *used partial slabs [used, M, 256] (to be summed by sbev_splitk_reduce_f32 or the row-chain tail)
+int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
+                              hipStream_t s) {
+    const int S = out_chunks(M, K);
+    *used = S;
+    OutArgs a{X, Wp, slabs, (int)M, K, (long long)ldx, (int)((M + 63) / 64), S};
+    const long long wgs = (long long)a.nrt * S;
+    SBEV_REQUIRE(wgs <= 0x7fffffffLL, "sbev_linear_splitk_bf16s: too many workgroups");
+    hipEvent_t e0, e1;
+    int st;
+    if (nimg == 3) {
+        constexpr int LDS = 65536;      // max(2 halves x 2 stages x 3 images x 4 KiB = 48 KiB, fold buffer 64 KiB)
+        st = reserve_lds(gemm_bf16s_out_kernel<3>, LDS, "sbev_linear_splitk_bf16s");
+        if (st != SBEV_OK) return st;
+        const bool prof = profile_begin(s, &e0, &e1, 2);
+        hipLaunchKernelGGL(gemm_bf16s_out_kernel<3>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
+        if (prof) profile_end(s, e0, e1, 2);
+    } else {
+        constexpr int LDS = 65536;
+        st = reserve_lds(gemm_bf16s_out_kernel<2>, LDS, "sbev_linear_splitk_bf16s");
+        if (st != SBEV_OK) return st;
+        const bool prof = profile_begin(s, &e0, &e1, 2);
+        hipLaunchKernelGGL(gemm_bf16s_out_kernel<2>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
+        if (prof) profile_end(s, e0, e1, 2);
+    }
+    return check_launch("sbev_linear_splitk_bf16s (gemm)");
+}
+}  // namespace sbev
+
+extern "C" int sbev_linear_splitk_bf16s(const float* X, const uint16_t* Wp, const float* bias, const float* residual,
+                                        const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                        int64_t M, int N, int K, int64_t ldx, int relu, int nimg, float* workspace,
+                                        sbev_stream_t stream) {
+    SBEV_REQUIRE(nimg == 2 || nimg == 3, "sbev_linear_splitk_bf16s: nimg=%d (2 = bf16x3, 3 = bf16x6)", nimg);
+    SBEV_REQUIRE(M >= 0 && sbev_linear_bf16s_out_ok(M > 0 ? M : 1, N, K), "sbev_linear_splitk_bf16s: needs N == 256, K %% 32 == 0, K >= 256 (N=%d K=%d)", N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && Wp && Y && workspace && ldx % 4 == 0 && ldx >= K, "sbev_linear_splitk_bf16s: bad pointers");
+    SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)workspace) & 15) == 0, "sbev_linear_splitk_bf16s: 16-byte alignment");
+    int used = 0;
+    const int st = sbev::launch_splitk_slabs_bf16s(X, Wp, M, K, ldx, nimg, workspace, &used, reinterpret_cast<hipStream_t>(stream));
+    if (st != SBEV_OK) return st;
+    return sbev_splitk_reduce_f32(workspace, used, bias, residual, ln_w, ln_b, ln_eps, Y, M, N, relu, stream);
+}

@@ -19,6 +19,7 @@ NATIVE = {
     'linear_ln_relu': 'hip: gemm + LayerNorm/ReLU reducer; Linear(3->D): linear3_ln_relu_kernel',
     'self_attention': 'hip: gemm (q|k|v|tau) + sasa_kernel (flash-style, v_mfma_f32_16x16x4_f32) + gemm (out-proj, fused residual)',
     'adaptive_mixing': 'hip: gemm (generator) + adaptive_mixing_kernel (v_mfma_f32_16x16x4_f32) + split-K gemm (out-proj, fused residual + LayerNorm)',
+    'linear_bf16s': 'hip: gemm_bf16s_gen_kernel / gemm_bf16s_out_kernel (v_mfma_f32_32x32x16_bf16 on hi + mid + lo bf16 images, fp32 accumulate)',
     'refine_bbox': 'hip: refine_kernel',
     'to_channels_last': 'hip: transpose_tiles_kernel',
 }
@@ -91,6 +92,69 @@ def linear(x, w, b, relu=False, residual=None, ln=None, ln_relu=False):
     if ln is not None:
         y = layer_norm(y, ln[0], ln[1], relu=ln_relu)
     return y
+
+
+# ---- split-bf16 Linears (csrc/gemm_bf16s.hip): nimg = 3 "bf16x6" (fp32-class), nimg = 2 "bf16x3" ------------------------------
+def split_bf16s_rows(x, nimg=3):
+    """fp32 [rows, K] -> int16 [nimg, rows, K]: the row-major bf16 planes hi (, mid), lo with x == sum of the planes exactly
+    (nimg = 3) / to 2^-17 relative (nimg = 2).  Operand format of linear_bf16s_gen."""
+    _dev(x)
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    rows, K = x2.shape
+    out = torch.empty(nimg, rows, K, device=x.device, dtype=torch.int16)
+    st = _lib.load().sbev_split_bf16s_rows(_p(x2), K, _p(out), rows, K, nimg, _stream())
+    _lib.check(st, 'sbev_split_bf16s_rows')
+    return out
+
+
+def pack_bf16s_frags(w, nimg=3):
+    """fp32 [N, K] -> int16 [N/32, K/16, nimg, 64, 8]: W's bf16 images in v_mfma_f32_32x32x16_bf16 operand order (the
+    out-projection weight format of linear_splitk_bf16s)."""
+    _dev(w)
+    w = w.contiguous()
+    N, K = w.shape
+    out = torch.empty(N // 32, K // 16, nimg, 64, 8, device=w.device, dtype=torch.int16)
+    st = _lib.load().sbev_pack_bf16s_frags(_p(w), K, _p(out), N, K, nimg, _stream())
+    _lib.check(st, 'sbev_pack_bf16s_frags')
+    return out
+
+
+def linear_bf16s_gen(x, w_planes, b, nimg=3, relu=False):
+    """y = act(x @ W.T + b) with W given as split_bf16s_rows planes [nimg, N, K]; x fp32 [.., K] is split here (one small
+    launch).  N % 256 == 0, K % 32 == 0 (the parameter generator's shape)."""
+    _dev(x, w_planes)
+    K, N = x.shape[-1], w_planes.shape[1]
+    xs = split_bf16s_rows(x, nimg)
+    M = xs.shape[1]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    st = _lib.load().sbev_linear_bf16s_gen(_p(xs), _p(w_planes), _p(b), _p(y), M, N, K, N, int(relu), nimg, _stream())
+    _lib.check(st, 'sbev_linear_bf16s_gen')
+    return y.reshape(*x.shape[:-1], N)
+
+
+def linear_splitk_bf16s(x, w_frags, b, nimg=3, residual=None, ln=None, relu=False):
+    """y = LayerNorm?(act(x @ W.T + b) + residual) with W given as pack_bf16s_frags [N/32, K/16, nimg, 64, 8], N == 256
+    (the out-projection's shape); x stays fp32 and is split inside the kernel."""
+    _dev(x, w_frags)
+    K = x.shape[-1]
+    N = w_frags.shape[0] * 32
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    lib = _lib.load()
+    plan = lib.sbev_linear_bf16s_out_plan(M, N, K)
+    if plan <= 0:
+        raise RuntimeError('sbev_linear_splitk_bf16s does not cover M=%d N=%d K=%d' % (M, N, K))
+    ws = _ws(plan * M * N * 4, x.device)
+    res2 = residual.reshape(-1, N).contiguous() if residual is not None else None
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    st = lib.sbev_linear_splitk_bf16s(_p(x2), _p(w_frags), _p(b), _p(res2), _p(ln[0] if ln else None), _p(ln[1] if ln else None),
+                                      1e-5, _p(y), M, N, K, K, int(relu), nimg, _p(ws), _stream())
+    _lib.check(st, 'sbev_linear_splitk_bf16s')
+    return y.reshape(*x.shape[:-1], N)
 
 
 class _LinearProblem(ctypes.Structure):

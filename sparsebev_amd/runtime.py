@@ -7,7 +7,8 @@ import torch
 from . import _lib
 
 MAX_LEVELS = 5
-GEMM_F32, GEMM_BF16X3 = 0, 1      # sbev_gemm_mode
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_BF16X3S = 0, 1, 2, 3      # sbev_gemm_mode
+GEMM_MODES = {'f32': GEMM_F32, 'bf16x3': GEMM_BF16X3, 'bf16x6': GEMM_BF16X6, 'bf16x3s': GEMM_BF16X3S}
 _f = ctypes.c_void_p
 
 
@@ -25,7 +26,7 @@ _WEIGHT_FIELDS = ['pe0_w', 'pe0_b', 'pe1_g', 'pe1_b', 'pe3_w', 'pe3_b', 'pe4_g',
                   'pg_w', 'pg_b', 'op_w', 'op_b', 'pg_w2', 'op_w2', 'ffn0_w', 'ffn0_b', 'ffn1_w', 'ffn1_b',
                   'norm1_g', 'norm1_b', 'norm2_g', 'norm2_b', 'norm3_g', 'norm3_b',
                   'cls0_w', 'cls0_b', 'cls1_g', 'cls1_b', 'cls3_w', 'cls3_b', 'cls4_g', 'cls4_b', 'cls6_w', 'cls6_b',
-                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b', 'chain_pack']
+                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b', 'chain_pack', 'pg_ws', 'op_wp']
 
 
 class DecoderWeights(ctypes.Structure):
@@ -99,6 +100,11 @@ class DecoderRuntime:
                                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                            'sbev_split_bf16x3_weights')
                 keep[name + '2'] = img
+        if self.gemm_mode in (GEMM_BF16X6, GEMM_BF16X3S):      # split-bf16 images for csrc/gemm_bf16s.hip (3 or 2 images)
+            from . import dense
+            nimg = 3 if self.gemm_mode == GEMM_BF16X6 else 2
+            keep['pg_ws'] = dense.split_bf16s_rows(keep['pg_w'], nimg)
+            keep['op_wp'] = dense.pack_bf16s_frags(keep['op_w'], nimg)
         w = DecoderWeights()
         for k in _WEIGHT_FIELDS:
             setattr(w, k, keep[k].data_ptr() if k in keep else None)

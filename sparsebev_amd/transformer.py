@@ -406,7 +406,8 @@ class SparseBEVTransformerDecoder(_Base):
         self.overlap = False        # opt-in two-stream fork/join in the C++ runtime (1: generator GEMM || sampling chain, 2: only the
                                     # classification branch aside): measured -3 % samples/s at c2 -- the big kernels fill every CU, and
                                     # the forked path cannot use the grouped branch launches
-        self.gemm_mode = 0          # 0 = exact fp32 MFMA (default); 1 = opt-in 3 x bf16 split for the two big mixing GEMMs
+        self.gemm_mode = 0          # the two big mixing GEMMs: 0 / 'f32' = exact f32-input MFMA (default); 2 / 'bf16x6' = fp32-class split on
+                                    # the bf16 matrix core (hi + mid + lo images, 6 products); 1 / 'bf16x3', 3 / 'bf16x3s' = 3 products
         self.value_forcing = None   # tests only: (bbox per layer, feat per layer) recorded from the reference; the differentiable path then
                                     # evaluates layer i+1 AT those values (x + (x_ref - x).detach()) with the autograd graph intact, so that
                                     # multi-layer gradients can be compared at 1e-4 although fp32 rounding noise grows ~5x per layer
@@ -429,9 +430,10 @@ class SparseBEVTransformerDecoder(_Base):
                                         or any(torch.is_tensor(f) and f.requires_grad for f in (mlvl_feats if isinstance(mlvl_feats, (list, tuple)) else ()))):
             return self.forward_differentiable(query_bbox, query_feat, mlvl_feats, feats, attn_mask, ctx)
         if not (layerwise or DUMP.enabled):
-            if self._runtime is None or self._runtime.gemm_mode != self.gemm_mode or self._runtime.overlap != self.overlap:
-                from .runtime import DecoderRuntime
-                self._runtime = DecoderRuntime(self, self.gemm_mode, self.overlap)
+            from .runtime import DecoderRuntime, GEMM_MODES
+            mode = GEMM_MODES.get(self.gemm_mode, self.gemm_mode)
+            if self._runtime is None or self._runtime.gemm_mode != mode or self._runtime.overlap != self.overlap:
+                self._runtime = DecoderRuntime(self, mode, self.overlap)
             return self._runtime.forward(query_bbox, query_feat, feats, ctx, attn_mask)
         cls_scores, bbox_preds = [], []
         with torch.no_grad():

@@ -1,0 +1,173 @@
+"""Split-bf16 Linears (csrc/gemm_bf16s.hip): bf16x6 = hi + mid + lo images, six products, fp32 accumulate on the bf16
+matrix core -- must be NOT NARROWER than the exact f32-MFMA kernels it may replace: both are compared with
+an fp64 evaluation of the same Linear on the same inputs, at the two shapes of AdaptiveMixing
+(models/sparsebev_transformer.py:358 parameter_generator, :378 out_proj) and at ragged / odd shapes."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason='needs a GPU')]
+
+from sparsebev_amd import _lib, dense  # noqa: E402
+
+DEV = 'cuda'
+
+
+def _planes_to_float(planes):
+    """int16 bf16 bit patterns [nimg, ...] -> fp32 values per image."""
+    return (planes.to(torch.int32) << 16).view(torch.float32)
+
+
+def _rand(shape, seed, scale=1.0, wide=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    if wide:       # 12 binades of magnitude, both signs: exercises every exponent alignment of the split
+        x = x * torch.exp2(torch.randint(-6, 7, shape, generator=g).float())
+    return x.to(DEV)
+
+
+@pytest.mark.parametrize('nimg', [2, 3])
+def test_split_images_are_an_exact_decomposition(nimg):
+    """hi (+ mid) + lo: each image is the RNE bf16 of the remainder; three images reproduce every fp32 value BIT FOR BIT,
+    two to 2^-17 relative.  (What 'fp32 operands on the bf16 matrix core' rests on.)"""
+    x = _rand((257, 256), 1, wide=True)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.0e-30, 65504.0], device=DEV)
+    planes = dense.split_bf16s_rows(x, nimg)
+    assert planes.shape == (nimg, 257, 256) and planes.dtype == torch.int16
+    img = _planes_to_float(planes)
+    # image 0 is torch's own RNE bf16 rounding
+    assert torch.equal(img[0], x.to(torch.bfloat16).float())
+    r = x - img[0]
+    assert torch.equal(img[1], r.to(torch.bfloat16).float())
+    if nimg == 3:
+        r2 = r - img[1]
+        assert torch.equal(img[2], r2.to(torch.bfloat16).float())
+        assert torch.equal((img[0].double() + img[1].double() + img[2].double()).float(), x)
+        assert torch.equal(img[0].double() + img[1].double() + img[2].double(), x.double())
+    else:
+        rel = ((img[0].double() + img[1].double()) - x.double()).abs() / x.double().abs().clamp_min(1e-300)
+        assert rel.max().item() <= 2.0 ** -17
+
+
+@pytest.mark.parametrize('nimg', [2, 3])
+def test_fragment_pack_is_the_mfma_operand_order(nimg):
+    """[N/32][K/16][img][lane][8]: lane l holds row 32 nf + (l & 31), k = 16 ks + 8 (l >> 5) + 0..7 of image img."""
+    N, K = 64, 96
+    w = _rand((N, K), 2, wide=True)
+    frags = dense.pack_bf16s_frags(w, nimg)
+    assert frags.shape == (N // 32, K // 16, nimg, 64, 8)
+    planes = dense.split_bf16s_rows(w, nimg)                       # [nimg, N, K]
+    lane = torch.arange(64, device=DEV)
+    for nf in range(N // 32):
+        for ks in range(K // 16):
+            rows = nf * 32 + (lane & 31)
+            k0 = ks * 16 + (lane >> 5) * 8
+            for img in range(nimg):
+                want = torch.stack([planes[img, rows, k0 + j] for j in range(8)], dim=1)
+                assert torch.equal(frags[nf, ks, img], want)
+
+
+def _errs(y, ref):
+    d = (y.double() - ref).abs()
+    return d.max().item(), d.pow(2).mean().sqrt().item()
+
+
+def _gen_all(x, w, b, relu=False):
+    """(bf16x6, bf16x3, exact f32) generator-shaped Linear on the same inputs."""
+    out = {}
+    for nimg in (3, 2):
+        out[nimg] = dense.linear_bf16s_gen(x, dense.split_bf16s_rows(w, nimg), b, nimg=nimg, relu=relu)
+    out['f32'] = dense.linear(x, w, b, relu=relu)
+    return out
+
+
+def test_generator_bf16x6_not_narrower_than_f32_mfma():
+    """(900, 32768, 256): max and rms error against fp64 of bf16x6 <= those of gemm_nt_f32_strip_kernel (the exact path)."""
+    M, N, K = 900, 32768, 256
+    x, w, b = _rand((M, K), 3), _rand((N, K), 4, K ** -0.5), _rand((N,), 5)
+    ys = _gen_all(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    e6, r6 = _errs(ys[3], ref)
+    e3, r3 = _errs(ys[2], ref)
+    ef, rf = _errs(ys['f32'], ref)
+    print('generator  max/rms err vs fp64: bf16x6 %.3e %.3e   f32-mfma %.3e %.3e   bf16x3 %.3e %.3e' % (e6, r6, ef, rf, e3, r3))
+    assert r6 <= rf and e6 <= ef, ('bf16x6 is narrower than the f32 MFMA kernel', e6, r6, ef, rf)
+    assert r3 < 6e-6 and e3 < 6e-5            # the 2^-16 class of the three-product mode
+    # and it is the same function: agreement with the exact kernel at fp32 round-off
+    assert (ys[3] - ys['f32']).abs().max().item() < 4e-6
+
+
+def test_out_projection_bf16x6_not_narrower_than_f32_mfma():
+    """(900, 256, 32768) split-K with the fused bias + residual + LayerNorm reducer."""
+    M, N, K = 900, 256, 32768
+    x = _rand((M, K), 6).clamp_min(0)          # post-ReLU activations, like the mixing output
+    w, b = _rand((N, K), 7, K ** -0.5), _rand((N,), 8)
+    res = _rand((M, N), 9)
+    ref_lin = x.double() @ w.double().t() + b.double()
+    y6 = dense.linear_splitk_bf16s(x, dense.pack_bf16s_frags(w, 3), b, nimg=3)
+    y3 = dense.linear_splitk_bf16s(x, dense.pack_bf16s_frags(w, 2), b, nimg=2)
+    yf = dense.linear(x, w, b)
+    e6, r6 = _errs(y6, ref_lin)
+    e3, r3 = _errs(y3, ref_lin)
+    ef, rf = _errs(yf, ref_lin)
+    print('out-proj   max/rms err vs fp64: bf16x6 %.3e %.3e   f32-mfma %.3e %.3e   bf16x3 %.3e %.3e' % (e6, r6, ef, rf, e3, r3))
+    assert r6 <= rf and e6 <= ef, ('bf16x6 is narrower than the f32 MFMA kernel', e6, r6, ef, rf)
+    assert r3 < 6e-6 and e3 < 6e-5
+    # fused epilogue: + residual, LayerNorm
+    gam, bet = _rand((N,), 10), _rand((N,), 11)
+    yl = dense.linear_splitk_bf16s(x, dense.pack_bf16s_frags(w, 3), b, nimg=3, residual=res, ln=(gam, bet))
+    ref = torch.nn.functional.layer_norm(ref_lin + res.double(), (N,), gam.double(), bet.double(), 1e-5)
+    assert (yl.double() - ref).abs().max().item() < 2e-5
+    # bit-reproducible (fixed summation order, no atomics)
+    assert torch.equal(y6, dense.linear_splitk_bf16s(x, dense.pack_bf16s_frags(w, 3), b, nimg=3))
+
+
+@pytest.mark.parametrize('nimg', [3, 2])
+@pytest.mark.parametrize('M', [1, 31, 32, 33, 97, 129, 900, 1600, 3600])
+@pytest.mark.parametrize('N,K,relu,use_bias', [(512, 256, False, True), (256, 32, True, True), (1024, 96, False, False)])
+def test_generator_kernel_ragged_rows(M, N, K, relu, use_bias, nimg):
+    """every row-fragment remainder (M % 32), 1..4 fragments per row tile and both waves' shares of a tile, short and odd K."""
+    x, w = _rand((M, K), M + N), _rand((N, K), M + K, K ** -0.5)
+    b = _rand((N,), 12) if use_bias else None
+    y = torch.full((M, N), float('nan'), device=DEV)
+    xs, ws = dense.split_bf16s_rows(x, nimg), dense.split_bf16s_rows(w, nimg)
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, int(relu), nimg, st) == 0, lib.sbev_last_error()
+    ref = x.double() @ w.double().t() + (b.double() if use_bias else 0.0)
+    if relu:
+        ref = ref.clamp_min(0)
+    tol = 2e-6 if nimg == 3 else 6e-5
+    assert (y.double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize('nimg', [3, 2])
+@pytest.mark.parametrize('M,K', [(1, 256), (33, 512), (64, 1024), (65, 2048), (100, 32768), (3200, 4096), (7, 32768 + 32)])
+def test_out_projection_kernel_ragged(M, K, nimg):
+    """1 or 2 row fragments per tile, odd slab counts per K chunk (the two wave quartets of a workgroup get unequal halves)."""
+    N = 256
+    x, w, b = _rand((M, K), M + K), _rand((N, K), K, K ** -0.5), _rand((N,), 13)
+    y = dense.linear_splitk_bf16s(x, dense.pack_bf16s_frags(w, nimg), b, nimg=nimg)
+    ref = x.double() @ w.double().t() + b.double()
+    tol = 3e-6 if nimg == 3 else 6e-5
+    assert (y.double() - ref).abs().max().item() < tol
+
+
+def test_shape_guards():
+    lib = _lib.load()
+    assert lib.sbev_linear_bf16s_gen_ok(900, 32768, 256) == 1 and lib.sbev_linear_bf16s_gen_ok(900, 32768 + 128, 256) == 0
+    assert lib.sbev_linear_bf16s_gen_ok(900, 32768, 250) == 0
+    assert lib.sbev_linear_bf16s_out_ok(900, 256, 32768) == 1 and lib.sbev_linear_bf16s_out_ok(900, 512, 32768) == 0
+    plan = lib.sbev_linear_bf16s_out_plan(900, 256, 32768)
+    assert 1 <= plan <= 64 and 240 <= plan * 15 <= 256        # 15 row tiles x plan chunks: one near-full round of the 256 CUs
+    assert lib.sbev_linear_bf16s_out_plan(900, 512, 32768) == 0
+    x = torch.zeros(4, 256, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.sbev_linear_bf16s_gen(p(x), p(x), None, p(x), 4, 100, 256, 100, 0, 3, st) == -1
+    assert lib.sbev_linear_bf16s_gen(p(x), p(x), None, p(x), 4, 256, 256, 256, 0, 4, st) == -1
+    assert b'nimg' in lib.sbev_last_error()

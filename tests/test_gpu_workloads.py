@@ -18,6 +18,7 @@ from sparsebev_amd.transformer import SparseBEVTransformer
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 DEV = 'cuda:0'
+GEMM_MODES_UNDER_TEST = ('bf16x6', 'bf16x3s', 'bf16x3')      # besides the exact f32 default
 PREFIX = 'decoder.decoder_layer.'
 
 # name: (pyramid, Q, T, per-GPU batch, feature dtype) -- bench.py's CONFIGS, BASELINE.json configs[1..4]
@@ -77,6 +78,17 @@ def test_one_layer_at_full_workload_shape_vs_oracle(name):
     assert (cls.cpu() - ref_cls).abs().max() < TOL                   # (c2 / c5: through the row-chain kernels)
     assert (box.cpu() - ref_box).abs().max() < TOL
     assert (lw_cls.cpu() - ref_cls).abs().max() < TOL and (lw_box.cpu() - ref_box).abs().max() < TOL
+    # the same assertion in every GEMM mode bench.py prints: split-bf16 parameter generator + out-projection
+    for mode in GEMM_MODES_UNDER_TEST:
+        model.decoder.gemm_mode = mode
+        try:
+            m_cls, m_box = model(bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas))
+            o_cls, o_box = runtime_op_by_op(model, bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas))
+        finally:
+            model.decoder.gemm_mode = 0
+        for got, want in ((m_cls, ref_cls), (m_box, ref_box), (o_cls, ref_cls), (o_box, ref_box)):
+            err = (got.cpu() - want).abs().max().item()
+            assert err < TOL, (name, mode, err)
 
 
 def test_c2_six_layers_teacher_forced_vs_oracle():
@@ -101,6 +113,15 @@ def test_c2_six_layers_teacher_forced_vs_oracle():
                 err = (got.cpu() - want).abs().max().item()
                 worst = max(worst, err)
                 assert err < TOL, (i, err)
+            for mode in GEMM_MODES_UNDER_TEST:                 # every layer, every GEMM mode, same 1e-4
+                model.decoder.gemm_mode = mode
+                try:
+                    m_cls, m_box = model(qb.to(DEV), qf.to(DEV), pyr, None, copy.deepcopy(metas))
+                finally:
+                    model.decoder.gemm_mode = 0
+                for got, want in ((m_cls[0], ref_cls[i]), (m_box[0], ref_box[i])):
+                    err = (got.cpu() - want).abs().max().item()
+                    assert err < TOL, (i, mode, err)
     # the free-running 6-layer forward stays finite and its first layer is the teacher-forced one
     model.decoder.num_layers = 6
     cls6, box6 = model(bbox.to(DEV), feat.to(DEV), pyr, None, copy.deepcopy(metas))

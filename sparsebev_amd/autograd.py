@@ -303,16 +303,45 @@ class AdaptiveMixing(torch.autograd.Function):
         return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None
 
 
+class FeatureTap(torch.autograd.Function):
+    """Where the feature-map gradient of a decoder call is handed to autograd -- ONCE.  The sampler backward of every layer
+    accumulates (atomics) into one channels-last buffer per level owned by the pyramid; six per-layer 735 MB gradient tensors
+    and their summation never exist.  This node turns the caller's feature tensors into a 1-element token that every
+    ``Sampling`` node of the call takes as an input: autograd's own dependency count then runs this node's backward after
+    exactly those Sampling backwards that the current backward pass reaches -- a loss on some layers only, a second pass
+    under ``retain_graph``, or a pass that reaches none of them all work, with no forward-time counter to go stale
+    (ADVICE r2, medium)."""
+
+    @staticmethod
+    def forward(ctx, pyramid, *orig_feats):
+        ctx.pyramid, ctx.n_feats = pyramid, len(orig_feats)
+        return orig_feats[0].new_zeros(1, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        pyr = ctx.pyramid
+        if getattr(pyr, '_grads', None) is None:           # no Sampling backward accumulated anything in this pass
+            return (None,) + (None,) * ctx.n_feats
+        return (None, *pyr.take_feature_grads())
+
+
+def feature_token(pyramid, orig_feats):
+    """The token Sampling nodes take when the caller's feature maps need a gradient (else None)."""
+    if not any(torch.is_tensor(f) and f.requires_grad for f in orig_feats):
+        return None
+    return FeatureTap.apply(pyramid, *orig_feats)
+
+
 class Sampling(torch.autograd.Function):
     """SparseBEVSampling.inner_forward after its two Linears (models/sparsebev_transformer.py:270-311): sample points,
     velocity warp, level softmax, projection + view selection (sampling_4d front half), multi-scale gather.  Saves only
     (query_bbox, packed offsets | logits); points, locations and weights are recomputed in backward.
 
-    Feature gradients are accumulated by atomics into ONE buffer per level shared by all layers of a decoder call
-    (``pyramid.grad_levels``) and handed to autograd by the last backward to run."""
+    Feature gradients are accumulated by atomics into ONE buffer per level shared by all layers of a decoder call and handed
+    to autograd by the call's ``FeatureTap`` node (``feat_token``; None when the features need no gradient)."""
 
     @staticmethod
-    def forward(ctx, query_bbox, both, pyramid, dctx, cfg, *orig_feats):
+    def forward(ctx, query_bbox, both, pyramid, dctx, cfg, feat_token=None):
         T, G, P, L, pc_range = cfg
         n_off = G * P * 3
         bbox = _c(query_bbox)
@@ -323,10 +352,7 @@ class Sampling(torch.autograd.Function):
         out = pyramid.sample(loc, w_bp, T, G)
         ctx.save_for_backward(bbox, both)
         ctx.pyramid, ctx.dctx, ctx.cfg = pyramid, dctx, cfg
-        ctx.n_feats = len(orig_feats)
-        ctx.feat_grad = any(f.requires_grad for f in orig_feats)
-        if ctx.feat_grad:
-            pyramid.pending_backward = getattr(pyramid, 'pending_backward', 0) + 1
+        ctx.feat_grad = feat_token is not None
         return out
 
     @staticmethod
@@ -352,12 +378,10 @@ class Sampling(torch.autograd.Function):
         st = lib.sbev_sampling_front_bwd(_p(bbox), _p(both), ld, ctypes.c_void_p(both.data_ptr() + 4 * n_off), ld, pc, B, Q, T, G, P, L,
                                          _p(gpts), _p(gw), _p(gboth), ctypes.c_void_p(gboth.data_ptr() + 4 * n_off), ld, _p(gbbox), _stream())
         _lib.check(st, 'sbev_sampling_front_bwd')
-        gfeats = [None] * ctx.n_feats
-        if ctx.feat_grad:
-            pyr.pending_backward -= 1
-            if pyr.pending_backward == 0:
-                gfeats = pyr.take_feature_grads()
-        return (gbbox, gboth, None, None, None, *gfeats)
+        # the feature gradient went into the shared buffers; the token's own gradient is a formal zero that orders FeatureTap
+        # behind this node
+        gtoken = torch.zeros(1, device=bbox.device, dtype=torch.float32) if ctx.feat_grad else None
+        return gbbox, gboth, None, None, None, gtoken
 
 
 class RefineBbox(torch.autograd.Function):

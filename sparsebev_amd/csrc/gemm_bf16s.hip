@@ -27,6 +27,18 @@
 #include <cstdlib>
 #include "sbev_common.hpp"
 
+// ---- ablation switches (tools/build_variant.sh; never defined in the product build) -------------------------------------------
+#ifdef SBEV_EXP_NOSTORE
+#define SBEV_EXP_STORE_COND && a.M < 0
+#else
+#define SBEV_EXP_STORE_COND
+#endif
+#ifdef SBEV_EXP_NOMFMA          // keep the fragment reads alive, drop the matrix work
+#define SBEV_MFMA(A, B, C) ([&]() { asm volatile("" ::"v"(A), "v"(B)); return C; }())
+#else
+#define SBEV_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -178,7 +190,11 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
         } else {
             const int q2 = q - NIMG * 8;
             const int img = q2 >> 4, blk = q2 & 15;
+#ifdef SBEV_EXP_HOTW
+            const int row = blk * 16 + lrow;
+#else
             const int row = n0 + blk * 16 + lrow;
+#endif
             gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws + (long long)img * a.N * K);
             voff[j] = (unsigned)row * (unsigned)K * 2u + (unsigned)lchunk * 16u;
             ldst[j] = (unsigned)(NIMG * G_AIMG + img * G_BIMG + blk * 1024);
@@ -212,7 +228,9 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
     for (int s = 0; s < ns; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of slab s has landed ...
         __syncthreads();                                     // ... everybody's has, and nobody reads the other stage any more
+#ifndef SBEV_EXP_NOGLDS
         if (s + 1 < ns) issue(s + 1, (s + 1) & 1);
+#endif
         const unsigned char* A = lds + (s & 1) * STAGE + (wr * 2) * 32 * 64;
         const unsigned char* B = lds + (s & 1) * STAGE + NIMG * G_AIMG + (wc * 2) * 32 * 64;
 #pragma unroll
@@ -233,13 +251,13 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
                     for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
                         for (int fb = 0; fb < 2; ++fb)
-                            acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb], 0, 0, 0);
+                            acc[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);
             } else if (nfa == 1) {
 #pragma unroll
                 for (int p = 0; p < PR::N; ++p)
 #pragma unroll
                     for (int fb = 0; fb < 2; ++fb)
-                        acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb], 0, 0, 0);
+                        acc[0][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb]);
             }
         }
     }
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa) {
         const int row = m0 + (wr * 2 + fa) * 32 + l31;
-        if (fa < nfa && row < M) {
+        if (fa < nfa && row < M SBEV_EXP_STORE_COND) {
             float* y = a.Y + (long long)row * a.ldy + n0 + wc * 64 + 4 * lh;
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb)
@@ -308,6 +326,9 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
     auto loadx = [&](int i, f32x4& v0, f32x4& v1) {      // slab i of this half (clamped: a dummy past the end)
         int sl = sb + i;
         sl = sl < last_slab ? sl : last_slab;
+#ifdef SBEV_EXP_HOTX
+        sl = sl & 7;
+#endif
         const float* p = xp + (long long)sl * 32;
         v0 = *reinterpret_cast<const f32x4*>(p);
         v1 = *reinterpret_cast<const f32x4*>(p + 4);
@@ -327,6 +348,9 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
     auto loadw = [&](int kk, bf16x8 (&w)[2][NIMG]) {     // k-step kk of this half (clamped)
         int ks = 2 * sb + kk;
         ks = ks < last_ks ? ks : last_ks;
+#ifdef SBEV_EXP_HOTW
+        ks = ks & 15;
+#endif
         const long long o = (long long)ks * NIMG * 64 * 8;
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
@@ -363,13 +387,13 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
                 for (int fa = 0; fa < 2; ++fa)
 #pragma unroll
                     for (int fb = 0; fb < 2; ++fb)
-                        acc[fa][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb], 0, 0, 0);
+                        acc[fa][fb] = SBEV_MFMA(w[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);
         } else {
 #pragma unroll
             for (int p = 0; p < PR::N; ++p)
 #pragma unroll
                 for (int fb = 0; fb < 2; ++fb)
-                    acc[0][fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb], 0, 0, 0);
+                    acc[0][fb] = SBEV_MFMA(w[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb]);
         }
     };
 
@@ -408,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
 #pragma unroll
     for (int fa = 0; fa < 2; ++fa) {
         const int row = m0 + fa * 32 + l31;
-        if (fa < nfa && row < M) {
+        if (fa < nfa && row < M SBEV_EXP_STORE_COND) {
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb)
 #pragma unroll

@@ -178,3 +178,29 @@ def test_chain_pack_size_is_a_pure_host_function(lib):
     assert lib.sbev_decoder_chain_pack(ctypes.byref(cfg), ctypes.byref(w), None, None) == -1                  # SBEV_EINVAL
     assert b'sbev_decoder_chain_pack' in lib.sbev_last_error()
     assert lib.sbev_decoder_row_chain(1) == 0
+
+
+def test_build_tracks_textual_include_fragments(monkeypatch):
+    """msmv_chunk.inc is #included by msmv_sampling.hip AND mixing.hip (the fused gather + mixing kernel): editing it must make
+    both objects stale -- the .so ships prebuilt to the GPU box, so a stale object would go unnoticed.  Also
+    every #include "..." of every translation unit has to be in the dependency list at all."""
+    from sparsebev_amd.csrc import build
+    deps = {os.path.basename(d) for d in build.header_deps()}
+    assert 'msmv_chunk.inc' in deps and 'sbev_common.hpp' in deps and 'sbev_hip.h' in deps
+    for src in build.UNITS:
+        text = open(os.path.join(build.HERE, src)).read()
+        for inc in re.findall(r'#include\s+"([^"]+)"', text):
+            assert os.path.basename(inc) in deps, '%s includes %s, which the build does not track' % (src, inc)
+    for hdr in [d for d in build.header_deps() if d.endswith(('.hpp', '.inc'))]:       # headers including headers
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(hdr).read()):
+            assert os.path.basename(inc) in deps, '%s includes %s, which the build does not track' % (hdr, inc)
+    # touch msmv_chunk.inc (virtually: a patched mtime) -> every unit that can include it is stale, so in particular its two users
+    real = os.path.getmtime
+    chunk = os.path.join(build.HERE, 'msmv_chunk.inc')
+    newest = max(real(build.object_path(s)) for s in build.UNITS if os.path.exists(build.object_path(s)))
+    monkeypatch.setattr(build.os.path, 'getmtime', lambda f: newest + 10.0 if os.path.abspath(f) == chunk else real(f))
+    stale = build.stale_units()
+    assert 'msmv_sampling.hip' in stale and 'mixing.hip' in stale
+    monkeypatch.undo()
+    users = [s for s in build.UNITS if 'msmv_chunk.inc' in open(os.path.join(build.HERE, s)).read()]
+    assert sorted(users) == ['mixing.hip', 'msmv_sampling.hip']

@@ -97,7 +97,7 @@ def test_generator_bf16x6_not_narrower_than_f32_mfma():
     assert r6 <= rf and e6 <= ef, ('bf16x6 is narrower than the f32 MFMA kernel', e6, r6, ef, rf)
     assert r3 < 6e-6 and e3 < 6e-5            # the 2^-16 class of the three-product mode
     # and it is the same function: agreement with the exact kernel at fp32 round-off
-    assert (ys[3] - ys['f32']).abs().max().item() < 4e-6
+    assert (ys[3] - ys['f32']).abs().max().item() < 2e-5          # (each is up to ~9e-6 from fp64 on these O(1..5) outputs)
 
 
 def test_out_projection_bf16x6_not_narrower_than_f32_mfma():

@@ -25,8 +25,32 @@ def t(fn, iters=30):
     return ts[len(ts) // 2] * 1e3
 
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument('--m', type=int, nargs='*', default=[900, 3200, 3600])
+ap.add_argument('--quick', action='store_true', help='new kernels only, no fp64 reference')
+args = ap.parse_args()
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for M in (900, 3200, 3600):
+if args.quick:
+    for M in args.m:
+        line = 'M=%4d ' % M
+        for nimg in (3, 2):
+            N, K = 32768, 256
+            x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') / K ** 0.5; b = torch.randn(N, device='cuda')
+            y = torch.empty(M, N, device='cuda')
+            ws = dense.split_bf16s_rows(w, nimg); xs = dense.split_bf16s_rows(x, nimg)
+            us = t(lambda: lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, 0, nimg, st))
+            line += ' gen x%d %6.1f us' % (6 if nimg == 3 else 3, us)
+            N, K = 256, 32768
+            x = torch.randn(M, K, device='cuda').clamp_min(0); w = torch.randn(N, K, device='cuda') / K ** 0.5
+            wp = dense.pack_bf16s_frags(w, nimg)
+            plan = lib.sbev_linear_bf16s_out_plan(M, N, K)
+            wsb = torch.empty(plan * M * N, device='cuda'); y = torch.empty(M, N, device='cuda')
+            us = t(lambda: lib.sbev_linear_splitk_bf16s(p(x), p(wp), p(b), None, None, None, 1e-5, p(y), M, N, K, K, 0, nimg, p(wsb), st))
+            line += ' out x%d %6.1f us |' % (6 if nimg == 3 else 3, us)
+        print(line)
+    sys.exit(0)
+for M in args.m:
     # generator
     N, K = 32768, 256
     x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') / K ** 0.5; b = torch.randn(N, device='cuda')

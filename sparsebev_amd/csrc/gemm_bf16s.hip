@@ -25,6 +25,7 @@
 //              W fragments come pre-packed in MFMA order (sbev_pack_bf16s_frags: 1 KiB per (32 columns, 16 k, image)), straight
 //              from L2 into registers (no sharing between waves to exploit: every wave owns its own 64 columns).
 #include <cstdlib>
+#include <type_traits>
 #include "sbev_common.hpp"
 
 // ---- ablation switches (tools/build_variant.sh; never defined in the product build) -------------------------------------------
@@ -133,7 +134,7 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
     sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
     asm volatile(
         "s_mov_b32 m0, %0\n\t"
-        "s_nop 0\n\t"
+        "s_nop 4\n\t"                       // M0 write -> LDS-DMA (1 state) and a readfirstlane'd base -> VMEM (5 states)
         "global_load_lds_dwordx4 %1, %2\n\t"
         :
         : "s"(lds_byte), "v"(voff), "s"(sbase)
@@ -278,6 +279,201 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
                 }
         }
     }
+}
+
+// ---- generator, version 2: persistent workgroups, 16-k stages in a 4-deep LDS ring, fragments one stage ahead ----------------------
+// Ablations of the kernel above (c2, bf16x6, 116 us): without its stores 93, without its MFMAs 73, with neither 50 -- the three
+// parts add up, i.e. NOTHING overlaps: one workgroup per CU, every wave in the same phase behind the per-slab barrier, the
+// fragment reads of a k-step in front of its MFMAs, the 128 KB epilogue of a tile before the next tile's first load.  Here
+//   * a workgroup is persistent (grid = CUs) and walks its tiles as ONE stream of 16-k stages: the LDS-DMA loads run three stages
+//     ahead across tile boundaries, the epilogue stores of a tile drain under the next tile's MFMAs;
+//   * the fragments of stage g + 1 are read (interleaved 1 : 2 by sched_group_barrier) among the MFMAs of stage g -- legal because
+//     the ring is 4 deep: stage g + 1 was published by the barrier at the top of iteration g, stage g + 3 is being filled;
+//   * counted waits: at the top of iteration g only the newest stage's loads of this wave may be outstanding (vector loads
+//     return in order, so "at most n outstanding" = everything older than the newest n has landed; stores in flight can only
+//     make the wait more conservative, and the two iterations behind an epilogue skip it: the epilogue drained the queue).
+constexpr int G2_ST_A = G_ROWS * 32, G2_ST_B = G_COLS * 32;      // bytes of one image of one 16-k stage (32 B per row)
+constexpr int G2_NST = 4;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+}
+
+template <int NIMG>
+__global__ __launch_bounds__(512) void gemm_bf16s_gen2_kernel(const GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
+    constexpr int STAGE = NIMG * (G2_ST_A + G2_ST_B);
+    constexpr int NQ = NIMG * 12;                                    // wave-loads (32 rows x 32 B) per stage
+    constexpr int NLMAX = (NQ + 7) / 8;
+    typedef Prods<NIMG> PR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int M = a.M, K = a.K, nk = K / 16;
+    // A workgroup keeps ONE row tile for its whole life (grid is a multiple of ntm) and walks column tiles: the fragment count
+    // of each wave is then a kernel-lifetime constant and the stage loop is instantiated per count (a per-tile branch around
+    // the MFMA block made hipcc copy all 64 accumulators per stage).
+    const int lw = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int rt = lw % a.ntm, ct0 = lw / a.ntm, cstep = (int)gridDim.x / a.ntm, nct = a.N / G_COLS;
+    const int my_tiles = ct0 < nct ? (nct - ct0 + cstep - 1) / cstep : 0;
+    const int G = my_tiles * nk;                                     // stages of this workgroup (even: K % 32 == 0)
+    if (G == 0) return;
+    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
+    const int nf = a.base + (rt < a.rem ? 1 : 0);
+    const int m0 = f0 * 32;
+    int nfa = nf - 2 * wr;                                           // this wave's row fragments: 0, 1 or 2
+    nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
+    const int nl = (NQ - wave + 7) / 8;                              // this wave's loads per stage
+
+    // ---- load cursor: load q = wave + 8 j is a (image, 32-row block) of A (this tile's rows: fixed) or of B (the column tile) -----
+    const int lrow = lane >> 1;
+    const unsigned lchunk = (unsigned)((lane & 1) ^ ((lane >> 4) & 1));
+    const unsigned char* gbase[NLMAX];
+    unsigned voff[NLMAX], ldst[NLMAX], vstep[NLMAX];
+#pragma unroll
+    for (int j = 0; j < NLMAX; ++j) {
+        const int q = wave + 8 * j;
+        if (q < NIMG * 4) {
+            const int img = q >> 2, blk = q & 3;
+            int row = m0 + blk * 32 + lrow;
+            row = row < M ? row : M - 1;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs + (long long)img * M * K);
+            ldst[j] = (unsigned)(img * G2_ST_A + blk * 1024);
+            voff[j] = (unsigned)row * (unsigned)K * 2u + lchunk * 16u;
+            vstep[j] = 0u;
+        } else {
+            const int q2 = q - NIMG * 4;
+            const int img = q2 >> 3, blk = q2 & 7;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws + (long long)img * a.N * K);
+            ldst[j] = (unsigned)(NIMG * G2_ST_A + img * G2_ST_B + blk * 1024);
+            voff[j] = (unsigned)(ct0 * G_COLS + blk * 32 + lrow) * (unsigned)K * 2u + lchunk * 16u;
+            vstep[j] = (unsigned)(cstep * G_COLS) * (unsigned)K * 2u;      // to the next column tile of this workgroup
+        }
+    }
+    int lk = 0, lg = 0;                                              // load cursor: k-step in its tile, stage index
+    auto issue_next = [&]() {
+        if (lg >= G) return;
+        const unsigned sb = (unsigned)((lg & (G2_NST - 1)) * STAGE);
+#pragma unroll
+        for (int j = 0; j < NLMAX; ++j)
+            if (j < nl) glds16(gbase[j] + (long long)lk * 32, voff[j], sb + ldst[j]);
+        ++lg;
+        if (++lk == nk) {
+            lk = 0;
+#pragma unroll
+            for (int j = 0; j < NLMAX; ++j) voff[j] += vstep[j];
+        }
+    };
+
+    // ---- compute side -----------------------------------------------------------------------------------------------------------
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned fo = (unsigned)l31 * 32u + ((unsigned)(lh ^ ((lane >> 3) & 1))) * 16u;
+    const unsigned aoff = (unsigned)(wr * 2) * 1024u + fo;
+    const unsigned boff = (unsigned)(NIMG * G2_ST_A) + (unsigned)(wc * 2) * 1024u + fo;
+
+    auto run = [&](auto nfa_c) {
+        constexpr int NFA = decltype(nfa_c)::value;
+        constexpr int NFR = NFA > 0 ? NFA : 1;
+        bf16x8 xf[2][NFR][NIMG], wf[2][2][NIMG];                     // [set][fragment][image]
+        f32x16 acc[NFR][2];
+        auto read_frags = [&](int g, int set) {
+            if constexpr (NFA > 0) {
+                const unsigned char* st = lds + (g & (G2_NST - 1)) * STAGE;
+#pragma unroll
+                for (int img = 0; img < NIMG; ++img) {
+                    wf[set][0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B);
+                    wf[set][1][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B + 1024);
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa) xf[set][fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + img * G2_ST_A + fa * 1024);
+                }
+            }
+        };
+        auto init_acc = [&](int n0) {
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + (wc * 2 + fb) * 32 + 8 * gq + 4 * lh);
+#pragma unroll
+                    for (int fa = 0; fa < NFR; ++fa)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[fa][fb][4 * gq + e] = bv[e];
+                }
+        };
+        int skip = 0;
+        auto top = [&](int g) {
+            // stage g + 1 (or g, at the very end) of this wave has landed: only the newest stage's loads may be outstanding
+            if (skip > 0) --skip;
+            else if (lg - 1 > g + 1 || (g + 1 >= G && lg - 1 > g)) {
+                if (nl == 5) wait_vmcnt<5>(); else if (nl == 4) wait_vmcnt<4>(); else wait_vmcnt<3>();
+            } else wait_vmcnt<0>();
+            __syncthreads();
+            issue_next();                                            // stage g + 3 into the buffer stage g - 1 left
+        };
+        // MFMAs of the current set with the reads of the next set interleaved (1 read per 2 MFMAs at two fragments)
+#define SBEV_G2_BODY(CUR)                                                                                   \
+        if constexpr (NFA > 0) {                                                                            \
+            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
+                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
+                    _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
+                        acc[fa][fb] = SBEV_MFMA(wf[CUR][fb][PR::ib(p)], xf[CUR][fa][PR::ia(p)], acc[fa][fb]); \
+            _Pragma("unroll") for (int i = 0; i < (2 + NFA) * NIMG; ++i) {                                  \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+                __builtin_amdgcn_sched_group_barrier(0x008, (PR::N * NFA * 2) / ((2 + NFA) * NIMG), 0);     \
+            }                                                                                               \
+        }
+        int cn0 = ct0 * G_COLS, ck = 0;
+        init_acc(cn0);
+        issue_next();
+        issue_next();
+        issue_next();
+        top(0);
+        read_frags(0, 0);
+        for (int g = 0; g < G; g += 2) {
+            read_frags(g + 1, 1);
+            SBEV_G2_BODY(0)
+            top(g + 1);
+            if (g + 2 < G) read_frags(g + 2, 0);
+            SBEV_G2_BODY(1)
+            ck += 2;
+            if (ck == nk) {
+                // epilogue of this tile: drain this wave's loads first (the next two top-of-iteration waits are then skipped and
+                // never wait for these stores), then 16-byte stores: a lane holds 4 consecutive columns of one row per 4 registers
+                wait_vmcnt<0>();
+                if constexpr (NFA > 0) {
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa) {
+                        const int row = m0 + (wr * 2 + fa) * 32 + l31;
+                        if (row < M SBEV_EXP_STORE_COND) {
+                            float* y = a.Y + (long long)row * a.ldy + cn0 + wc * 64 + 4 * lh;
+#pragma unroll
+                            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                                for (int gq = 0; gq < 4; ++gq) {
+                                    f32x4 v = {acc[fa][fb][4 * gq], acc[fa][fb][4 * gq + 1], acc[fa][fb][4 * gq + 2], acc[fa][fb][4 * gq + 3]};
+                                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                                    *reinterpret_cast<f32x4*>(y + fb * 32 + 8 * gq) = v;
+                                }
+                        }
+                    }
+                }
+                ck = 0;
+                skip = 2;
+                cn0 += cstep * G_COLS;
+                if (cn0 < a.N) init_acc(cn0);
+            }
+            if (g + 2 < G) top(g + 2);
+        }
+#undef SBEV_G2_BODY
+    };
+    if (nfa == 2) run(std::integral_constant<int, 2>{});
+    else if (nfa == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
 }
 
 // ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
@@ -445,6 +641,185 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
     }
 }
 
+// ---- out-projection, version 2: 3-deep X stage ring, fragments one k-step ahead, X two slabs ahead in registers ------------------
+// Same ablation as for the generator (c2, bf16x6: 104 us; without MFMAs 61, with neither MFMAs nor stores 57): the X stream (118 MB
+// of fp32 from HBM, one 16 KB slab in flight per workgroup), the split, the fragment reads and the MFMAs ran one after the other.
+// Here a k-step's MFMAs are issued with the NEXT k-step's fragment reads and W loads in front of them, the split + LDS write of slab
+// it + 2 rides in the second k-step, and two slabs of X are in flight per thread.  The fragment count of a workgroup's row tile
+// is a template parameter of the loop (a branch around the MFMAs costs accumulator copies), as is the unequal last iteration.
+template <int NIMG>
+__global__ __launch_bounds__(512) void gemm_bf16s_out2_kernel(const OutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int HSTAGE = NIMG * O_IMG;        // one half's stage
+    constexpr int NST = 3;
+    typedef Prods<NIMG> PR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wc = wave & 3;  // K half of the chunk, 64-column quarter
+    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
+    const int M = a.M;
+    const int m0 = rt * 64;
+    const int nfa = (M - m0) > 32 ? 2 : 1;      // row fragments of this tile
+    const int nslab = a.K / 32;
+    const int c0 = (int)((long long)nslab * chunk / a.S), c1 = (int)((long long)nslab * (chunk + 1) / a.S);
+    const int n_all = c1 - c0, n0h = (n_all + 1) / 2;
+    const int sb = half == 0 ? c0 : c0 + n0h;            // first slab of this half
+    const int nh = half == 0 ? n0h : n_all - n0h;        // its slabs (half 0 may have one more)
+    const int nmin = n_all - n0h;                        // iterations both halves compute in
+
+    const int th = tid & 255;
+    const int srow = th >> 2, skq = th & 3;
+    int grow = m0 + srow;
+    grow = grow < M ? grow : M - 1;
+    const float* xp = a.X + (long long)grow * a.ldx + skq * 8;
+    const unsigned wofs = (unsigned)(srow * 64 + ((skq ^ ((srow >> 2) & 3)) * 16));
+    unsigned char* hst = lds + half * (NST * HSTAGE);    // this half's stage ring
+    const int last_slab = nh > 0 ? sb + nh - 1 : c1 - 1;
+    auto loadx = [&](int i, f32x4& v0, f32x4& v1) {      // slab i of this half (clamped: a dummy past the end)
+        int sl = sb + i;
+        sl = sl < last_slab ? sl : last_slab;
+#ifdef SBEV_EXP_HOTX
+        sl = sl & 7;
+#endif
+        const float* p = xp + (long long)sl * 32;
+        v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));         // streamed once: keep L2 for W
+        v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    };
+    auto stagex = [&](int i, const f32x4 v0, const f32x4 v1) {       // slab i -> ring slot i % 3
+        u32x4 im[NIMG];
+        split8<NIMG>(v0, v1, im);
+        unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) *reinterpret_cast<u32x4*>(st + img * O_IMG) = im[img];
+    };
+    const int KS = a.K / 16;
+    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
+    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
+    const int last_ks = 2 * last_slab + 1;
+    auto loadw = [&](int kk, bf16x8 (&w)[2][NIMG]) {     // k-step kk of this half (clamped)
+        int ks = 2 * sb + kk;
+        ks = ks < last_ks ? ks : last_ks;
+#ifdef SBEV_EXP_HOTW
+        ks = ks & 15;
+#endif
+        const long long o = (long long)ks * NIMG * 64 * 8;
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) {
+            w[0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
+            w[1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
+        }
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned swz = (unsigned)((lane >> 2) & 3);
+    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
+    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
+
+    auto run = [&](auto nfa_c) {
+        constexpr int NFA = decltype(nfa_c)::value;
+        f32x16 acc[NFA][2];
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+        auto readx = [&](int i, int j, bf16x8 (&xf)[NFA][NIMG]) {      // fragments of slab i, k-step j
+            const unsigned char* A = hst + (i % NST) * HSTAGE + (j ? fo1 : fo0);
+#pragma unroll
+            for (int img = 0; img < NIMG; ++img)
+#pragma unroll
+                for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(A + img * O_IMG + fa * 32 * 64);
+        };
+#define SBEV_O2_MMA(XF, W)                                                                                  \
+        _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                                   \
+            _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                              \
+                _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                            \
+                    acc[fa][fb] = SBEV_MFMA(W[fb][PR::ib(p)], XF[fa][PR::ia(p)], acc[fa][fb]);
+        f32x4 xa0, xa1, xb0, xb1;                             // X register ring: slabs it + 2 (even it: a, odd: b) ...
+        bf16x8 wA[2][NIMG], wB[2][NIMG], xfA[NFA][NIMG], xfB[NFA][NIMG];
+        // prologue: slabs 0 and 1 staged, 2 and 3 requested, W of k-step 0 requested, fragments of (slab 0, k-step 0) read
+        loadx(0, xa0, xa1);
+        loadx(1, xb0, xb1);
+        loadw(0, wA);
+        stagex(0, xa0, xa1);
+        loadx(2, xa0, xa1);
+        stagex(1, xb0, xb1);
+        loadx(3, xb0, xb1);
+        __syncthreads();
+        readx(0, 0, xfA);
+        // one iteration = one slab; `it` even uses the a registers for slab it + 2, odd the b registers
+        // (ZERO: the unequal last iteration -- half 1 has no slab left and multiplies zeros instead of branching around the MFMAs)
+#define SBEV_O2_ZERO(XF)                                                                                    \
+        if (half == 1) {                                                                                    \
+            _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                              \
+                _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) XF[fa][img][e] = (__bf16)0.f;             \
+        }
+#define SBEV_O2_ITER(IT, X0, X1, ZERO)                                                                      \
+        {                                                                                                   \
+            loadw(2 * (IT) + 1, wB);                                                                        \
+            readx((IT), 1, xfB);                                                                            \
+            if (ZERO) { SBEV_O2_ZERO(xfA) SBEV_O2_ZERO(xfB) }                                               \
+            SBEV_O2_MMA(xfA, wA)                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            loadw(2 * (IT) + 2, wA);                                                                        \
+            stagex((IT) + 2, X0, X1);                                                                       \
+            loadx((IT) + 4, X0, X1);                                                                        \
+            __syncthreads();              /* slab IT + 1 (staged one iteration ago) is published */         \
+            readx((IT) + 1, 0, xfA);                                                                        \
+            SBEV_O2_MMA(xfB, wB)                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+        }
+        int it = 0;
+        for (; it + 1 < nmin; it += 2) {
+            SBEV_O2_ITER(it, xa0, xa1, false)
+            SBEV_O2_ITER(it + 1, xb0, xb1, false)
+        }
+        if (it < nmin) {
+            SBEV_O2_ITER(it, xa0, xa1, false)
+            ++it;
+            if (it < n0h) SBEV_O2_ITER(it, xb0, xb1, true)
+        } else if (it < n0h) {
+            SBEV_O2_ITER(it, xa0, xa1, true)
+        }
+#undef SBEV_O2_ZERO
+#undef SBEV_O2_ITER
+#undef SBEV_O2_MMA
+        // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab
+        __syncthreads();
+        f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * 16) * 64 + lane;       // [wc][fa][fb][g][lane] float4
+        if (half == 1) {
+#pragma unroll
+            for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+        }
+        __syncthreads();
+        if (half == 1) return;
+        float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa) {
+            const int row = m0 + fa * 32 + l31;
+            if (row < M SBEV_EXP_STORE_COND) {
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
+                        const f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
+                        *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
+                    }
+            }
+        }
+    };
+    if (nfa == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
 template <typename Kern>
 int reserve_lds(Kern k, int bytes, const char* what) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -516,6 +891,34 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     int st;
+    static const bool v1 = getenv("SBEV_BF16S_GEN_V1") != nullptr;       // A/B switch: the one-tile-per-workgroup kernel
+    if (!v1) {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+            return n;
+        }();
+        // one row tile per workgroup for life: grid = a multiple of ntm, at most the CU count, at most the tile count
+        long long per = cus / ntm < 1 ? 1 : cus / ntm;
+        if (per > N / G_COLS) per = N / G_COLS;
+        const unsigned grid = (unsigned)(per * ntm);
+        if (nimg == 3) {
+            constexpr int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B);
+            st = reserve_lds(gemm_bf16s_gen2_kernel<3>, LDS, "sbev_linear_bf16s_gen");
+            if (st != SBEV_OK) return st;
+            const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+            hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<3>, dim3(grid), dim3(512), LDS, s, a);
+            if (prof) sbev::profile_end(s, e0, e1, 1);
+        } else {
+            constexpr int LDS = G2_NST * 2 * (G2_ST_A + G2_ST_B);
+            st = reserve_lds(gemm_bf16s_gen2_kernel<2>, LDS, "sbev_linear_bf16s_gen");
+            if (st != SBEV_OK) return st;
+            const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+            hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<2>, dim3(grid), dim3(512), LDS, s, a);
+            if (prof) sbev::profile_end(s, e0, e1, 1);
+        }
+        return sbev::check_launch("sbev_linear_bf16s_gen");
+    }
     if (nimg == 3) {
         constexpr int LDS = 2 * 3 * (G_AIMG + G_BIMG);
         st = reserve_lds(gemm_bf16s_gen_kernel<3>, LDS, "sbev_linear_bf16s_gen");
@@ -554,6 +957,25 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
     SBEV_REQUIRE(wgs <= 0x7fffffffLL, "sbev_linear_splitk_bf16s: too many workgroups");
     hipEvent_t e0, e1;
     int st;
+    static const bool v1 = getenv("SBEV_BF16S_OUT_V1") != nullptr;       // A/B switch: the un-pipelined kernel
+    if (!v1) {
+        if (nimg == 3) {
+            constexpr int LDS = 2 * 3 * 3 * O_IMG;      // 2 halves x 3 stages x 3 images x 4 KiB = 72 KiB (>= the 64 KiB fold buffer)
+            st = reserve_lds(gemm_bf16s_out2_kernel<3>, LDS, "sbev_linear_splitk_bf16s");
+            if (st != SBEV_OK) return st;
+            const bool prof = profile_begin(s, &e0, &e1, 2);
+            hipLaunchKernelGGL(gemm_bf16s_out2_kernel<3>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
+            if (prof) profile_end(s, e0, e1, 2);
+        } else {
+            constexpr int LDS = 65536;                  // 48 KiB of stages, 64 KiB fold buffer
+            st = reserve_lds(gemm_bf16s_out2_kernel<2>, LDS, "sbev_linear_splitk_bf16s");
+            if (st != SBEV_OK) return st;
+            const bool prof = profile_begin(s, &e0, &e1, 2);
+            hipLaunchKernelGGL(gemm_bf16s_out2_kernel<2>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
+            if (prof) profile_end(s, e0, e1, 2);
+        }
+        return check_launch("sbev_linear_splitk_bf16s (gemm)");
+    }
     if (nimg == 3) {
         constexpr int LDS = 65536;      // max(2 halves x 2 stages x 3 images x 4 KiB = 48 KiB, fold buffer 64 KiB)
         st = reserve_lds(gemm_bf16s_out_kernel<3>, LDS, "sbev_linear_splitk_bf16s");

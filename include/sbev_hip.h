@@ -369,12 +369,15 @@ int sbev_linear_splitk_bf16x3(const float* X, const uint16_t* W2, const float* b
  * rounds away per step -- fp32-class, not bit-equal to fp32 math.  nimg = 2 ("bf16x3"): hi + lo, three products, 2^-16 class.
  * Replaces: torch.nn.Linear of AdaptiveMixing.parameter_generator / out_proj (models/sparsebev_transformer.py:358,378).
  *
- *   sbev_split_bf16s_rows   X [rows, ldx] fp32 -> out [nimg][rows][K] bf16 row-major planes (sbev_bf16s_image_elems elements);
- *                           the generator's two operands (W once per weight update, X once per call).  K % 8 == 0.
- *   sbev_pack_bf16s_frags   W [N, ldw] fp32 -> out [N/32][K/16][nimg][64][8] bf16, the MFMA operand order (same element count);
- *                           the out-projection's weight.  N % 32 == 0, K % 16 == 0.
- *   sbev_linear_bf16s_gen   Y [M, ldy] = X W^T + bias (ReLU optional) from split planes Xs / Ws.  N % 256 == 0, K % 32 == 0,
- *                           K <= 4096 (sbev_linear_bf16s_gen_ok).
+ *   sbev_split_bf16s_rows   X [rows, ldx] fp32 -> out [nimg][rows][K] bf16 row-major planes (rows * K * nimg elements): the
+ *                           images themselves (image i = RNE_bf16 of what images < i left over).  K % 8 == 0.
+ *   sbev_pack_bf16s_frags   W [N, ldw] fp32 -> out [ceil(N/32)][K/16][nimg][64][8] bf16 (sbev_bf16s_image_elems(N, K, nimg)
+ *                           elements): the same images in v_mfma_f32_32x32x16_bf16 operand order -- lane l of fragment (nf, ks)
+ *                           holds row 32 nf + (l & 31), k = 16 ks + 8 (l >> 5) + 0..7; a ragged last block repeats row N - 1.
+ *                           The operand format of both kernels (weights once per weight update, the generator's X once per
+ *                           call); K % 16 == 0.
+ *   sbev_linear_bf16s_gen   Y [M, ldy] = X W^T + bias (ReLU optional) from the fragment images Xs / Ws.  N % 256 == 0,
+ *                           K % 32 == 0, K <= 4096 (sbev_linear_bf16s_gen_ok).
  *   sbev_linear_splitk_bf16s  Y = LayerNorm?(relu?(X W^T + bias) + residual) for N == 256, K % 32 == 0 (sbev_linear_bf16s_out_ok):
  *                           X stays fp32 [M, ldx] and is split inside the kernel; workspace = sbev_linear_bf16s_out_plan(M, N, K)
  *                           partial slabs [plan, M, 256] fp32, summed in a fixed order (bit-reproducible) by sbev_splitk_reduce_f32.
@@ -532,7 +535,7 @@ typedef struct sbev_decoder_weights {
     const float *cls0_w, *cls0_b, *cls1_g, *cls1_b, *cls3_w, *cls3_b, *cls4_g, *cls4_b, *cls6_w, *cls6_b;  /* cls_branch.* */
     const float *reg0_w, *reg0_b, *reg2_w, *reg2_b, *reg4_w, *reg4_b;                                        /* reg_branch.* */
     const float *chain_pack;   /* sbev_decoder_chain_pack image of the small Linears' weights, or NULL (op-by-op launches) */
-    const uint16_t *pg_ws;     /* gemm_mode 2 / 3: sbev_split_bf16s_rows planes of pg_w (3 / 2 images); else NULL */
+    const uint16_t *pg_ws;     /* gemm_mode 2 / 3: sbev_pack_bf16s_frags image of pg_w (3 / 2 images); else NULL */
     const uint16_t *op_wp;     /* gemm_mode 2 / 3: sbev_pack_bf16s_frags image of op_w (3 / 2 images); else NULL */
 } sbev_decoder_weights;
 

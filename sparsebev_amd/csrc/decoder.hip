@@ -60,7 +60,8 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.c0 = k.take(BQ * D); b.c1 = k.take(BQ * D); b.r0 = k.take(BQ * D); b.r1 = k.take(BQ * D);
     b.reg = k.take(BQ * c.code_size);
     b.bbox = k.take(BQ * 10);
-    b.x1s = k.take(2 * BQ * D);    // x1 as bf16 images: the generator's operand in the split-bf16 modes (2 or 3 images of 2 bytes)
+    b.x1s = k.take(2 * BQ * D + 64 * (size_t)D);   // x1 as bf16 image fragments (<= 3 images of 2 bytes, rows padded to 32): the
+                                                   // generator's operand in the split-bf16 modes
     b.bytes = k.off;
     return b;
 }
@@ -190,9 +191,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     SBEV_REQUIRE(nimg == 0 || (sbev_linear_bf16s_gen_ok(BQ, pgN, D) && sbev_linear_bf16s_out_ok(BQ, D, mixN)),
                  "sbev_decoder_forward: gemm_mode %d does not cover this shape (rows %lld, generator %d x %d, out-projection %d x %d)",
                  cfg->gemm_mode, (long long)BQ, pgN, D, D, mixN);
-    auto generator_bf16s = [&](sbev_stream_t st) -> int {      // x1 -> bf16 planes (once per layer) -> Y = X W^T + b
+    auto generator_bf16s = [&](sbev_stream_t st) -> int {      // x1 -> bf16 image fragments (once per layer) -> Y = X W^T + b
         uint16_t* xs = reinterpret_cast<uint16_t*>(b.x1s);
-        int e = sbev_split_bf16s_rows(b.x1, D, xs, BQ, D, nimg, st);
+        int e = sbev_pack_bf16s_frags(b.x1, D, xs, (int)BQ, D, nimg, st);
         if (e != SBEV_OK) return e;
         return sbev_linear_bf16s_gen(xs, w->pg_ws, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg, st);
     };

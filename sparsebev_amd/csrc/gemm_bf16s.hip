@@ -109,12 +109,14 @@ template <int NIMG>
 __global__ void pack_frags_kernel(const float* w, long long ldw, unsigned short* out, int N, int K) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int KS = K / 16;
-    if (i >= (long long)(N / 32) * KS * 64) return;
+    if (i >= (long long)((N + 31) / 32) * KS * 64) return;
     const int lane = (int)(i & 63);
     const long long f = i >> 6;
     const int ks = (int)(f % KS);
     const int nf = (int)(f / KS);
-    const float* p = w + (long long)(nf * 32 + (lane & 31)) * ldw + ks * 16 + (lane >> 5) * 8;
+    int row = nf * 32 + (lane & 31);
+    row = row < N ? row : N - 1;                     // a ragged last block repeats the last row (its outputs are never stored)
+    const float* p = w + (long long)row * ldw + ks * 16 + (lane >> 5) * 8;
     u32x4 im[NIMG];
     split8<NIMG>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), im);
 #pragma unroll
@@ -143,8 +145,8 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 
 // ==== generator-shaped GEMM ======================================================================================================
 struct GenArgs {
-    const unsigned short* Xs;    // [NIMG][M][K] bf16 planes
-    const unsigned short* Ws;    // [NIMG][N][K]
+    const unsigned short* Xs;    // [ceil(M/32)][K/16][NIMG][64][8] bf16 fragments (sbev_pack_bf16s_frags)
+    const unsigned short* Ws;    // [N/32][K/16][NIMG][64][8]
     const float* bias;           // [N] or null
     float* Y;                    // [M, ldy]
     int M, N, K;
@@ -154,137 +156,16 @@ struct GenArgs {
 };
 
 constexpr int G_ROWS = 128, G_COLS = 256;
-constexpr int G_AIMG = G_ROWS * 64, G_BIMG = G_COLS * 64;        // bytes of one image of one stage (32 k = 64 B per row)
 
-template <int NIMG>
-__global__ __launch_bounds__(512) void gemm_bf16s_gen_kernel(const GenArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
-    constexpr int STAGE = NIMG * (G_AIMG + G_BIMG);
-    constexpr int NLOAD = 3 * NIMG;                                  // wave-loads per wave and slab (NIMG * 24 / 8 waves)
-    typedef Prods<NIMG> PR;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;                         // waves w and w + 4 (one SIMD) own the two row halves
-    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int ct = (int)(logical / (unsigned)a.ntm), rt = (int)(logical % (unsigned)a.ntm);
-    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
-    const int nf = a.base + (rt < a.rem ? 1 : 0);
-    const int m0 = f0 * 32, n0 = ct * G_COLS;
-    int nfa = nf - 2 * wr;                                           // this wave's row fragments: 0, 1 or 2
-    nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
-    const int M = a.M, K = a.K;
-
-    // --- the slab loads of this wave: load q = wave * NLOAD + j is a (image, 16-row block) of A or B -------------------------
-    const unsigned char* gbase[NLOAD];
-    unsigned voff[NLOAD], ldst[NLOAD];
-    const int lrow = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);      // source chunk of LDS slot lane & 3 in row lrow
-#pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-        const int q = wave * NLOAD + j;
-        if (q < NIMG * 8) {
-            const int img = q >> 3, blk = q & 7;
-            int row = m0 + blk * 16 + lrow;
-            row = row < M ? row : M - 1;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs + (long long)img * M * K);
-            voff[j] = (unsigned)row * (unsigned)K * 2u + (unsigned)lchunk * 16u;
-            ldst[j] = (unsigned)(img * G_AIMG + blk * 1024);
-        } else {
-            const int q2 = q - NIMG * 8;
-            const int img = q2 >> 4, blk = q2 & 15;
-#ifdef SBEV_EXP_HOTW
-            const int row = blk * 16 + lrow;
-#else
-            const int row = n0 + blk * 16 + lrow;
-#endif
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws + (long long)img * a.N * K);
-            voff[j] = (unsigned)row * (unsigned)K * 2u + (unsigned)lchunk * 16u;
-            ldst[j] = (unsigned)(NIMG * G_AIMG + img * G_BIMG + blk * 1024);
-        }
-    }
-    auto issue = [&](int s, int st) {
-#pragma unroll
-        for (int j = 0; j < NLOAD; ++j) glds16(gbase[j] + (long long)s * 64, voff[j], (unsigned)(st * STAGE) + ldst[j]);
-    };
-
-    // --- accumulators start from the bias: D rows = W rows (output columns), D columns = X rows ----------------------------------
-    f32x16 acc[2][2];
-    const int l31 = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + (wc * 2 + fb) * 32 + 8 * g + 4 * lh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[0][fb][4 * g + e] = acc[1][fb][4 * g + e] = bv[e];
-        }
-
-    // fragment read offsets: row (tile row l31) * 64 B + swizzled chunk of k-step j
-    const unsigned swz = (unsigned)((lane >> 2) & 3);
-    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
-    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
-
-    const int ns = K / 32;
-    issue(0, 0);
-    for (int s = 0; s < ns; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of slab s has landed ...
-        __syncthreads();                                     // ... everybody's has, and nobody reads the other stage any more
-#ifndef SBEV_EXP_NOGLDS
-        if (s + 1 < ns) issue(s + 1, (s + 1) & 1);
-#endif
-        const unsigned char* A = lds + (s & 1) * STAGE + (wr * 2) * 32 * 64;
-        const unsigned char* B = lds + (s & 1) * STAGE + NIMG * G_AIMG + (wc * 2) * 32 * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned fo = j ? fo1 : fo0;
-            bf16x8 xf[2][NIMG], wf[2][NIMG];
-#pragma unroll
-            for (int img = 0; img < NIMG; ++img) {
-                wf[0][img] = *reinterpret_cast<const bf16x8*>(B + img * G_BIMG + fo);
-                wf[1][img] = *reinterpret_cast<const bf16x8*>(B + img * G_BIMG + 32 * 64 + fo);
-                xf[0][img] = *reinterpret_cast<const bf16x8*>(A + img * G_AIMG + fo);
-                xf[1][img] = *reinterpret_cast<const bf16x8*>(A + img * G_AIMG + 32 * 64 + fo);
-            }
-            if (nfa == 2) {
-#pragma unroll
-                for (int p = 0; p < PR::N; ++p)
-#pragma unroll
-                    for (int fa = 0; fa < 2; ++fa)
-#pragma unroll
-                        for (int fb = 0; fb < 2; ++fb)
-                            acc[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);
-            } else if (nfa == 1) {
-#pragma unroll
-                for (int p = 0; p < PR::N; ++p)
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb)
-                        acc[0][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb]);
-            }
-        }
-    }
-
-    // --- epilogue: a lane holds 4 consecutive output columns of one row per 4 accumulator registers -> 16-byte stores --------------
-#pragma unroll
-    for (int fa = 0; fa < 2; ++fa) {
-        const int row = m0 + (wr * 2 + fa) * 32 + l31;
-        if (fa < nfa && row < M SBEV_EXP_STORE_COND) {
-            float* y = a.Y + (long long)row * a.ldy + n0 + wc * 64 + 4 * lh;
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
-                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    *reinterpret_cast<f32x4*>(y + fb * 32 + 8 * g) = v;
-                }
-        }
-    }
-}
-
-// ---- generator, version 2: persistent workgroups, 16-k stages in a 4-deep LDS ring, fragments one stage ahead ----------------------
-// Ablations of the kernel above (c2, bf16x6, 116 us): without its stores 93, without its MFMAs 73, with neither 50 -- the three
-// parts add up, i.e. NOTHING overlaps: one workgroup per CU, every wave in the same phase behind the per-slab barrier, the
-// fragment reads of a k-step in front of its MFMAs, the 128 KB epilogue of a tile before the next tile's first load.  Here
+// ---- generator: persistent workgroups, 16-k stages in a 4-deep LDS ring, fragments one stage ahead ----------------------------------
+// History (c2, bf16x6): the first version -- one 128 x 256 tile per workgroup, 32-k slabs, two LDS stages
+// filled from ROW-MAJOR bf16 planes, one barrier per slab -- ran 116 us; without its stores 93, without its MFMAs 73, with neither
+// 50: the three parts add up, NOTHING overlapped (one workgroup per CU, every wave in the same phase behind the barrier, the
+// fragment reads of a k-step in front of its MFMAs, the 128 KB epilogue of a tile before the next tile's first load), and the
+// 64-byte-per-row pieces of a row-major operand made every LDS-DMA instruction touch 16 cache lines (32 at 16-k stages).  Here
+//   * both operands are pre-packed in MFMA fragment order (sbev_pack_bf16s_frags): a stage is made of whole 1-KiB fragments, an
+//     LDS-DMA instruction copies one of them verbatim (8 full cache lines, lane-linear) and a ds_read_b128 at lane x 16 reads
+//     it back conflict-free -- no swizzle, no address arithmetic per lane;
 //   * a workgroup is persistent (grid = CUs) and walks its tiles as ONE stream of 16-k stages: the LDS-DMA loads run three stages
 //     ahead across tile boundaries, the epilogue stores of a tile drain under the next tile's MFMAs;
 //   * the fragments of stage g + 1 are read (interleaved 1 : 2 by sched_group_barrier) among the MFMAs of stage g -- legal because
@@ -329,29 +210,30 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen2_kernel(const GenArgs a) {
     nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
     const int nl = (NQ - wave + 7) / 8;                              // this wave's loads per stage
 
-    // ---- load cursor: load q = wave + 8 j is a (image, 32-row block) of A (this tile's rows: fixed) or of B (the column tile) -----
-    const int lrow = lane >> 1;
-    const unsigned lchunk = (unsigned)((lane & 1) ^ ((lane >> 4) & 1));
+    // ---- load cursor: load q = wave + 8 j is one fragment = (image, 32-row block) of A (this tile's rows: fixed) or of B (the
+    // column tile); in memory the fragments of a row block are [k-step][image][1 KiB] --------------------------------------------
+    const unsigned voff = (unsigned)lane * 16u;
     const unsigned char* gbase[NLMAX];
-    unsigned voff[NLMAX], ldst[NLMAX], vstep[NLMAX];
+    unsigned ldst[NLMAX];
+    long long gstep[NLMAX];
+    const int nfrag = (M + 31) / 32;
+    const long long blkbytes = (long long)nk * NIMG * 1024;          // one 32-row block, all k-steps and images
 #pragma unroll
     for (int j = 0; j < NLMAX; ++j) {
         const int q = wave + 8 * j;
         if (q < NIMG * 4) {
             const int img = q >> 2, blk = q & 3;
-            int row = m0 + blk * 32 + lrow;
-            row = row < M ? row : M - 1;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs + (long long)img * M * K);
+            int fb = f0 + blk;
+            fb = fb < nfrag ? fb : nfrag - 1;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs) + fb * blkbytes + img * 1024;
             ldst[j] = (unsigned)(img * G2_ST_A + blk * 1024);
-            voff[j] = (unsigned)row * (unsigned)K * 2u + lchunk * 16u;
-            vstep[j] = 0u;
+            gstep[j] = -(long long)nk * NIMG * 1024;                  // next tile: the same rows again
         } else {
             const int q2 = q - NIMG * 4;
             const int img = q2 >> 3, blk = q2 & 7;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws + (long long)img * a.N * K);
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws) + (long long)(ct0 * 8 + blk) * blkbytes + img * 1024;
             ldst[j] = (unsigned)(NIMG * G2_ST_A + img * G2_ST_B + blk * 1024);
-            voff[j] = (unsigned)(ct0 * G_COLS + blk * 32 + lrow) * (unsigned)K * 2u + lchunk * 16u;
-            vstep[j] = (unsigned)(cstep * G_COLS) * (unsigned)K * 2u;      // to the next column tile of this workgroup
+            gstep[j] = (long long)(cstep * 8) * blkbytes - (long long)nk * NIMG * 1024;      // to the next column tile of this workgroup
         }
     }
     int lk = 0, lg = 0;                                              // load cursor: k-step in its tile, stage index
@@ -359,21 +241,22 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen2_kernel(const GenArgs a) {
         if (lg >= G) return;
         const unsigned sb = (unsigned)((lg & (G2_NST - 1)) * STAGE);
 #pragma unroll
-        for (int j = 0; j < NLMAX; ++j)
-            if (j < nl) glds16(gbase[j] + (long long)lk * 32, voff[j], sb + ldst[j]);
+        for (int j = 0; j < NLMAX; ++j) {
+            if (j < nl) glds16(gbase[j], voff, sb + ldst[j]);
+            gbase[j] += NIMG * 1024;                                 // next k-step of the same row block
+        }
         ++lg;
         if (++lk == nk) {
             lk = 0;
 #pragma unroll
-            for (int j = 0; j < NLMAX; ++j) voff[j] += vstep[j];
+            for (int j = 0; j < NLMAX; ++j) gbase[j] += gstep[j];
         }
     };
 
     // ---- compute side -----------------------------------------------------------------------------------------------------------
     const int l31 = lane & 31, lh = lane >> 5;
-    const unsigned fo = (unsigned)l31 * 32u + ((unsigned)(lh ^ ((lane >> 3) & 1))) * 16u;
-    const unsigned aoff = (unsigned)(wr * 2) * 1024u + fo;
-    const unsigned boff = (unsigned)(NIMG * G2_ST_A) + (unsigned)(wc * 2) * 1024u + fo;
+    const unsigned aoff = (unsigned)(wr * 2) * 1024u + voff;
+    const unsigned boff = (unsigned)(NIMG * G2_ST_A) + (unsigned)(wc * 2) * 1024u + voff;
 
     auto run = [&](auto nfa_c) {
         constexpr int NFA = decltype(nfa_c)::value;
@@ -832,6 +715,8 @@ int reserve_lds(Kern k, int bytes, const char* what) {
 
 // K chunks of the out-projection: fill the 256 CUs with (64-row tile x chunk) workgroups in whole rounds, at least 8 slabs each
 int out_chunks(long long M, int K) {
+    static const int forced = getenv("SBEV_BF16S_OUT_CHUNKS") ? atoi(getenv("SBEV_BF16S_OUT_CHUNKS")) : 0;      // experiments
+    if (forced > 0 && forced <= K / 32 / 8) return forced;
     const long long nrt = (M + 63) / 64;
     const int max_s = K / 32 / 8 < 1 ? 1 : K / 32 / 8;
     int best = 1;
@@ -846,7 +731,7 @@ int out_chunks(long long M, int K) {
 
 }  // namespace
 
-extern "C" int64_t sbev_bf16s_image_elems(int64_t rows, int K, int nimg) { return rows * K * nimg; }
+extern "C" int64_t sbev_bf16s_image_elems(int64_t rows, int K, int nimg) { return (rows + 31) / 32 * 32 * K * nimg; }
 
 extern "C" int sbev_split_bf16s_rows(const float* X, int64_t ldx, uint16_t* out, int64_t rows, int K, int nimg, sbev_stream_t stream) {
     SBEV_REQUIRE(rows >= 0 && K >= 8 && K % 8 == 0 && (nimg == 2 || nimg == 3), "sbev_split_bf16s_rows: K=%d (multiple of 8), nimg=%d (2 or 3)", K, nimg);
@@ -861,9 +746,9 @@ extern "C" int sbev_split_bf16s_rows(const float* X, int64_t ldx, uint16_t* out,
 }
 
 extern "C" int sbev_pack_bf16s_frags(const float* W, int64_t ldw, uint16_t* out, int N, int K, int nimg, sbev_stream_t stream) {
-    SBEV_REQUIRE(N >= 32 && N % 32 == 0 && K >= 16 && K % 16 == 0 && (nimg == 2 || nimg == 3), "sbev_pack_bf16s_frags: N=%d (multiple of 32), K=%d (multiple of 16), nimg=%d", N, K, nimg);
+    SBEV_REQUIRE(N >= 1 && K >= 16 && K % 16 == 0 && (nimg == 2 || nimg == 3), "sbev_pack_bf16s_frags: N=%d, K=%d (multiple of 16), nimg=%d (2 or 3)", N, K, nimg);
     SBEV_REQUIRE(W && out && ldw >= K && ldw % 4 == 0 && (((uintptr_t)W | (uintptr_t)out) & 15) == 0, "sbev_pack_bf16s_frags: null / unaligned pointer or bad ldw");
-    const long long n = (long long)(N / 32) * (K / 16) * 64;
+    const long long n = (long long)((N + 31) / 32) * (K / 16) * 64;
     const dim3 grid((unsigned)((n + 255) / 256));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (nimg == 3) hipLaunchKernelGGL(pack_frags_kernel<3>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K);
@@ -871,9 +756,11 @@ extern "C" int sbev_pack_bf16s_frags(const float* W, int64_t ldw, uint16_t* out,
     return sbev::check_launch("sbev_pack_bf16s_frags");
 }
 
+static int ntm_of(int64_t M) { return (int)(((M + 31) / 32 + 3) / 4); }      // row tiles of <= 4 fragments
+
 extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {
     return M >= 1 && M <= 0x7fffffffLL / 1024 && N >= 256 && N % 256 == 0 && K >= 32 && K % 32 == 0 && K <= 4096 &&
-           (long long)N * K * 2 < 0x7fffffffLL && M * K * 2 < 0x7fffffffLL;
+           ntm_of(M) <= 256;
 }
 
 extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K,
@@ -886,52 +773,31 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     const int nfrag = (int)((M + 31) / 32);
     const int ntm = (nfrag + 3) / 4;
     GenArgs a{Xs, Ws, bias, Y, (int)M, N, K, (long long)ldy, relu, ntm, nfrag / ntm, nfrag % ntm};
-    const long long tiles = (long long)ntm * (N / G_COLS);
-    SBEV_REQUIRE(tiles <= 0x7fffffffLL, "sbev_linear_bf16s_gen: too many tiles");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     int st;
-    static const bool v1 = getenv("SBEV_BF16S_GEN_V1") != nullptr;       // A/B switch: the one-tile-per-workgroup kernel
-    if (!v1) {
-        static const int cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-            return n;
-        }();
-        // one row tile per workgroup for life: grid = a multiple of ntm, at most the CU count, at most the tile count
-        long long per = cus / ntm < 1 ? 1 : cus / ntm;
-        if (per > N / G_COLS) per = N / G_COLS;
-        const unsigned grid = (unsigned)(per * ntm);
-        if (nimg == 3) {
-            constexpr int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B);
-            st = reserve_lds(gemm_bf16s_gen2_kernel<3>, LDS, "sbev_linear_bf16s_gen");
-            if (st != SBEV_OK) return st;
-            const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-            hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<3>, dim3(grid), dim3(512), LDS, s, a);
-            if (prof) sbev::profile_end(s, e0, e1, 1);
-        } else {
-            constexpr int LDS = G2_NST * 2 * (G2_ST_A + G2_ST_B);
-            st = reserve_lds(gemm_bf16s_gen2_kernel<2>, LDS, "sbev_linear_bf16s_gen");
-            if (st != SBEV_OK) return st;
-            const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-            hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<2>, dim3(grid), dim3(512), LDS, s, a);
-            if (prof) sbev::profile_end(s, e0, e1, 1);
-        }
-        return sbev::check_launch("sbev_linear_bf16s_gen");
-    }
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    // one row tile per workgroup for life: grid = a multiple of ntm, at most the CU count, at most the tile count
+    long long per = cus / ntm < 1 ? 1 : cus / ntm;
+    if (per > N / G_COLS) per = N / G_COLS;
+    const unsigned grid = (unsigned)(per * ntm);
     if (nimg == 3) {
-        constexpr int LDS = 2 * 3 * (G_AIMG + G_BIMG);
-        st = reserve_lds(gemm_bf16s_gen_kernel<3>, LDS, "sbev_linear_bf16s_gen");
+        constexpr int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B);
+        st = reserve_lds(gemm_bf16s_gen2_kernel<3>, LDS, "sbev_linear_bf16s_gen");
         if (st != SBEV_OK) return st;
         const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-        hipLaunchKernelGGL(gemm_bf16s_gen_kernel<3>, dim3((unsigned)tiles), dim3(512), LDS, s, a);
+        hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<3>, dim3(grid), dim3(512), LDS, s, a);
         if (prof) sbev::profile_end(s, e0, e1, 1);
     } else {
-        constexpr int LDS = 2 * 2 * (G_AIMG + G_BIMG);
-        st = reserve_lds(gemm_bf16s_gen_kernel<2>, LDS, "sbev_linear_bf16s_gen");
+        constexpr int LDS = G2_NST * 2 * (G2_ST_A + G2_ST_B);
+        st = reserve_lds(gemm_bf16s_gen2_kernel<2>, LDS, "sbev_linear_bf16s_gen");
         if (st != SBEV_OK) return st;
         const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-        hipLaunchKernelGGL(gemm_bf16s_gen_kernel<2>, dim3((unsigned)tiles), dim3(512), LDS, s, a);
+        hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<2>, dim3(grid), dim3(512), LDS, s, a);
         if (prof) sbev::profile_end(s, e0, e1, 1);
     }
     return sbev::check_launch("sbev_linear_bf16s_gen");

@@ -110,26 +110,26 @@ def split_bf16s_rows(x, nimg=3):
 
 
 def pack_bf16s_frags(w, nimg=3):
-    """fp32 [N, K] -> int16 [N/32, K/16, nimg, 64, 8]: W's bf16 images in v_mfma_f32_32x32x16_bf16 operand order (the
-    out-projection weight format of linear_splitk_bf16s)."""
+    """fp32 [N, K] -> int16 [ceil(N/32), K/16, nimg, 64, 8]: the bf16 images of W in v_mfma_f32_32x32x16_bf16 operand order
+    (a ragged last 32-row block repeats row N - 1) -- the operand format of linear_bf16s_gen and linear_splitk_bf16s."""
     _dev(w)
-    w = w.contiguous()
+    w = w.reshape(-1, w.shape[-1]).contiguous()
     N, K = w.shape
-    out = torch.empty(N // 32, K // 16, nimg, 64, 8, device=w.device, dtype=torch.int16)
+    out = torch.empty((N + 31) // 32, K // 16, nimg, 64, 8, device=w.device, dtype=torch.int16)
     st = _lib.load().sbev_pack_bf16s_frags(_p(w), K, _p(out), N, K, nimg, _stream())
     _lib.check(st, 'sbev_pack_bf16s_frags')
     return out
 
 
-def linear_bf16s_gen(x, w_planes, b, nimg=3, relu=False):
-    """y = act(x @ W.T + b) with W given as split_bf16s_rows planes [nimg, N, K]; x fp32 [.., K] is split here (one small
-    launch).  N % 256 == 0, K % 32 == 0 (the parameter generator's shape)."""
-    _dev(x, w_planes)
-    K, N = x.shape[-1], w_planes.shape[1]
-    xs = split_bf16s_rows(x, nimg)
-    M = xs.shape[1]
+def linear_bf16s_gen(x, w_frags, b, nimg=3, relu=False):
+    """y = act(x @ W.T + b) with W given as pack_bf16s_frags [N/32, K/16, nimg, 64, 8]; x fp32 [.., K] is split and packed
+    here (one small launch).  N % 256 == 0, K % 32 == 0 (the parameter generator's shape)."""
+    _dev(x, w_frags)
+    K, N = x.shape[-1], w_frags.shape[0] * 32
+    xs = pack_bf16s_frags(x, nimg)
+    M = x.numel() // K
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    st = _lib.load().sbev_linear_bf16s_gen(_p(xs), _p(w_planes), _p(b), _p(y), M, N, K, N, int(relu), nimg, _stream())
+    st = _lib.load().sbev_linear_bf16s_gen(_p(xs), _p(w_frags), _p(b), _p(y), M, N, K, N, int(relu), nimg, _stream())
     _lib.check(st, 'sbev_linear_bf16s_gen')
     return y.reshape(*x.shape[:-1], N)
 

@@ -103,7 +103,7 @@ class DecoderRuntime:
         if self.gemm_mode in (GEMM_BF16X6, GEMM_BF16X3S):      # split-bf16 images for csrc/gemm_bf16s.hip (3 or 2 images)
             from . import dense
             nimg = 3 if self.gemm_mode == GEMM_BF16X6 else 2
-            keep['pg_ws'] = dense.split_bf16s_rows(keep['pg_w'], nimg)
+            keep['pg_ws'] = dense.pack_bf16s_frags(keep['pg_w'], nimg)
             keep['op_wp'] = dense.pack_bf16s_frags(keep['op_w'], nimg)
         w = DecoderWeights()
         for k in _WEIGHT_FIELDS:

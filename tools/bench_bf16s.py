@@ -38,7 +38,7 @@ if args.quick:
             N, K = 32768, 256
             x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') / K ** 0.5; b = torch.randn(N, device='cuda')
             y = torch.empty(M, N, device='cuda')
-            ws = dense.split_bf16s_rows(w, nimg); xs = dense.split_bf16s_rows(x, nimg)
+            ws = dense.pack_bf16s_frags(w, nimg); xs = dense.pack_bf16s_frags(x, nimg)
             us = t(lambda: lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, 0, nimg, st))
             line += ' gen x%d %6.1f us' % (6 if nimg == 3 else 3, us)
             N, K = 256, 32768
@@ -60,9 +60,9 @@ for M in args.m:
     err = (dense.linear(x, w, b).double() - ref).abs().max().item()
     print('gen  M=%4d f32-mfma   %7.1f us  %6.1f TF        err %.2e' % (M, us, 2.0 * M * N * K / us / 1e6, err))
     for nimg in (3, 2):
-        ws = dense.split_bf16s_rows(w, nimg)
-        xs = dense.split_bf16s_rows(x, nimg)
-        us_split = t(lambda: dense.split_bf16s_rows(x, nimg))
+        ws = dense.pack_bf16s_frags(w, nimg)
+        xs = dense.pack_bf16s_frags(x, nimg)
+        us_split = t(lambda: dense.pack_bf16s_frags(x, nimg))
         fn = lambda: lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, 0, nimg, st)
         us = t(fn)
         err = (y.double() - ref).abs().max().item()

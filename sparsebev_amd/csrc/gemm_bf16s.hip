@@ -359,6 +359,222 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen2_kernel(const GenArgs a) {
     else run(std::integral_constant<int, 0>{});
 }
 
+// ---- generator, ping-pong version: the two row-halves of a workgroup run one barrier phase apart ------------------------------------
+// PMC of the kernel above (c2, bf16x6, 106 us): the matrix pipe is busy for 49 % of the waves' lifetime, the waves spend 48 % of it
+// stalled on instruction issue and 32 % in s_waitcnt / s_barrier -- the two waves of a SIMD (rows 0-63 and 64-127 of the tile: waves
+// w and w + 4) run in lock-step behind the shared barrier, want the matrix pipe in the same cycles and leave it idle together.
+// Here they alternate: per 16-k stage a wave has a FETCH phase (its share of the LDS-DMA loads three stages ahead, a counted wait,
+// the stage's fragments LDS -> registers, a finished tile's stores) and a COMPUTE phase (the stage's MFMAs, nothing else), with a
+// barrier after each; the second row-half simply takes one extra barrier before its first phase (and the first one after its
+// last), so on every SIMD one wave computes while the other fetches.  A single fragment set per wave is enough (nothing is
+// loaded during COMPUTE), which pays for a second accumulator set: the five small products of a k-step (<= 2^-8 of the sum) are
+// summed apart from the hi x hi product and added once per tile, so the full-magnitude accumulator is rounded once per k-step
+// instead of six times -- measured on the out-projection the error of these kernels is accumulation rounding (it falls as
+// 1 / sqrt(K chunks)), not the dropped 2^-24-class products.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt_n(int n) {          // n wave-uniform, 0 .. 10
+    switch (n) {
+        case 0: wait_vmcnt_imm<0>(); break;
+        case 3: wait_vmcnt_imm<3>(); break;
+        case 4: wait_vmcnt_imm<4>(); break;
+        case 5: wait_vmcnt_imm<5>(); break;
+        case 6: wait_vmcnt_imm<6>(); break;
+        case 8: wait_vmcnt_imm<8>(); break;
+        case 10: wait_vmcnt_imm<10>(); break;
+        default: wait_vmcnt_imm<0>(); break;
+    }
+}
+
+template <int NIMG>
+__global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
+    constexpr int STAGE = NIMG * (G2_ST_A + G2_ST_B);
+    constexpr int NQ = NIMG * 12;                                    // fragments (1 KiB) per stage
+    constexpr int NLMAX = (NQ + 7) / 8;
+    typedef Prods<NIMG> PR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                         // wr: row half = phase group (waves w, w + 4 share a SIMD)
+    const int M = a.M, nk = a.K / 16;
+    const int lw = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int rt = lw % a.ntm, ct0 = lw / a.ntm, cstep = (int)gridDim.x / a.ntm, nct = a.N / G_COLS;
+    const int my_tiles = ct0 < nct ? (nct - ct0 + cstep - 1) / cstep : 0;
+    const int G = my_tiles * nk;                                     // stages of this workgroup
+    if (G == 0) return;
+    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
+    const int nf = a.base + (rt < a.rem ? 1 : 0);
+    const int m0 = f0 * 32;
+    int nfa = nf - 2 * wr;                                           // this wave's row fragments: 0, 1 or 2 (fixed for its life)
+    nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
+    const int nl = (NQ - wave + 7) / 8;                              // this wave's loads per stage
+
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned char* gbase[NLMAX];
+    unsigned ldst[NLMAX];
+    long long gstep[NLMAX];
+    const int nfrag = (M + 31) / 32;
+    const long long blkbytes = (long long)nk * NIMG * 1024;          // one 32-row block, all k-steps and images
+#pragma unroll
+    for (int j = 0; j < NLMAX; ++j) {
+        const int q = wave + 8 * j;
+        if (q < NIMG * 4) {
+            const int img = q >> 2, blk = q & 3;
+            int fb = f0 + blk;
+            fb = fb < nfrag ? fb : nfrag - 1;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs) + fb * blkbytes + img * 1024;
+            ldst[j] = (unsigned)(img * G2_ST_A + blk * 1024);
+            gstep[j] = -(long long)nk * NIMG * 1024;
+        } else {
+            const int q2 = q - NIMG * 4;
+            const int img = q2 >> 3, blk = q2 & 7;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws) + (long long)(ct0 * 8 + blk) * blkbytes + img * 1024;
+            ldst[j] = (unsigned)(NIMG * G2_ST_A + img * G2_ST_B + blk * 1024);
+            gstep[j] = (long long)(cstep * 8) * blkbytes - (long long)nk * NIMG * 1024;
+        }
+    }
+    int lk = 0, lg = 0;                                              // load cursor: k-step in its tile, next stage to issue
+    auto issue_next = [&]() {
+        if (lg >= G) return;
+        const unsigned sb = (unsigned)((lg & (G2_NST - 1)) * STAGE);
+#pragma unroll
+        for (int j = 0; j < NLMAX; ++j) {
+            if (j < nl) glds16(gbase[j], voff, sb + ldst[j]);
+            gbase[j] += NIMG * 1024;
+        }
+        ++lg;
+        if (++lk == nk) {
+            lk = 0;
+#pragma unroll
+            for (int j = 0; j < NLMAX; ++j) gbase[j] += gstep[j];
+        }
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned aoff = (unsigned)(wr * 2) * 1024u + voff;
+    const unsigned boff = (unsigned)(NIMG * G2_ST_A) + (unsigned)(wc * 2) * 1024u + voff;
+
+    auto run = [&](auto nfa_c) {
+        constexpr int NFA = decltype(nfa_c)::value;
+        constexpr int NFR = NFA > 0 ? NFA : 1;
+        bf16x8 xf[NFR][NIMG], wf[2][NIMG];
+        f32x16 acc[NFR][2], accs[NFR][2];                            // hi x hi (+ bias) | the small products
+        auto init_acc = [&](int ti) {                                // tile ti of this workgroup: its bias slice waits in LDS
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + G2_NST * STAGE + (ti * G_COLS + (wc * 2 + fb) * 32 + 8 * gq + 4 * lh) * 4);
+#pragma unroll
+                    for (int fa = 0; fa < NFR; ++fa)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc[fa][fb][4 * gq + e] = bv[e]; accs[fa][fb][4 * gq + e] = 0.f; }
+                }
+        };
+        auto store_tile = [&](int n0) {                              // acc already holds hi x hi + small products
+            if constexpr (NFA > 0) {
+                if (a.relu) {                                        // one uniform branch, not one per store
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[fa][fb][e] = fmaxf(acc[fa][fb][e], 0.f);
+                }
+#pragma unroll
+                for (int fa = 0; fa < NFA; ++fa) {
+                    const int row = m0 + (wr * 2 + fa) * 32 + l31;
+                    if (row < M SBEV_EXP_STORE_COND) {
+                        float* y = a.Y + (long long)row * a.ldy + n0 + wc * 64 + 4 * lh;
+#pragma unroll
+                        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                const f32x4 v = {acc[fa][fb][4 * gq], acc[fa][fb][4 * gq + 1], acc[fa][fb][4 * gq + 2], acc[fa][fb][4 * gq + 3]};
+                                *reinterpret_cast<f32x4*>(y + fb * 32 + 8 * gq) = v;
+                            }
+                    }
+                }
+            }
+        };
+        int cn0 = ct0 * G_COLS, ck = 0, ti = 0;
+        bool pending = false;                                        // a finished tile (columns cn0) waits for its stores
+        // the bias slices of this workgroup's column tiles -> LDS (behind the stage ring), once: a global load per tile would
+        // make hipcc wait vmcnt(0) in the middle of the LDS-DMA pipeline
+        for (int i = tid; i < my_tiles * G_COLS; i += 512) {
+            const int t = i / G_COLS, c = i - t * G_COLS;
+            reinterpret_cast<float*>(lds + G2_NST * STAGE)[i] = a.bias ? a.bias[(ct0 + t * cstep) * G_COLS + c] : 0.f;
+        }
+        __syncthreads();
+        init_acc(0);
+        issue_next();
+        issue_next();
+        issue_next();
+        wait_vmcnt_imm<0>();
+        __syncthreads();
+        if (wr == 1) __syncthreads();                                // the second row-half runs one phase behind
+        for (int g = 0; g < G; ++g) {
+            // ---- FETCH(g): loads of stage g + 3; stage g + 1 of this wave landed (only newer loads may be outstanding: vector
+            // loads return in order; a store in flight can only make the wait longer); fragments of stage g -> registers
+            issue_next();
+            {
+                const int hi = lg - 1, need = g + 1 < G ? g + 1 : g;
+                wait_vmcnt_n(hi > need ? (hi - need) * nl : 0);
+            }
+            if constexpr (NFA > 0) {
+                const unsigned char* st = lds + (g & (G2_NST - 1)) * STAGE;
+#pragma unroll
+                for (int img = 0; img < NIMG; ++img) {
+                    wf[0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B);
+                    wf[1][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B + 1024);
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + img * G2_ST_A + fa * 1024);
+                }
+            }
+            if (pending) {                                           // the previous tile's stores ride in this phase
+                store_tile(cn0);
+                cn0 += cstep * G_COLS;
+                ++ti;
+                init_acc(ti < my_tiles ? ti : 0);
+                pending = false;
+            }
+            __syncthreads();
+            // ---- COMPUTE(g): nothing but MFMAs (the partner wave of this SIMD is in its FETCH phase)
+            if constexpr (NFA > 0) {
+#pragma unroll
+                for (int p = 0; p < PR::N - 1; ++p)
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                        for (int fb = 0; fb < 2; ++fb)
+                            accs[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], accs[fa][fb]);
+#pragma unroll
+                for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb)
+                        acc[fa][fb] = SBEV_MFMA(wf[fb][0], xf[fa][0], acc[fa][fb]);
+            }
+            if (++ck == nk) {
+                ck = 0;
+                pending = true;
+                if constexpr (NFA > 0) {
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                        for (int fb = 0; fb < 2; ++fb) acc[fa][fb] += accs[fa][fb];
+                }
+            }
+            __syncthreads();
+        }
+        if (wr == 0) __syncthreads();
+        if (pending) store_tile(cn0);
+    };
+    if (nfa == 2) run(std::integral_constant<int, 2>{});
+    else if (nfa == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+}
+
 // ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
 struct OutArgs {
     const float* X;              // [M, ldx] fp32
@@ -370,159 +586,6 @@ struct OutArgs {
 };
 
 constexpr int O_IMG = 64 * 64;                  // bytes of one image of one half's stage (64 rows x 32 k)
-
-template <int NIMG>
-__global__ __launch_bounds__(512) void gemm_bf16s_out_kernel(const OutArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int HSTAGE = NIMG * O_IMG;        // one half's stage
-    typedef Prods<NIMG> PR;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, wc = wave & 3;  // K half of the chunk, 64-column quarter
-    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
-    const int M = a.M;
-    const int m0 = rt * 64;
-    int nfa = (M - m0 + 31) / 32;               // row fragments of this tile: 1 or 2
-    nfa = nfa > 2 ? 2 : nfa;
-    // slabs (32 k) of this chunk, split between the two halves
-    const int nslab = a.K / 32;
-    const int c0 = (int)((long long)nslab * chunk / a.S), c1 = (int)((long long)nslab * (chunk + 1) / a.S);
-    const int n_all = c1 - c0, n0h = (n_all + 1) / 2;
-    const int sb = half == 0 ? c0 : c0 + n0h;            // first slab of this half
-    const int nh = half == 0 ? n0h : n_all - n0h;        // its slabs (the other half may have one more)
-    const int nit = n0h;
-
-    // --- X staging: thread t' of a half loads 8 floats of row t' >> 2, splits them, writes NIMG 16-byte chunks ------------------
-    const int th = tid & 255;
-    const int srow = th >> 2, skq = th & 3;
-    int grow = m0 + srow;
-    grow = grow < M ? grow : M - 1;
-    const float* xp = a.X + (long long)grow * a.ldx + skq * 8;
-    const unsigned wofs = (unsigned)(srow * 64 + ((skq ^ ((srow >> 2) & 3)) * 16));
-    unsigned char* hst = lds + half * (2 * HSTAGE);      // this half's two stages
-    const int last_slab = nh > 0 ? sb + nh - 1 : c1 - 1;
-    auto loadx = [&](int i, f32x4& v0, f32x4& v1) {      // slab i of this half (clamped: a dummy past the end)
-        int sl = sb + i;
-        sl = sl < last_slab ? sl : last_slab;
-#ifdef SBEV_EXP_HOTX
-        sl = sl & 7;
-#endif
-        const float* p = xp + (long long)sl * 32;
-        v0 = *reinterpret_cast<const f32x4*>(p);
-        v1 = *reinterpret_cast<const f32x4*>(p + 4);
-    };
-    auto stagex = [&](int st, const f32x4 v0, const f32x4 v1) {
-        u32x4 im[NIMG];
-        split8<NIMG>(v0, v1, im);
-#pragma unroll
-        for (int img = 0; img < NIMG; ++img) *reinterpret_cast<u32x4*>(hst + st * HSTAGE + img * O_IMG + wofs) = im[img];
-    };
-
-    // --- W fragments of this wave's two 32-column blocks, one k-step at a time ---------------------------------------------------
-    const int KS = a.K / 16;
-    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
-    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
-    const int last_ks = 2 * last_slab + 1;
-    auto loadw = [&](int kk, bf16x8 (&w)[2][NIMG]) {     // k-step kk of this half (clamped)
-        int ks = 2 * sb + kk;
-        ks = ks < last_ks ? ks : last_ks;
-#ifdef SBEV_EXP_HOTW
-        ks = ks & 15;
-#endif
-        const long long o = (long long)ks * NIMG * 64 * 8;
-#pragma unroll
-        for (int img = 0; img < NIMG; ++img) {
-            w[0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
-            w[1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int fa = 0; fa < 2; ++fa)
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
-
-    const int l31 = lane & 31, lh = lane >> 5;
-    const unsigned swz = (unsigned)((lane >> 2) & 3);
-    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
-    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
-
-    auto kstep = [&](int st, int j, const bf16x8 (&w)[2][NIMG]) {
-        const unsigned char* A = hst + st * HSTAGE + (j ? fo1 : fo0);
-        bf16x8 xf[2][NIMG];
-#pragma unroll
-        for (int img = 0; img < NIMG; ++img) {
-            xf[0][img] = *reinterpret_cast<const bf16x8*>(A + img * O_IMG);
-            xf[1][img] = *reinterpret_cast<const bf16x8*>(A + img * O_IMG + 32 * 64);
-        }
-        if (nfa == 2) {
-#pragma unroll
-            for (int p = 0; p < PR::N; ++p)
-#pragma unroll
-                for (int fa = 0; fa < 2; ++fa)
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb)
-                        acc[fa][fb] = SBEV_MFMA(w[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);
-        } else {
-#pragma unroll
-            for (int p = 0; p < PR::N; ++p)
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb)
-                    acc[0][fb] = SBEV_MFMA(w[fb][PR::ib(p)], xf[0][PR::ia(p)], acc[0][fb]);
-        }
-    };
-
-    // --- pipeline: X two slabs ahead in registers / one ahead in LDS, W one k-step ahead in registers ---------------------------
-    f32x4 x0, x1;
-    bf16x8 wA[2][NIMG], wB[2][NIMG];
-    loadx(0, x0, x1);
-    loadw(0, wA);
-    stagex(0, x0, x1);
-    loadx(1, x0, x1);
-    for (int it = 0; it < nit; ++it) {
-        __syncthreads();                       // slab `it` is staged; nobody reads the other stage any more
-        if (it + 1 < nit) stagex((it + 1) & 1, x0, x1);
-        loadx(it + 2, x0, x1);
-        loadw(2 * it + 1, wB);
-        if (it < nh) kstep(it & 1, 0, wA);
-        loadw(2 * it + 2, wA);
-        if (it < nh) kstep(it & 1, 1, wB);
-    }
-
-    // --- fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab ----------------------------------------
-    __syncthreads();
-    f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * 16) * 64 + lane;       // [wc][fa][fb][g][lane] float4
-    if (half == 1) {
-#pragma unroll
-        for (int fa = 0; fa < 2; ++fa)
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
-    }
-    __syncthreads();
-    if (half == 1) return;
-    float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
-#pragma unroll
-    for (int fa = 0; fa < 2; ++fa) {
-        const int row = m0 + fa * 32 + l31;
-        if (fa < nfa && row < M SBEV_EXP_STORE_COND) {
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
-                    const f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
-                    *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
-                }
-        }
-    }
-}
 
 // ---- out-projection, version 2: 3-deep X stage ring, fragments one k-step ahead, X two slabs ahead in registers ------------------
 // Same ablation as for the generator (c2, bf16x6: 104 us; without MFMAs 61, with neither MFMAs nor stores 57): the X stream (118 MB
@@ -703,6 +766,175 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out2_kernel(const OutArgs a) {
     else run(std::integral_constant<int, 1>{});
 }
 
+// ---- out-projection, ping-pong version: the two K halves of a workgroup run one barrier phase apart ----------------------------------
+// PMC of the kernel above (c2, bf16x6, 100 us): matrix pipe busy 62 % of the waves' lifetime, 55 % of it spent stalled on issue, 27 %
+// in waits -- again the two waves of a SIMD (the same 64 columns of the two K halves: waves w and w + 4) in lock-step.  As in the
+// generator a slab now has a FETCH phase (fragments of the slab LDS -> registers; split + LDS write of the slab two ahead; the X
+// loads four ahead) and a COMPUTE phase (its 48 MFMAs, then the W fragment loads of the next slab, which land during the following
+// FETCH), a barrier after each, and the second K half takes one extra barrier up front: on every SIMD one wave computes while the
+// other fetches.  The halves never touch each other's LDS ring; they meet only in the final fold.
+template <int NIMG>
+__global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int HSTAGE = NIMG * O_IMG;        // one half's stage
+    constexpr int NST = 3;
+    typedef Prods<NIMG> PR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wc = wave & 3;  // K half of the chunk = phase group, 64-column quarter
+    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
+    const int M = a.M;
+    const int m0 = rt * 64;
+    const int nfa = (M - m0) > 32 ? 2 : 1;      // row fragments of this tile
+    const int nslab = a.K / 32;
+    const int c0 = (int)((long long)nslab * chunk / a.S), c1 = (int)((long long)nslab * (chunk + 1) / a.S);
+    const int n_all = c1 - c0, n0h = (n_all + 1) / 2;
+    const int sb = half == 0 ? c0 : c0 + n0h;            // first slab of this half
+    const int nh = half == 0 ? n0h : n_all - n0h;        // its slabs (half 0 may have one more)
+
+    const int th = tid & 255;
+    const int srow = th >> 2, skq = th & 3;
+    int grow = m0 + srow;
+    grow = grow < M ? grow : M - 1;
+    const float* xp = a.X + (long long)grow * a.ldx + skq * 8;
+    const unsigned wofs = (unsigned)(srow * 64 + ((skq ^ ((srow >> 2) & 3)) * 16));
+    unsigned char* hst = lds + half * (NST * HSTAGE);    // this half's stage ring
+    const int last_slab = nh > 0 ? sb + nh - 1 : c1 - 1;
+    auto loadx = [&](int i, f32x4& v0, f32x4& v1) {      // slab i of this half (clamped: a dummy past the end)
+        int sl = sb + i;
+        sl = sl < last_slab ? sl : last_slab;
+#ifdef SBEV_EXP_HOTX
+        sl = sl & 7;
+#endif
+        const float* p = xp + (long long)sl * 32;
+        v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));         // streamed once: keep L2 for W
+        v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    };
+    auto stagex = [&](int i, const f32x4 v0, const f32x4 v1) {       // slab i -> ring slot i % 3
+        u32x4 im[NIMG];
+        split8<NIMG>(v0, v1, im);
+        unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) *reinterpret_cast<u32x4*>(st + img * O_IMG) = im[img];
+    };
+    const int KS = a.K / 16;
+    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
+    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
+    auto loadw = [&](int i, bf16x8 (&w)[2][2][NIMG]) {   // both k-steps of slab i of this half (clamped)
+        int sl = sb + i;
+        sl = sl < last_slab ? sl : last_slab;
+#ifdef SBEV_EXP_HOTW
+        sl = sl & 7;
+#endif
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long o = (long long)(2 * sl + j) * NIMG * 64 * 8;
+#pragma unroll
+            for (int img = 0; img < NIMG; ++img) {
+                w[j][0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
+                w[j][1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
+            }
+        }
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned swz = (unsigned)((lane >> 2) & 3);
+    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
+    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
+
+    auto run = [&](auto nfa_c) {
+        constexpr int NFA = decltype(nfa_c)::value;
+        f32x16 acc[NFA][2];
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+        f32x4 xa0, xa1, xb0, xb1;                             // X register ring: slab s + 2 waits in a (s even) / b (s odd)
+        bf16x8 w[2][2][NIMG], xf[2][NFA][NIMG];               // [k-step][fragment][image]
+        // prologue: slabs 0 and 1 staged, 2 and 3 requested, W of slab 0 requested
+        loadx(0, xa0, xa1);
+        loadx(1, xb0, xb1);
+        loadw(0, w);
+        stagex(0, xa0, xa1);
+        loadx(2, xa0, xa1);
+        stagex(1, xb0, xb1);
+        loadx(3, xb0, xb1);
+        __syncthreads();
+        if (half == 1) __syncthreads();                       // the second K half runs one phase behind
+#define SBEV_O3_SLAB(S_, X0, X1)                                                                            \
+        {                                                                                                   \
+            /* FETCH */                                                                                     \
+            {                                                                                               \
+                const unsigned char* A = hst + ((S_) % NST) * HSTAGE;                                       \
+                _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
+                    _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa) {                                    \
+                        xf[0][fa][img] = *reinterpret_cast<const bf16x8*>(A + fo0 + img * O_IMG + fa * 32 * 64); \
+                        xf[1][fa][img] = *reinterpret_cast<const bf16x8*>(A + fo1 + img * O_IMG + fa * 32 * 64); \
+                    }                                                                                       \
+                if ((S_) >= nh) {      /* the unequal last slab: this half has none left and multiplies zeros */ \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                        _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                  \
+                            _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                          \
+                                _Pragma("unroll") for (int e = 0; e < 8; ++e) xf[j][fa][img][e] = (__bf16)0.f; \
+                }                                                                                           \
+                stagex((S_) + 2, X0, X1);                                                                   \
+                loadx((S_) + 4, X0, X1);                                                                    \
+            }                                                                                               \
+            __syncthreads();                                                                                \
+            /* COMPUTE */                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+                _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                           \
+                    _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                      \
+                        _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                    \
+                            acc[fa][fb] = SBEV_MFMA(w[j][fb][PR::ib(p)], xf[j][fa][PR::ia(p)], acc[fa][fb]); \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            loadw((S_) + 1, w);                                                                             \
+            __syncthreads();                                                                                \
+        }
+        int sl = 0;
+        for (; sl + 1 < n0h; sl += 2) {
+            SBEV_O3_SLAB(sl, xa0, xa1)
+            SBEV_O3_SLAB(sl + 1, xb0, xb1)
+        }
+        if (sl < n0h) SBEV_O3_SLAB(sl, xa0, xa1)
+#undef SBEV_O3_SLAB
+        if (half == 0) __syncthreads();
+        // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab
+        __syncthreads();
+        f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * 16) * 64 + lane;       // [wc][fa][fb][g][lane] float4
+        if (half == 1) {
+#pragma unroll
+            for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+        }
+        __syncthreads();
+        if (half == 1) return;
+        float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa) {
+            const int row = m0 + fa * 32 + l31;
+            if (row < M SBEV_EXP_STORE_COND) {
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
+                        const f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
+                        *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
+                    }
+            }
+        }
+    };
+    if (nfa == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
 template <typename Kern>
 int reserve_lds(Kern k, int bytes, const char* what) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -785,6 +1017,38 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     long long per = cus / ntm < 1 ? 1 : cus / ntm;
     if (per > N / G_COLS) per = N / G_COLS;
     const unsigned grid = (unsigned)(per * ntm);
+    static const bool v2 = getenv("SBEV_BF16S_GEN_V2") != nullptr;       // A/B switch: the lock-step kernel
+    if (!v2) {
+        // the bias slices of a workgroup's column tiles wait in LDS behind the stage ring: at most 16 tiles (16 KiB) per launch,
+        // wider matrices take several launches over column ranges
+        const int nct = N / G_COLS;
+        const long long max_ct = per * 16;
+        for (long long c0 = 0; c0 < nct; c0 += max_ct) {
+            const int nc = (int)(nct - c0 < max_ct ? nct - c0 : max_ct);
+            GenArgs ac = a;
+            ac.Ws = Ws + c0 * 8 * (long long)(K / 16) * nimg * 512;      // 8 fragment blocks of 32 columns per tile
+            ac.bias = bias ? bias + c0 * G_COLS : nullptr;
+            ac.Y = Y + c0 * G_COLS;
+            ac.N = nc * G_COLS;
+            const long long pc = per < nc ? per : nc;
+            const unsigned gridc = (unsigned)(pc * ntm);
+            const int bias_bytes = (int)((nc + pc - 1) / pc) * G_COLS * 4;
+            const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+            if (nimg == 3) {
+                const int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B) + bias_bytes;
+                st = reserve_lds(gemm_bf16s_gen3_kernel<3>, LDS, "sbev_linear_bf16s_gen");
+                if (st != SBEV_OK) return st;
+                hipLaunchKernelGGL(gemm_bf16s_gen3_kernel<3>, dim3(gridc), dim3(512), LDS, s, ac);
+            } else {
+                const int LDS = G2_NST * 2 * (G2_ST_A + G2_ST_B) + bias_bytes;
+                st = reserve_lds(gemm_bf16s_gen3_kernel<2>, LDS, "sbev_linear_bf16s_gen");
+                if (st != SBEV_OK) return st;
+                hipLaunchKernelGGL(gemm_bf16s_gen3_kernel<2>, dim3(gridc), dim3(512), LDS, s, ac);
+            }
+            if (prof) sbev::profile_end(s, e0, e1, 1);
+        }
+        return sbev::check_launch("sbev_linear_bf16s_gen");
+    }
     if (nimg == 3) {
         constexpr int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B);
         st = reserve_lds(gemm_bf16s_gen2_kernel<3>, LDS, "sbev_linear_bf16s_gen");
@@ -823,40 +1087,23 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
     SBEV_REQUIRE(wgs <= 0x7fffffffLL, "sbev_linear_splitk_bf16s: too many workgroups");
     hipEvent_t e0, e1;
     int st;
-    static const bool v1 = getenv("SBEV_BF16S_OUT_V1") != nullptr;       // A/B switch: the un-pipelined kernel
-    if (!v1) {
-        if (nimg == 3) {
-            constexpr int LDS = 2 * 3 * 3 * O_IMG;      // 2 halves x 3 stages x 3 images x 4 KiB = 72 KiB (>= the 64 KiB fold buffer)
-            st = reserve_lds(gemm_bf16s_out2_kernel<3>, LDS, "sbev_linear_splitk_bf16s");
-            if (st != SBEV_OK) return st;
-            const bool prof = profile_begin(s, &e0, &e1, 2);
-            hipLaunchKernelGGL(gemm_bf16s_out2_kernel<3>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
-            if (prof) profile_end(s, e0, e1, 2);
-        } else {
-            constexpr int LDS = 65536;                  // 48 KiB of stages, 64 KiB fold buffer
-            st = reserve_lds(gemm_bf16s_out2_kernel<2>, LDS, "sbev_linear_splitk_bf16s");
-            if (st != SBEV_OK) return st;
-            const bool prof = profile_begin(s, &e0, &e1, 2);
-            hipLaunchKernelGGL(gemm_bf16s_out2_kernel<2>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
-            if (prof) profile_end(s, e0, e1, 2);
-        }
-        return check_launch("sbev_linear_splitk_bf16s (gemm)");
+    static const bool v2 = getenv("SBEV_BF16S_OUT_V2") != nullptr;       // A/B switch: the lock-step kernel
+    constexpr int LDS3 = 2 * 3 * 3 * O_IMG;     // 2 halves x 3 stages x 3 images x 4 KiB = 72 KiB (>= the 64 KiB fold buffer)
+    constexpr int LDS2 = 65536;                 // two images: 48 KiB of stages, 64 KiB fold buffer
+#define SBEV_LAUNCH_OUT(KERN, LDSB)                                                              \
+    {                                                                                            \
+        st = reserve_lds(KERN, LDSB, "sbev_linear_splitk_bf16s");                                \
+        if (st != SBEV_OK) return st;                                                            \
+        const bool prof = profile_begin(s, &e0, &e1, 2);                                         \
+        hipLaunchKernelGGL(KERN, dim3((unsigned)wgs), dim3(512), LDSB, s, a);                    \
+        if (prof) profile_end(s, e0, e1, 2);                                                     \
     }
-    if (nimg == 3) {
-        constexpr int LDS = 65536;      // max(2 halves x 2 stages x 3 images x 4 KiB = 48 KiB, fold buffer 64 KiB)
-        st = reserve_lds(gemm_bf16s_out_kernel<3>, LDS, "sbev_linear_splitk_bf16s");
-        if (st != SBEV_OK) return st;
-        const bool prof = profile_begin(s, &e0, &e1, 2);
-        hipLaunchKernelGGL(gemm_bf16s_out_kernel<3>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
-        if (prof) profile_end(s, e0, e1, 2);
+    if (!v2) {
+        if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<3>, LDS3) else SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<2>, LDS2)
     } else {
-        constexpr int LDS = 65536;
-        st = reserve_lds(gemm_bf16s_out_kernel<2>, LDS, "sbev_linear_splitk_bf16s");
-        if (st != SBEV_OK) return st;
-        const bool prof = profile_begin(s, &e0, &e1, 2);
-        hipLaunchKernelGGL(gemm_bf16s_out_kernel<2>, dim3((unsigned)wgs), dim3(512), LDS, s, a);
-        if (prof) profile_end(s, e0, e1, 2);
+        if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out2_kernel<3>, LDS3) else SBEV_LAUNCH_OUT(gemm_bf16s_out2_kernel<2>, LDS2)
     }
+#undef SBEV_LAUNCH_OUT
     return check_launch("sbev_linear_splitk_bf16s (gemm)");
 }
 }  // namespace sbev

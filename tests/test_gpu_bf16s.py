@@ -127,7 +127,7 @@ def test_out_projection_bf16x6_not_narrower_than_f32_mfma():
 
 @pytest.mark.parametrize('nimg', [3, 2])
 @pytest.mark.parametrize('M', [1, 31, 32, 33, 97, 129, 900, 1600, 3600])
-@pytest.mark.parametrize('N,K,relu,use_bias', [(512, 256, False, True), (256, 32, True, True), (1024, 96, False, False)])
+@pytest.mark.parametrize('N,K,relu,use_bias', [(512, 256, False, True), (256, 32, True, True), (1024, 96, False, False), (77824, 256, False, True)])
 def test_generator_kernel_ragged_rows(M, N, K, relu, use_bias, nimg):
     """every row-fragment remainder (M % 32), 1..4 fragments per row tile and both waves' shares of a tile, short and odd K."""
     x, w = _rand((M, K), M + N), _rand((N, K), M + K, K ** -0.5)
@@ -141,7 +141,7 @@ def test_generator_kernel_ragged_rows(M, N, K, relu, use_bias, nimg):
     ref = x.double() @ w.double().t() + (b.double() if use_bias else 0.0)
     if relu:
         ref = ref.clamp_min(0)
-    tol = 2e-6 if nimg == 3 else 6e-5
+    tol = 1e-5 if nimg == 3 else 6e-5          # fp32 class (the exact kernel: 9e-6 on outputs this size) / the 2^-16 class
     assert (y.double() - ref).abs().max().item() < tol
 
 

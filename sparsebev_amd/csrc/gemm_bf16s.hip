@@ -40,6 +40,17 @@
 #define SBEV_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 #endif
 
+#ifdef SBEV_EXP_TRACE            // per-phase shader-clock stamps of waves 0 and 4 of workgroup 0 (tools/exp/trace_bf16s.py)
+__device__ unsigned long long g_sbev_trace[2][512][8];
+#define SBEV_TRACE(G_, SLOT_)                                                                               \
+    if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && (G_) < 512) g_sbev_trace[wave >> 2][G_][SLOT_] = __builtin_readcyclecounter();
+extern "C" int sbev_debug_trace_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbev_trace), sizeof(g_sbev_trace));
+}
+#else
+#define SBEV_TRACE(G_, SLOT_)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -155,210 +166,22 @@ struct GenArgs {
     int ntm, base, rem;          // row tiles: the first `rem` have base + 1 fragments of 32 rows, the others `base`
 };
 
-constexpr int G_ROWS = 128, G_COLS = 256;
+constexpr int G_COLS = 256;                     // columns of a workgroup tile (8 fragments); rows: 128 or 256 (RF)
 
-// ---- generator: persistent workgroups, 16-k stages in a 4-deep LDS ring, fragments one stage ahead ----------------------------------
-// History (c2, bf16x6): the first version -- one 128 x 256 tile per workgroup, 32-k slabs, two LDS stages
-// filled from ROW-MAJOR bf16 planes, one barrier per slab -- ran 116 us; without its stores 93, without its MFMAs 73, with neither
-// 50: the three parts add up, NOTHING overlapped (one workgroup per CU, every wave in the same phase behind the barrier, the
-// fragment reads of a k-step in front of its MFMAs, the 128 KB epilogue of a tile before the next tile's first load), and the
-// 64-byte-per-row pieces of a row-major operand made every LDS-DMA instruction touch 16 cache lines (32 at 16-k stages).  Here
-//   * both operands are pre-packed in MFMA fragment order (sbev_pack_bf16s_frags): a stage is made of whole 1-KiB fragments, an
-//     LDS-DMA instruction copies one of them verbatim (8 full cache lines, lane-linear) and a ds_read_b128 at lane x 16 reads
-//     it back conflict-free -- no swizzle, no address arithmetic per lane;
-//   * a workgroup is persistent (grid = CUs) and walks its tiles as ONE stream of 16-k stages: the LDS-DMA loads run three stages
-//     ahead across tile boundaries, the epilogue stores of a tile drain under the next tile's MFMAs;
-//   * the fragments of stage g + 1 are read (interleaved 1 : 2 by sched_group_barrier) among the MFMAs of stage g -- legal because
-//     the ring is 4 deep: stage g + 1 was published by the barrier at the top of iteration g, stage g + 3 is being filled;
-//   * counted waits: at the top of iteration g only the newest stage's loads of this wave may be outstanding (vector loads
-//     return in order, so "at most n outstanding" = everything older than the newest n has landed; stores in flight can only
-//     make the wait more conservative, and the two iterations behind an epilogue skip it: the epilogue drained the queue).
-constexpr int G2_ST_A = G_ROWS * 32, G2_ST_B = G_COLS * 32;      // bytes of one image of one 16-k stage (32 B per row)
-constexpr int G2_NST = 4;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-}
-
-template <int NIMG>
-__global__ __launch_bounds__(512) void gemm_bf16s_gen2_kernel(const GenArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
-    constexpr int STAGE = NIMG * (G2_ST_A + G2_ST_B);
-    constexpr int NQ = NIMG * 12;                                    // wave-loads (32 rows x 32 B) per stage
-    constexpr int NLMAX = (NQ + 7) / 8;
-    typedef Prods<NIMG> PR;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int M = a.M, K = a.K, nk = K / 16;
-    // A workgroup keeps ONE row tile for its whole life (grid is a multiple of ntm) and walks column tiles: the fragment count
-    // of each wave is then a kernel-lifetime constant and the stage loop is instantiated per count (a per-tile branch around
-    // the MFMA block made hipcc copy all 64 accumulators per stage).
-    const int lw = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-    const int rt = lw % a.ntm, ct0 = lw / a.ntm, cstep = (int)gridDim.x / a.ntm, nct = a.N / G_COLS;
-    const int my_tiles = ct0 < nct ? (nct - ct0 + cstep - 1) / cstep : 0;
-    const int G = my_tiles * nk;                                     // stages of this workgroup (even: K % 32 == 0)
-    if (G == 0) return;
-    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
-    const int nf = a.base + (rt < a.rem ? 1 : 0);
-    const int m0 = f0 * 32;
-    int nfa = nf - 2 * wr;                                           // this wave's row fragments: 0, 1 or 2
-    nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
-    const int nl = (NQ - wave + 7) / 8;                              // this wave's loads per stage
-
-    // ---- load cursor: load q = wave + 8 j is one fragment = (image, 32-row block) of A (this tile's rows: fixed) or of B (the
-    // column tile); in memory the fragments of a row block are [k-step][image][1 KiB] --------------------------------------------
-    const unsigned voff = (unsigned)lane * 16u;
-    const unsigned char* gbase[NLMAX];
-    unsigned ldst[NLMAX];
-    long long gstep[NLMAX];
-    const int nfrag = (M + 31) / 32;
-    const long long blkbytes = (long long)nk * NIMG * 1024;          // one 32-row block, all k-steps and images
-#pragma unroll
-    for (int j = 0; j < NLMAX; ++j) {
-        const int q = wave + 8 * j;
-        if (q < NIMG * 4) {
-            const int img = q >> 2, blk = q & 3;
-            int fb = f0 + blk;
-            fb = fb < nfrag ? fb : nfrag - 1;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs) + fb * blkbytes + img * 1024;
-            ldst[j] = (unsigned)(img * G2_ST_A + blk * 1024);
-            gstep[j] = -(long long)nk * NIMG * 1024;                  // next tile: the same rows again
-        } else {
-            const int q2 = q - NIMG * 4;
-            const int img = q2 >> 3, blk = q2 & 7;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws) + (long long)(ct0 * 8 + blk) * blkbytes + img * 1024;
-            ldst[j] = (unsigned)(NIMG * G2_ST_A + img * G2_ST_B + blk * 1024);
-            gstep[j] = (long long)(cstep * 8) * blkbytes - (long long)nk * NIMG * 1024;      // to the next column tile of this workgroup
-        }
-    }
-    int lk = 0, lg = 0;                                              // load cursor: k-step in its tile, stage index
-    auto issue_next = [&]() {
-        if (lg >= G) return;
-        const unsigned sb = (unsigned)((lg & (G2_NST - 1)) * STAGE);
-#pragma unroll
-        for (int j = 0; j < NLMAX; ++j) {
-            if (j < nl) glds16(gbase[j], voff, sb + ldst[j]);
-            gbase[j] += NIMG * 1024;                                 // next k-step of the same row block
-        }
-        ++lg;
-        if (++lk == nk) {
-            lk = 0;
-#pragma unroll
-            for (int j = 0; j < NLMAX; ++j) gbase[j] += gstep[j];
-        }
-    };
-
-    // ---- compute side -----------------------------------------------------------------------------------------------------------
-    const int l31 = lane & 31, lh = lane >> 5;
-    const unsigned aoff = (unsigned)(wr * 2) * 1024u + voff;
-    const unsigned boff = (unsigned)(NIMG * G2_ST_A) + (unsigned)(wc * 2) * 1024u + voff;
-
-    auto run = [&](auto nfa_c) {
-        constexpr int NFA = decltype(nfa_c)::value;
-        constexpr int NFR = NFA > 0 ? NFA : 1;
-        bf16x8 xf[2][NFR][NIMG], wf[2][2][NIMG];                     // [set][fragment][image]
-        f32x16 acc[NFR][2];
-        auto read_frags = [&](int g, int set) {
-            if constexpr (NFA > 0) {
-                const unsigned char* st = lds + (g & (G2_NST - 1)) * STAGE;
-#pragma unroll
-                for (int img = 0; img < NIMG; ++img) {
-                    wf[set][0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B);
-                    wf[set][1][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B + 1024);
-#pragma unroll
-                    for (int fa = 0; fa < NFA; ++fa) xf[set][fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + img * G2_ST_A + fa * 1024);
-                }
-            }
-        };
-        auto init_acc = [&](int n0) {
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + (wc * 2 + fb) * 32 + 8 * gq + 4 * lh);
-#pragma unroll
-                    for (int fa = 0; fa < NFR; ++fa)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[fa][fb][4 * gq + e] = bv[e];
-                }
-        };
-        int skip = 0;
-        auto top = [&](int g) {
-            // stage g + 1 (or g, at the very end) of this wave has landed: only the newest stage's loads may be outstanding
-            if (skip > 0) --skip;
-            else if (lg - 1 > g + 1 || (g + 1 >= G && lg - 1 > g)) {
-                if (nl == 5) wait_vmcnt<5>(); else if (nl == 4) wait_vmcnt<4>(); else wait_vmcnt<3>();
-            } else wait_vmcnt<0>();
-            __syncthreads();
-            issue_next();                                            // stage g + 3 into the buffer stage g - 1 left
-        };
-        // MFMAs of the current set with the reads of the next set interleaved (1 read per 2 MFMAs at two fragments)
-#define SBEV_G2_BODY(CUR)                                                                                   \
-        if constexpr (NFA > 0) {                                                                            \
-            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
-                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
-                    _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
-                        acc[fa][fb] = SBEV_MFMA(wf[CUR][fb][PR::ib(p)], xf[CUR][fa][PR::ia(p)], acc[fa][fb]); \
-            _Pragma("unroll") for (int i = 0; i < (2 + NFA) * NIMG; ++i) {                                  \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
-                __builtin_amdgcn_sched_group_barrier(0x008, (PR::N * NFA * 2) / ((2 + NFA) * NIMG), 0);     \
-            }                                                                                               \
-        }
-        int cn0 = ct0 * G_COLS, ck = 0;
-        init_acc(cn0);
-        issue_next();
-        issue_next();
-        issue_next();
-        top(0);
-        read_frags(0, 0);
-        for (int g = 0; g < G; g += 2) {
-            read_frags(g + 1, 1);
-            SBEV_G2_BODY(0)
-            top(g + 1);
-            if (g + 2 < G) read_frags(g + 2, 0);
-            SBEV_G2_BODY(1)
-            ck += 2;
-            if (ck == nk) {
-                // epilogue of this tile: drain this wave's loads first (the next two top-of-iteration waits are then skipped and
-                // never wait for these stores), then 16-byte stores: a lane holds 4 consecutive columns of one row per 4 registers
-                wait_vmcnt<0>();
-                if constexpr (NFA > 0) {
-#pragma unroll
-                    for (int fa = 0; fa < NFA; ++fa) {
-                        const int row = m0 + (wr * 2 + fa) * 32 + l31;
-                        if (row < M SBEV_EXP_STORE_COND) {
-                            float* y = a.Y + (long long)row * a.ldy + cn0 + wc * 64 + 4 * lh;
-#pragma unroll
-                            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                                for (int gq = 0; gq < 4; ++gq) {
-                                    f32x4 v = {acc[fa][fb][4 * gq], acc[fa][fb][4 * gq + 1], acc[fa][fb][4 * gq + 2], acc[fa][fb][4 * gq + 3]};
-                                    if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                                    *reinterpret_cast<f32x4*>(y + fb * 32 + 8 * gq) = v;
-                                }
-                        }
-                    }
-                }
-                ck = 0;
-                skip = 2;
-                cn0 += cstep * G_COLS;
-                if (cn0 < a.N) init_acc(cn0);
-            }
-            if (g + 2 < G) top(g + 2);
-        }
-#undef SBEV_G2_BODY
-    };
-    if (nfa == 2) run(std::integral_constant<int, 2>{});
-    else if (nfa == 1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 0>{});
-}
-
+// ---- generator -----------------------------------------------------------------------------------------------------------------
+// History (c2, bf16x6), every step measured on the MI355X:
+//   v1  one 128 x 256 tile per workgroup, 32-k slabs, two LDS stages filled from ROW-MAJOR bf16 planes, a barrier per slab: 116 us;
+//       without its stores 93, without its MFMAs 73, with neither 50 -- the parts add up, nothing overlapped.
+//   v2  persistent workgroups, 16-k stages in a 4-deep LDS-DMA ring, fragments read one stage ahead between the MFMAs
+//       (sched_group_barrier), epilogue under the next tile: 132 us (!) -- the 32-byte-per-row pieces of a row-major operand made
+//       every LDS-DMA instruction touch 32 cache lines.  With both operands pre-packed in MFMA fragment order (whole 1-KiB pieces,
+//       lane-linear, conflict-free ds_read_b128 at lane x 16, no swizzle): 106 us.  PMC: matrix pipe busy 49 % of the waves' lifetime,
+//       48 % of it stalled on issue, 32 % in waits -- the two waves of a SIMD in lock-step behind the shared barrier.
+//   v3  ping-pong (below), 128 x 256 tiles: 108 us.  An in-kernel cycle trace shows why: FETCH = 1150 cycles (LDS-DMA issue 510 +
+//       counted wait 360 + fragment reads 200 + barrier 84) against COMPUTE = 850 (24 MFMAs); the L2 -> CU path delivers only
+//       ~21 B/clk/CU to this kernel (the out-projection's W stream: ~30), and a 128 x 256 x 16-k stage needs 36 KB per 1536 MFMA
+//       cycles = 23 B/clk.  Both kernels were bound by operand delivery, not by latency or issue order.
+//   v4  256 x 256 tiles (wave = 128 x 64, 128 accumulator registers): 48 KB per 3072 MFMA cycles = 16 B/clk.
 // ---- generator, ping-pong version: the two row-halves of a workgroup run one barrier phase apart ------------------------------------
 // PMC of the kernel above (c2, bf16x6, 106 us): the matrix pipe is busy for 49 % of the waves' lifetime, the waves spend 48 % of it
 // stalled on instruction issue and 32 % in s_waitcnt / s_barrier -- the two waves of a SIMD (rows 0-63 and 64-127 of the tile: waves
@@ -371,6 +194,14 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen2_kernel(const GenArgs a) {
 // summed apart from the hi x hi product and added once per tile, so the full-magnitude accumulator is rounded once per k-step
 // instead of six times -- measured on the out-projection the error of these kernels is accumulation rounding (it falls as
 // 1 / sqrt(K chunks)), not the dropped 2^-24-class products.
+// phase boundary of the ping-pong kernels: a barrier no instruction may be scheduled across (hipcc otherwise moves register-only
+// MFMAs of the COMPUTE phase over a plain __syncthreads() into the FETCH phase, where they collide with the partner wave's)
+__device__ __forceinline__ void phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_imm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -384,15 +215,21 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {          // n wave-uniform
         case 6: wait_vmcnt_imm<6>(); break;
         case 8: wait_vmcnt_imm<8>(); break;
         case 10: wait_vmcnt_imm<10>(); break;
+        case 12: wait_vmcnt_imm<12>(); break;
         default: wait_vmcnt_imm<0>(); break;
     }
 }
 
-template <int NIMG>
+// RF = row fragments (32 rows) per wave: 2 -> 128 x 256 tiles, 4-deep ring, split accumulators; 4 -> 256 x 256 tiles, 3-deep ring
+template <int NIMG, int RF>
 __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
-    constexpr int STAGE = NIMG * (G2_ST_A + G2_ST_B);
-    constexpr int NQ = NIMG * 12;                                    // fragments (1 KiB) per stage
+    constexpr int AF = 2 * RF;                                       // row fragments of a tile (A side); 8 column fragments (B side)
+    constexpr int ST_A = AF * 1024, ST_B = 8 * 1024;                 // bytes of one image of one 16-k stage
+    constexpr int STAGE = NIMG * (ST_A + ST_B);
+    constexpr int NST = RF == 2 ? 4 : 3;                             // LDS ring depth; loads run NST - 1 stages ahead
+    constexpr bool SPLIT_ACC = RF == 2;                              // second accumulator set for the small products
+    constexpr int NQ = NIMG * (AF + 8);                              // fragments (1 KiB) per stage
     constexpr int NLMAX = (NQ + 7) / 8;
     typedef Prods<NIMG> PR;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -407,8 +244,8 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
     const int nf = a.base + (rt < a.rem ? 1 : 0);
     const int m0 = f0 * 32;
-    int nfa = nf - 2 * wr;                                           // this wave's row fragments: 0, 1 or 2 (fixed for its life)
-    nfa = nfa < 0 ? 0 : (nfa > 2 ? 2 : nfa);
+    int nfa = nf - RF * wr;                                          // this wave's row fragments: 0 .. RF (fixed for its life)
+    nfa = nfa < 0 ? 0 : (nfa > RF ? RF : nfa);
     const int nl = (NQ - wave + 7) / 8;                              // this wave's loads per stage
 
     const unsigned voff = (unsigned)lane * 16u;
@@ -420,25 +257,25 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
 #pragma unroll
     for (int j = 0; j < NLMAX; ++j) {
         const int q = wave + 8 * j;
-        if (q < NIMG * 4) {
-            const int img = q >> 2, blk = q & 3;
+        if (q < NIMG * AF) {
+            const int img = q / AF, blk = q % AF;
             int fb = f0 + blk;
             fb = fb < nfrag ? fb : nfrag - 1;
             gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs) + fb * blkbytes + img * 1024;
-            ldst[j] = (unsigned)(img * G2_ST_A + blk * 1024);
+            ldst[j] = (unsigned)(img * ST_A + blk * 1024);
             gstep[j] = -(long long)nk * NIMG * 1024;
         } else {
-            const int q2 = q - NIMG * 4;
+            const int q2 = q - NIMG * AF;
             const int img = q2 >> 3, blk = q2 & 7;
             gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws) + (long long)(ct0 * 8 + blk) * blkbytes + img * 1024;
-            ldst[j] = (unsigned)(NIMG * G2_ST_A + img * G2_ST_B + blk * 1024);
+            ldst[j] = (unsigned)(NIMG * ST_A + img * ST_B + blk * 1024);
             gstep[j] = (long long)(cstep * 8) * blkbytes - (long long)nk * NIMG * 1024;
         }
     }
     int lk = 0, lg = 0;                                              // load cursor: k-step in its tile, next stage to issue
     auto issue_next = [&]() {
         if (lg >= G) return;
-        const unsigned sb = (unsigned)((lg & (G2_NST - 1)) * STAGE);
+        const unsigned sb = (unsigned)((lg % NST) * STAGE);
 #pragma unroll
         for (int j = 0; j < NLMAX; ++j) {
             if (j < nl) glds16(gbase[j], voff, sb + ldst[j]);
@@ -452,24 +289,28 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         }
     };
     const int l31 = lane & 31, lh = lane >> 5;
-    const unsigned aoff = (unsigned)(wr * 2) * 1024u + voff;
-    const unsigned boff = (unsigned)(NIMG * G2_ST_A) + (unsigned)(wc * 2) * 1024u + voff;
+    const unsigned aoff = (unsigned)(wr * RF) * 1024u + voff;
+    const unsigned boff = (unsigned)(NIMG * ST_A) + (unsigned)(wc * 2) * 1024u + voff;
 
     auto run = [&](auto nfa_c) {
         constexpr int NFA = decltype(nfa_c)::value;
         constexpr int NFR = NFA > 0 ? NFA : 1;
         bf16x8 xf[NFR][NIMG], wf[2][NIMG];
-        f32x16 acc[NFR][2], accs[NFR][2];                            // hi x hi (+ bias) | the small products
+        constexpr int NFS = SPLIT_ACC ? NFR : 1;
+        f32x16 acc[NFR][2], accs[NFS][2];                            // hi x hi (+ bias) | the small products (SPLIT_ACC)
         auto init_acc = [&](int ti) {                                // tile ti of this workgroup: its bias slice waits in LDS
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + G2_NST * STAGE + (ti * G_COLS + (wc * 2 + fb) * 32 + 8 * gq + 4 * lh) * 4);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + NST * STAGE + (ti * G_COLS + (wc * 2 + fb) * 32 + 8 * gq + 4 * lh) * 4);
 #pragma unroll
                     for (int fa = 0; fa < NFR; ++fa)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { acc[fa][fb][4 * gq + e] = bv[e]; accs[fa][fb][4 * gq + e] = 0.f; }
+                        for (int e = 0; e < 4; ++e) {
+                            acc[fa][fb][4 * gq + e] = bv[e];
+                            if constexpr (SPLIT_ACC) accs[fa][fb][4 * gq + e] = 0.f;
+                        }
                 }
         };
         auto store_tile = [&](int n0) {                              // acc already holds hi x hi + small products
@@ -484,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                 }
 #pragma unroll
                 for (int fa = 0; fa < NFA; ++fa) {
-                    const int row = m0 + (wr * 2 + fa) * 32 + l31;
+                    const int row = m0 + (wr * RF + fa) * 32 + l31;
                     if (row < M SBEV_EXP_STORE_COND) {
                         float* y = a.Y + (long long)row * a.ldy + n0 + wc * 64 + 4 * lh;
 #pragma unroll
@@ -504,32 +345,34 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         // make hipcc wait vmcnt(0) in the middle of the LDS-DMA pipeline
         for (int i = tid; i < my_tiles * G_COLS; i += 512) {
             const int t = i / G_COLS, c = i - t * G_COLS;
-            reinterpret_cast<float*>(lds + G2_NST * STAGE)[i] = a.bias ? a.bias[(ct0 + t * cstep) * G_COLS + c] : 0.f;
+            reinterpret_cast<float*>(lds + NST * STAGE)[i] = a.bias ? a.bias[(ct0 + t * cstep) * G_COLS + c] : 0.f;
         }
         __syncthreads();
         init_acc(0);
-        issue_next();
-        issue_next();
-        issue_next();
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i) issue_next();
         wait_vmcnt_imm<0>();
         __syncthreads();
-        if (wr == 1) __syncthreads();                                // the second row-half runs one phase behind
+        if (wr == 1) phase_barrier();                                // the second row-half runs one phase behind
         for (int g = 0; g < G; ++g) {
-            // ---- FETCH(g): loads of stage g + 3; stage g + 1 of this wave landed (only newer loads may be outstanding: vector
+            // ---- FETCH(g): loads of stage g + NST - 1; stage g + 1 of this wave landed (only newer loads may be outstanding: vector
             // loads return in order; a store in flight can only make the wait longer); fragments of stage g -> registers
+            SBEV_TRACE(g, 0)
             issue_next();
+            SBEV_TRACE(g, 1)
             {
                 const int hi = lg - 1, need = g + 1 < G ? g + 1 : g;
                 wait_vmcnt_n(hi > need ? (hi - need) * nl : 0);
             }
+            SBEV_TRACE(g, 2)
             if constexpr (NFA > 0) {
-                const unsigned char* st = lds + (g & (G2_NST - 1)) * STAGE;
+                const unsigned char* st = lds + (g % NST) * STAGE;
 #pragma unroll
                 for (int img = 0; img < NIMG; ++img) {
-                    wf[0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B);
-                    wf[1][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * G2_ST_B + 1024);
+                    wf[0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * ST_B);
+                    wf[1][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * ST_B + 1024);
 #pragma unroll
-                    for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + img * G2_ST_A + fa * 1024);
+                    for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + img * ST_A + fa * 1024);
                 }
             }
             if (pending) {                                           // the previous tile's stores ride in this phase
@@ -539,7 +382,9 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                 init_acc(ti < my_tiles ? ti : 0);
                 pending = false;
             }
-            __syncthreads();
+            SBEV_TRACE(g, 3)
+            phase_barrier();
+            SBEV_TRACE(g, 4)
             // ---- COMPUTE(g): nothing but MFMAs (the partner wave of this SIMD is in its FETCH phase)
             if constexpr (NFA > 0) {
 #pragma unroll
@@ -547,8 +392,10 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
 #pragma unroll
                     for (int fa = 0; fa < NFA; ++fa)
 #pragma unroll
-                        for (int fb = 0; fb < 2; ++fb)
-                            accs[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], accs[fa][fb]);
+                        for (int fb = 0; fb < 2; ++fb) {
+                            if constexpr (SPLIT_ACC) accs[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], accs[fa][fb]);
+                            else acc[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);
+                        }
 #pragma unroll
                 for (int fa = 0; fa < NFA; ++fa)
 #pragma unroll
@@ -558,21 +405,27 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
             if (++ck == nk) {
                 ck = 0;
                 pending = true;
-                if constexpr (NFA > 0) {
+                if constexpr (NFA > 0 && SPLIT_ACC) {
 #pragma unroll
                     for (int fa = 0; fa < NFA; ++fa)
 #pragma unroll
                         for (int fb = 0; fb < 2; ++fb) acc[fa][fb] += accs[fa][fb];
                 }
             }
-            __syncthreads();
+            SBEV_TRACE(g, 5)
+            phase_barrier();
+            SBEV_TRACE(g, 6)
         }
-        if (wr == 0) __syncthreads();
+        if (wr == 0) phase_barrier();
         if (pending) store_tile(cn0);
     };
-    if (nfa == 2) run(std::integral_constant<int, 2>{});
-    else if (nfa == 1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 0>{});
+    if (nfa == RF) run(std::integral_constant<int, RF>{});
+    else if (nfa == RF - 1) run(std::integral_constant<int, RF - 1>{});
+    else if (nfa == 0) run(std::integral_constant<int, 0>{});
+    else if constexpr (RF == 4) {
+        if (nfa == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 1>{});
+    }
 }
 
 // ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
@@ -586,185 +439,6 @@ struct OutArgs {
 };
 
 constexpr int O_IMG = 64 * 64;                  // bytes of one image of one half's stage (64 rows x 32 k)
-
-// ---- out-projection, version 2: 3-deep X stage ring, fragments one k-step ahead, X two slabs ahead in registers ------------------
-// Same ablation as for the generator (c2, bf16x6: 104 us; without MFMAs 61, with neither MFMAs nor stores 57): the X stream (118 MB
-// of fp32 from HBM, one 16 KB slab in flight per workgroup), the split, the fragment reads and the MFMAs ran one after the other.
-// Here a k-step's MFMAs are issued with the NEXT k-step's fragment reads and W loads in front of them, the split + LDS write of slab
-// it + 2 rides in the second k-step, and two slabs of X are in flight per thread.  The fragment count of a workgroup's row tile
-// is a template parameter of the loop (a branch around the MFMAs costs accumulator copies), as is the unequal last iteration.
-template <int NIMG>
-__global__ __launch_bounds__(512) void gemm_bf16s_out2_kernel(const OutArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int HSTAGE = NIMG * O_IMG;        // one half's stage
-    constexpr int NST = 3;
-    typedef Prods<NIMG> PR;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, wc = wave & 3;  // K half of the chunk, 64-column quarter
-    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
-    const int M = a.M;
-    const int m0 = rt * 64;
-    const int nfa = (M - m0) > 32 ? 2 : 1;      // row fragments of this tile
-    const int nslab = a.K / 32;
-    const int c0 = (int)((long long)nslab * chunk / a.S), c1 = (int)((long long)nslab * (chunk + 1) / a.S);
-    const int n_all = c1 - c0, n0h = (n_all + 1) / 2;
-    const int sb = half == 0 ? c0 : c0 + n0h;            // first slab of this half
-    const int nh = half == 0 ? n0h : n_all - n0h;        // its slabs (half 0 may have one more)
-    const int nmin = n_all - n0h;                        // iterations both halves compute in
-
-    const int th = tid & 255;
-    const int srow = th >> 2, skq = th & 3;
-    int grow = m0 + srow;
-    grow = grow < M ? grow : M - 1;
-    const float* xp = a.X + (long long)grow * a.ldx + skq * 8;
-    const unsigned wofs = (unsigned)(srow * 64 + ((skq ^ ((srow >> 2) & 3)) * 16));
-    unsigned char* hst = lds + half * (NST * HSTAGE);    // this half's stage ring
-    const int last_slab = nh > 0 ? sb + nh - 1 : c1 - 1;
-    auto loadx = [&](int i, f32x4& v0, f32x4& v1) {      // slab i of this half (clamped: a dummy past the end)
-        int sl = sb + i;
-        sl = sl < last_slab ? sl : last_slab;
-#ifdef SBEV_EXP_HOTX
-        sl = sl & 7;
-#endif
-        const float* p = xp + (long long)sl * 32;
-        v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));         // streamed once: keep L2 for W
-        v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
-    };
-    auto stagex = [&](int i, const f32x4 v0, const f32x4 v1) {       // slab i -> ring slot i % 3
-        u32x4 im[NIMG];
-        split8<NIMG>(v0, v1, im);
-        unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
-#pragma unroll
-        for (int img = 0; img < NIMG; ++img) *reinterpret_cast<u32x4*>(st + img * O_IMG) = im[img];
-    };
-    const int KS = a.K / 16;
-    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
-    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
-    const int last_ks = 2 * last_slab + 1;
-    auto loadw = [&](int kk, bf16x8 (&w)[2][NIMG]) {     // k-step kk of this half (clamped)
-        int ks = 2 * sb + kk;
-        ks = ks < last_ks ? ks : last_ks;
-#ifdef SBEV_EXP_HOTW
-        ks = ks & 15;
-#endif
-        const long long o = (long long)ks * NIMG * 64 * 8;
-#pragma unroll
-        for (int img = 0; img < NIMG; ++img) {
-            w[0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
-            w[1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
-        }
-    };
-    const int l31 = lane & 31, lh = lane >> 5;
-    const unsigned swz = (unsigned)((lane >> 2) & 3);
-    const unsigned fo0 = (unsigned)l31 * 64u + (((unsigned)lh) ^ swz) * 16u;
-    const unsigned fo1 = (unsigned)l31 * 64u + ((2u + (unsigned)lh) ^ swz) * 16u;
-
-    auto run = [&](auto nfa_c) {
-        constexpr int NFA = decltype(nfa_c)::value;
-        f32x16 acc[NFA][2];
-#pragma unroll
-        for (int fa = 0; fa < NFA; ++fa)
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
-        auto readx = [&](int i, int j, bf16x8 (&xf)[NFA][NIMG]) {      // fragments of slab i, k-step j
-            const unsigned char* A = hst + (i % NST) * HSTAGE + (j ? fo1 : fo0);
-#pragma unroll
-            for (int img = 0; img < NIMG; ++img)
-#pragma unroll
-                for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(A + img * O_IMG + fa * 32 * 64);
-        };
-#define SBEV_O2_MMA(XF, W)                                                                                  \
-        _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                                   \
-            _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                              \
-                _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                            \
-                    acc[fa][fb] = SBEV_MFMA(W[fb][PR::ib(p)], XF[fa][PR::ia(p)], acc[fa][fb]);
-        f32x4 xa0, xa1, xb0, xb1;                             // X register ring: slabs it + 2 (even it: a, odd: b) ...
-        bf16x8 wA[2][NIMG], wB[2][NIMG], xfA[NFA][NIMG], xfB[NFA][NIMG];
-        // prologue: slabs 0 and 1 staged, 2 and 3 requested, W of k-step 0 requested, fragments of (slab 0, k-step 0) read
-        loadx(0, xa0, xa1);
-        loadx(1, xb0, xb1);
-        loadw(0, wA);
-        stagex(0, xa0, xa1);
-        loadx(2, xa0, xa1);
-        stagex(1, xb0, xb1);
-        loadx(3, xb0, xb1);
-        __syncthreads();
-        readx(0, 0, xfA);
-        // one iteration = one slab; `it` even uses the a registers for slab it + 2, odd the b registers
-        // (ZERO: the unequal last iteration -- half 1 has no slab left and multiplies zeros instead of branching around the MFMAs)
-#define SBEV_O2_ZERO(XF)                                                                                    \
-        if (half == 1) {                                                                                    \
-            _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                              \
-                _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
-                    _Pragma("unroll") for (int e = 0; e < 8; ++e) XF[fa][img][e] = (__bf16)0.f;             \
-        }
-#define SBEV_O2_ITER(IT, X0, X1, ZERO)                                                                      \
-        {                                                                                                   \
-            loadw(2 * (IT) + 1, wB);                                                                        \
-            readx((IT), 1, xfB);                                                                            \
-            if (ZERO) { SBEV_O2_ZERO(xfA) SBEV_O2_ZERO(xfB) }                                               \
-            SBEV_O2_MMA(xfA, wA)                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                              \
-            loadw(2 * (IT) + 2, wA);                                                                        \
-            stagex((IT) + 2, X0, X1);                                                                       \
-            loadx((IT) + 4, X0, X1);                                                                        \
-            __syncthreads();              /* slab IT + 1 (staged one iteration ago) is published */         \
-            readx((IT) + 1, 0, xfA);                                                                        \
-            SBEV_O2_MMA(xfB, wB)                                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                                              \
-        }
-        int it = 0;
-        for (; it + 1 < nmin; it += 2) {
-            SBEV_O2_ITER(it, xa0, xa1, false)
-            SBEV_O2_ITER(it + 1, xb0, xb1, false)
-        }
-        if (it < nmin) {
-            SBEV_O2_ITER(it, xa0, xa1, false)
-            ++it;
-            if (it < n0h) SBEV_O2_ITER(it, xb0, xb1, true)
-        } else if (it < n0h) {
-            SBEV_O2_ITER(it, xa0, xa1, true)
-        }
-#undef SBEV_O2_ZERO
-#undef SBEV_O2_ITER
-#undef SBEV_O2_MMA
-        // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab
-        __syncthreads();
-        f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * 16) * 64 + lane;       // [wc][fa][fb][g][lane] float4
-        if (half == 1) {
-#pragma unroll
-            for (int fa = 0; fa < NFA; ++fa)
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
-        }
-        __syncthreads();
-        if (half == 1) return;
-        float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
-#pragma unroll
-        for (int fa = 0; fa < NFA; ++fa) {
-            const int row = m0 + fa * 32 + l31;
-            if (row < M SBEV_EXP_STORE_COND) {
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
-                        const f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
-                        *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
-                    }
-            }
-        }
-    };
-    if (nfa == 2) run(std::integral_constant<int, 2>{});
-    else run(std::integral_constant<int, 1>{});
-}
 
 // ---- out-projection, ping-pong version: the two K halves of a workgroup run one barrier phase apart ----------------------------------
 // PMC of the kernel above (c2, bf16x6, 100 us): matrix pipe busy 62 % of the waves' lifetime, 55 % of it spent stalled on issue, 27 %
@@ -821,20 +495,17 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
     const int KS = a.K / 16;
     const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
     const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
-    auto loadw = [&](int i, bf16x8 (&w)[2][2][NIMG]) {   // both k-steps of slab i of this half (clamped)
+    auto loadw = [&](int i, int j, bf16x8 (&w)[2][NIMG]) {   // k-step j of slab i of this half (clamped)
         int sl = sb + i;
         sl = sl < last_slab ? sl : last_slab;
 #ifdef SBEV_EXP_HOTW
         sl = sl & 7;
 #endif
+        const long long o = (long long)(2 * sl + j) * NIMG * 64 * 8;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long o = (long long)(2 * sl + j) * NIMG * 64 * 8;
-#pragma unroll
-            for (int img = 0; img < NIMG; ++img) {
-                w[j][0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
-                w[j][1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
-            }
+        for (int img = 0; img < NIMG; ++img) {
+            w[0][img] = *reinterpret_cast<const bf16x8*>(wb0 + o + img * 512);
+            w[1][img] = *reinterpret_cast<const bf16x8*>(wb1 + o + img * 512);
         }
     };
     const int l31 = lane & 31, lh = lane >> 5;
@@ -856,17 +527,19 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
         // prologue: slabs 0 and 1 staged, 2 and 3 requested, W of slab 0 requested
         loadx(0, xa0, xa1);
         loadx(1, xb0, xb1);
-        loadw(0, w);
+        loadw(0, 0, w[0]);
+        loadw(0, 1, w[1]);
         stagex(0, xa0, xa1);
         loadx(2, xa0, xa1);
         stagex(1, xb0, xb1);
         loadx(3, xb0, xb1);
         __syncthreads();
-        if (half == 1) __syncthreads();                       // the second K half runs one phase behind
+        if (half == 1) phase_barrier();                       // the second K half runs one phase behind
 #define SBEV_O3_SLAB(S_, X0, X1)                                                                            \
         {                                                                                                   \
             /* FETCH */                                                                                     \
             {                                                                                               \
+                SBEV_TRACE(S_, 0)                                                                           \
                 const unsigned char* A = hst + ((S_) % NST) * HSTAGE;                                       \
                 _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
                     _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa) {                                    \
@@ -879,19 +552,35 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
                             _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                          \
                                 _Pragma("unroll") for (int e = 0; e < 8; ++e) xf[j][fa][img][e] = (__bf16)0.f; \
                 }                                                                                           \
+                SBEV_TRACE(S_, 1)                                                                           \
+                if ((S_) > 0) loadw((S_), 1, w[1]);   /* needed a FETCH + half a COMPUTE from now */        \
+                SBEV_TRACE(S_, 2)                                                                           \
                 stagex((S_) + 2, X0, X1);                                                                   \
                 loadx((S_) + 4, X0, X1);                                                                    \
+                SBEV_TRACE(S_, 3)                                                                           \
             }                                                                                               \
-            __syncthreads();                                                                                \
-            /* COMPUTE */                                                                                   \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
-                _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                           \
-                    _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                      \
-                        _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                    \
-                            acc[fa][fb] = SBEV_MFMA(w[j][fb][PR::ib(p)], xf[j][fa][PR::ia(p)], acc[fa][fb]); \
+            phase_barrier();                                                                                \
+            SBEV_TRACE(S_, 4)                                                                               \
+            /* COMPUTE: k-step 0, then k-step 1 with the next slab's k-step-0 W loads riding between its MFMAs (the registers  */ \
+            /* they overwrite are dead once k-step 0 has issued); the k-step-1 W loads go out in the next FETCH                */ \
+            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
+                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
+                    _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
+                        acc[fa][fb] = SBEV_MFMA(w[0][fb][PR::ib(p)], xf[0][fa][PR::ia(p)], acc[fa][fb]);    \
             __builtin_amdgcn_sched_barrier(0);                                                              \
-            loadw((S_) + 1, w);                                                                             \
-            __syncthreads();                                                                                \
+            loadw((S_) + 1, 0, w[0]);                                                                       \
+            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
+                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
+                    _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
+                        acc[fa][fb] = SBEV_MFMA(w[1][fb][PR::ib(p)], xf[1][fa][PR::ia(p)], acc[fa][fb]);    \
+            _Pragma("unroll") for (int i = 0; i < 2 * NIMG; ++i) {                                          \
+                __builtin_amdgcn_sched_group_barrier(0x008, (PR::N * NFA * 2) / (2 * NIMG), 0);             \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                          \
+            }                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            SBEV_TRACE(S_, 5)                                                                               \
+            phase_barrier();                                                                                \
+            SBEV_TRACE(S_, 6)                                                                               \
         }
         int sl = 0;
         for (; sl + 1 < n0h; sl += 2) {
@@ -900,7 +589,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
         }
         if (sl < n0h) SBEV_O3_SLAB(sl, xa0, xa1)
 #undef SBEV_O3_SLAB
-        if (half == 0) __syncthreads();
+        if (half == 0) phase_barrier();
         // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab
         __syncthreads();
         f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * 16) * 64 + lane;       // [wc][fa][fb][g][lane] float4
@@ -988,7 +677,7 @@ extern "C" int sbev_pack_bf16s_frags(const float* W, int64_t ldw, uint16_t* out,
     return sbev::check_launch("sbev_pack_bf16s_frags");
 }
 
-static int ntm_of(int64_t M) { return (int)(((M + 31) / 32 + 3) / 4); }      // row tiles of <= 4 fragments
+static int ntm_of(int64_t M) { return (int)(((M + 31) / 32 + 7) / 8); }      // row tiles of <= 8 fragments
 
 extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {
     return M >= 1 && M <= 0x7fffffffLL / 1024 && N >= 256 && N % 256 == 0 && K >= 32 && K % 32 == 0 && K <= 4096 &&
@@ -1003,11 +692,15 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     SBEV_REQUIRE(Xs && Ws && Y && ldy >= N && ldy % 4 == 0, "sbev_linear_bf16s_gen: bad pointers / leading dimension");
     SBEV_REQUIRE((((uintptr_t)Xs | (uintptr_t)Ws | (uintptr_t)Y) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0), "sbev_linear_bf16s_gen: 16-byte alignment");
     const int nfrag = (int)((M + 31) / 32);
-    const int ntm = (nfrag + 3) / 4;
+    // 256-row tiles (wave = 128 x 64) carry 1.5x the MFMA work per operand byte; 128-row tiles only where they fill the chip
+    // better (few rows) -- SBEV_BF16S_GEN_RF=2/4 forces one (A/B runs)
+    static const int forced_rf = getenv("SBEV_BF16S_GEN_RF") ? atoi(getenv("SBEV_BF16S_GEN_RF")) : 0;
+    const int rf = forced_rf == 2 || forced_rf == 4 ? forced_rf : (nfrag > 4 ? 4 : 2);
+    const int tf = 2 * rf;
+    const int ntm = (nfrag + tf - 1) / tf;
     GenArgs a{Xs, Ws, bias, Y, (int)M, N, K, (long long)ldy, relu, ntm, nfrag / ntm, nfrag % ntm};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
-    int st;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
@@ -1016,52 +709,34 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     // one row tile per workgroup for life: grid = a multiple of ntm, at most the CU count, at most the tile count
     long long per = cus / ntm < 1 ? 1 : cus / ntm;
     if (per > N / G_COLS) per = N / G_COLS;
-    const unsigned grid = (unsigned)(per * ntm);
-    static const bool v2 = getenv("SBEV_BF16S_GEN_V2") != nullptr;       // A/B switch: the lock-step kernel
-    if (!v2) {
-        // the bias slices of a workgroup's column tiles wait in LDS behind the stage ring: at most 16 tiles (16 KiB) per launch,
-        // wider matrices take several launches over column ranges
-        const int nct = N / G_COLS;
-        const long long max_ct = per * 16;
-        for (long long c0 = 0; c0 < nct; c0 += max_ct) {
-            const int nc = (int)(nct - c0 < max_ct ? nct - c0 : max_ct);
-            GenArgs ac = a;
-            ac.Ws = Ws + c0 * 8 * (long long)(K / 16) * nimg * 512;      // 8 fragment blocks of 32 columns per tile
-            ac.bias = bias ? bias + c0 * G_COLS : nullptr;
-            ac.Y = Y + c0 * G_COLS;
-            ac.N = nc * G_COLS;
-            const long long pc = per < nc ? per : nc;
-            const unsigned gridc = (unsigned)(pc * ntm);
-            const int bias_bytes = (int)((nc + pc - 1) / pc) * G_COLS * 4;
-            const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-            if (nimg == 3) {
-                const int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B) + bias_bytes;
-                st = reserve_lds(gemm_bf16s_gen3_kernel<3>, LDS, "sbev_linear_bf16s_gen");
-                if (st != SBEV_OK) return st;
-                hipLaunchKernelGGL(gemm_bf16s_gen3_kernel<3>, dim3(gridc), dim3(512), LDS, s, ac);
-            } else {
-                const int LDS = G2_NST * 2 * (G2_ST_A + G2_ST_B) + bias_bytes;
-                st = reserve_lds(gemm_bf16s_gen3_kernel<2>, LDS, "sbev_linear_bf16s_gen");
-                if (st != SBEV_OK) return st;
-                hipLaunchKernelGGL(gemm_bf16s_gen3_kernel<2>, dim3(gridc), dim3(512), LDS, s, ac);
-            }
-            if (prof) sbev::profile_end(s, e0, e1, 1);
+    // the bias slices of a workgroup's column tiles wait in LDS behind the stage ring: at most 16 tiles (16 KiB) per launch,
+    // wider matrices take several launches over column ranges
+    const int nct = N / G_COLS;
+    const long long max_ct = per * 16;
+    for (long long c0 = 0; c0 < nct; c0 += max_ct) {
+        const int nc = (int)(nct - c0 < max_ct ? nct - c0 : max_ct);
+        GenArgs ac = a;
+        ac.Ws = Ws + c0 * 8 * (long long)(K / 16) * nimg * 512;      // 8 fragment blocks of 32 columns per tile
+        ac.bias = bias ? bias + c0 * G_COLS : nullptr;
+        ac.Y = Y + c0 * G_COLS;
+        ac.N = nc * G_COLS;
+        const long long pc = per < nc ? per : nc;
+        const unsigned gridc = (unsigned)(pc * ntm);
+        const int bias_bytes = (int)((nc + pc - 1) / pc) * G_COLS * 4;
+        const int lds = (rf == 2 ? 4 : 3) * nimg * (tf + 8) * 1024 + bias_bytes;
+        int st;
+        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+#define SBEV_LAUNCH_GEN(NI, RFV)                                                                            \
+        {                                                                                                   \
+            st = reserve_lds(gemm_bf16s_gen3_kernel<NI, RFV>, lds, "sbev_linear_bf16s_gen");                \
+            if (st != SBEV_OK) return st;                                                                   \
+            hipLaunchKernelGGL((gemm_bf16s_gen3_kernel<NI, RFV>), dim3(gridc), dim3(512), lds, s, ac);      \
         }
-        return sbev::check_launch("sbev_linear_bf16s_gen");
-    }
-    if (nimg == 3) {
-        constexpr int LDS = G2_NST * 3 * (G2_ST_A + G2_ST_B);
-        st = reserve_lds(gemm_bf16s_gen2_kernel<3>, LDS, "sbev_linear_bf16s_gen");
-        if (st != SBEV_OK) return st;
-        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-        hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<3>, dim3(grid), dim3(512), LDS, s, a);
-        if (prof) sbev::profile_end(s, e0, e1, 1);
-    } else {
-        constexpr int LDS = G2_NST * 2 * (G2_ST_A + G2_ST_B);
-        st = reserve_lds(gemm_bf16s_gen2_kernel<2>, LDS, "sbev_linear_bf16s_gen");
-        if (st != SBEV_OK) return st;
-        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
-        hipLaunchKernelGGL(gemm_bf16s_gen2_kernel<2>, dim3(grid), dim3(512), LDS, s, a);
+        if (nimg == 3 && rf == 4) SBEV_LAUNCH_GEN(3, 4)
+        else if (nimg == 3) SBEV_LAUNCH_GEN(3, 2)
+        else if (rf == 4) SBEV_LAUNCH_GEN(2, 4)
+        else SBEV_LAUNCH_GEN(2, 2)
+#undef SBEV_LAUNCH_GEN
         if (prof) sbev::profile_end(s, e0, e1, 1);
     }
     return sbev::check_launch("sbev_linear_bf16s_gen");
@@ -1087,7 +762,6 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
     SBEV_REQUIRE(wgs <= 0x7fffffffLL, "sbev_linear_splitk_bf16s: too many workgroups");
     hipEvent_t e0, e1;
     int st;
-    static const bool v2 = getenv("SBEV_BF16S_OUT_V2") != nullptr;       // A/B switch: the lock-step kernel
     constexpr int LDS3 = 2 * 3 * 3 * O_IMG;     // 2 halves x 3 stages x 3 images x 4 KiB = 72 KiB (>= the 64 KiB fold buffer)
     constexpr int LDS2 = 65536;                 // two images: 48 KiB of stages, 64 KiB fold buffer
 #define SBEV_LAUNCH_OUT(KERN, LDSB)                                                              \
@@ -1098,11 +772,7 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
         hipLaunchKernelGGL(KERN, dim3((unsigned)wgs), dim3(512), LDSB, s, a);                    \
         if (prof) profile_end(s, e0, e1, 2);                                                     \
     }
-    if (!v2) {
-        if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<3>, LDS3) else SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<2>, LDS2)
-    } else {
-        if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out2_kernel<3>, LDS3) else SBEV_LAUNCH_OUT(gemm_bf16s_out2_kernel<2>, LDS2)
-    }
+    if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<3>, LDS3) else SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<2>, LDS2)
 #undef SBEV_LAUNCH_OUT
     return check_launch("sbev_linear_splitk_bf16s (gemm)");
 }

@@ -1,0 +1,31 @@
+"""Per-phase cycle stamps of the ping-pong generator (variant library built with -DSBEV_EXP_TRACE)."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sparsebev_amd import _lib, dense
+lib = _lib.load()
+p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+M, N, K, nimg = 900, 32768, 256, 3
+x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') / 16; b = torch.randn(N, device='cuda')
+y = torch.empty(M, N, device='cuda')
+ws = dense.pack_bf16s_frags(w, nimg); xs = dense.pack_bf16s_frags(x, nimg)
+for _ in range(3):
+    lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, 0, nimg, st)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (2 * 512 * 8))()
+raw = ctypes.CDLL(_lib.LIB_PATH)
+raw.sbev_debug_trace_read.argtypes = [ctypes.c_void_p]
+assert raw.sbev_debug_trace_read(buf) == 0
+import numpy as np
+t = np.array(buf, dtype=np.uint64).reshape(2, 512, 8).astype(np.int64)
+names = ['issue', 'wait', 'reads+st', 'bar1', 'mfma', 'bar2', 'next']
+for grp in (0, 1):
+    print('group', grp, ' (cycles) issue | vmcnt wait | frag reads (+stores) | barrier | MFMAs | barrier | -> next FETCH')
+    for g in list(range(0, 6)) + list(range(14, 20)) + [40, 41, 62, 63]:
+        r = t[grp, g]
+        nxt = t[grp, g + 1, 0] if g + 1 < 64 else r[6]
+        d = [r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], nxt - r[6]]
+        print('  g=%2d' % g, ' '.join('%6d' % v for v in d), '  total', nxt - r[0])
+    tot = t[grp, 63, 6] - t[grp, 0, 0]
+    print('  64 stages:', tot, 'cycles ->', tot / 64, 'per stage')

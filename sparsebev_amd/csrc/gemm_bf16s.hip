@@ -298,20 +298,22 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         bf16x8 xf[NFR][NIMG], wf[2][NIMG];
         constexpr int NFS = SPLIT_ACC ? NFR : 1;
         f32x16 acc[NFR][2], accs[NFS][2];                            // hi x hi (+ bias) | the small products (SPLIT_ACC)
+        // D rows = X rows, D columns = W rows (output columns): a lane holds ONE output column (n = lane & 31 of its fragment) and
+        // 16 rows, so a register of the 64 lanes is two full 128-byte lines of the output -- the epilogue stores whole lines
+        // (the transposed orientation's 16-byte stores wrote 32-byte pieces of 32 different rows per instruction: 330 cycles
+        // each, 19k cycles of a 55k-cycle tile in the cycle trace)
         auto init_acc = [&](int ti) {                                // tile ti of this workgroup: its bias slice waits in LDS
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
+            for (int fb = 0; fb < 2; ++fb) {
+                const float bv = reinterpret_cast<const float*>(lds + NST * STAGE)[ti * G_COLS + (wc * 2 + fb) * 32 + l31];
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(lds + NST * STAGE + (ti * G_COLS + (wc * 2 + fb) * 32 + 8 * gq + 4 * lh) * 4);
+                for (int fa = 0; fa < NFR; ++fa)
 #pragma unroll
-                    for (int fa = 0; fa < NFR; ++fa)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[fa][fb][4 * gq + e] = bv[e];
-                            if constexpr (SPLIT_ACC) accs[fa][fb][4 * gq + e] = 0.f;
-                        }
-                }
+                    for (int e = 0; e < 16; ++e) {
+                        acc[fa][fb][e] = bv;
+                        if constexpr (SPLIT_ACC) accs[fa][fb][e] = 0.f;
+                    }
+            }
         };
         auto store_tile = [&](int n0) {                              // acc already holds hi x hi + small products
             if constexpr (NFA > 0) {
@@ -325,16 +327,27 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                 }
 #pragma unroll
                 for (int fa = 0; fa < NFA; ++fa) {
-                    const int row = m0 + (wr * RF + fa) * 32 + l31;
-                    if (row < M SBEV_EXP_STORE_COND) {
-                        float* y = a.Y + (long long)row * a.ldy + n0 + wc * 64 + 4 * lh;
+                    const int r0 = m0 + (wr * RF + fa) * 32;         // register e: row r0 + (e & 3) + 8 (e >> 2) + 4 lh
+                    float* y = a.Y + (long long)(r0 + 4 * lh) * a.ldy + n0 + wc * 64 + l31;
+                    // a running row pointer, opaque to the optimiser (it otherwise keeps 64 row addresses per tile in spilled SGPRs)
+                    if (r0 + 32 <= M SBEV_EXP_STORE_COND) {          // whole fragment inside the matrix: no per-lane masks
 #pragma unroll
-                        for (int fb = 0; fb < 2; ++fb)
+                        for (int e = 0; e < 16; ++e) {
+                            y[0] = acc[fa][0][e];
+                            y[32] = acc[fa][1][e];
+                            y += (e & 3) == 3 ? 5 * a.ldy : a.ldy;
+                            asm volatile("" : "+v"(y));
+                        }
+                    } else {
 #pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) {
-                                const f32x4 v = {acc[fa][fb][4 * gq], acc[fa][fb][4 * gq + 1], acc[fa][fb][4 * gq + 2], acc[fa][fb][4 * gq + 3]};
-                                *reinterpret_cast<f32x4*>(y + fb * 32 + 8 * gq) = v;
+                        for (int e = 0; e < 16; ++e) {
+                            if (r0 + 4 * lh + (e & 3) + 8 * (e >> 2) < M SBEV_EXP_STORE_COND) {
+                                y[0] = acc[fa][0][e];
+                                y[32] = acc[fa][1][e];
                             }
+                            y += (e & 3) == 3 ? 5 * a.ldy : a.ldy;
+                            asm volatile("" : "+v"(y));
+                        }
                     }
                 }
             }
@@ -393,14 +406,14 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                     for (int fa = 0; fa < NFA; ++fa)
 #pragma unroll
                         for (int fb = 0; fb < 2; ++fb) {
-                            if constexpr (SPLIT_ACC) accs[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], accs[fa][fb]);
-                            else acc[fa][fb] = SBEV_MFMA(wf[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);
+                            if constexpr (SPLIT_ACC) accs[fa][fb] = SBEV_MFMA(xf[fa][PR::ia(p)], wf[fb][PR::ib(p)], accs[fa][fb]);
+                            else acc[fa][fb] = SBEV_MFMA(xf[fa][PR::ia(p)], wf[fb][PR::ib(p)], acc[fa][fb]);
                         }
 #pragma unroll
                 for (int fa = 0; fa < NFA; ++fa)
 #pragma unroll
                     for (int fb = 0; fb < 2; ++fb)
-                        acc[fa][fb] = SBEV_MFMA(wf[fb][0], xf[fa][0], acc[fa][fb]);
+                        acc[fa][fb] = SBEV_MFMA(xf[fa][0], wf[fb][0], acc[fa][fb]);
             }
             if (++ck == nk) {
                 ck = 0;

@@ -22,10 +22,11 @@ t = np.array(buf, dtype=np.uint64).reshape(2, 512, 8).astype(np.int64)
 names = ['issue', 'wait', 'reads+st', 'bar1', 'mfma', 'bar2', 'next']
 for grp in (0, 1):
     print('group', grp, ' (cycles) issue | vmcnt wait | frag reads (+stores) | barrier | MFMAs | barrier | -> next FETCH')
-    for g in list(range(0, 6)) + list(range(14, 20)) + [40, 41, 62, 63]:
+    G = int((t[grp, :, 0] > 0).sum())
+    for g in list(range(0, 6)) + list(range(14, 20)) + [G - 2]:
         r = t[grp, g]
-        nxt = t[grp, g + 1, 0] if g + 1 < 64 else r[6]
+        nxt = t[grp, g + 1, 0] if g + 1 < G else r[6]
         d = [r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], nxt - r[6]]
         print('  g=%2d' % g, ' '.join('%6d' % v for v in d), '  total', nxt - r[0])
-    tot = t[grp, 63, 6] - t[grp, 0, 0]
-    print('  64 stages:', tot, 'cycles ->', tot / 64, 'per stage')
+    tot = t[grp, G - 1, 6] - t[grp, 0, 0]
+    print('  %d stages:' % G, tot, 'cycles ->', tot / G, 'per stage')

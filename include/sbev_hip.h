@@ -553,6 +553,11 @@ int64_t sbev_decoder_chain_pack_floats(const sbev_decoder_config* cfg);
 int sbev_decoder_chain_pack(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights, float* out, sbev_stream_t stream);
 int sbev_decoder_row_chain(int enable);
 
+/* Kernel launches per layer sbev_decoder_forward enqueues for this config and weight set under the current process-wide switches
+ * (row chains, gather + mixing fusion), -1 on an invalid config: 6 with the row chains, 17 op by op, + 1 for the two-launch gather
+ * + mixing, + 1 for the activation split of the split-bf16 GEMM modes. */
+int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights);
+
 /* Bytes of scratch sbev_decoder_forward needs for this config (-1 on an invalid config). */
 int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg);
 
@@ -582,6 +587,12 @@ int sbev_decoder_capture(const sbev_decoder_config* cfg, const sbev_decoder_weig
                          const float* time_diff, const float* lidar2img, const float* vel_div,
                          const uint8_t* attn_mask, float* cls_out, float* bbox_out,
                          void* workspace, int64_t workspace_bytes, sbev_stream_t stream, sbev_graph** out);
+/* Capture of ANY sequence of this library's launches on `stream` (explicit, non-default) between the two calls -- e.g. the per-level
+ * NCHW -> NHWC relayout followed by sbev_decoder_forward: the whole per-sample step as one replayable graph.  Nothing executes
+ * during the capture; every buffer the recorded launches read or write must outlive the graph.  sbev_capture_end(stream, NULL)
+ * abandons a capture (after a failed call inside it). */
+int sbev_capture_begin(sbev_stream_t stream);
+int sbev_capture_end(sbev_stream_t stream, sbev_graph** out);
 int sbev_graph_launch(sbev_graph* graph, sbev_stream_t stream);
 int64_t sbev_graph_num_nodes(const sbev_graph* graph);   /* kernel nodes recorded (-1 for NULL) */
 int sbev_graph_destroy(sbev_graph* graph);

@@ -57,6 +57,7 @@ SIGNATURES = {
     'sbev_linear3_ln_relu_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp,
                                                 ctypes.c_int64, ctypes.c_int, _vp]),
     'sbev_decoder_workspace_bytes': (ctypes.c_int64, [_vp]),
+    'sbev_decoder_launches_per_layer': (ctypes.c_int, [_vp, _vp]),
     'sbev_decoder_forward': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, ctypes.c_int64, _vp]),
     'sbev_profile_sampler': (ctypes.c_int, [ctypes.c_int]),
@@ -95,6 +96,8 @@ SIGNATURES = {
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     'sbev_decoder_capture': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
+    'sbev_capture_begin': (ctypes.c_int, [_vp]),
+    'sbev_capture_end': (ctypes.c_int, [_vp, _vp]),
     'sbev_graph_launch': (ctypes.c_int, [_vp, _vp]),
     'sbev_graph_num_nodes': (ctypes.c_int64, [_vp]),
     'sbev_graph_destroy': (ctypes.c_int, [_vp]),

@@ -129,6 +129,24 @@ struct ProfCallScope {      // see sbev_profile_stride below
 };
 }  // namespace sbev
 
+// Kernel launches sbev_decoder_forward enqueues per layer for this config / weight set under the current switches (what
+// bench.py reports; the decision code is the forward's own)
+extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, const sbev_decoder_weights* w) {
+    if (validate(cfg) != SBEV_OK || !w) return -1;
+    const sbev_decoder_config& c = *cfg;
+    const int64_t BQ = (int64_t)c.B * c.Q;
+    const bool fork = c.overlap != 0;
+    const bool chain = g_row_chain.load(std::memory_order_relaxed) != 0 && w->chain_pack != nullptr && !fork && sbev::row_chain_supported(c) &&
+                       sbev::row_chain_pays(BQ);
+    const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
+                       sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
+    const int split = (c.gemm_mode == SBEV_GEMM_BF16X6 || c.gemm_mode == SBEV_GEMM_BF16X3S) ? 1      // x1 -> bf16 image fragments
+                      : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
+    // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
+    // op by op: 17 with the fused gather + mixing
+    return (chain ? 6 : 17) + (fused ? 0 : 1) + split;
+}
+
 extern "C" int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg) {
     if (validate(cfg) != SBEV_OK) return -1;
     return (int64_t)carve(*cfg, nullptr).bytes;
@@ -491,6 +509,39 @@ extern "C" int sbev_decoder_capture(const sbev_decoder_config* cfg, const sbev_d
     if (st != SBEV_OK) {
         if (g) (void)hipGraphDestroy(g);
         return st;
+    }
+    TRY(hip_ok(e, "hipStreamEndCapture"));
+    sbev_graph* h = new sbev_graph();
+    h->graph = g;
+    (void)hipGraphGetNodes(g, nullptr, &h->nodes);
+    const hipError_t ei = hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        delete h;
+        return hip_ok(ei, "hipGraphInstantiate");
+    }
+    *out = h;
+    return SBEV_OK;
+}
+
+// Generic capture of ANY sequence of this library's launches (e.g. the per-level feature relayout followed by the decoder step)
+extern "C" int sbev_capture_begin(sbev_stream_t stream) {
+    SBEV_REQUIRE(stream, "sbev_capture_begin: needs an explicit (non-default) stream to capture on");
+    {
+        std::lock_guard<std::mutex> lk(sbev::g_prof_mu);
+        SBEV_REQUIRE(sbev::g_prof_mask == 0, "sbev_capture_begin: launch profiling is on (events cannot be read back from a captured graph)");
+    }
+    (void)aux();   // create the side stream / events outside the capture
+    return hip_ok(hipStreamBeginCapture(reinterpret_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+}
+
+extern "C" int sbev_capture_end(sbev_stream_t stream, sbev_graph** out) {
+    SBEV_REQUIRE(stream, "sbev_capture_end: null stream");
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(reinterpret_cast<hipStream_t>(stream), &g);   // always end the capture
+    if (!out) {                                     // abort: the caller's sequence failed, drop whatever was recorded
+        if (g) (void)hipGraphDestroy(g);
+        return SBEV_OK;
     }
     TRY(hip_ok(e, "hipStreamEndCapture"));
     sbev_graph* h = new sbev_graph();

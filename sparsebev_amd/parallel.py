@@ -12,6 +12,46 @@ import torch
 import torch.distributed as dist
 
 
+def gpu_numa_cpus(device_index):
+    """CPUs of the NUMA node the GPU hangs off (sysfs: /sys/bus/pci/devices/<bdf>/numa_node -> node<N>/cpulist), or None when
+    the topology is not exposed (containers, single-node hosts report -1)."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus or None
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+def pin_to_gpu_numa_node(device_index, local_rank=0, ranks_on_node=1):
+    """Pin this process's host threads next to its GPU: the CPUs of the GPU's NUMA node, and within the node an equal share
+    per rank that shares it (N host processes on one box otherwise migrate across sockets and each spins up a full-size
+    thread pool).  Returns the CPU set applied, or None when nothing was changed."""
+    cpus = gpu_numa_cpus(device_index)
+    if not cpus or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        allowed = sorted(cpus & os.sched_getaffinity(0))
+        if not allowed:
+            return None
+        if ranks_on_node > 1:                       # ranks whose GPUs share this node split it
+            share = max(1, len(allowed) // ranks_on_node)
+            mine = allowed[(local_rank % ranks_on_node) * share:(local_rank % ranks_on_node + 1) * share] or allowed
+        else:
+            mine = allowed
+        os.sched_setaffinity(0, set(mine))
+        return set(mine)
+    except OSError:
+        return None
+
+
 def init_distributed(n_gpus_requested=1, backend=None, force_group=False):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run sets them),
     bind this process to its GPU and create the process group when WORLD_SIZE > 1 (or when ``force_group`` asks for a
@@ -28,6 +68,12 @@ def init_distributed(n_gpus_requested=1, backend=None, force_group=False):
     device = torch.device('cuda', local) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)
+        if world > 1 and os.environ.get('SBEV_NO_NUMA_PIN') != '1':
+            # ranks on GPUs of the same NUMA node share its CPUs: count them (same sysfs answer on every rank)
+            mine = gpu_numa_cpus(local)
+            if mine:
+                same = [i for i in range(min(world, torch.cuda.device_count())) if gpu_numa_cpus(i) == mine]
+                pin_to_gpu_numa_node(local, same.index(local) if local in same else 0, max(1, len(same)))
     if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')

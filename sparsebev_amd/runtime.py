@@ -55,10 +55,18 @@ class DecoderRuntime:
         self._weights = None
         self._ws = None
         self._ws_key = None
+        self._params = None        # cached parameter list (re-collected every 64 signature checks)
+        self._sig_calls = 0
+        self.step_graphs = StepGraphs(self)
 
     # -- weights -----------------------------------------------------------------------------------------
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.decoder.parameters())
+        # walking the module tree costs ~0.15 ms; the Parameter OBJECTS of a module only change when somebody assigns new ones
+        # (load_state_dict / .to() / optimizers update them in place), so the list is cached and re-collected every 64th call
+        self._sig_calls += 1
+        if self._params is None or (self._sig_calls & 63) == 0:
+            self._params = list(self.decoder.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self._params)
 
     def _bind(self):
         layer = self.decoder.decoder_layer
@@ -119,19 +127,27 @@ class DecoderRuntime:
         n_pack = lib.sbev_decoder_chain_pack_floats(ctypes.byref(cfg))
         if n_pack > 0:
             pack = torch.empty(n_pack, device=attn_in_w.device, dtype=torch.float32)
-            _lib.check(lib.sbev_decoder_chain_pack(ctypes.byref(cfg), ctypes.byref(w), _ptr(pack),
-                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'sbev_decoder_chain_pack')
-            keep['chain_pack'] = pack
-            w.chain_pack = pack.data_ptr()
+            st = lib.sbev_decoder_chain_pack(ctypes.byref(cfg), ctypes.byref(w), _ptr(pack),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if st == 0:
+                keep['chain_pack'] = pack
+                w.chain_pack = pack.data_ptr()
+            elif not getattr(DecoderRuntime, '_warned_chain', False):
+                # e.g. a device without 160 KB of LDS per workgroup: the op-by-op launches compute the same layer
+                import warnings
+                warnings.warn('sparsebev_amd: row-chain weight image unavailable (%s): running the op-by-op launches'
+                              % lib.sbev_last_error().decode('utf-8', 'replace'))
+                DecoderRuntime._warned_chain = True
         self._keep, self._weights = keep, w
         self._attn_in_rows = attn_in_w.shape[0]
 
     # -- forward -----------------------------------------------------------------------------------------
-    def _prepare(self, query_bbox, query_feat, pyramid, ctx, attn_mask):
+    def _prepare(self, query_bbox, query_feat, pyramid, ctx, attn_mask, own_workspace=False):
         sig = self._signature()
         if sig != self._sig:
             self._bind()
             self._sig = sig
+            self.step_graphs.clear()        # graphs of the previous weight images can never be hit again: free them now
         dec, layer = self.decoder, self.decoder.decoder_layer
         smp = layer.sampling
         B, Q, D = query_feat.shape
@@ -162,10 +178,14 @@ class DecoderRuntime:
         if need < 0:
             raise _lib.SbevError('sbev_decoder_workspace_bytes: ' + lib.sbev_last_error().decode())
         key = (str(dev), need)
-        if self._ws is None or self._ws_key != key:
-            self._ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
-            self._ws_key = key
-        ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
+        if own_workspace:                   # a captured graph keeps its workspace for life (eager calls share the runtime's)
+            ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+        else:
+            if self._ws is None or self._ws_key != key:
+                self._ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+                self._ws_key = key
+            ws = self._ws
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         cls = torch.empty(cfg.num_layers, B, Q, cfg.num_classes, device=dev, dtype=torch.float32)
         box = torch.empty(cfg.num_layers, B, Q, cfg.code_size, device=dev, dtype=torch.float32)
         feats = (ctypes.c_void_p * cfg.L)(*[f.data_ptr() for f in pyramid.levels])
@@ -174,8 +194,23 @@ class DecoderRuntime:
         args = (ctypes.byref(cfg), ctypes.byref(self._weights), feats, _ptr(qb), _ptr(qf),
                 _ptr(ctx.time_diff), _ptr(ctx.lidar2img), _ptr(ctx.vel_div), _ptr(mask),
                 _ptr(cls), _ptr(box), ctypes.c_void_p(ws_ptr), need)
-        keep = (cfg, feats, qb, qf, mask, pyramid, ctx, self._ws, self._keep)
+        keep = (cfg, feats, qb, qf, mask, pyramid, ctx, ws, self._keep)
         return args, keep, cls, box
+
+    def launches_per_layer(self, B, Q):
+        """What sbev_decoder_forward would enqueue per layer for a [B, Q] call with the bound weights (asks the library)."""
+        if self._weights is None:
+            self._bind()
+            self._sig = self._signature()
+        dec, layer = self.decoder, self.decoder.decoder_layer
+        smp = layer.sampling
+        cfg = DecoderConfig()
+        cfg.B, cfg.Q, cfg.T, cfg.N, cfg.G, cfg.P, cfg.L = B, Q, smp.num_frames, 6, smp.num_groups, smp.num_points, smp.num_levels
+        cfg.D, cfg.H, cfg.ffn = layer.embed_dims, layer.self_attn.num_heads, layer.ffn.layers[0][0].weight.shape[0]
+        cfg.num_classes, cfg.code_size, cfg.num_layers = layer.num_classes, layer.code_size, dec.num_layers
+        cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
+        cfg.gemm_mode, cfg.overlap = self.gemm_mode, int(self.overlap)
+        return int(_lib.load().sbev_decoder_launches_per_layer(ctypes.byref(cfg), ctypes.byref(self._weights)))
 
     def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
         """pyramid: transformer.FeaturePyramid; ctx: transformer.DecoderContext.  Returns (cls, bbox) stacked over
@@ -199,6 +234,128 @@ class DecoderRuntime:
         st = _lib.load().sbev_decoder_capture(*args, ctypes.c_void_p(side.cuda_stream), ctypes.byref(handle))
         _lib.check(st, 'sbev_decoder_capture')
         return DecoderGraph(handle, keep, cls, box)
+
+
+class StepGraphs:
+    """hipGraph replay of the whole per-call step for callers that pass the SAME tensors again -- a serving loop that refreshes
+    queries / feature maps in place (bench.py, the reference's timing.py): from the second pointer-identical call on, the
+    feature relayout (NCHW inputs) and all decoder launches are ONE captured graph; per call the host packs the per-sample
+    constants (time_diff, lidar2img), refreshes the graph's device copy of them through the pinned upload ring and launches.
+    Results are bit-identical to the eager path (same kernels, same order).  A new tensor (other address / shape / dtype), a
+    weight update, another attention mask object or a changed ring slot table misses the cache and runs eagerly; the second
+    such call captures its own graph (at most ``MAX`` are kept, least recently used first out).
+    Replaces per-call Python + launch overhead of the reference's eager module chain (models/sparsebev_transformer.py:86-97)."""
+
+    MAX = 8
+
+    def __init__(self, runtime):
+        self.rt = runtime
+        self.entries = {}          # key -> dict(graph, ctx_buf, layout, keep, cls, box) or None (seen once, not captured yet)
+        self.replays = 0
+        self.captures = 0
+
+    def clear(self):
+        for e in self.entries.values():
+            if e:
+                e['graph'].destroy()
+        self.entries.clear()
+
+    @staticmethod
+    def _feat_key(feats):
+        if hasattr(feats, 'levels'):        # FeaturePyramid / RingPyramid: resident channels-last buffers (+ the ring's slot table)
+            return ('pyr', tuple((f.data_ptr(), tuple(f.shape), f.dtype) for f in feats.levels),
+                    tuple(getattr(feats, 'frame_slots', ())), getattr(feats, 'n_slots', 0))
+        return ('list', tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats))
+
+    def run(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
+        """(cls, box) of the graph's own output buffers (the caller clones or post-processes out of place), or None when this
+        call has to take the eager path."""
+        rt = self.rt
+        if _STATE['profile'] or not (query_bbox.is_cuda and query_bbox.is_contiguous() and query_feat.is_contiguous()):
+            return None                      # (bracketing launches with HIP events needs the eager enqueue)
+        if attn_mask is not None and not (attn_mask.is_cuda and attn_mask.dtype == torch.uint8 and attn_mask.is_contiguous()):
+            return None                      # the runtime would convert it into a temporary: no stable pointer to capture
+        if not hasattr(mlvl_feats, 'levels') and not all(torch.is_tensor(f) and f.is_cuda for f in mlvl_feats):
+            return None
+        from . import transformer as TR
+        sig = rt._signature()
+        key = (query_bbox.data_ptr(), query_feat.data_ptr(), tuple(query_feat.shape), self._feat_key(mlvl_feats),
+               None if attn_mask is None else (attn_mask.data_ptr(), tuple(attn_mask.shape)), sig,
+               torch.cuda.current_device(), _STATE['row_chain'], _STATE['fuse'], _lib.load().sbev_get_box_convention(),
+               rt.decoder.num_layers, tuple(rt.decoder.pc_range))
+        e = self.entries.get(key, False)
+        if e is False:                       # first sighting: eager this time, capture if it comes again
+            if len(self.entries) >= self.MAX:
+                old = next(iter(self.entries))
+                if self.entries[old]:
+                    self.entries[old]['graph'].destroy()
+                del self.entries[old]
+            self.entries[key] = None
+            return None
+        B = query_bbox.shape[0]
+        if e is None:
+            e = self._capture(key, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, B)
+            if e is None:
+                return None
+        else:
+            packed, layout, ih, iw = TR.DecoderContext.pack(img_metas, B)
+            if layout != e['layout'] or (ih, iw) != e['image']:
+                return None                  # other camera count / image size: not this graph's step
+            TR._upload(packed, query_bbox.device, out=e['ctx_buf'])
+        self.entries[key] = self.entries.pop(key)            # most recently used last
+        e['graph'].replay()
+        self.replays += 1
+        return e['graph'].cls, e['graph'].box
+
+    def _capture(self, key, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, B):
+        from . import transformer as TR
+        rt, lib = self.rt, _lib.load()
+        dev = query_bbox.device
+        ctx = TR.DecoderContext(img_metas, B, dev)
+        ctx_buf = ctx.buffer                                  # the graph reads the constants from this tensor on every replay
+        relayout = []                                         # (source NCHW tensor, resident NHWC buffer)
+        if hasattr(mlvl_feats, 'levels'):
+            pyramid = mlvl_feats
+        else:
+            pyramid = TR.FeaturePyramid.__new__(TR.FeaturePyramid)
+            f0 = mlvl_feats[0]
+            pyramid.B, TN, pyramid.GC = f0.shape[0], f0.shape[1], f0.shape[2]
+            pyramid.T = TN // TR.N_VIEWS
+            pyramid.levels, pyramid.copied = [], 0
+            for f in mlvl_feats:
+                nhwc = f.permute(0, 1, 3, 4, 2)
+                if not nhwc.is_contiguous():
+                    if f.dtype != torch.float32 or not f.is_contiguous():
+                        return None          # a layout the in-graph relayout kernel does not take: eager path
+                    buf = torch.empty(f.shape[0], TN, f.shape[3], f.shape[4], pyramid.GC, device=dev, dtype=torch.float32)
+                    relayout.append((f, buf))
+                    nhwc = buf
+                    pyramid.copied += 1
+                pyramid.levels.append(nhwc.reshape(pyramid.B * TN, f.shape[3], f.shape[4], pyramid.GC))
+        args, keep, cls, box = rt._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask, own_workspace=True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        sp = ctypes.c_void_p(side.cuda_stream)
+        _lib.check(lib.sbev_capture_begin(sp), 'sbev_capture_begin')
+        ok = True
+        try:
+            for f, buf in relayout:
+                TN, GC, H, W = f.shape[1], f.shape[2], f.shape[3], f.shape[4]
+                st = lib.sbev_nchw_to_nhwc_f32(_ptr(f), _ptr(buf), f.shape[0] * TN, GC, H * W, sp)
+                ok = ok and st == 0
+            ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
+        finally:
+            handle = ctypes.c_void_p()
+            st = lib.sbev_capture_end(sp, ctypes.byref(handle) if ok else None)
+        if not ok:
+            raise _lib.SbevError('graph capture of the decoder step failed: ' + lib.sbev_last_error().decode())
+        _lib.check(st, 'sbev_capture_end')
+        torch.cuda.current_stream().wait_stream(side)
+        graph = DecoderGraph(handle, (keep, relayout, mlvl_feats, pyramid, ctx, query_bbox, query_feat, attn_mask), cls, box)
+        e = {'graph': graph, 'ctx_buf': ctx_buf, 'layout': ctx.layout, 'image': (ctx.image_h, ctx.image_w)}
+        self.entries[key] = e
+        self.captures += 1
+        return e
 
 
 class DecoderGraph:
@@ -227,10 +384,15 @@ class DecoderGraph:
             pass
 
 
+# process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
+_STATE = {'row_chain': True, 'fuse': True, 'profile': 0}
+
+
 def fuse_sample_mix(enable):
     """Gather + adaptive mixing as one launch inside sbev_decoder_forward where the fused kernel covers the shape (default on;
     results are bit-identical either way).  ``SBEV_NO_SAMPLE_MIX=1`` in the environment switches it off for A/B runs."""
     _lib.check(_lib.load().sbev_decoder_fuse_sample_mix(int(bool(enable))), 'sbev_decoder_fuse_sample_mix')
+    _STATE['fuse'] = bool(enable)
 
 
 def row_chain(enable):
@@ -238,12 +400,14 @@ def row_chain(enable):
     launches with the rows in LDS instead of one launch per op (default on where the kernels cover the layer's shape; results
     agree to fp32 round-off, not bit for bit).  ``SBEV_NO_ROW_CHAIN=1`` in the environment switches it off for A/B runs."""
     _lib.check(_lib.load().sbev_decoder_row_chain(int(bool(enable))), 'sbev_decoder_row_chain')
+    _STATE['row_chain'] = bool(enable)
 
 
 def profile_sampler(enable):
     """enable: False / True (sampler launches only) or an int mask (1 sampler | 2 generator GEMM | 4 out-projection GEMM |
     8 fused gather + mixing)."""
     _lib.load().sbev_profile_sampler(int(enable))
+    _STATE['profile'] = int(enable)
 
 
 def profile_stride(every_n_calls):

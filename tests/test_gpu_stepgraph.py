@@ -1,0 +1,141 @@
+"""Static-step hipGraph replay (runtime.StepGraphs): a caller that passes the SAME tensors again gets the whole step -- feature
+relayout + all layers -- as one captured graph from the second identical call on.  The replay must be indistinguishable from the
+eager enqueue: bit-identical outputs, in-place input refreshes and new per-sample constants honoured, weight updates and switch
+changes never served from a stale graph, no aliasing of returned tensors."""
+import copy
+
+import pytest
+import torch
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason='needs a GPU')]
+
+from sparsebev_amd import runtime, synthetic as S  # noqa: E402
+from sparsebev_amd.transformer import SparseBEVTransformer  # noqa: E402
+
+DEV = 'cuda:0'
+PREFIX = 'decoder.decoder_layer.'
+
+
+def build(T, L, seed, num_layers=2, graph=True):
+    params = S.make_params(seed, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=num_layers, num_levels=L, num_classes=10,
+                             code_size=10, pc_range=S.PC_RANGE)
+    m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
+    m = m.to(DEV).eval()
+    m.decoder.static_graph = graph
+    return m
+
+
+def inputs(B=1, Q=64, T=2, pyr='tiny', seed=3):
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=seed)]
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=seed + 1)]
+    return feats, bbox, feat, S.make_img_metas(B, T, ih, iw), len(sizes)
+
+
+def test_replay_is_bit_identical_and_follows_in_place_refreshes():
+    feats, bbox, feat, metas, L = inputs()
+    g, e = build(2, L, 11), build(2, L, 11, graph=False)
+    outs = [g(bbox, feat, list(feats), None, metas) for _ in range(3)]          # eager, capture + replay, replay
+    sg = g.decoder._runtime.step_graphs
+    assert sg.captures == 1 and sg.replays == 2
+    ref = e(bbox, feat, list(feats), None, metas)
+    for o in outs:
+        assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1])
+    assert outs[1][0].data_ptr() != outs[2][0].data_ptr()                       # every call returns its own tensors
+    # refresh queries and one feature level IN PLACE: the graph reads through the captured pointers
+    feat.mul_(0.5)
+    feats[0].add_(0.25)
+    got, want = g(bbox, feat, list(feats), None, metas), e(bbox, feat, list(feats), None, metas)
+    assert sg.replays == 3 and not torch.equal(got[0], ref[0])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # new per-sample constants (other camera matrices / timestamps) with the same tensors: refreshed through the upload ring
+    m2 = copy.deepcopy(metas)
+    for m in m2:
+        m['lidar2img'] = [x * 1.01 for x in m['lidar2img']]
+        m['img_timestamp'] = [t + 0.05 * i for i, t in enumerate(m['img_timestamp'])]
+    got, want = g(bbox, feat, list(feats), None, m2), e(bbox, feat, list(feats), None, m2)
+    assert sg.replays == 4
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the decoder called directly hands out clones too (a replay overwrites the graph's own buffers)
+    a = g.decoder(bbox, feat, list(feats), None, metas)
+    b = g.decoder(bbox, feat, list(feats), None, m2)
+    assert a[0].data_ptr() != b[0].data_ptr() and not torch.equal(a[1], b[1])
+
+
+def test_new_tensors_weight_updates_and_switches_never_hit_a_stale_graph():
+    feats, bbox, feat, metas, L = inputs(seed=5)
+    g, e = build(2, L, 12), build(2, L, 12, graph=False)
+    for _ in range(2):
+        g(bbox, feat, list(feats), None, metas)
+    sg = g.decoder._runtime.step_graphs
+    assert sg.captures == 1
+    # another tensor (same values, other address): eager first, then its own graph
+    feat2 = feat.clone()
+    r0 = g(bbox, feat2, list(feats), None, metas)
+    assert sg.captures == 1 and sg.replays == 1
+    r1 = g(bbox, feat2, list(feats), None, metas)
+    assert sg.captures == 2 and torch.equal(r0[0], r1[0])
+    # an in-place weight update bumps _version: re-bind, old graphs dropped, new values everywhere
+    with torch.no_grad():
+        for m in (g, e):
+            m.decoder.decoder_layer.mixing.out_proj.bias.add_(0.125)
+            m.decoder.decoder_layer.ffn.layers[1].weight.mul_(1.5)
+    got = [g(bbox, feat, list(feats), None, metas) for _ in range(3)]
+    want = e(bbox, feat, list(feats), None, metas)
+    assert len(g.decoder._runtime.step_graphs.entries) == 1
+    for o in got:
+        assert torch.equal(o[0], want[0]) and torch.equal(o[1], want[1])
+    assert not torch.equal(want[0], r0[0])
+    # process-wide switches are part of the key: op-by-op launches are not served from the row-chain graph
+    runtime.row_chain(False)
+    try:
+        o1 = g(bbox, feat, list(feats), None, metas)
+        o2 = g(bbox, feat, list(feats), None, metas)
+        w = e(bbox, feat, list(feats), None, metas)
+        assert torch.equal(o1[0], w[0]) and torch.equal(o2[0], w[0])
+    finally:
+        runtime.row_chain(True)
+    # a different layer count on the same module (tests do this) is another step
+    g.decoder.num_layers = e.decoder.num_layers = 1
+    assert g(bbox, feat, list(feats), None, metas)[0].shape[0] == 1
+    assert torch.equal(g(bbox, feat, list(feats), None, metas)[0], e(bbox, feat, list(feats), None, metas)[0])
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'bf16x3s'])
+def test_graph_replay_in_every_gemm_mode_and_with_nhwc_inputs(mode):
+    feats, bbox, feat, metas, L = inputs(Q=100, T=8, pyr='tiny', seed=9)
+    g, e = build(8, L, 13), build(8, L, 13, graph=False)
+    g.decoder.gemm_mode = e.decoder.gemm_mode = mode
+    nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]      # channels-last memory: zero-copy
+    for fl in (feats, nhwc):
+        want = e(bbox, feat, list(fl), None, metas)
+        for _ in range(3):
+            got = g(bbox, feat, list(fl), None, metas)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert g.decoder._runtime.step_graphs.captures == 2
+
+
+def test_online_ring_phases_are_separate_graphs():
+    from sparsebev_amd.cache import FrameFeatureCache
+    T = 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    feats = [f.to(DEV) for f in S.make_features(1, T, sizes, seed=21)]
+    bbox, feat = [t.to(DEV) for t in S.make_queries(1, 49, seed=22)]
+    metas = S.make_img_metas(1, T, ih, iw)
+    g, e = build(T, len(sizes), 14), build(T, len(sizes), 14, graph=False)
+    rings = [FrameFeatureCache(T, n_slots=T) for _ in range(2)]
+    per_frame = [[f[:, t * 6:(t + 1) * 6].contiguous() for f in feats] for t in range(T)]
+    for r in rings:
+        for fr in reversed(per_frame):
+            r.push(fr)
+    for i in range(3 * T):                      # three laps around the ring: lap 1 eager, lap 2 captures, lap 3 replays
+        for r in rings:
+            r.push(per_frame[i % T])
+        got = g(bbox, feat, rings[0].pyramid(), None, metas)
+        want = e(bbox, feat, rings[1].pyramid(), None, metas)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), i
+    sg = g.decoder._runtime.step_graphs
+    assert sg.captures == T and sg.replays == 2 * T

@@ -68,6 +68,17 @@ class DecoderRuntime:
             self._params = list(self.decoder.parameters())
         return tuple((p.data_ptr(), p._version) for p in self._params)
 
+    def _ensure_bound(self):
+        """(Re-)bind when a parameter was replaced or modified in place; returns the current signature."""
+        sig = self._signature()
+        if sig != self._sig:
+            rebind = self._sig is not None
+            self._bind()
+            self._sig = sig
+            if rebind:
+                self.step_graphs.clear()    # graphs of the previous weight images can never be hit again: free them now
+        return sig
+
     def _bind(self):
         layer = self.decoder.decoder_layer
         for p in layer.parameters():
@@ -143,11 +154,7 @@ class DecoderRuntime:
 
     # -- forward -----------------------------------------------------------------------------------------
     def _prepare(self, query_bbox, query_feat, pyramid, ctx, attn_mask, own_workspace=False):
-        sig = self._signature()
-        if sig != self._sig:
-            self._bind()
-            self._sig = sig
-            self.step_graphs.clear()        # graphs of the previous weight images can never be hit again: free them now
+        sig = self._ensure_bound()
         dec, layer = self.decoder, self.decoder.decoder_layer
         smp = layer.sampling
         B, Q, D = query_feat.shape
@@ -199,9 +206,7 @@ class DecoderRuntime:
 
     def launches_per_layer(self, B, Q):
         """What sbev_decoder_forward would enqueue per layer for a [B, Q] call with the bound weights (asks the library)."""
-        if self._weights is None:
-            self._bind()
-            self._sig = self._signature()
+        self._ensure_bound()
         dec, layer = self.decoder, self.decoder.decoder_layer
         smp = layer.sampling
         cfg = DecoderConfig()
@@ -278,7 +283,7 @@ class StepGraphs:
         if not hasattr(mlvl_feats, 'levels') and not all(torch.is_tensor(f) and f.is_cuda for f in mlvl_feats):
             return None
         from . import transformer as TR
-        sig = rt._signature()
+        sig = rt._ensure_bound()
         key = (query_bbox.data_ptr(), query_feat.data_ptr(), tuple(query_feat.shape), self._feat_key(mlvl_feats),
                None if attn_mask is None else (attn_mask.data_ptr(), tuple(attn_mask.shape)), sig,
                torch.cuda.current_device(), _STATE['row_chain'], _STATE['fuse'], _lib.load().sbev_get_box_convention(),

@@ -201,7 +201,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
         self.mixing.init_weights()
         nn.init.constant_(self.cls_branch[-1].bias, float(-math.log((1 - 0.01) / 0.01)))   # bias_init_with_prob(0.01)
 
-    def forward_train(self, query_bbox, query_feat, feats, attn_mask, ctx, orig_feats=()):
+    def forward_train(self, query_bbox, query_feat, feats, attn_mask, ctx, feat_token=None):
         """The same layer with every op as a differentiable node (sparsebev_amd.autograd: HIP forward + HIP backward),
         unfused where a fused inference launch would hide an activation the backward needs.  Dropout (attention
         probabilities 0.1, the two FFN dropouts 0.1 -- mmcv defaults the reference's layer is built with,
@@ -225,7 +225,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
         both = AG.linear(x, torch.cat([smp.sampling_offset.weight, smp.scale_weights.weight], 0),
                          torch.cat([smp.sampling_offset.bias, smp.scale_weights.bias], 0))
         cfg = (smp.num_frames, smp.num_groups, smp.num_points, smp.num_levels, tuple(smp.pc_range))
-        sampled = AG.Sampling.apply(query_bbox, both, feats, ctx, cfg, *orig_feats)
+        sampled = AG.Sampling.apply(query_bbox, both, feats, ctx, cfg, feat_token)     # feat_token: AG.feature_token (None: frozen features)
         # adaptive mixing (+ identity), norm2
         x = AG.layer_norm(AG.AdaptiveMixing.apply(sampled, x, mix.parameter_generator.weight, mix.parameter_generator.bias,
                                                   mix.out_proj.weight, mix.out_proj.bias, mix.out_points, self.recompute_mixing),
@@ -482,6 +482,7 @@ class SparseBEVTransformerDecoder(_Base):
         if feats.levels[0].dtype != torch.float32:
             raise NotImplementedError('training needs fp32 feature maps (bf16 storage is an inference format)')
         orig = [f for f in mlvl_feats if torch.is_tensor(f)] if isinstance(mlvl_feats, (list, tuple)) else []
+        token = AG.feature_token(feats, orig)       # ONE node hands the shared feature-gradient buffers to autograd (or None)
         layer = self.decoder_layer
         saved = (layer.self_attn.attn_drop, layer.ffn_drop)
         if not self.training:
@@ -489,7 +490,7 @@ class SparseBEVTransformerDecoder(_Base):
         try:
             cls_scores, bbox_preds = [], []
             for i in range(self.num_layers):
-                query_feat, cls_score, bbox_pred = layer.forward_train(query_bbox, query_feat, feats, attn_mask, ctx, orig)
+                query_feat, cls_score, bbox_pred = layer.forward_train(query_bbox, query_feat, feats, attn_mask, ctx, token)
                 query_bbox = bbox_pred.detach()
                 cls_scores.append(cls_score)
                 bbox_preds.append(bbox_pred)

@@ -219,7 +219,7 @@ def test_sampling_function_vs_oracle_autograd(T, L, pyr):
     dev_feats = [f.to(DEV).requires_grad_(True) for f in feats]
     pyrd, ctx = FeaturePyramid(dev_feats), DecoderContext(metas, B, torch.device(DEV))
     bd, sd = bbox.to(DEV).requires_grad_(True), both.to(DEV).requires_grad_(True)
-    out = AG.Sampling.apply(bd, sd, pyrd, ctx, (T, G, P, L, tuple(S.PC_RANGE)), *dev_feats)
+    out = AG.Sampling.apply(bd, sd, pyrd, ctx, (T, G, P, L, tuple(S.PC_RANGE)), AG.feature_token(pyrd, dev_feats))
     out.backward(gy.to(DEV))
     # oracle: the same chain in torch (grid_sample sampler = the reference's native path), autograd
     bc, sc = bbox.clone().requires_grad_(True), both.clone().requires_grad_(True)
@@ -348,6 +348,43 @@ def test_g11_free_running_gradients_stay_close_to_the_reference(tag, bound):
     errs, _ = _g11_run(tag)
     worst = max(errs.items(), key=lambda kv: kv[1])
     assert worst[1] < bound, sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+
+
+@torch.enable_grad()
+def test_feature_gradient_with_partial_layer_loss_and_repeated_backward():
+    """The feature-map gradient is handed over by ONE node per decoder call (autograd.FeatureTap) that autograd runs after exactly
+    the sampler backwards the current pass reaches (a forward-time counter lost the gradient when the loss touched
+    only some layers and went negative on a second backward).  (a) a loss on layer 0's scores only = the 1-layer module's
+    gradient; (b) two backward passes under retain_graph accumulate twice the gradient, none is dropped or kept back."""
+    B, Q, T, L = 1, 36, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=16)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    base = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=17)]
+
+    def run(num_layers, loss_of, passes=1):
+        model = build(T, L, 15, num_layers).eval()
+        fs = [f.clone().requires_grad_(True) for f in base]
+        cls, box = model(bbox, feat, list(fs), None, copy.deepcopy(metas))
+        loss = loss_of(cls, box)
+        for i in range(passes):
+            loss.backward(retain_graph=i + 1 < passes)
+        return [f.grad for f in fs]
+
+    # (a) only layer 0 of a 2-layer decoder is in the loss: layer 1's Sampling node never runs its backward
+    part = run(2, lambda c, b: c[0].sum() + b[0].pow(2).sum())
+    one = run(1, lambda c, b: c[0].sum() + b[0].pow(2).sum())
+    for gp, go in zip(part, one):
+        assert gp is not None and torch.isfinite(gp).all() and gp.abs().max() > 0
+        assert (gp - go).abs().max() <= 1e-5 * go.abs().max()          # (atomics: summation order differs run to run)
+    # (b) the same graph differentiated twice
+    once = run(2, lambda c, b: c.sum() + b.sum())
+    twice = run(2, lambda c, b: c.sum() + b.sum(), passes=2)
+    for g1, g2 in zip(once, twice):
+        assert g2 is not None and (g2 - 2 * g1).abs().max() <= 1e-5 * g1.abs().max()
+    # (c) a loss that reaches no Sampling node at all leaves the features without gradient (and nothing allocated behind)
+    none = run(2, lambda c, b: (c * 0).sum().detach().requires_grad_(True))
+    assert all(g is None for g in none)
 
 
 @torch.enable_grad()

@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3g; mkdir -p $O
 cd $R
 timeout 600 python -m pytest tests/test_gpu_stepgraph.py -x -q 2>&1 | tail -15
-timeout 600 python bench.py --no-cpu-baseline --no-detector --no-live-pmc --no-alt --steps 30 2>$O/bench.err | tail -1 > $O/bench.json; tail -3 $O/bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-detector --no-live-pmc --steps 30 2>$O/bench.err | tail -1 > $O/bench.json; tail -3 $O/bench.err
 python -c "
 import json
 d=json.load(open('$O/bench.json'))

@@ -121,12 +121,20 @@ CONFIGS = {
     # configs[4] at one sample per GPU: ViT-scale 1600x640 maps, 5 levels, bf16 feature STORAGE (fp32 math), channels-last
     # as a bf16 neck would emit them (2.1 GB of features per sample): the large-feature-map HBM stress
     'c5': ('eva02_1600x640', 900, 8, 1, torch.bfloat16),
+    # the reference's own largest config (configs/vit_eva02_1600x640_trainval_future.py:54-58): 1600 queries, 15 frames (7 past +
+    # 7 future), 8 sampling points, 5 levels; bf16 feature storage like c5 -- 3.9 GB of features per sample
+    'c6': ('eva02_1600x640', 1600, 15, 1, torch.bfloat16, 8),
 }
 
 
-def build_model(T, L, device):
+def cfg_fields(cfg):
+    """(pyramid, Q, T, per-GPU batch, feature dtype, sampling points)"""
+    return tuple(cfg[:5]) + ((cfg[5] if len(cfg) > 5 else 4),)
+
+
+def build_model(T, L, device, P=4):
     torch.manual_seed(0)
-    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=6, num_levels=L, num_classes=10,
+    m = SparseBEVTransformer(256, num_frames=T, num_points=P, num_layers=6, num_levels=L, num_classes=10,
                              code_size=10, pc_range=S.PC_RANGE)
     m.init_weights()
     S.randomize_zero_init(m, std=0.02, seed=0)      # query-dependent offsets / mixing weights / tau (SURVEY 8d)
@@ -138,7 +146,7 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0, thread_sweep=(8, 16, 32, 64
     validated against golden vectors, timed on this box's host cores.  Bounded sample: 1 warm-up + up to 3
     timed samples or ~max_seconds, whichever comes first."""
     from oracle import sparsebev_oracle as O       # checker / baseline only -- never on the product path
-    pyr, Q, T, B, _ = cfg
+    pyr, Q, T, B, _, P = cfg_fields(cfg)
     ih, iw, sizes = S.PYRAMIDS[pyr]
     cores = os.cpu_count() or 1
     params = O.strip_prefix({k: v.detach().cpu().float() for k, v in model_state.items()})
@@ -151,9 +159,9 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0, thread_sweep=(8, 16, 32, 64
         best = None
         for nt in [n for n in thread_sweep if n <= cores] or [cores]:
             torch.set_num_threads(nt)
-            O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1)
+            O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1, num_points=P)
             t0 = time.perf_counter()
-            O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1)
+            O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1, num_points=P)
             dt1 = time.perf_counter() - t0
             if best is None or dt1 < best[0]:
                 best = (dt1, nt)
@@ -162,11 +170,11 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0, thread_sweep=(8, 16, 32, 64
         threads = best[1]
         torch.set_num_threads(threads)
         t0 = time.perf_counter()
-        O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE)
+        O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_points=P)
         warm = time.perf_counter() - t0
         n, t0 = 0, time.perf_counter()
         while n < 3 and (n == 0 or (time.perf_counter() - t0) + warm < max_seconds):
-            O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE)
+            O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_points=P)
             n += 1
         dt = time.perf_counter() - t0
     cores_used = threads
@@ -179,9 +187,9 @@ def cpu_baseline(cfg, model_state, max_seconds=30.0, thread_sweep=(8, 16, 32, 64
 def gpu_quick(config, device, steps=30, warmup=5):
     """decoder samples/s of another config (same method as the timed region, fewer steps): used for the c1 leg next to its
     CPU baseline -- c1 is the reference's own CPU-runnable case (BASELINE.json configs[0]), never `value`."""
-    pyr, Q, T, B, fdtype = CONFIGS[config]
+    pyr, Q, T, B, fdtype, P = cfg_fields(CONFIGS[config])
     ih, iw, sizes = S.PYRAMIDS[pyr]
-    model = build_model(T, len(sizes), device)
+    model = build_model(T, len(sizes), device, P)
     feats = S.make_features(B, T, sizes, seed=0, device=device, dtype=fdtype)
     bbox, qfeat = [t.to(device) for t in S.make_queries(B, Q, seed=0)]
     metas = S.make_img_metas(B, T, ih, iw)
@@ -196,9 +204,9 @@ def gpu_quick(config, device, steps=30, warmup=5):
     return round(steps * B / dt, 2), model
 
 
-def ops_sample_mix_supported(L, T):
+def ops_sample_mix_supported(L, T, P=4):
     from sparsebev_amd import ops
-    return os.environ.get('SBEV_NO_SAMPLE_MIX') != '1' and ops.sample_mix_supported(L, 64, 4, T, 4)
+    return os.environ.get('SBEV_NO_SAMPLE_MIX') != '1' and ops.sample_mix_supported(L, 64, P, T, 4)
 
 
 def mfma_util():
@@ -293,11 +301,11 @@ def main():
     if world > 1:
         torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))      # N host processes share the box: no 256-thread pools each
     cfg = CONFIGS[args.config]
-    pyr, Q, T, B, fdtype = cfg
+    pyr, Q, T, B, fdtype, P_cfg = cfg_fields(cfg)
     ih, iw, sizes = S.PYRAMIDS[pyr]
     L = len(sizes)
 
-    model = build_model(T, L, device)
+    model = build_model(T, L, device, P_cfg)
     model.decoder.gemm_mode = args.gemm
     model.decoder.overlap = args.overlap
     shard = SampleShard(rank, world)
@@ -331,7 +339,7 @@ def main():
     # The timed region runs un-instrumented: with the same input tensors every step the module replays ONE captured hipGraph per
     # step (feature relayout + 6 layers; runtime.StepGraphs), and HIP events cannot be read back from a graph.  The kernel
     # timings for the roofline fields come from extra EAGER steps right after it (same inputs, same cache state).
-    fused_cfg = ops_sample_mix_supported(L, T) and not (L == 5 and fdtype == torch.float32)     # the runtime's own rule (csrc/decoder.hip)
+    fused_cfg = ops_sample_mix_supported(L, T, P_cfg) and not (L == 5 and fdtype == torch.float32)     # the runtime's own rule (csrc/decoder.hip)
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -46,7 +46,17 @@ def gemm(A, a_kmajor, lda, B, b_kmajor, ldb, M, N, K, out=None, ldc=None, accumu
     return out
 
 
-_WT_CACHE = {}
+import weakref
+
+_WT_CACHE = weakref.WeakKeyDictionary()      # parameter tensor -> (version, W^T); entries die with their parameter
+
+
+def invalidate_caches():
+    """Drop every cached W^T.  Needed after writes that do not bump a tensor's ``_version`` -- ``p.data.copy_(...)`` as mmcv's
+    Fp16OptimizerHook / EMA hooks do -- before the next backward; ordinary optimizers (in-place ops on the parameter) are
+    detected through ``_version`` and need nothing.  ``SparseBEVTransformerDecoder.invalidate_caches()`` calls this and
+    re-binds the inference runtime's packed weight images."""
+    _WT_CACHE.clear()
 
 
 def _transposed(w):
@@ -56,22 +66,20 @@ def _transposed(w):
     instead of a 128 x 128-tile split-K launch + slab sum: 33 us), the strip kernel for grad_mixed (K = 256 -> 32 768 columns),
     the register-tile split-K kernel for the generator's input gradient (K = 32 768).  Costs one 2 x 33.5 MB transpose per
     big weight and optimizer step (12 us each)."""
-    # cached for leaf tensors only (parameters), matched by OBJECT identity -- the entry keeps the tensor alive, so a recycled
-    # address or id can never alias a stale entry; temporaries (the packed q | k | v | tau weight) are transposed each time
-    key = id(w)
+    # cached for leaf tensors only (parameters), keyed by the tensor OBJECT through a weak reference: the cache never keeps a
+    # parameter alive and a recycled address can never alias a stale entry; temporaries (the packed q | k | v | tau weight)
+    # are transposed each time.  Writes through ``.data`` do not bump ``_version``: see invalidate_caches().
     cacheable = w.is_leaf
     if cacheable:
-        hit = _WT_CACHE.get(key)
-        if hit is not None and hit[0] is w and hit[1] == w._version and hit[2].device == w.device:
-            return hit[2]
+        hit = _WT_CACHE.get(w)
+        if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+            return hit[1]
     N, K = w.shape
     wt = torch.empty(K, N, device=w.device, dtype=torch.float32)
     st = _lib.load().sbev_nchw_to_nhwc_f32(_p(_c(w.detach())), _p(wt), 1, N, K, _stream())      # [1, R = N, S = K] -> [1, S, R]
     _lib.check(st, 'sbev_nchw_to_nhwc_f32 (weight transpose)')
     if cacheable:
-        if len(_WT_CACHE) > 128:
-            _WT_CACHE.clear()
-        _WT_CACHE[key] = (w, w._version, wt)
+        _WT_CACHE[w] = (w._version, wt)
     return wt
 
 

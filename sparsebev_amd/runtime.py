@@ -72,7 +72,7 @@ class DecoderRuntime:
         """(Re-)bind when a parameter was replaced or modified in place; returns the current signature."""
         sig = self._signature()
         if sig != self._sig:
-            rebind = self._sig is not None
+            rebind = self._sig is not None            # (() = invalidated by hand: also a re-bind)
             self._bind()
             self._sig = sig
             if rebind:

@@ -473,6 +473,15 @@ class SparseBEVTransformerDecoder(_Base):
         with torch.no_grad():
             return self._forward_layerwise(query_bbox, query_feat, feats, attn_mask, ctx)
 
+    def invalidate_caches(self):
+        """Call after weight writes that bypass autograd's version counter (``p.data.copy_(...)``: mmcv's Fp16OptimizerHook copying
+        the fp32 master weights back, EMA hooks): drops the cached W^T of the backward and makes the inference runtime re-pack
+        its weight images (row-chain pack, split-bf16 images) and drop its captured graphs.  In-place ops on the parameters
+        themselves (every torch optimizer) are detected automatically."""
+        AG.invalidate_caches()
+        if self._runtime is not None:
+            self._runtime._sig = ()         # never equal to a real signature: the next call re-binds (and clears the step graphs)
+
     def forward_differentiable(self, query_bbox, query_feat, mlvl_feats, feats, attn_mask, ctx):
         """Training / fine-tuning path (grad enabled and something requires grad): every op a HIP forward + HIP backward
         node; dropout only in train() mode.  Mirrors models/sparsebev_transformer.py:86-101 including the detach of the

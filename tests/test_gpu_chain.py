@@ -81,10 +81,17 @@ def test_row_chains_equal_op_by_op_to_roundoff(B, Q, T, pyr, layers):
     model, _ = build(T, L, 12, layers)
     a, b = both(model, bbox, feat, feats, metas)
     assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    # Free-running, the two paths differ by fp32 summation order only; a random-init layer amplifies any input difference (rounding
+    # noise included) by up to ~8x (2e-6 -> 2.6e-2 over 6 layers between two CPU implementations).  So: one
+    # layer deep 2e-5, two deep 3e-4, and from there every layer at most 10x the previous layer's deviation -- a defect of the
+    # deeper launches (tail + next front) would break the growth law, which a flat bound could not see.  The one-layer-deep
+    # comparison of EVERY layer is test_row_chains_every_layer_from_the_same_inputs.
+    prev = 0.0
     for l in range(layers):
-        tol = 2e-5 if l == 0 else 3e-4 if l == 1 else 0.2
-        assert (a[0][l] - b[0][l]).abs().max() < tol, (l, (a[0][l] - b[0][l]).abs().max().item())
-        assert (a[1][l] - b[1][l]).abs().max() < tol, l
+        dev = max((a[0][l] - b[0][l]).abs().max().item(), (a[1][l] - b[1][l]).abs().max().item())
+        tol = 2e-5 if l == 0 else 3e-4 if l == 1 else 10.0 * max(prev, 3e-5)
+        assert dev < tol, (l, dev, prev)
+        prev = dev
     # run-to-run bit determinism, and rows do not depend on which workgroup / tile position computes them
     a2 = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])

@@ -136,10 +136,18 @@ def test_dump_taps_match_reference_recording(tmp_path):
     td = O.time_diff_from_metas(metas, B)
     taps = []
     O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1, taps=taps)
-    # sample points differ by device-libm ulps, so compare the mask loosely here (bitwise parity of the projection
-    # itself is asserted on identical inputs in test_gpu_sampling.py)
-    agree = (valid == taps[0]['valid']).float().mean().item()
-    assert agree > 0.999, agree
+    # The sample points come out of device expf / sinf / cosf / atan2f, ulps away from the CPU's libm, so the decoder-level mask can
+    # differ from the oracle's ONLY where a point projects onto a decision boundary of the hit test (image border u, v in {0, 1},
+    # depth homo == eps); the projection itself is bit-exact on identical points (test_gpu_sampling.py).  Assert exactly that:
+    # every differing point lies within 1e-4 (normalised image units / metres) of a boundary, and there are at most 3 of them.
+    ref_valid, ref_uvh = taps[0]['valid'], taps[0]['uvh']
+    diff = valid != ref_valid
+    n_diff = int(diff.sum())
+    if n_diff:
+        u, v, h = ref_uvh[..., 0], ref_uvh[..., 1], ref_uvh[..., 2]
+        margin = torch.stack([u.abs(), (u - 1).abs(), v.abs(), (v - 1).abs(), (h - 1e-5).abs()]).min(0).values
+        assert margin[diff].max().item() < 1e-4, (n_diff, margin[diff].max().item())
+    assert n_diff <= 3, n_diff
     tau = torch.load(os.path.join(str(tmp_path), 'sasa_tau_stage0.pth'))
     assert tau.shape == (B, Q, 8)
     # the dump path (layer-by-layer) and the runtime path give the same numbers

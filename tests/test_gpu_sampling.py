@@ -218,10 +218,16 @@ def test_msmv_backward_full_size_vs_oracle_sample():
     ops.msmv_sampling(fl, lc, ww).backward(gout)
     b = 5
     gf, gl, gw = O.msmv_sampling_backward([f[b:b + 1].cpu() for f in feats], loc[b:b + 1].cpu(), wbp[b:b + 1].cpu(), gout[b:b + 1].cpu())
-    assert (ww.grad[b:b + 1].cpu() - gw).abs().max() < 5e-4
-    assert (lc.grad[b:b + 1].cpu() - gl).abs().max() < 5e-4 * max(1.0, gl.abs().max().item())
+    # 1e-4 of each gradient's own scale (the north-star tolerance, relative: these gradients are sums of up to hundreds of
+    # O(1) terms -- grad_loc multiplies by the map size, a level-3 pixel collects every tap of its 22 x 8 map -- so an absolute
+    # 1e-4 would be below fp32 resolution of the values themselves; summation order differs: in-wave tree / float atomics
+    # against the oracle's index_add)
+    def rel(a, r):
+        return ((a - r).abs().max() / r.abs().max().clamp_min(1.0)).item()
+    assert rel(ww.grad[b:b + 1].cpu(), gw) < 1e-4, rel(ww.grad[b:b + 1].cpu(), gw)
+    assert rel(lc.grad[b:b + 1].cpu(), gl) < 1e-4, rel(lc.grad[b:b + 1].cpu(), gl)
     for a, r in zip(fl, gf):
-        assert (a.grad[b:b + 1].cpu() - r).abs().max() < 5e-4
+        assert rel(a.grad[b:b + 1].cpu(), r) < 1e-4, (rel(a.grad[b:b + 1].cpu(), r), r.abs().max().item())
 
 
 @pytest.mark.parametrize('P,L,C', [(6, 4, 64), (1, 5, 64), (9, 2, 64), (5, 3, 24)])

@@ -139,3 +139,23 @@ def test_online_ring_phases_are_separate_graphs():
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), i
     sg = g.decoder._runtime.step_graphs
     assert sg.captures == T and sg.replays == 2 * T
+
+
+def test_data_writes_are_picked_up_after_invalidate_caches():
+    """``p.data.copy_()`` (mmcv's Fp16OptimizerHook, EMA hooks) does not bump ``_version``: the runtime's packed weight images and
+    captured graphs are refreshed by ``decoder.invalidate_caches()``."""
+    feats, bbox, feat, metas, L = inputs(seed=31)
+    g, e = build(2, L, 15), build(2, L, 15, graph=False)
+    for _ in range(2):
+        g(bbox, feat, list(feats), None, metas)
+    for m in (g, e):
+        p = m.decoder.decoder_layer.ffn.layers[1].weight
+        v = p._version
+        p.data.mul_(1.5)
+        assert p._version == v
+    g.decoder.invalidate_caches()
+    e.decoder.invalidate_caches()
+    want = e(bbox, feat, list(feats), None, metas)
+    for _ in range(3):
+        got = g(bbox, feat, list(feats), None, metas)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])

@@ -27,19 +27,21 @@ WORKLOADS = {
     'c3': ('r50_704x256', 400, 8, 8, torch.float32),
     'c4': ('r101_1408x512', 900, 8, 4, torch.float32),
     'c5': ('eva02_1600x640', 900, 8, 1, torch.bfloat16),
+    # the reference's own largest config (configs/vit_eva02_1600x640_trainval_future.py:54-58): 15 frames, 8 points, 1600 queries
+    'c6': ('eva02_1600x640', 1600, 15, 1, torch.bfloat16, 8),
 }
 
 
-def build(T, L, seed, num_layers=1):
-    params = S.make_params(seed, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
-    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=num_layers, num_levels=L, num_classes=10,
+def build(T, L, seed, num_layers=1, P=4):
+    params = S.make_params(seed, embed_dims=256, num_frames=T, num_points=P, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=P, num_layers=num_layers, num_levels=L, num_classes=10,
                              code_size=10, pc_range=S.PC_RANGE)
     m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
     return m.to(DEV).eval(), params
 
 
 def workload(name, seed):
-    pyr, Q, T, B, dt = WORKLOADS[name]
+    pyr, Q, T, B, dt = WORKLOADS[name][:5]
     ih, iw, sizes = S.PYRAMIDS[pyr]
     feats = S.make_features(B, T, sizes, seed=seed, device=DEV, dtype=dt)        # generated on the device, left resident
     if dt != torch.float32:                                                      # a bf16 neck hands channels-last memory over
@@ -49,7 +51,11 @@ def workload(name, seed):
     return feats, bbox, feat, metas, (B, Q, T, len(sizes))
 
 
-def oracle_per_sample(params, bbox, feat, feats_dev, metas, num_layers=1, forced=None):
+def points_of(name):
+    return WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else 4
+
+
+def oracle_per_sample(params, bbox, feat, feats_dev, metas, num_layers=1, forced=None, P=4):
     """O.decoder one sample at a time on the widened-to-fp32 CPU copy of that sample's features (kernel-semantics sampler)."""
     from oracle import sparsebev_oracle as O
     cls, box, x = [], [], []
@@ -57,24 +63,24 @@ def oracle_per_sample(params, bbox, feat, feats_dev, metas, num_layers=1, forced
         fb = [f[b:b + 1].float().cpu().contiguous() for f in feats_dev]
         fi = None if forced is None else [(qb[b:b + 1], qf[b:b + 1]) for qb, qf in forced]
         c, bb, xx = O.decoder(params, bbox[b:b + 1], feat[b:b + 1], fb, metas[b:b + 1], S.PC_RANGE, num_layers=num_layers,
-                              sampler=O.msmv_sampling_kernel_semantics, forced_inputs=fi)
+                              num_points=P, sampler=O.msmv_sampling_kernel_semantics, forced_inputs=fi)
         cls.append(c), box.append(bb), x.append(xx)
         del fb
     return torch.cat(cls, 1), torch.cat(box, 1), torch.cat(x, 1)
 
 
-@pytest.mark.parametrize('name', ['c2', 'c3', 'c4', 'c5'])
+@pytest.mark.parametrize('name', ['c2', 'c3', 'c4', 'c5', 'c6'])
 def test_one_layer_at_full_workload_shape_vs_oracle(name):
     """One decoder layer at the full workload shape (all B samples, the real pyramid), C++ runtime and layer-by-layer
     path, against the oracle: cls / bbox / query_feat to 1e-4."""
     feats, bbox, feat, metas, (B, Q, T, L) = workload(name, seed=101)
-    model, params = build(T, L, seed=100)
+    model, params = build(T, L, seed=100, P=points_of(name))
     cls, box = model(bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas))
     assert cls.shape == (1, B, Q, 10) and box.shape == (1, B, Q, 10)
     lw_cls, lw_box = model(bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas), layerwise=True)
     rt_cls, rt_box = runtime_op_by_op(model, bbox.to(DEV), feat.to(DEV), list(feats), None, copy.deepcopy(metas))
     assert torch.equal(rt_cls, lw_cls) and torch.equal(rt_box, lw_box)
-    ref_cls, ref_box, _ = oracle_per_sample(params, bbox, feat, feats, metas)
+    ref_cls, ref_box, _ = oracle_per_sample(params, bbox, feat, feats, metas, P=points_of(name))
     assert (cls.cpu() - ref_cls).abs().max() < TOL                   # (c2 / c5: through the row-chain kernels)
     assert (box.cpu() - ref_box).abs().max() < TOL
     assert (lw_cls.cpu() - ref_cls).abs().max() < TOL and (lw_box.cpu() - ref_box).abs().max() < TOL
@@ -129,13 +135,13 @@ def test_c2_six_layers_teacher_forced_vs_oracle():
     assert (cls6[0].cpu() - ref_cls[0]).abs().max() < TOL
 
 
-@pytest.mark.parametrize('name', ['c3', 'c4', 'c5'])
+@pytest.mark.parametrize('name', ['c3', 'c4', 'c5', 'c6'])
 def test_full_workload_six_layer_properties(name):
     """Six layers at the full c3 / c4 / c5 shapes: size-independent properties (the 6-layer oracle at these sizes is
     minutes of CPU): bit determinism run to run, the C++ runtime equals the layer-by-layer path bit for bit, finite
     outputs, and a sample computed alone equals the same sample inside the batch to rounding."""
     feats, bbox, feat, metas, (B, Q, T, L) = workload(name, seed=121)
-    model, _ = build(T, L, seed=120, num_layers=6)
+    model, _ = build(T, L, seed=120, num_layers=6, P=points_of(name))
     qb, qf = bbox.to(DEV), feat.to(DEV)
     cls, box = model(qb, qf, list(feats), None, copy.deepcopy(metas))
     cls2, box2 = model(qb, qf, list(feats), None, copy.deepcopy(metas))

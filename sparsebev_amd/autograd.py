@@ -48,7 +48,7 @@ def gemm(A, a_kmajor, lda, B, b_kmajor, ldb, M, N, K, out=None, ldc=None, accumu
 
 import weakref
 
-_WT_CACHE = weakref.WeakKeyDictionary()      # parameter tensor -> (version, W^T); entries die with their parameter
+_WT_CACHE = {}      # id(parameter) -> (weak reference to it, version, W^T); a dead or recycled id never matches (`ref() is w`)
 
 
 def invalidate_caches():
@@ -66,20 +66,23 @@ def _transposed(w):
     instead of a 128 x 128-tile split-K launch + slab sum: 33 us), the strip kernel for grad_mixed (K = 256 -> 32 768 columns),
     the register-tile split-K kernel for the generator's input gradient (K = 32 768).  Costs one 2 x 33.5 MB transpose per
     big weight and optimizer step (12 us each)."""
-    # cached for leaf tensors only (parameters), keyed by the tensor OBJECT through a weak reference: the cache never keeps a
-    # parameter alive and a recycled address can never alias a stale entry; temporaries (the packed q | k | v | tau weight)
+    # cached for leaf tensors only (parameters), keyed by id() with a weak reference to the tensor OBJECT beside it (a
+    # WeakKeyDictionary would compare tensors with ==): the cache never keeps a parameter alive, a recycled id never matches; temporaries (the packed q | k | v | tau weight)
     # are transposed each time.  Writes through ``.data`` do not bump ``_version``: see invalidate_caches().
     cacheable = w.is_leaf
     if cacheable:
-        hit = _WT_CACHE.get(w)
-        if hit is not None and hit[0] == w._version and hit[1].device == w.device:
-            return hit[1]
+        hit = _WT_CACHE.get(id(w))
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:
+            return hit[2]
     N, K = w.shape
     wt = torch.empty(K, N, device=w.device, dtype=torch.float32)
     st = _lib.load().sbev_nchw_to_nhwc_f32(_p(_c(w.detach())), _p(wt), 1, N, K, _stream())      # [1, R = N, S = K] -> [1, S, R]
     _lib.check(st, 'sbev_nchw_to_nhwc_f32 (weight transpose)')
     if cacheable:
-        _WT_CACHE[w] = (w._version, wt)
+        if len(_WT_CACHE) >= 64:                    # drop the entries of parameters that are gone
+            for k in [k for k, v in _WT_CACHE.items() if v[0]() is None]:
+                del _WT_CACHE[k]
+        _WT_CACHE[id(w)] = (weakref.ref(w), w._version, wt)
     return wt
 
 

@@ -44,11 +44,21 @@
 __device__ unsigned long long g_sbev_trace[2][512][8];
 #define SBEV_TRACE(G_, SLOT_)                                                                               \
     if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && (G_) < 512) g_sbev_trace[wave >> 2][G_][SLOT_] = __builtin_readcyclecounter();
+__device__ unsigned long long g_sbev_wgtime[1024][4];     // per workgroup: realtime (100 MHz) and shader clock at start / end
+#define SBEV_WGTIME(I_)                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                            \
+        g_sbev_wgtime[blockIdx.x][2 * (I_)] = __builtin_amdgcn_s_memrealtime();                             \
+        g_sbev_wgtime[blockIdx.x][2 * (I_) + 1] = __builtin_readcyclecounter();                             \
+    }
 extern "C" int sbev_debug_trace_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbev_trace), sizeof(g_sbev_trace));
 }
+extern "C" int sbev_debug_wgtime_read(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbev_wgtime), sizeof(g_sbev_wgtime));
+}
 #else
 #define SBEV_TRACE(G_, SLOT_)
+#define SBEV_WGTIME(I_)
 #endif
 
 namespace {
@@ -154,6 +164,35 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
         : "memory");
 }
 
+// the NIMG images of one (32-row block, k-step): 1 KiB apart in memory AND in the LDS stage -> one M0 / base set-up for all of them
+template <int NIMG>
+__device__ __forceinline__ void glds16_images(const void* sbase, unsigned voff, unsigned lds_byte) {
+    lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte);
+    const unsigned long long sb = (unsigned long long)sbase;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
+    sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+    if constexpr (NIMG == 3)
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+            :
+            : "s"(lds_byte), "v"(voff), "s"(sbase)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 4\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+            :
+            : "s"(lds_byte), "v"(voff), "s"(sbase)
+            : "memory");
+}
+
 // ==== generator-shaped GEMM ======================================================================================================
 struct GenArgs {
     const unsigned short* Xs;    // [ceil(M/32)][K/16][NIMG][64][8] bf16 fragments (sbev_pack_bf16s_frags)
@@ -209,6 +248,7 @@ __device__ __forceinline__ void wait_vmcnt_imm() {
 __device__ __forceinline__ void wait_vmcnt_n(int n) {          // n wave-uniform, 0 .. 10
     switch (n) {
         case 0: wait_vmcnt_imm<0>(); break;
+        case 2: wait_vmcnt_imm<2>(); break;
         case 3: wait_vmcnt_imm<3>(); break;
         case 4: wait_vmcnt_imm<4>(); break;
         case 5: wait_vmcnt_imm<5>(); break;
@@ -229,12 +269,13 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     constexpr int STAGE = NIMG * (ST_A + ST_B);
     constexpr int NST = RF == 2 ? 4 : 3;                             // LDS ring depth; loads run NST - 1 stages ahead
     constexpr bool SPLIT_ACC = RF == 2;                              // second accumulator set for the small products
-    constexpr int NQ = NIMG * (AF + 8);                              // fragments (1 KiB) per stage
-    constexpr int NLMAX = (NQ + 7) / 8;
+    constexpr int NBLK = AF + 8;                                     // 32-row blocks per stage (A rows, then B columns): NIMG KiB each
+    constexpr int NLMAX = (NBLK + 7) / 8;
     typedef Prods<NIMG> PR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;                         // wr: row half = phase group (waves w, w + 4 share a SIMD)
+    SBEV_WGTIME(0)
     const int M = a.M, nk = a.K / 16;
     const int lw = (int)xcd_contiguous(blockIdx.x, gridDim.x);
     const int rt = lw % a.ntm, ct0 = lw / a.ntm, cstep = (int)gridDim.x / a.ntm, nct = a.N / G_COLS;
@@ -246,7 +287,8 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     const int m0 = f0 * 32;
     int nfa = nf - RF * wr;                                          // this wave's row fragments: 0 .. RF (fixed for its life)
     nfa = nfa < 0 ? 0 : (nfa > RF ? RF : nfa);
-    const int nl = (NQ - wave + 7) / 8;                              // this wave's loads per stage
+    const int nlb = (NBLK - wave + 7) / 8;                           // this wave's blocks per stage (NIMG loads each)
+    const int nl = nlb * NIMG;
 
     const unsigned voff = (unsigned)lane * 16u;
     const unsigned char* gbase[NLMAX];
@@ -256,20 +298,16 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     const long long blkbytes = (long long)nk * NIMG * 1024;          // one 32-row block, all k-steps and images
 #pragma unroll
     for (int j = 0; j < NLMAX; ++j) {
-        const int q = wave + 8 * j;
-        if (q < NIMG * AF) {
-            const int img = q / AF, blk = q % AF;
-            int fb = f0 + blk;
+        const int q = wave + 8 * j;                                  // block q of the stage: the stage image is [block][image][1 KiB]
+        ldst[j] = (unsigned)(q * NIMG * 1024);
+        if (q < AF) {
+            int fb = f0 + q;
             fb = fb < nfrag ? fb : nfrag - 1;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs) + fb * blkbytes + img * 1024;
-            ldst[j] = (unsigned)(img * ST_A + blk * 1024);
-            gstep[j] = -(long long)nk * NIMG * 1024;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Xs) + fb * blkbytes;
+            gstep[j] = -(long long)nk * NIMG * 1024;                  // next tile: the same rows again
         } else {
-            const int q2 = q - NIMG * AF;
-            const int img = q2 >> 3, blk = q2 & 7;
-            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws) + (long long)(ct0 * 8 + blk) * blkbytes + img * 1024;
-            ldst[j] = (unsigned)(NIMG * ST_A + img * ST_B + blk * 1024);
-            gstep[j] = (long long)(cstep * 8) * blkbytes - (long long)nk * NIMG * 1024;
+            gbase[j] = reinterpret_cast<const unsigned char*>(a.Ws) + (long long)(ct0 * 8 + (q - AF)) * blkbytes;
+            gstep[j] = (long long)(cstep * 8) * blkbytes - (long long)nk * NIMG * 1024;      // to the next column tile of this workgroup
         }
     }
     int lk = 0, lg = 0;                                              // load cursor: k-step in its tile, next stage to issue
@@ -278,7 +316,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         const unsigned sb = (unsigned)((lg % NST) * STAGE);
 #pragma unroll
         for (int j = 0; j < NLMAX; ++j) {
-            if (j < nl) glds16(gbase[j], voff, sb + ldst[j]);
+            if (j < nlb) glds16_images<NIMG>(gbase[j], voff, sb + ldst[j]);
             gbase[j] += NIMG * 1024;
         }
         ++lg;
@@ -289,8 +327,8 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         }
     };
     const int l31 = lane & 31, lh = lane >> 5;
-    const unsigned aoff = (unsigned)(wr * RF) * 1024u + voff;
-    const unsigned boff = (unsigned)(NIMG * ST_A) + (unsigned)(wc * 2) * 1024u + voff;
+    const unsigned aoff = (unsigned)(wr * RF) * (NIMG * 1024u) + voff;
+    const unsigned boff = (unsigned)(AF + wc * 2) * (NIMG * 1024u) + voff;
 
     auto run = [&](auto nfa_c) {
         constexpr int NFA = decltype(nfa_c)::value;
@@ -371,22 +409,22 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
             // ---- FETCH(g): loads of stage g + NST - 1; stage g + 1 of this wave landed (only newer loads may be outstanding: vector
             // loads return in order; a store in flight can only make the wait longer); fragments of stage g -> registers
             SBEV_TRACE(g, 0)
-            issue_next();
-            SBEV_TRACE(g, 1)
-            {
-                const int hi = lg - 1, need = g + 1 < G ? g + 1 : g;
-                wait_vmcnt_n(hi > need ? (hi - need) * nl : 0);
-            }
-            SBEV_TRACE(g, 2)
-            if constexpr (NFA > 0) {
+            if constexpr (NFA > 0) {                                 // (stage g landed and was published a phase ago)
                 const unsigned char* st = lds + (g % NST) * STAGE;
 #pragma unroll
                 for (int img = 0; img < NIMG; ++img) {
-                    wf[0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * ST_B);
-                    wf[1][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * ST_B + 1024);
+                    wf[0][img] = *reinterpret_cast<const bf16x8*>(st + boff + img * 1024);
+                    wf[1][img] = *reinterpret_cast<const bf16x8*>(st + boff + (NIMG + img) * 1024);
 #pragma unroll
-                    for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + img * ST_A + fa * 1024);
+                    for (int fa = 0; fa < NFA; ++fa) xf[fa][img] = *reinterpret_cast<const bf16x8*>(st + aoff + (fa * NIMG + img) * 1024);
                 }
+            }
+            SBEV_TRACE(g, 1)
+            issue_next();
+            SBEV_TRACE(g, 2)
+            {
+                const int hi = lg - 1, need = g + 1 < G ? g + 1 : g;
+                wait_vmcnt_n(hi > need ? (hi - need) * nl : 0);
             }
             if (pending) {                                           // the previous tile's stores ride in this phase
                 store_tile(cn0);
@@ -431,6 +469,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         }
         if (wr == 0) phase_barrier();
         if (pending) store_tile(cn0);
+        SBEV_WGTIME(1)
     };
     if (nfa == RF) run(std::integral_constant<int, RF>{});
     else if (nfa == RF - 1) run(std::integral_constant<int, RF - 1>{});
@@ -568,18 +607,28 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
                 SBEV_TRACE(S_, 1)                                                                           \
                 if ((S_) > 0) loadw((S_), 1, w[1]);   /* needed a FETCH + half a COMPUTE from now */        \
                 SBEV_TRACE(S_, 2)                                                                           \
-                stagex((S_) + 2, X0, X1);                                                                   \
-                loadx((S_) + 4, X0, X1);                                                                    \
                 SBEV_TRACE(S_, 3)                                                                           \
             }                                                                                               \
             phase_barrier();                                                                                \
             SBEV_TRACE(S_, 4)                                                                               \
-            /* COMPUTE: k-step 0, then k-step 1 with the next slab's k-step-0 W loads riding between its MFMAs (the registers  */ \
-            /* they overwrite are dead once k-step 0 has issued); the k-step-1 W loads go out in the next FETCH                */ \
+            /* COMPUTE: k-step 0 with the split + LDS write of the slab two ahead and the X loads four ahead riding between its */ \
+            /* MFMAs (a 32-cycle MFMA hides ~5 single-issue instructions; in the FETCH phase the same ~60 VALU ops cost 1000     */ \
+            /* cycles of the partner's matrix time), then k-step 1 with the next slab's k-step-0 W loads between its MFMAs (the  */ \
+            /* registers they overwrite are dead once k-step 0 has issued); the k-step-1 W loads go out in the next FETCH        */ \
+            stagex((S_) + 2, X0, X1);                                                                       \
+            loadx((S_) + 4, X0, X1);                                                                        \
             _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
                 _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
                     _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
                         acc[fa][fb] = SBEV_MFMA(w[0][fb][PR::ib(p)], xf[0][fa][PR::ia(p)], acc[fa][fb]);    \
+            _Pragma("unroll") for (int i = 0; i < PR::N * NFA * 2 - 2; ++i) {                               \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                          \
+            }                                                                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x200, NIMG, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                              \
             __builtin_amdgcn_sched_barrier(0);                                                              \
             loadw((S_) + 1, 0, w[0]);                                                                       \
             _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \

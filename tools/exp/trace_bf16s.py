@@ -30,3 +30,16 @@ for grp in (0, 1):
         print('  g=%2d' % g, ' '.join('%6d' % v for v in d), '  total', nxt - r[0])
     tot = t[grp, G - 1, 6] - t[grp, 0, 0]
     print('  %d stages:' % G, tot, 'cycles ->', tot / G, 'per stage')
+
+buf2 = (ctypes.c_ulonglong * (1024 * 4))()
+raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p]
+assert raw.sbev_debug_wgtime_read(buf2) == 0
+w = np.array(buf2, dtype=np.uint64).reshape(1024, 4).astype(np.int64)
+w = w[w[:, 0] > 0]
+t0 = w[:, 0].min()
+print('%d workgroups; realtime ticks (100 MHz = 10 ns): start min/max %d / %d, end min/max %d / %d' % (len(w), 0, (w[:, 0] - t0).max(), (w[:, 2] - t0).min(), (w[:, 2] - t0).max()))
+life_rt = (w[:, 2] - w[:, 0]); life_ck = (w[:, 3] - w[:, 1])
+print('lifetime realtime ticks: min %d median %d max %d ; shader-counter ticks: min %d median %d max %d ; counter ticks per realtime tick: %.1f (x 100 MHz = counter rate)'
+      % (life_rt.min(), np.median(life_rt), life_rt.max(), life_ck.min(), np.median(life_ck), life_ck.max(), np.median(life_ck / np.maximum(life_rt, 1))))
+order = np.argsort(w[:, 2])
+print('slowest workgroups (index, lifetime rt):', [(int(i), int(life_rt[i])) for i in order[-6:]], ' fastest:', [(int(i), int(life_rt[i])) for i in order[:6]])

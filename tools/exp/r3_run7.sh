@@ -2,7 +2,6 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3f; mkdir -p $O
 cd $R
-echo S34; SBEV_BF16S_OUT_CHUNKS=34 python tools/bench_bf16s.py --quick --m 900 2>/dev/null
 timeout 600 python bench.py --no-cpu-baseline --no-detector --no-live-pmc --steps 30 2>/dev/null | tail -1 > $O/bench.json
 python -c "
 import json
@@ -10,4 +9,3 @@ d=json.load(open('$O/bench.json'))
 print('value', d['value'], 'host_issue', d['host_issue_ms_per_step'])
 for k,v in d.get('alt_gemm',{}).items(): print(k, {a:b for a,b in v.items() if a!='gemm'})
 "
-timeout 1200 python -m pytest tests/test_gpu_workloads.py -x -q 2>&1 | tail -5

@@ -237,6 +237,9 @@ def detector_standin(args, T, L, Q, B, ih, iw, sizes, device, transformer):
     head.transformer.load_state_dict(transformer.state_dict())
     with torch.no_grad():
         head.init_query_bbox.weight[:, 2] = 0.5
+        # random-init class bias is -4.6 (sigmoid 0.01 < the 0.05 score threshold: the decode would compact NOTHING and the figure
+        # would time an empty post-process); a trained head keeps a few hundred boxes -- bias 0 puts ~half the scores above it
+        head.transformer.decoder.decoder_layer.cls_branch[-1].bias.zero_()
     head = head.to(device).eval()
     metas = S.make_img_metas(B, T, ih, iw)
     ring = FrameFeatureCache(T, n_slots=T)
@@ -252,7 +255,7 @@ def detector_standin(args, T, L, Q, B, ih, iw, sizes, device, transformer):
 
     def step():
         frame()
-        outs = head(ring.pyramid(), copy.deepcopy(metas))
+        outs = head(ring.pyramid(), metas)
         return head.get_bboxes(outs, metas)
 
     for _ in range(max(3, args.warmup // 2)):
@@ -339,7 +342,7 @@ def main():
     # The timed region runs un-instrumented: with the same input tensors every step the module replays ONE captured hipGraph per
     # step (feature relayout + 6 layers; runtime.StepGraphs), and HIP events cannot be read back from a graph.  The kernel
     # timings for the roofline fields come from extra EAGER steps right after it (same inputs, same cache state).
-    fused_cfg = ops_sample_mix_supported(L, T, P_cfg) and not (L == 5 and fdtype == torch.float32)     # the runtime's own rule (csrc/decoder.hip)
+    fused_cfg = ops_sample_mix_supported(L, T, P_cfg) and not (L == 5 and fdtype == torch.float32 and os.environ.get('SBEV_NO_FUSE_L5F32'))     # the runtime's own rule (csrc/decoder.hip)
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -7,6 +7,7 @@
 // The launch sequence is static for a given config, which also makes it capturable into a hipGraph by the
 // caller (the stream may be in capture mode: no call in here is capture-illegal).
 #include <atomic>
+#include <cstdlib>
 #include "sbev_common.hpp"
 
 #include <mutex>
@@ -69,6 +70,10 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
 // gather + mixing in one launch (sbev_sample_mix_f32) where supported; sbev_decoder_fuse_sample_mix(0) restores the two
 // launches (A/B measurements; results are bit-identical)
 std::atomic<int> g_fuse_sample_mix{1};
+// 5 fp32 levels: the fused instantiation needed 168 registers + spills for 3 waves per SIMD in round 2 (-1.8 % at config 4) and
+// kept the two launches; with the lean chunk code (msmv_chunk.inc, round 3) it fits 168 without a spill.  SBEV_NO_FUSE_L5F32=1
+// restores the two launches (A/B).
+std::atomic<int> g_fuse_l5_f32{getenv("SBEV_NO_FUSE_L5F32") ? 0 : 1};
 
 // the row-local op chains of a layer as three launches (row_chain.hip) when the caller supplied packed weights
 // (sbev_decoder_weights.chain_pack); sbev_decoder_row_chain(0) restores the op-by-op launches (A/B measurements)
@@ -139,7 +144,7 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
     const bool chain = g_row_chain.load(std::memory_order_relaxed) != 0 && w->chain_pack != nullptr && !fork && sbev::row_chain_supported(c) &&
                        sbev::row_chain_pays(BQ);
     const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                       sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
+                       sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
     const int split = (c.gemm_mode == SBEV_GEMM_BF16X6 || c.gemm_mode == SBEV_GEMM_BF16X3S) ? 1      // x1 -> bf16 image fragments
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
     // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
@@ -237,7 +242,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                               sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
+                               sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
             if (fused) {
                 TRY(sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
                                         c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, stream));
@@ -299,10 +304,10 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                                     c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
         // gather + adaptive mixing: ONE launch when the fused kernel covers the shape (the sampled features then never
         // touch HBM), else the sampler followed by the mixing kernel (same arithmetic, bit-identical results)
-        // (not for 5 fp32 levels: the fused instantiation needs 168 registers + spills for 3 waves per SIMD there and measured
-        // 272 vs 277 samples/s at config 4; 4 fp32 levels +1.6 % at config 2, 5 bf16 levels +4.3 % at config 5)
+        // (round 2 kept two launches for 5 fp32 levels: 168 registers + spills, 272 vs 277 samples/s at config 4; the lean chunk code
+        // of round 3 fits without spills -- g_fuse_l5_f32; 4 fp32 levels +1.6 % at config 2, 5 bf16 levels +4.3 % at config 5)
         const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                           sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32);
+                           sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
         if (!fused) {
             if (c.n_slots > 0)
                 TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
                 for (int l = 0; l < L; ++l)
                     base[l] = reinterpret_cast<const FT*>(m.feat[l]) + (long long)ubo * m.stride_bo[l] + (long long)g * m.stride_g + j4;
                 const int npts = 4;
-                const bool chan_ok = true;
+                [[maybe_unused]] const bool chan_ok = true;
                 {
                     const MsmvArgs& a = m;                      // the included chunk code names its argument block `a`
 #include "msmv_chunk.inc"

@@ -202,5 +202,5 @@ def test_build_tracks_textual_include_fragments(monkeypatch):
     stale = build.stale_units()
     assert 'msmv_sampling.hip' in stale and 'mixing.hip' in stale
     monkeypatch.undo()
-    users = [s for s in build.UNITS if 'msmv_chunk.inc' in open(os.path.join(build.HERE, s)).read()]
+    users = [s for s in build.UNITS if re.search(r'#include\s+"msmv_chunk\.inc"', open(os.path.join(build.HERE, s)).read())]
     assert sorted(users) == ['mixing.hip', 'msmv_sampling.hip']

@@ -26,23 +26,11 @@
 
 namespace {
 
-constexpr int R = 4;                 // rows (queries) per workgroup
 constexpr int NWAVE = 8;
 constexpr int DM = 256, FF = 512;    // embed_dims, ffn width (host-checked)
 constexpr int LDX = DM + 8;          // LDS row strides: == 8 (mod 32) so the A read (4 rows x 16 k per 32 lanes) is conflict-free
 constexpr int LDH = FF + 8;
-constexpr int ITEM_FLOATS = 64 * 128;   // one item's packed weights (32 KB)
-constexpr int MAX_SLOTS = 16;
-
-// LDS map (float offsets)
-constexpr int OFF_X2 = 0;                    // x2 (norm2 output) / x (attention input rows) / att rows
-constexpr int OFF_X3 = OFF_X2 + R * LDX;     // x3 = the layer's output rows (next layer's query_feat) / x1
-constexpr int OFF_H = OFF_X3 + R * LDX;      // ffn hidden rows; dead after ffn.layers.1, then:
-constexpr int OFF_C = OFF_H;                 //   classification-branch rows / position-encoder rows
-constexpr int OFF_R = OFF_H + R * LDX;       //   regression-branch rows
-constexpr int OFF_P = OFF_H + 2 * R * LDX;   // partial sums [MAX_SLOTS][R][64]     (2 R LDX >= R LDH)
-constexpr int LDS_FLOATS = OFF_P + MAX_SLOTS * R * 64;
-static_assert(2 * R * LDX >= R * LDH, "branch rows alias the ffn hidden rows");
+static_assert(2 * LDX >= LDH, "branch rows alias the ffn hidden rows");
 
 // The small vectors (biases, LayerNorm weights, the 3 -> 256 position-encoder weight) live behind the packed matrices in the
 // chain_pack image, grouped per chain, and are copied into LDS at kernel start (one contiguous copy; every epilogue would
@@ -63,8 +51,9 @@ enum Pre { PRE_SLABS, PRE_FRONT, PRE_ATT };
 struct Lin {
     const float* wp;     // packed weights of this Linear
     int in_off, ld;      // LDS rows it reads
-    int KH;              // K / 128
+    int KH;              // k-pieces per column group (RG = 1: K / 128)
     int items;           // 64-column groups x KH
+    int chunks;          // 16-k chunks per item = K / (16 KH); a multiple of 4
 };
 struct Unit {
     Lin a, b;            // b.items == 0: one Linear
@@ -119,17 +108,43 @@ struct ChainArgs {
 // make these waits (and the compiler's own) more conservative.
 constexpr int RING_SLOTS = 3;
 constexpr int CHUNK_FLOATS = 1024;
-constexpr int OFF_RING = LDS_FLOATS;                                      // [NWAVE][RING_SLOTS][CHUNK_FLOATS]
-constexpr int OFF_DUMP = OFF_RING + NWAVE * RING_SLOTS * CHUNK_FLOATS;     // [NWAVE][64] sink of the warm-up loads
-constexpr int OFF_PARAM = OFF_DUMP + NWAVE * 64;                           // the launch's small vectors (PV_* offsets)
-constexpr int LDS_TOTAL_FLOATS = OFF_PARAM + PV_FRONT_END;
-static_assert(LDS_TOTAL_FLOATS * 4 <= 160 * 1024, "LDS budget of one CU");
+
+// Rows per workgroup: R = 4 RG, RG = 1, 2 or 4 row groups of the 4-row MFMA (template parameter of the kernels).
+//   RG = 1 (<= 1024 rows, round 2): the LDS-DMA ring above, items of 64 columns x 128 k, 16 partial-sum slots.
+//   RG = 2 / 4 (round 3: up to 2048 / 4096 rows in ONE round of workgroups -- the batch configs, 3200 and 3600 rows, and the
+//     1600-query config): every weight chunk multiplies RG row groups (RG x the MFMAs per byte streamed: at RG = 4 the launch
+//     is as much MFMA- as stream-bound), so the LDS goes to the rows, the chunks travel global -> VGPR (a ring of 4 chunks =
+//     64 registers, waits counted by the compiler), and a wave keeps a column group's k-pieces in its accumulators: items are
+//     64 columns x (K / KH) k with KH chosen so that a unit has ~8 items -> 8 partial-sum slots.
+// LDS map (float offsets):
+template <int RG>
+struct Lay {
+    static constexpr int R = 4 * RG;
+    static constexpr bool WIDE = RG > 1;
+    static constexpr int MAX_SLOTS = WIDE ? 8 : 16;
+    static constexpr int OFF_X2 = 0;                    // x2 (norm2 output) / x (attention input rows) / att rows
+    static constexpr int OFF_X3 = OFF_X2 + R * LDX;     // x3 = the layer's output rows (next layer's query_feat) / x1
+    static constexpr int OFF_H = OFF_X3 + R * LDX;      // ffn hidden rows; dead after ffn.layers.1, then:
+    static constexpr int OFF_C = OFF_H;                 //   classification-branch rows / position-encoder rows
+    static constexpr int OFF_R = OFF_H + R * LDX;       //   regression-branch rows
+    static constexpr int OFF_P = OFF_H + 2 * R * LDX;   // partial sums [MAX_SLOTS][R][64]     (2 R LDX >= R LDH)
+    static constexpr int LDS_FLOATS = OFF_P + MAX_SLOTS * R * 64;
+    static constexpr int OFF_RING = LDS_FLOATS;                                                      // [NWAVE][RING_SLOTS][CHUNK_FLOATS]
+    static constexpr int OFF_DUMP = OFF_RING + (WIDE ? 0 : NWAVE * RING_SLOTS * CHUNK_FLOATS);     // [NWAVE][64] sink of the warm-up loads
+    static constexpr int OFF_PARAM = OFF_DUMP + NWAVE * 64;                                          // the launch's small vectors (PV_* offsets)
+    static constexpr int LDS_TOTAL_FLOATS = OFF_PARAM + PV_FRONT_END;
+    static constexpr int RPW = (R + NWAVE - 1) / NWAVE;                                              // input rows per wave in the prologue
+    static_assert(LDS_TOTAL_FLOATS * 4 <= 160 * 1024, "LDS budget of one CU");
+};
+struct Offs { int x2, x3, h, c, r; };        // the same offsets for the host-side unit tables
+template <int RG> constexpr Offs offs_of() { return Offs{Lay<RG>::OFF_X2, Lay<RG>::OFF_X3, Lay<RG>::OFF_H, Lay<RG>::OFF_C, Lay<RG>::OFF_R}; }
 
 // L2 warm-up.  The L2 is cold for the weights at every launch (a whole layer of GEMM / gather traffic went through it), and
 // the workgroups of an XCD stream the same lines in near lock-step, so each line's HBM / Infinity-Cache miss latency would be
 // seen by all of them, every round.  Instead the workgroups of an XCD (workgroup i runs on XCD i % 8) split the launch's
 // weight span between them and touch one dword per 128-byte line of their slice up front, while the prologue runs; the
 // loads go to an LDS sink (no register to keep alive) and are older than every chunk load, so the counted waits stay valid.
+template <int RG>
 __device__ __forceinline__ void warm_l2(const ChainArgs& a, int wave, int lane) {
     const int per_xcd = ((int)gridDim.x + 7) / 8;
     const int parts = per_xcd < 32 ? per_xcd : 32;
@@ -137,7 +152,7 @@ __device__ __forceinline__ void warm_l2(const ChainArgs& a, int wave, int lane) 
     const int n = (a.warm_lines + parts - 1) / parts;
     const int l0 = part * n;
     const int l1 = min(a.warm_lines, l0 + n);
-    const unsigned dump = (unsigned)(OFF_DUMP + wave * 64) * 4u;
+    const unsigned dump = (unsigned)(Lay<RG>::OFF_DUMP + wave * 64) * 4u;
     for (int l = l0 + wave * 64; l < l1; l += NWAVE * 64) {
         const int line = min(l + lane, l1 - 1);
         const unsigned voff = (unsigned)line * 128u;
@@ -168,7 +183,7 @@ __device__ __forceinline__ void walk_settle(const ChainArgs& a, Walk& w, int wav
 __device__ __forceinline__ const float* item_weights(const Unit& un, int it) {
     const bool second = it >= un.a.items;
     const Lin& l = second ? un.b : un.a;
-    return l.wp + (long long)(it - (second ? un.a.items : 0)) * ITEM_FLOATS;
+    return l.wp + (long long)(it - (second ? un.a.items : 0)) * (l.chunks * CHUNK_FLOATS);
 }
 
 // (M0 carries the LDS destination of an LDS-DMA load and is written inside the asm block; hipcc does not use M0 anywhere else
@@ -189,6 +204,7 @@ __device__ __forceinline__ void issue_chunk(const float* g, unsigned lds_byte, u
 struct Stream {
     Walk iw;             // item of the next chunk to issue
     const float* g;      // its weights (next chunk)
+    int nchunk;          // chunks of that item
     int issued, used;    // chunk counters
     int islot, uslot;    // issued % RING_SLOTS, used % RING_SLOTS
     unsigned ring_byte;  // LDS byte address of this wave's ring
@@ -198,7 +214,11 @@ struct Stream {
 __device__ __forceinline__ void stream_seek(const ChainArgs& a, Stream& st, int wave) {
     walk_settle(a, st.iw, wave);
     st.iw.step = 0;
-    if (st.iw.u < a.n_units) st.g = item_weights(a.units[st.iw.u], st.iw.it);
+    if (st.iw.u < a.n_units) {
+        const Unit& un = a.units[st.iw.u];
+        st.g = item_weights(un, st.iw.it);
+        st.nchunk = st.iw.it >= un.a.items ? un.b.chunks : un.a.chunks;
+    }
 }
 
 __device__ __forceinline__ void stream_issue(const ChainArgs& a, Stream& st, int wave) {
@@ -206,11 +226,27 @@ __device__ __forceinline__ void stream_issue(const ChainArgs& a, Stream& st, int
     issue_chunk(st.g + st.iw.step * CHUNK_FLOATS, st.ring_byte + (unsigned)st.islot * (CHUNK_FLOATS * 4), st.voff);
     ++st.issued;
     st.islot = st.islot == RING_SLOTS - 1 ? 0 : st.islot + 1;
-    if (++st.iw.step == 8) {
+    if (++st.iw.step == st.nchunk) {
         st.iw.it += NWAVE;
         stream_seek(a, st, wave);
     }
 }
+
+// RG > 1: the next chunk of the stream into 16 registers (four 1 KB wave-loads; the compiler counts the waits)
+struct RChunk { float4 q[4]; };
+// The loads are UNCONDITIONAL (past the end of the stream a wave re-reads the first chunk of its last item, <= 16 KB per wave):
+// a load under a branch would make the number of younger loads unknown to the compiler, which then waits vmcnt(0) before every
+// chunk instead of vmcnt(12).
+__device__ __forceinline__ void stream_load(const ChainArgs& a, Stream& st, int wave, int lane, RChunk& c) {
+    const float* g = st.g + st.iw.step * CHUNK_FLOATS + lane * 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) c.q[m] = *reinterpret_cast<const float4*>(g + 256 * m);
+    if (st.iw.u < a.n_units && ++st.iw.step == st.nchunk) {
+        st.iw.it += NWAVE;
+        stream_seek(a, st, wave);
+    }
+}
+constexpr int RDEPTH = 4;        // chunks in registers per wave (one multiplying, three on their way)
 
 #define SBEV_MF(KK, BV) acc[(KK) & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, BV, acc[(KK) & 1], 4, KK, 0);
 #define SBEV_MSTEP(m, q) SBEV_MF(4 * (m) + 0, q.x) SBEV_MF(4 * (m) + 1, q.y) SBEV_MF(4 * (m) + 2, q.z) SBEV_MF(4 * (m) + 3, q.w)
@@ -219,6 +255,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one item (64 columns x 128 k) of Linear `l`: 8 chunks from the ring; partial sums -> P[slot]
 __device__ __forceinline__ void mma_item(const ChainArgs& a, Stream& st, const Lin& l, int j, float* smem, int pslot, int lane, int wave) {
+    constexpr int R = 4, OFF_RING = Lay<1>::OFF_RING, OFF_P = Lay<1>::OFF_P;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const int kh = j % l.KH;
     const float* arow = smem + l.in_off + kh * 128 + (lane & 3) * l.ld + (lane >> 2);
@@ -247,6 +284,50 @@ __device__ __forceinline__ void mma_item(const ChainArgs& a, Stream& st, const L
     p[0] = t.x; p[64] = t.y; p[128] = t.z; p[192] = t.w;
 }
 
+// RG > 1: one item (64 columns x 16 l.chunks k) for the workgroup's RG row groups; the chunk registers rb[d] are consumed and
+// refilled in ring order (l.chunks is a multiple of RDEPTH, so slot d of the ring is a compile-time register set)
+template <int RG>
+__device__ __forceinline__ void mma_item_wide(const ChainArgs& a, Stream& st, RChunk (&rb)[RDEPTH], const Lin& l, int j, float* smem, int pslot,
+                                              int lane, int wave) {
+    constexpr int NACC = RG >= 4 ? 1 : 2;          // >= 4 independent accumulator chains back to back
+    f32x4 acc[RG][NACC];
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[rg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kh = j % l.KH;
+    const float* arow = smem + l.in_off + kh * (l.chunks * 16) + (lane & 3) * l.ld + (lane >> 2);
+    float avn[RG];                                 // the A registers (16 k x 4 rows per row group) of the NEXT chunk: read one chunk ahead
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) avn[rg] = arow[rg * 4 * l.ld];
+    for (int s0 = 0; s0 < l.chunks; s0 += RDEPTH) {
+#pragma unroll
+        for (int d = 0; d < RDEPTH; ++d) {
+            float av[RG];
+            const int nxt = min(s0 + d + 1, l.chunks - 1);
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) { av[rg] = avn[rg]; avn[rg] = arow[nxt * 16 + rg * 4 * l.ld]; }
+            __builtin_amdgcn_sched_barrier(0);
+#define SBEV_MW(KK, BV)                                                                                                     \
+    _Pragma("unroll") for (int rg = 0; rg < RG; ++rg)                                                                        \
+        acc[rg][(KK) % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg], BV, acc[rg][(KK) % NACC], 4, KK, 0);
+#define SBEV_MWSTEP(m, q) SBEV_MW(4 * (m) + 0, q.x) SBEV_MW(4 * (m) + 1, q.y) SBEV_MW(4 * (m) + 2, q.z) SBEV_MW(4 * (m) + 3, q.w)
+            SBEV_MWSTEP(0, rb[d].q[0]) SBEV_MWSTEP(1, rb[d].q[1]) SBEV_MWSTEP(2, rb[d].q[2]) SBEV_MWSTEP(3, rb[d].q[3])
+#undef SBEV_MWSTEP
+#undef SBEV_MW
+            __builtin_amdgcn_sched_barrier(0);
+            stream_load(a, st, wave, lane, rb[d]);       // refill: three chunks stay in flight while the next one multiplies
+        }
+    }
+    float* p = smem + Lay<RG>::OFF_P + pslot * (Lay<RG>::R * 64) + lane;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+        f32x4 t = acc[rg][0];
+        if (NACC == 2) t += acc[rg][NACC - 1];
+        p[(rg * 4 + 0) * 64] = t.x; p[(rg * 4 + 1) * 64] = t.y; p[(rg * 4 + 2) * 64] = t.z; p[(rg * 4 + 3) * 64] = t.w;
+    }
+}
+
 __device__ __forceinline__ float wsum(float v) { return sbev::wave_sum_dpp(v); }
 
 // LayerNorm over 256 columns held as 4 per lane (column = lane + 64 c).  The weights are fetched (LDS) by LnW's constructor,
@@ -273,7 +354,7 @@ __device__ __forceinline__ void ln4(float (&v)[4], const LnW& w, float eps, bool
 
 // partial sums of 4 column groups (cg0 .. cg0 + 3) of a Linear whose items start at slot `base`: k-halves added in order, + bias.
 // KH is 2 (K = 256) or 4 (K = 512): specialised so that all LDS reads are in flight before the first add.
-template <int KH>
+template <int KH, int R>
 __device__ __forceinline__ void gather4_t(float (&v)[4], const float* P, int base, int cg0, int row, int lane, const float* bias, int bias0) {
     float t[4][KH];
 #pragma unroll
@@ -288,10 +369,12 @@ __device__ __forceinline__ void gather4_t(float (&v)[4], const float* P, int bas
         v[c] = s + bias[bias0 + lane + 64 * c];
     }
 }
+template <int R>
 __device__ __forceinline__ void gather4(float (&v)[4], const float* P, int base, int KH, int cg0, int row, int lane, const float* bias,
                                         int bias0) {
-    if (KH == 2) gather4_t<2>(v, P, base, cg0, row, lane, bias, bias0);
-    else gather4_t<4>(v, P, base, cg0, row, lane, bias, bias0);
+    if (KH == 1) gather4_t<1, R>(v, P, base, cg0, row, lane, bias, bias0);
+    else if (KH == 2) gather4_t<2, R>(v, P, base, cg0, row, lane, bias, bias0);
+    else gather4_t<4, R>(v, P, base, cg0, row, lane, bias, bias0);
 }
 
 __device__ __forceinline__ void store_rows(float* smem, int off, int ld, int row, int lane, const float (&v)[4]) {
@@ -300,7 +383,9 @@ __device__ __forceinline__ void store_rows(float* smem, int off, int ld, int row
 }
 
 // position_encoder[0..2]: Linear(3 -> 256) + LayerNorm + ReLU of one row (sparsebev_transformer.py:116-119), into LDS
+template <int RG>
 __device__ __forceinline__ void pe0_row(const ChainArgs& a, float* smem, int row, int lane, float x0, float x1, float x2) {
+    constexpr int OFF_PARAM = Lay<RG>::OFF_PARAM, OFF_C = Lay<RG>::OFF_C;
     const float* pv = smem + OFF_PARAM;
     const LnW lw(pv + PV_PE1G, pv + PV_PE1B, lane);
     float v[4];
@@ -315,27 +400,41 @@ __device__ __forceinline__ void pe0_row(const ChainArgs& a, float* smem, int row
 }
 
 // PRE: how the input rows are produced (compile-time: the three chains are three instantiations)
-template <int PRE>
+template <int PRE, int RG>
 __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // LDS_TOTAL_FLOATS (dynamic: > 64 KB)
+    using L = Lay<RG>;
+    constexpr int R = L::R, RPW = L::RPW, OFF_X2 = L::OFF_X2, OFF_X3 = L::OFF_X3, OFF_H = L::OFF_H, OFF_C = L::OFF_C, OFF_R = L::OFF_R,
+                  OFF_P = L::OFF_P, OFF_PARAM = L::OFF_PARAM;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // L::LDS_TOTAL_FLOATS (dynamic: > 64 KB)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long row0 = (long long)blockIdx.x * R;
     float* P = smem + OFF_P;
 
-    // the weight stream starts before anything else: two chunks in flight
+    // the weight stream starts before anything else: three chunks in flight
     SBEV_TRACE(0)
-    warm_l2(a, wave, lane);
+    warm_l2<RG>(a, wave, lane);
     Stream st;
     st.iw = Walk{0, wave, 0};
     st.issued = st.used = st.islot = st.uslot = 0;
-    st.ring_byte = (unsigned)(OFF_RING + wave * (RING_SLOTS * CHUNK_FLOATS)) * 4u;
+    st.ring_byte = (unsigned)(L::OFF_RING + wave * (RING_SLOTS * CHUNK_FLOATS)) * 4u;
     st.voff = (unsigned)lane * 16u;
-    st.g = nullptr;
+    st.g = a.warm;           // (valid for stream_load's unconditional loads even if this wave has no item)
+    st.nchunk = 8;
     stream_seek(a, st, wave);
-    stream_issue(a, st, wave);
-    stream_issue(a, st, wave);
-    stream_issue(a, st, wave);
+    RChunk rb[RDEPTH];
+    if constexpr (L::WIDE) {
+#pragma unroll
+        for (int d = 0; d < RDEPTH; ++d) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) rb[d].q[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            stream_load(a, st, wave, lane, rb[d]);
+        }
+    } else {
+        stream_issue(a, st, wave);
+        stream_issue(a, st, wave);
+        stream_issue(a, st, wave);
+    }
 
     // ---- prologue: every global load of it is issued before the first wait (one memory latency, not one per phase) -----
     const float* pv = smem + OFF_PARAM;
@@ -346,38 +445,47 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         const int i4 = (int)threadIdx.x + j * 64 * NWAVE;
         pq[j] = *reinterpret_cast<const float4*>(a.vec + 4 * min(i4, a.vec_n / 4 - 1));
     }
-    const int prow = wave;                               // waves 0 .. R-1 own one input row each
-    const long long pg = row0 + prow;
-    const bool plive = wave < R && pg < a.M;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), r4 = t;
-    float v0[4] = {0.f, 0.f, 0.f, 0.f}, v1[4] = {0.f, 0.f, 0.f, 0.f};
-    float bx = 0.f, by = 0.f, bz = 0.f;
-    if (PRE == PRE_SLABS) {
-        // mixing.out_proj: sum of the split-K slabs (16 independent loads in flight, added in slab order); lane = 4 columns
-        if (plive) {
-            r4 = *reinterpret_cast<const float4*>(a.x1 + pg * DM + lane * 4);
-            for (int z0 = 0; z0 < a.splits; z0 += 16) {
-                float4 q[16];
+    // input rows: wave w owns rows w, w + 8 (RG = 4) of the workgroup
+    float4 t[RPW], r4[RPW];
+    float v0[RPW][4], v1[RPW][4];
+    float bx[RPW], by[RPW], bz[RPW];
+    bool plive[RPW];
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    q[j] = *reinterpret_cast<const float4*>(a.slabs + ((long long)min(z0 + j, a.splits - 1) * a.M + pg) * DM + lane * 4);
+    for (int pi = 0; pi < RPW; ++pi) {
+        const int prow = wave + pi * NWAVE;
+        const long long pg = row0 + prow;
+        plive[pi] = prow < R && pg < a.M;
+        t[pi] = make_float4(0.f, 0.f, 0.f, 0.f); r4[pi] = t[pi];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) asm volatile("" ::"v"(q[j].x), "v"(q[j].y), "v"(q[j].z), "v"(q[j].w));   // all 16 issued first
+        for (int c = 0; c < 4; ++c) v0[pi][c] = v1[pi][c] = 0.f;
+        bx[pi] = by[pi] = bz[pi] = 0.f;
+        if (PRE == PRE_SLABS) {
+            // mixing.out_proj: sum of the split-K slabs (16 independent loads in flight, added in slab order); lane = 4 columns
+            if (plive[pi]) {
+                r4[pi] = *reinterpret_cast<const float4*>(a.x1 + pg * DM + lane * 4);
+                for (int z0 = 0; z0 < a.splits; z0 += 16) {
+                    float4 q[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const float m = z0 + j < a.splits ? 1.f : 0.f;        // (a select, not a branch: hipcc sinks the loads into branches)
-                    t.x += q[j].x * m; t.y += q[j].y * m; t.z += q[j].z * m; t.w += q[j].w * m;
+                    for (int j = 0; j < 16; ++j)
+                        q[j] = *reinterpret_cast<const float4*>(a.slabs + ((long long)min(z0 + j, a.splits - 1) * a.M + pg) * DM + lane * 4);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) asm volatile("" ::"v"(q[j].x), "v"(q[j].y), "v"(q[j].z), "v"(q[j].w));   // all 16 issued first
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float m = z0 + j < a.splits ? 1.f : 0.f;        // (a select, not a branch: hipcc sinks the loads into branches)
+                        t[pi].x += q[j].x * m; t[pi].y += q[j].y * m; t[pi].z += q[j].z * m; t[pi].w += q[j].w * m;
+                    }
                 }
             }
-        }
-    } else if (plive) {
-        const float* src = PRE == PRE_FRONT ? a.feat : a.att;
+        } else if (plive[pi]) {
+            const float* src = PRE == PRE_FRONT ? a.feat : a.att;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v0[c] = src[pg * DM + lane + 64 * c];
-        if (PRE == PRE_FRONT) { bx = a.bbox[pg * 10]; by = a.bbox[pg * 10 + 1]; bz = a.bbox[pg * 10 + 2]; }
-        if (PRE == PRE_ATT) {        // the residual of the out-projection: x rows, kept in LDS until the first epilogue
+            for (int c = 0; c < 4; ++c) v0[pi][c] = src[pg * DM + lane + 64 * c];
+            if (PRE == PRE_FRONT) { bx[pi] = a.bbox[pg * 10]; by[pi] = a.bbox[pg * 10 + 1]; bz[pi] = a.bbox[pg * 10 + 2]; }
+            if (PRE == PRE_ATT) {        // the residual of the out-projection: x rows, kept in LDS until the first epilogue
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v1[c] = a.x[pg * DM + lane + 64 * c];
+                for (int c = 0; c < 4; ++c) v1[pi][c] = a.x[pg * DM + lane + 64 * c];
+            }
         }
     }
 #pragma unroll
@@ -388,22 +496,27 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         if (i4 < a.vec_n / 4) *reinterpret_cast<float4*>(smem + OFF_PARAM + a.vec_off + 4 * i4) = pq[j];
     }
     __syncthreads();
-    if (wave < R) {
+#pragma unroll
+    for (int pi = 0; pi < RPW; ++pi) {
+        const int prow = wave + pi * NWAVE;
+        if (prow >= R) continue;
         if (PRE == PRE_SLABS) {
             // + bias + residual x1 -> norm2 (sparsebev_transformer.py:171)
+            float4 tt = t[pi];
+            const float4 rr = r4[pi];
             const float4 b4 = *reinterpret_cast<const float4*>(pv + PV_OP_B + lane * 4);
-            if (plive) { t.x = (t.x + b4.x) + r4.x; t.y = (t.y + b4.y) + r4.y; t.z = (t.z + b4.z) + r4.z; t.w = (t.w + b4.w) + r4.w; }
-            const float mean = wsum((t.x + t.y) + (t.z + t.w)) * (1.f / DM);
-            const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+            if (plive[pi]) { tt.x = (tt.x + b4.x) + rr.x; tt.y = (tt.y + b4.y) + rr.y; tt.z = (tt.z + b4.z) + rr.z; tt.w = (tt.w + b4.w) + rr.w; }
+            const float mean = wsum((tt.x + tt.y) + (tt.z + tt.w)) * (1.f / DM);
+            const float dx = tt.x - mean, dy = tt.y - mean, dz = tt.z - mean, dw = tt.w - mean;
             const float rstd = rsqrtf(wsum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / DM) + a.eps);
             const float4 g4 = *reinterpret_cast<const float4*>(pv + PV_N2G + lane * 4);
             const float4 n4 = *reinterpret_cast<const float4*>(pv + PV_N2B + lane * 4);
             *reinterpret_cast<float4*>(smem + OFF_X2 + prow * LDX + lane * 4) =
                 make_float4(dx * rstd * g4.x + n4.x, dy * rstd * g4.y + n4.y, dz * rstd * g4.z + n4.z, dw * rstd * g4.w + n4.w);
         } else {
-            store_rows(smem, PRE == PRE_FRONT ? OFF_X3 : OFF_X2, LDX, prow, lane, v0);
-            if (PRE == PRE_ATT) store_rows(smem, OFF_R, LDX, prow, lane, v1);
-            if (PRE == PRE_FRONT) pe0_row(a, smem, prow, lane, bx, by, bz);
+            store_rows(smem, PRE == PRE_FRONT ? OFF_X3 : OFF_X2, LDX, prow, lane, v0[pi]);
+            if (PRE == PRE_ATT) store_rows(smem, OFF_R, LDX, prow, lane, v1[pi]);
+            if (PRE == PRE_FRONT) pe0_row<RG>(a, smem, prow, lane, bx[pi], by[pi], bz[pi]);
         }
     }
     __syncthreads();
@@ -414,7 +527,8 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         const int items = un.a.items + un.b.items;
         for (int it = wave; it < items; it += NWAVE) {
             const bool second = it >= un.a.items;
-            mma_item(a, st, second ? un.b : un.a, it - (second ? un.a.items : 0), smem, it, lane, wave);
+            if constexpr (L::WIDE) mma_item_wide<RG>(a, st, rb, second ? un.b : un.a, it - (second ? un.a.items : 0), smem, it, lane, wave);
+            else mma_item(a, st, second ? un.b : un.a, it - (second ? un.a.items : 0), smem, it, lane, wave);
         }
         SBEV_TRACE(2 + 4 * u)
         __syncthreads();
@@ -427,7 +541,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             float v[4];
             switch (un.epi) {
             case EPI_FFN0: {     // relu(x2 W0^T + b0): side = column half
-                gather4(v, P, 0, un.a.KH, side * 4, row, lane, pv + PV_FFN0_B, side * 256);
+                gather4<R>(v, P, 0, un.a.KH, side * 4, row, lane, pv + PV_FFN0_B, side * 256);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) smem[OFF_H + row * LDH + side * 256 + lane + 64 * c] = fmaxf(v[c], 0.f);
             } break;
@@ -437,7 +551,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                 float res[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) res[c] = smem[OFF_X2 + row * LDX + lane + 64 * c];
-                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_FFN1_B, 0);
+                gather4<R>(v, P, 0, un.a.KH, 0, row, lane, pv + PV_FFN1_B, 0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] += res[c];
                 ln4(v, lw, a.eps, false);
@@ -452,11 +566,11 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                 const bool first = un.epi == EPI_BR1;
                 if (side == 0) {
                     const LnW lw(pv + (first ? PV_CLS1G : PV_CLS4G), pv + (first ? PV_CLS1B : PV_CLS4B), lane);
-                    gather4(v, P, 0, un.a.KH, 0, row, lane, pv + (first ? PV_CLS0_B : PV_CLS3_B), 0);
+                    gather4<R>(v, P, 0, un.a.KH, 0, row, lane, pv + (first ? PV_CLS0_B : PV_CLS3_B), 0);
                     ln4(v, lw, a.eps, true);
                     store_rows(smem, OFF_C, LDX, row, lane, v);
                 } else {
-                    gather4(v, P, un.a.items, un.b.KH, 0, row, lane, pv + (first ? PV_REG0_B : PV_REG2_B), 0);
+                    gather4<R>(v, P, un.a.items, un.b.KH, 0, row, lane, pv + (first ? PV_REG0_B : PV_REG2_B), 0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
                     store_rows(smem, OFF_R, LDX, row, lane, v);
@@ -492,7 +606,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                         const float x0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(ob, 0));
                         const float x1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(ob, 1));
                         const float x2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(ob, 2));
-                        pe0_row(a, smem, row, lane, x0, x1, x2);
+                        pe0_row<RG>(a, smem, row, lane, x0, x1, x2);
                     }
                 }
             } break;
@@ -502,7 +616,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                 float res[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) res[c] = smem[OFF_X3 + row * LDX + lane + 64 * c];
-                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_PE3_B, 0);
+                gather4<R>(v, P, 0, un.a.KH, 0, row, lane, pv + PV_PE3_B, 0);
                 ln4(v, lw, a.eps, true);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] += res[c];
@@ -531,7 +645,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                 float res[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) res[c] = smem[OFF_R + row * LDX + lane + 64 * c];     // x rows, staged by the prologue
-                gather4(v, P, 0, un.a.KH, 0, row, lane, pv + PV_AOUT_B, 0);
+                gather4<R>(v, P, 0, un.a.KH, 0, row, lane, pv + PV_AOUT_B, 0);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] += res[c];
                 ln4(v, lw, a.eps, false);
@@ -624,13 +738,27 @@ PackMap pack_map(const sbev_decoder_config& c) {
     return m;
 }
 
-Lin lin(const float* wp, int in_off, int ld, int N, int K, int cg0 = 0, int ncg = -1) {
-    const int KH = K / 128;
+// column groups [cg0, cg0 + ncg) of a packed [N, K] weight as items of K / KH k each.  kh = 0: K / 128 (the RG = 1 items)
+Lin lin(const float* wp, int in_off, int ld, int N, int K, int kh = 0, int cg0 = 0, int ncg = -1) {
+    const int KH = kh > 0 ? kh : K / 128;
     const int all = (N + 63) / 64;
     if (ncg < 0) ncg = all - cg0;
-    return Lin{wp + (long long)cg0 * KH * ITEM_FLOATS, in_off, ld, KH, ncg * KH};
+    return Lin{wp + (long long)cg0 * K * 64, in_off, ld, KH, ncg * KH, K / (16 * KH)};
 }
-const Lin kNone{nullptr, 0, LDX, 1, 0};
+const Lin kNone{nullptr, 0, LDX, 1, 0, 8};
+
+// k-pieces per column group of a unit with `cgs` column groups in all: RG = 1 keeps 128-k items; RG > 1 aims at 8 items per
+// unit (one per wave; each piece at least 64 k = RDEPTH chunks)
+int pieces(int rg, int cgs, int K) {
+    if (rg == 1) return 0;
+    int kh = 1;
+    while (kh * 2 * cgs <= NWAVE && K / (kh * 2) >= 16 * RDEPTH) kh *= 2;
+    return kh;
+}
+
+// rows per workgroup = 4 rg: the smallest of 4, 8, 16 that covers the rows with one round of workgroups (256 CUs)
+int row_groups(long long rows) { return rows <= 256 * 4 ? 1 : rows <= 256 * 8 ? 2 : 4; }
+Offs offs(int rg) { return rg == 1 ? offs_of<1>() : rg == 2 ? offs_of<2>() : offs_of<4>(); }
 
 }  // namespace
 
@@ -641,10 +769,14 @@ bool row_chain_supported(const sbev_decoder_config& c) {
            c.attn_in_rows <= PV_QKV_PAD && c.G * c.P * (3 + c.L) <= 256 && (long long)c.B * c.Q < 0x7fffffffLL;
 }
 
-// One workgroup per 4 rows streams every weight: that pays while the launch is a single wave of workgroups (<= 256 CUs).
-// Measured (samples/s with / without the chains): config 2 (900 rows) 350 / 328, config 5 387 / 358; config 3 (3200 rows)
-// 747 / 755, config 4 (3600 rows) 271 / 272 -- larger batches keep the op-by-op launches, whose tiles amortise the weights.
-bool row_chain_pays(long long rows) { return rows <= 256 * R; }
+// Every workgroup streams every weight: that pays while the launch is a single round of workgroups (<= 256 CUs).
+// Measured (samples/s with / without the chains), 4 rows per workgroup: config 2 (900 rows) 350 / 328, config 5 387 / 358; config 3
+// (3200 rows) 747 / 755, config 4 (3600 rows) 271 / 272 -- so larger batches take 8 or 16 rows per workgroup (round 3), and beyond
+// 4096 rows the op-by-op launches, whose tiles amortise the weights, stay.  SBEV_CHAIN_MAX_ROWS overrides the limit (A/B).
+bool row_chain_pays(long long rows) {
+    static const long long limit = getenv("SBEV_CHAIN_MAX_ROWS") ? atoll(getenv("SBEV_CHAIN_MAX_ROWS")) : 256 * 16;
+    return rows <= limit && rows <= 256 * 16;
+}
 
 static void fill_common(ChainArgs& a, const sbev_decoder_config& c, float eps) {
     a.M = (long long)c.B * c.Q;
@@ -655,32 +787,36 @@ static void fill_common(ChainArgs& a, const sbev_decoder_config& c, float eps) {
     a.soN = c.G * c.P * (3 + c.L);
 }
 
-static int add_front(ChainArgs& a, int n, const sbev_decoder_config& c, const float* pk, const PackMap& m) {
-    a.units[n++] = Unit{lin(pk + m.pe3, OFF_C, LDX, c.D, c.D), kNone, EPI_PE3, 0};
+static int add_front(ChainArgs& a, int n, const sbev_decoder_config& c, const float* pk, const PackMap& m, int rg) {
+    const Offs o = offs(rg);
+    a.units[n++] = Unit{lin(pk + m.pe3, o.c, LDX, c.D, c.D, pieces(rg, c.D / 64, c.D)), kNone, EPI_PE3, 0};
     const int ncg = (c.attn_in_rows + 63) / 64;
-    for (int cg0 = 0; cg0 < ncg; cg0 += 8)
-        a.units[n++] = Unit{lin(pk + m.attn_in, OFF_X2, LDX, c.attn_in_rows, c.D, cg0, ncg - cg0 < 8 ? ncg - cg0 : 8), kNone, EPI_QKV, cg0 * 64};
+    for (int cg0 = 0; cg0 < ncg; cg0 += 8) {
+        const int n_here = ncg - cg0 < 8 ? ncg - cg0 : 8;
+        a.units[n++] = Unit{lin(pk + m.attn_in, o.x2, LDX, c.attn_in_rows, c.D, pieces(rg, n_here, c.D), cg0, n_here), kNone, EPI_QKV, cg0 * 64};
+    }
     return n;
 }
 
 // the kernels use 159 KB of dynamic LDS: raised once per instantiation (also from sbev_decoder_chain_pack, so that the first
 // launch may already be inside a stream capture)
-template <int PRE>
+template <int PRE, int RG>
 static hipError_t lds_attr() {
     static std::atomic<unsigned long long> done{0};      // bit d: raised on device d (a process may drive several devices)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_FLOATS * 4);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE, RG>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, Lay<RG>::LDS_TOTAL_FLOATS * 4);
     if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
     return e;
 }
 
-template <int PRE>
+template <int PRE, int RG>
 static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
-    const hipError_t attr = lds_attr<PRE>();
+    constexpr int R = Lay<RG>::R, LDS_TOTAL_FLOATS = Lay<RG>::LDS_TOTAL_FLOATS;
+    const hipError_t attr = lds_attr<PRE, RG>();
     if (attr != hipSuccess) {
         set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, LDS_TOTAL_FLOATS * 4, hipGetErrorString(attr));
         return SBEV_ELAUNCH;
@@ -694,7 +830,7 @@ static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
     if (!tr) { (void)hipMalloc(&tr, 64 * 8 * 8 * 64); (void)hipMemset(tr, 0, 64 * 8 * 8 * 64); }
     b.trace = tr + (calls % 64) * 512;
 #endif
-    hipLaunchKernelGGL(row_chain_kernel<PRE>, dim3((unsigned)((a.M + R - 1) / R)), dim3(64 * NWAVE), LDS_TOTAL_FLOATS * 4, s, b);
+    hipLaunchKernelGGL((row_chain_kernel<PRE, RG>), dim3((unsigned)((a.M + R - 1) / R)), dim3(64 * NWAVE), LDS_TOTAL_FLOATS * 4, s, b);
 #ifdef SBEV_CHAIN_TRACE
     if (++calls == 13) {        // the first step's 13 launches
         (void)hipDeviceSynchronize();
@@ -714,12 +850,19 @@ static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
     return check_launch(what);
 }
 
-bool chain_lds_ready() {
-    return lds_attr<PRE_SLABS>() == hipSuccess && lds_attr<PRE_FRONT>() == hipSuccess && lds_attr<PRE_ATT>() == hipSuccess;
+template <int RG>
+static bool lds_ready_rg() {
+    return lds_attr<PRE_SLABS, RG>() == hipSuccess && lds_attr<PRE_FRONT, RG>() == hipSuccess && lds_attr<PRE_ATT, RG>() == hipSuccess;
 }
+bool chain_lds_ready() { return lds_ready_rg<1>() && lds_ready_rg<2>() && lds_ready_rg<4>(); }
 
-static int launch(const ChainArgs& a, hipStream_t s, const char* what) {
-    return a.pre == PRE_SLABS ? launch_t<PRE_SLABS>(a, s, what) : a.pre == PRE_FRONT ? launch_t<PRE_FRONT>(a, s, what) : launch_t<PRE_ATT>(a, s, what);
+template <int RG>
+static int launch_rg(const ChainArgs& a, hipStream_t s, const char* what) {
+    return a.pre == PRE_SLABS ? launch_t<PRE_SLABS, RG>(a, s, what) : a.pre == PRE_FRONT ? launch_t<PRE_FRONT, RG>(a, s, what)
+                                                                                          : launch_t<PRE_ATT, RG>(a, s, what);
+}
+static int launch(const ChainArgs& a, int rg, hipStream_t s, const char* what) {
+    return rg == 1 ? launch_rg<1>(a, s, what) : rg == 2 ? launch_rg<2>(a, s, what) : launch_rg<4>(a, s, what);
 }
 
 // position encoder + attention in-projection of the FIRST layer (the later layers' run at the end of the previous tail)
@@ -730,11 +873,12 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
     fill_common(a, c, eps);
     a.pre = PRE_FRONT;
     a.bbox = bbox; a.feat = feat; a.x = x; a.qkvt = qkvt;
-    a.n_units = add_front(a, 0, c, w.chain_pack, m);
+    const int rg = row_groups(a.M);
+    a.n_units = add_front(a, 0, c, w.chain_pack, m, rg);
     a.warm = w.chain_pack + m.pe3;
     a.warm_lines = (int)((m.attn_out - m.pe3) / 32);
     a.vec = w.chain_pack + m.vec + PV_TAIL_END; a.vec_off = PV_TAIL_END; a.vec_n = PV_FRONT_END - PV_TAIL_END;
-    return launch(a, s, "row chain (front)");
+    return launch(a, rg, s, "row chain (front)");
 }
 
 // attention out-projection + residual + norm1 -> x1, sampling Linear -> sample points -> projection (loc, level weights)
@@ -748,13 +892,15 @@ int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& 
     a.att = att; a.x = const_cast<float*>(x); a.x1_out = x1; a.so = nullptr;
     a.proj = sbev_ops::sample_point_args(bbox, time_diff, lidar2img, c.pc_range, c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w,
                                          c.eps_homo, loc_bp, w_bp);
-    a.units[0] = Unit{lin(w.chain_pack + m.attn_out, OFF_X2, LDX, c.D, c.D), kNone, EPI_AOUT, 0};
-    a.units[1] = Unit{lin(w.chain_pack + m.samp, OFF_X3, LDX, a.soN, c.D), kNone, EPI_SAMP, 0};
+    const int rg = row_groups(a.M);
+    const Offs o = offs(rg);
+    a.units[0] = Unit{lin(w.chain_pack + m.attn_out, o.x2, LDX, c.D, c.D, pieces(rg, c.D / 64, c.D)), kNone, EPI_AOUT, 0};
+    a.units[1] = Unit{lin(w.chain_pack + m.samp, o.x3, LDX, a.soN, c.D, pieces(rg, (a.soN + 63) / 64, c.D)), kNone, EPI_SAMP, 0};
     a.n_units = 2;
     a.warm = w.chain_pack + m.attn_out;
     a.warm_lines = (int)((m.vec - m.attn_out) / 32);
     a.vec = w.chain_pack + m.vec + PV_FRONT_END; a.vec_off = 0; a.vec_n = PV_ATTN_END;
-    return launch(a, s, "row chain (attention)");
+    return launch(a, rg, s, "row chain (attention)");
 }
 
 // out_proj slabs -> norm2 -> ffn -> norm3 -> branches -> refine_bbox [-> the next layer's position encoder + in-projection]
@@ -769,17 +915,23 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
     a.slabs = slabs; a.splits = splits; a.x1 = x1; a.bbox = bbox; a.vel_div = vel_div;
     a.x3 = x3; a.cls_out = cls_out; a.box_out = box_out; a.front = with_front; a.x = x; a.qkvt = qkvt;
     int n = 0;
-    a.units[n++] = Unit{lin(pk + m.ffn0, OFF_X2, LDX, c.ffn, c.D), kNone, EPI_FFN0, 0};
-    a.units[n++] = Unit{lin(pk + m.ffn1, OFF_H, LDH, c.D, c.ffn), kNone, EPI_FFN1, 0};
-    a.units[n++] = Unit{lin(pk + m.cls0, OFF_X3, LDX, c.D, c.D), lin(pk + m.reg0, OFF_X3, LDX, c.D, c.D), EPI_BR1, 0};
-    a.units[n++] = Unit{lin(pk + m.cls3, OFF_C, LDX, c.D, c.D), lin(pk + m.reg2, OFF_R, LDX, c.D, c.D), EPI_BR2, 0};
-    a.units[n++] = Unit{lin(pk + m.cls6, OFF_C, LDX, c.num_classes, c.D), lin(pk + m.reg4, OFF_R, LDX, c.code_size, c.D), EPI_OUT, 0};
-    if (with_front) n = add_front(a, n, c, pk, m);
+    const int rg = row_groups(a.M);
+    const Offs o = offs(rg);
+    const int dcg = c.D / 64;
+    a.units[n++] = Unit{lin(pk + m.ffn0, o.x2, LDX, c.ffn, c.D, pieces(rg, c.ffn / 64, c.D)), kNone, EPI_FFN0, 0};
+    a.units[n++] = Unit{lin(pk + m.ffn1, o.h, LDH, c.D, c.ffn, pieces(rg, dcg, c.ffn)), kNone, EPI_FFN1, 0};
+    a.units[n++] = Unit{lin(pk + m.cls0, o.x3, LDX, c.D, c.D, pieces(rg, 2 * dcg, c.D)), lin(pk + m.reg0, o.x3, LDX, c.D, c.D, pieces(rg, 2 * dcg, c.D)),
+                        EPI_BR1, 0};
+    a.units[n++] = Unit{lin(pk + m.cls3, o.c, LDX, c.D, c.D, pieces(rg, 2 * dcg, c.D)), lin(pk + m.reg2, o.r, LDX, c.D, c.D, pieces(rg, 2 * dcg, c.D)),
+                        EPI_BR2, 0};
+    a.units[n++] = Unit{lin(pk + m.cls6, o.c, LDX, c.num_classes, c.D, pieces(rg, 2, c.D)), lin(pk + m.reg4, o.r, LDX, c.code_size, c.D, pieces(rg, 2, c.D)),
+                        EPI_OUT, 0};
+    if (with_front) n = add_front(a, n, c, pk, m, rg);
     a.n_units = n;
     a.warm = pk + m.ffn0;
     a.warm_lines = (int)(((with_front ? m.attn_out : m.pe3) - m.ffn0) / 32);
     a.vec = pk + m.vec; a.vec_off = 0; a.vec_n = with_front ? PV_FRONT_END : PV_TAIL_END;
-    return launch(a, s, "row chain (tail)");
+    return launch(a, rg, s, "row chain (tail)");
 }
 
 }  // namespace sbev
@@ -796,7 +948,7 @@ extern "C" int sbev_decoder_chain_pack(const sbev_decoder_config* cfg, const sbe
     const sbev_decoder_config& c = *cfg;
     const PackMap m = pack_map(c);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    SBEV_REQUIRE(sbev::chain_lds_ready(), "sbev_decoder_chain_pack: the device refuses %d bytes of LDS per workgroup", LDS_TOTAL_FLOATS * 4);
+    SBEV_REQUIRE(sbev::chain_lds_ready(), "sbev_decoder_chain_pack: the device refuses %d bytes of LDS per workgroup", Lay<1>::LDS_TOTAL_FLOATS * 4);
     struct Job { const float* W; long long off; int N, K; };
     const Job jobs[12] = {{w->ffn0_w, m.ffn0, c.ffn, c.D}, {w->ffn1_w, m.ffn1, c.D, c.ffn}, {w->cls0_w, m.cls0, c.D, c.D},
                           {w->reg0_w, m.reg0, c.D, c.D}, {w->cls3_w, m.cls3, c.D, c.D}, {w->reg2_w, m.reg2, c.D, c.D},

@@ -115,13 +115,13 @@ constexpr int CHUNK_FLOATS = 1024;
 //     1600-query config): every weight chunk multiplies RG row groups (RG x the MFMAs per byte streamed: at RG = 4 the launch
 //     is as much MFMA- as stream-bound), so the LDS goes to the rows, the chunks travel global -> VGPR (a ring of 4 chunks =
 //     64 registers, waits counted by the compiler), and a wave keeps a column group's k-pieces in its accumulators: items are
-//     64 columns x (K / KH) k with KH chosen so that a unit has ~8 items -> 8 partial-sum slots.
+//     64 columns x (K / KH) k with KH chosen by pieces() so that a unit has ~8 items (<= 12 partial-sum slots).
 // LDS map (float offsets):
 template <int RG>
 struct Lay {
     static constexpr int R = 4 * RG;
     static constexpr bool WIDE = RG > 1;
-    static constexpr int MAX_SLOTS = WIDE ? 8 : 16;
+    static constexpr int MAX_SLOTS = WIDE ? 12 : 16;
     static constexpr int OFF_X2 = 0;                    // x2 (norm2 output) / x (attention input rows) / att rows
     static constexpr int OFF_X3 = OFF_X2 + R * LDX;     // x3 = the layer's output rows (next layer's query_feat) / x1
     static constexpr int OFF_H = OFF_X3 + R * LDX;      // ffn hidden rows; dead after ffn.layers.1, then:
@@ -460,23 +460,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         for (int c = 0; c < 4; ++c) v0[pi][c] = v1[pi][c] = 0.f;
         bx[pi] = by[pi] = bz[pi] = 0.f;
         if (PRE == PRE_SLABS) {
-            // mixing.out_proj: sum of the split-K slabs (16 independent loads in flight, added in slab order); lane = 4 columns
-            if (plive[pi]) {
-                r4[pi] = *reinterpret_cast<const float4*>(a.x1 + pg * DM + lane * 4);
-                for (int z0 = 0; z0 < a.splits; z0 += 16) {
-                    float4 q[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        q[j] = *reinterpret_cast<const float4*>(a.slabs + ((long long)min(z0 + j, a.splits - 1) * a.M + pg) * DM + lane * 4);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) asm volatile("" ::"v"(q[j].x), "v"(q[j].y), "v"(q[j].z), "v"(q[j].w));   // all 16 issued first
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float m = z0 + j < a.splits ? 1.f : 0.f;        // (a select, not a branch: hipcc sinks the loads into branches)
-                        t[pi].x += q[j].x * m; t[pi].y += q[j].y * m; t[pi].z += q[j].z * m; t[pi].w += q[j].w * m;
-                    }
-                }
-            }
+            if (plive[pi]) r4[pi] = *reinterpret_cast<const float4*>(a.x1 + pg * DM + lane * 4);
         } else if (plive[pi]) {
             const float* src = PRE == PRE_FRONT ? a.feat : a.att;
 #pragma unroll
@@ -486,6 +470,32 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v1[pi][c] = a.x[pg * DM + lane + 64 * c];
             }
+        }
+    }
+    if (PRE == PRE_SLABS) {
+        // mixing.out_proj: sum of the split-K slabs -- 16 independent loads in flight per wave (all of its rows' together), added in
+        // slab order; lane = 4 columns.  A dead row reads the last row's slabs (no branch: hipcc sinks loads into branches) x 0.
+        constexpr int NB = 16 / RPW;
+        for (int z0 = 0; z0 < a.splits; z0 += NB) {
+            float4 q[RPW][NB];
+#pragma unroll
+            for (int pi = 0; pi < RPW; ++pi) {
+                const long long pg = min(row0 + wave + pi * NWAVE, a.M - 1);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    q[pi][j] = *reinterpret_cast<const float4*>(a.slabs + ((long long)min(z0 + j, a.splits - 1) * a.M + pg) * DM + lane * 4);
+            }
+#pragma unroll
+            for (int pi = 0; pi < RPW; ++pi)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(q[pi][j].x), "v"(q[pi][j].y), "v"(q[pi][j].z), "v"(q[pi][j].w));   // all issued first
+#pragma unroll
+            for (int pi = 0; pi < RPW; ++pi)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float m = (z0 + j < a.splits && plive[pi]) ? 1.f : 0.f;
+                    t[pi].x += q[pi][j].x * m; t[pi].y += q[pi][j].y * m; t[pi].z += q[pi][j].z * m; t[pi].w += q[pi][j].w * m;
+                }
         }
     }
 #pragma unroll
@@ -749,11 +759,19 @@ const Lin kNone{nullptr, 0, LDX, 1, 0, 8};
 
 // k-pieces per column group of a unit with `cgs` column groups in all: RG = 1 keeps 128-k items; RG > 1 aims at 8 items per
 // unit (one per wave; each piece at least 64 k = RDEPTH chunks)
+// -- <= 12 slots; cost of a choice = sum over its rounds of (chunks per item) x (1 for a round of 5 .. 8 items: two waves per SIMD
+// share the MFMA pipe; 1/2 for a last round of <= 4 items: waves 0 .. 3 sit on four different SIMDs)
 int pieces(int rg, int cgs, int K) {
     if (rg == 1) return 0;
-    int kh = 1;
-    while (kh * 2 * cgs <= NWAVE && K / (kh * 2) >= 16 * RDEPTH) kh *= 2;
-    return kh;
+    static const bool tie_large = getenv("SBEV_CHAIN_TIE_SMALL") == nullptr;      // equal cost: more, shorter items (A/B switch)
+    int best = 1;
+    double best_cost = 1e30;
+    for (int kh = 1; kh <= 4 && cgs * kh <= 12 && K / kh >= 16 * RDEPTH; kh *= 2) {
+        const int items = cgs * kh, full = items / NWAVE, rest = items % NWAVE;
+        const double cost = (K / (16.0 * kh)) * (full + (rest == 0 ? 0.0 : rest <= 4 ? 0.5 : 1.0));
+        if (tie_large ? cost < best_cost + 1e-9 : cost < best_cost - 1e-9) { best_cost = cost; best = kh; }
+    }
+    return best;
 }
 
 // rows per workgroup = 4 rg: the smallest of 4, 8, 16 that covers the rows with one round of workgroups (256 CUs)

@@ -21,6 +21,7 @@
 //   * the [Pout,C] result is transposed through LDS so the workgroup writes its 32 KiB as contiguous 16-byte stores.
 // Other Pin keep the generic path (x, M, S staged in LDS, y1 through LDS).
 #include "sbev_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -107,11 +108,13 @@ __device__ __forceinline__ void block_mean_rstd(float s_w, float m2_w, float n_w
 #define SBEV_SAMPLE_MIX_WAVES 3          // waves per SIMD asked of the register allocator for the fused instantiations: 184 -> 151 VGPRs, no
                                          // spills, 318 -> 326 samples/s at config 2 (unfused 320; requesting M / S before the gather: 313..319)
 #endif
-template <int L>
-constexpr int mix_min_waves() { return L > 0 ? SBEV_SAMPLE_MIX_WAVES : 1; }
+template <int L, int RT>
+constexpr int mix_min_waves() { return L > 0 && RT <= 4 ? SBEV_SAMPLE_MIX_WAVES : L > 0 ? 2 : 1; }   // RT = 8: 128 registers of x fragments
 
-template <int RT, bool WIDE, int L = 0, typename FT = float>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_waves<L>()))) void adaptive_mixing_kernel(const typename MixArgsOf<L>::type a) {
+// PAD: Pin % 16 != 0 on the WIDE path (round 3; the last row tile of x and the last k block of S are partly padding) and, fused,
+// 4 or 8 points per frame -- a template parameter so that the Pin % 16 == 0, P = 4 instantiations stay exactly the tuned code of rounds 1-2
+template <int RT, bool WIDE, int L = 0, typename FT = float, bool PAD = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_waves<L, RT>()))) void adaptive_mixing_kernel(const typename MixArgsOf<L>::type a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
     const int lds_s = Pin + 4;                                  // S row stride
@@ -134,13 +137,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 
     // ---- stage x, M, S (coalesced float4) --------------------------------------------------------------
     const int fi = lane & 15, fk = lane >> 4;                   // fragment row/col index, k sub-index
-    f32x4 xf[WIDE ? RT : 1][C / 16];                            // WIDE: A fragments of matmul 1, x[r*16 + fi][16 blk + 4 fk ..]
+    // fused, more than 4 row tiles: the gathered rows stay in LDS (ON the S buffer, see alias_x) and matmul 1 reads its A fragments
+    // from there block by block -- 8 row tiles of resident fragments would be 128 registers next to the 64 of the parked S
+    constexpr bool XLDS = L > 0 && RT > 4;
+    const float* Xrows = nullptr;
+    f32x4 xf[WIDE && !XLDS ? RT : 1][C / 16];                   // WIDE: A fragments of matmul 1, x[r*16 + fi][16 blk + 4 fk ..]
     if (WIDE && L == 0) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int blk = 0; blk < C / 16; ++blk)
-                xf[r][blk] = *reinterpret_cast<const f32x4*>(xg + (r * 16 + fi) * C + 16 * blk + 4 * fk);
+            for (int blk = 0; blk < C / 16; ++blk) {
+                // rows >= Pin of the last tile (Pin % 16 != 0) are zero padding: a valid address, then a select
+                const int row = PAD && r == RT - 1 ? min(r * 16 + fi, Pin - 1) : r * 16 + fi;
+                xf[r][blk] = *reinterpret_cast<const f32x4*>(xg + row * C + 16 * blk + 4 * fk);
+                if (PAD && r == RT - 1 && r * 16 + fi >= Pin) xf[r][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
     }
     for (int i = tid; i < (WIDE ? 0 : RT * 16 * (C / 4)); i += 256) {
         const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
     // behind matmul 1 and the staging barrier only waits for M
     f32x4 sreg[WIDE ? 2 * RT : 1];
 #define SBEV_LOAD_S() \
-    _Pragma("unroll") for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (tid + 256 * k) * 4);
+    _Pragma("unroll") for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (PAD ? min((tid + 256 * k) * 4, POUT * Pin - 4) : (tid + 256 * k) * 4));
     if (WIDE && (L == 0 || SBEV_SAMPLE_MIX_PREFETCH)) { SBEV_LOAD_S() }
     for (int i = tid; i < (WIDE ? 0 : POUT * Pin / 4); i += 256) {
         const int r = (i * 4) / Pin, c4 = (i * 4) % Pin;
@@ -174,7 +185,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
     if constexpr (L > 0) {
         // ---- fused gather: x rows t*4 + p of this (query, group) item, frames t = wave, wave + 4, ... -------------------
         // (the M / S requests above are already in flight: their HBM latency hides under the gather)
-        float* Xg = Ss + POUT * lds_s;                          // [Pin][LDA], behind S; dead once xf is loaded
+        // [Pin][LDA]: behind S; dead once xf is loaded.  Pin > 64 (S alone is 36 .. 62 KiB): ON S instead, which is written only after
+        // every wave has taken its x fragments (one more barrier) -- 2 workgroups per CU instead of 1
+        const bool alias_x = RT > 4;                            // (Pin > 64)
+        float* Xg = alias_x ? Ss : Ss + POUT * lds_s;
         {
             const MsmvArgs& m = a.s;
             const int G = m.G, T = m.T, Q = m.Q;
@@ -185,18 +199,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             const int k = lane >> 4;
             const int j4 = (lane & 15) * 4;
             const float nm1 = (float)(m.N - 1);
-            auto fetch_lv = [&](int t) {
+            // unit u = 4-point chunk h of frame t: u = t * (P / 4) + h, P = 4 or 8 points per frame and group
+            // (PAD = false is the tuned P = 4 instantiation: pcs and Pq fold to constants and this is the round-2 loop over frames)
+            const int pcs = PAD ? m.P >> 3 : 0;                 // log2(P / 4)
+            const int Pq = PAD ? m.P : 4;
+            const int NU = T << pcs;
+            auto fetch_lv = [&](int u) {
+                const int t = u >> pcs, h = u - (t << pcs);
                 const long long it = ((long long)(b * (unsigned)T + t) * G + g) * Q + q;      // (b', q) with b' = (b*T + t)*G + g
                 float v = 0.f;
-                if (lane < 12) v = m.loc[it * 12 + lane];
-                if (lane >= 16 && lane < 16 + 4 * L) v = m.w[it * (4 * L) + (lane - 16)];
+                if (lane < 12) v = m.loc[(it * Pq + h * 4) * 3 + lane];
+                if (lane >= 16 && lane < 16 + 4 * L) v = m.w[(it * Pq + h * 4) * L + (lane - 16)];
                 return v;
             };
-            float lv_next = wave < T ? fetch_lv(wave) : 0.f;
+            float lv_next = wave < NU ? fetch_lv(wave) : 0.f;
 #pragma unroll 1
-            for (int t = wave; t < T; t += 4) {
+            for (int u = wave; u < NU; u += 4) {
+                const int t = u >> pcs;
                 const float lv = lv_next;
-                if (t + 4 < T) lv_next = fetch_lv(t + 4);
+                if (u + 4 < NU) lv_next = fetch_lv(u + 4);
                 unsigned ubo = b * (unsigned)T + (unsigned)t;
                 if (m.ring_T) ubo = b * (unsigned)m.n_slots + (unsigned)m.slots[t];
                 const FT* base[L];
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
                     sv.y = corner_reduce_scatter(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
                     sv.z = corner_reduce_scatter(acc[0].z, acc[1].z, acc[2].z, acc[3].z);
                     sv.w = corner_reduce_scatter(acc[0].w, acc[1].w, acc[2].w, acc[3].w);
-                    *reinterpret_cast<float4*>(&Xg[(t * 4 + k) * LDA + j4]) = sv;       // row k of the wave = point k of frame t
+                    *reinterpret_cast<float4*>(&Xg[(u * 4 + k) * LDA + j4]) = sv;       // row k of the wave = point k of unit u
                 }
             }
         }
@@ -223,11 +244,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             SBEV_LOAD_S()
         }
         __syncthreads();
+        Xrows = Xg;
+        if constexpr (!XLDS) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+            for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int blk = 0; blk < C / 16; ++blk)
-                xf[r][blk] = *reinterpret_cast<const f32x4*>(&Xg[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
+                for (int blk = 0; blk < C / 16; ++blk) {
+                    const int row = PAD && r == RT - 1 ? min(r * 16 + fi, Pin - 1) : r * 16 + fi;
+                    xf[r][blk] = *reinterpret_cast<const f32x4*>(&Xg[row * LDA + 16 * blk + 4 * fk]);
+                    if (PAD && r == RT - 1 && r * 16 + fi >= Pin) xf[r][blk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            if (alias_x) __syncthreads();
+        }
     }
 #undef SBEV_LOAD_MF
 #undef SBEV_LOAD_S
@@ -250,7 +278,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
         f32x4 a4[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            if (WIDE) a4[r] = xf[r][blk];
+            if constexpr (XLDS) {
+                const int row = PAD && r == RT - 1 ? min(r * 16 + fi, Pin - 1) : r * 16 + fi;
+                a4[r] = *reinterpret_cast<const f32x4*>(&Xrows[row * LDA + 16 * blk + 4 * fk]);
+                if (PAD && r == RT - 1 && r * 16 + fi >= Pin) a4[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else if (WIDE) a4[r] = xf[r][blk];
             else a4[r] = *reinterpret_cast<const f32x4*>(&Xs[(r * 16 + fi) * LDA + 16 * blk + 4 * fk]);
         }
 #pragma unroll
@@ -258,6 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r][j], bq[j], acc1[r], 0, 0, 0);
     }
+    if constexpr (XLDS) __syncthreads();                        // every wave is done with the gathered rows: S may land on them
     // C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg
     // ---- LayerNorm over all Pin*64 elements (no affine, biased variance), ReLU --------------------------
     const float nw1 = (float)(Pin * 16);                       // this wave's 16 columns x Pin rows
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 #pragma unroll
         for (int k = 0; k < 2 * RT; ++k) {
             const int i4 = (tid + 256 * k) * 4;
-            *reinterpret_cast<f32x4*>(&Ss[(i4 / Pin) * lds_s + i4 % Pin]) = sreg[k];
+            if (!PAD || i4 < POUT * Pin) *reinterpret_cast<f32x4*>(&Ss[(i4 / Pin) * lds_s + i4 % Pin]) = sreg[k];
         }
     }
     float mean1, rstd1;
@@ -306,8 +339,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[j] = acc1[blk][j];   // y1[16 blk + 4 fk + j][cw + fi]: this lane's own accumulators
             f32x4 a4[POUT / 16];
+            // k >= Pin (last block, Pin % 16 != 0): the A value is zeroed -- y1's padding rows are finite but not 0 after LayerNorm
+            const bool kpad = PAD && blk == RT - 1 && 16 * blk + 4 * fk >= Pin;
+            const int kc = kpad ? 0 : 16 * blk + 4 * fk;
 #pragma unroll
-            for (int r = 0; r < POUT / 16; ++r) a4[r] = *reinterpret_cast<const f32x4*>(&Ss[(r * 16 + fi) * lds_s + 16 * blk + 4 * fk]);
+            for (int r = 0; r < POUT / 16; ++r) {
+                a4[r] = *reinterpret_cast<const f32x4*>(&Ss[(r * 16 + fi) * lds_s + kc]);
+                if (kpad) a4[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -366,7 +405,7 @@ int launch_mix_w(const MixArgs& a, hipStream_t s) {
     const size_t out_floats = (size_t)POUT * LDY;
     if (floats < out_floats) floats = out_floats;
     const size_t bytes = (floats + 8) * sizeof(float);
-    auto k = adaptive_mixing_kernel<RT, WIDE>;
+    auto k = a.Pin % 16 == 0 || !WIDE ? adaptive_mixing_kernel<RT, WIDE> : adaptive_mixing_kernel<RT, WIDE, 0, float, true>;
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) {
@@ -380,17 +419,21 @@ int launch_mix_w(const MixArgs& a, hipStream_t s) {
 
 template <int RT>
 int launch_mix(const MixArgs& a, hipStream_t s) {
-    return a.Pin % 16 == 0 ? launch_mix_w<RT, true>(a, s) : launch_mix_w<RT, false>(a, s);
+    static const bool generic = getenv("SBEV_MIX_GENERIC") != nullptr;      // A/B: the LDS-staged path for Pin % 16 != 0 (rounds 1-2)
+    return a.Pin % 16 == 0 || !generic ? launch_mix_w<RT, true>(a, s) : launch_mix_w<RT, false>(a, s);
 }
 
 template <int RT, int L, typename FT>
 int launch_sample_mix(const SampleMixArgs& a, hipStream_t s) {
     const int Pin = a.Pin;
-    size_t floats = (size_t)POUT * (Pin + 4) + (size_t)Pin * LDA;        // S, then the gathered x behind it
+    size_t floats = (size_t)POUT * (Pin + 4) + (Pin > 64 ? 0 : (size_t)Pin * LDA);        // S, then the gathered x behind it (Pin > 64: on it)
     const size_t out_floats = (size_t)POUT * LDY;
     if (floats < out_floats) floats = out_floats;
     const size_t bytes = (floats + 8) * sizeof(float);
-    auto k = adaptive_mixing_kernel<RT, true, L, FT>;
+    auto k = adaptive_mixing_kernel<RT, true, L, FT, true>;
+    if constexpr (RT <= 4) {
+        if (a.Pin % 16 == 0 && a.s.P == 4) k = adaptive_mixing_kernel<RT, true, L, FT>;      // the tuned instantiation (4 points per frame, whole row tiles)
+    }
     hipEvent_t e0, e1;
     const bool prof = sbev::profile_begin(s, &e0, &e1, 3);
     hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(256), bytes, s, a);
@@ -400,11 +443,12 @@ int launch_sample_mix(const SampleMixArgs& a, hipStream_t s) {
 
 template <int L, typename FT>
 int launch_sample_mix_rt(const SampleMixArgs& a, hipStream_t s) {
-    switch (a.Pin / 16) {
+    switch ((a.Pin + 15) / 16) {
         case 1: return launch_sample_mix<1, L, FT>(a, s);
         case 2: return launch_sample_mix<2, L, FT>(a, s);
         case 3: return launch_sample_mix<3, L, FT>(a, s);
-        default: return launch_sample_mix<4, L, FT>(a, s);
+        case 4: return launch_sample_mix<4, L, FT>(a, s);
+        default: return launch_sample_mix<8, L, FT>(a, s);
     }
 }
 
@@ -434,7 +478,9 @@ extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, flo
 }
 
 extern "C" int sbev_sample_mix_supported(int L, int C, int P, int T, int gdiv, int G) {
-    return (L == 4 || L == 5) && C == 64 && P == 4 && gdiv == G && T >= 1 && (T * P) % 16 == 0 && T * P <= 64;
+    // T * P in 4 .. 64 (row tiles 1 .. 4) or 113 .. 120 (8 row tiles: the 15-frame, 8-point configuration); P = 4 or 8 points per chunked frame
+    const int pin = T * P;
+    return (L == 4 || L == 5) && C == 64 && (P == 4 || P == 8) && gdiv == G && T >= 1 && (pin <= 64 || (pin > 112 && pin <= 120));
 }
 
 extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
@@ -443,7 +489,7 @@ extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, 
                                    const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
                                    const float* params, float* y, int Pout, float eps, sbev_stream_t stream) {
     SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_sample_mix_f32: null descriptor array");
-    SBEV_REQUIRE(sbev_sample_mix_supported(L, Cg, P, T, G, G), "sbev_sample_mix_f32: needs L in {4,5}, C = 64, P = 4, T*P in {16,32,48,64} (got L=%d C=%d P=%d T=%d)", L, Cg, P, T);
+    SBEV_REQUIRE(sbev_sample_mix_supported(L, Cg, P, T, G, G), "sbev_sample_mix_f32: needs L in {4,5}, C = 64, P in {4,8}, T*P in 4..64 or 116..120 (got L=%d C=%d P=%d T=%d)", L, Cg, P, T);
     SBEV_REQUIRE(Pout == POUT, "sbev_sample_mix_f32: built for 128 out points");
     SBEV_REQUIRE(B >= 0 && Q >= 0 && N >= 1 && G >= 1, "sbev_sample_mix_f32: bad sizes");
     SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16, "sbev_sample_mix_f32: feat_dtype %d", feat_dtype);

@@ -127,8 +127,9 @@ def test_round2_entry_points_validate_without_gpu(lib):
     pc = (ctypes.c_double * 6)(-51.2, -51.2, -5, 51.2, 51.2, 3)
     # shape coverage table of the fused gather + mixing launch
     assert lib.sbev_sample_mix_supported(4, 64, 4, 8, 4, 4) == 1 and lib.sbev_sample_mix_supported(5, 64, 4, 16, 4, 4) == 1
-    assert lib.sbev_sample_mix_supported(4, 64, 4, 2, 4, 4) == 0          # T*P = 8
-    assert lib.sbev_sample_mix_supported(4, 64, 8, 8, 4, 4) == 0          # P = 8
+    assert lib.sbev_sample_mix_supported(4, 64, 4, 2, 4, 4) == 1          # T*P = 8: padded row tile (round 3)
+    assert lib.sbev_sample_mix_supported(4, 64, 8, 8, 4, 4) == 1 and lib.sbev_sample_mix_supported(5, 64, 8, 15, 4, 4) == 1     # P = 8; the 15 x 8 shape
+    assert lib.sbev_sample_mix_supported(4, 64, 8, 12, 4, 4) == 0 and lib.sbev_sample_mix_supported(4, 64, 6, 4, 4, 4) == 0    # 96 in_points; P = 6
     assert lib.sbev_sample_mix_supported(4, 32, 4, 8, 4, 4) == 0          # C = 32
     assert lib.sbev_sample_mix_supported(4, 64, 4, 8, 1, 4) == 0          # reference layout (gdiv != G)
     # generic GEMM: empty problems are fine, bad leading dimensions are refused

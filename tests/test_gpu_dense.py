@@ -84,7 +84,7 @@ def test_linear_rejects_cpu_and_misaligned():
         dense.linear(torch.zeros(4, 3, device=DEV), torch.zeros(4, 3, device=DEV), None)
 
 
-@pytest.mark.parametrize('Pin,BQ', [(4, 37), (8, 37), (32, 37), (60, 37), (32, 3200), (32, 3600)])
+@pytest.mark.parametrize('Pin,BQ', [(4, 37), (8, 37), (12, 37), (20, 37), (32, 37), (60, 37), (100, 37), (116, 5), (120, 37), (32, 3200), (32, 3600), (120, 1600)])
 def test_adaptive_mixing_core_vs_fp64(Pin, BQ):
     import ctypes
     from sparsebev_amd import _lib

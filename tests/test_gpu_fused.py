@@ -25,12 +25,18 @@ def mixing(x, params, out_points=128):
     return y
 
 
-@pytest.mark.parametrize('B,Q,T,pyr,dtype', [(1, 900, 8, 'tiny', torch.float32), (2, 37, 4, 'tiny5', torch.float32),
-                                             (1, 100, 8, 'tiny5', torch.bfloat16), (3, 5, 16, 'tiny', torch.bfloat16),
-                                             (1, 64, 12, 'r50_704x256', torch.float32)])
-def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtype):
+@pytest.mark.parametrize('B,Q,T,pyr,dtype,P', [(1, 900, 8, 'tiny', torch.float32, 4), (2, 37, 4, 'tiny5', torch.float32, 4),
+                                               (1, 100, 8, 'tiny5', torch.bfloat16, 4), (3, 5, 16, 'tiny', torch.bfloat16, 4),
+                                               (1, 64, 12, 'r50_704x256', torch.float32, 4),
+                                               # round 3: in_points not a multiple of 16 (12, 20, 60), 8 points per frame (two chunks),
+                                               # the 15-frame x 8-point shape (120 in_points: 8 row tiles, gathered rows on the S buffer)
+                                               (2, 20, 3, 'tiny', torch.float32, 4), (1, 30, 5, 'tiny5', torch.float32, 4),
+                                               (1, 33, 15, 'tiny', torch.bfloat16, 4), (1, 30, 8, 'tiny', torch.float32, 8),
+                                               (1, 50, 15, 'tiny5', torch.bfloat16, 8), (2, 21, 15, 'tiny', torch.float32, 8),
+                                               (1, 40, 15, 'tiny5', torch.float32, 8)])
+def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtype, P):
     ih, iw, sizes = S.PYRAMIDS[pyr]
-    L, G, P, C = len(sizes), 4, 4, 64
+    L, G, C = len(sizes), 4, 64
     g = torch.Generator(device=DEV).manual_seed(B * 100 + Q + T)
     levels = [torch.randn(B * T * 6, h, w, G * C, generator=g, device=DEV).to(dtype) for h, w in sizes]
     loc = torch.rand(B * T * G, Q, P, 3, generator=g, device=DEV) * 1.3 - 0.15          # incl. a border band and outside points
@@ -62,21 +68,22 @@ def test_fused_launch_on_the_frame_ring():
 
 
 def test_unsupported_shapes_are_refused_and_the_runtime_falls_back():
-    assert not ops.sample_mix_supported(4, 64, 8, 2, 4)        # P = 8
-    assert not ops.sample_mix_supported(4, 64, 4, 2, 4)        # T*P = 8: not a multiple of 16
+    assert not ops.sample_mix_supported(4, 64, 6, 2, 4)        # P = 6: not whole 4-point chunks
+    assert not ops.sample_mix_supported(4, 64, 8, 12, 4)       # T*P = 96: 5 .. 7 row tiles are not instantiated
     assert not ops.sample_mix_supported(3, 64, 4, 8, 4)
-    levels = [torch.zeros(12, 4, 4, 256, device=DEV) for _ in range(4)]
+    assert ops.sample_mix_supported(4, 64, 8, 2, 4) and ops.sample_mix_supported(5, 64, 8, 15, 4) and ops.sample_mix_supported(4, 64, 4, 2, 4)
+    levels = [torch.zeros(12, 4, 4, 256, device=DEV) for _ in range(3)]
     with pytest.raises(RuntimeError):
-        ops.sample_mix(levels, 1, 2, 4, torch.zeros(8, 3, 4, 3, device=DEV), torch.zeros(8, 3, 4, 4, device=DEV),
+        ops.sample_mix(levels, 1, 2, 4, torch.zeros(8, 3, 4, 3, device=DEV), torch.zeros(8, 3, 4, 3, device=DEV),
                        torch.zeros(1, 3, 4 * (4096 + 128 * 8), device=DEV), 128)
 
 
-@pytest.mark.parametrize('T,L,pyr', [(8, 4, 'tiny'), (4, 5, 'tiny5'), (2, 4, 'tiny')])
-def test_decoder_runtime_fused_equals_unfused(T, L, pyr):
+@pytest.mark.parametrize('T,L,pyr,P', [(8, 4, 'tiny', 4), (4, 5, 'tiny5', 4), (2, 4, 'tiny', 4), (15, 5, 'tiny5', 8), (3, 4, 'tiny', 4)])
+def test_decoder_runtime_fused_equals_unfused(T, L, pyr, P):
     B, Q = 2, 100
     ih, iw, sizes = S.PYRAMIDS[pyr]
-    params = S.make_params(3, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
-    m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=3, num_levels=L, pc_range=S.PC_RANGE)
+    params = S.make_params(3, embed_dims=256, num_frames=T, num_points=P, num_levels=L)
+    m = SparseBEVTransformer(256, num_frames=T, num_points=P, num_layers=3, num_levels=L, pc_range=S.PC_RANGE)
     m.load_state_dict({PREFIX + k: v for k, v in params.items()}, strict=True)
     m = m.to(DEV).eval()
     bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=4)]

@@ -44,7 +44,9 @@ enum sbev_gemm_mode {
     SBEV_GEMM_F32 = 0,      /* exact: f32-input MFMA */
     SBEV_GEMM_BF16X3 = 1,   /* opt-in 3 x bf16 split (rounds 1-2 kernels, gemm_bf16x3.hip) */
     SBEV_GEMM_BF16X6 = 2,   /* fp32-class: hi + mid + lo bf16 images, 6 products, fp32 accumulate (gemm_bf16s.hip) */
-    SBEV_GEMM_BF16X3S = 3   /* 3 x bf16 split on the gemm_bf16s.hip kernels */
+    SBEV_GEMM_BF16X3S = 3,  /* 3 x bf16 split on the gemm_bf16s.hip kernels */
+    SBEV_GEMM_F16X3 = 4,    /* fp32-class: scaled fp16 hi + lo images, 3 products (hl, lh, hh), fp32 accumulate (gemm_bf16s.hip) */
+    SBEV_GEMM_F16X4 = 5     /* the same with all 4 products */
 };
 
 /* Output layouts of the sampler. */
@@ -395,6 +397,41 @@ int sbev_linear_splitk_bf16s(const float* X, const uint16_t* Wp, const float* bi
                              int64_t M, int N, int K, int64_t ldx, int relu, int nimg, float* workspace,
                              sbev_stream_t stream);
 
+/*
+ * fp16 hi + lo Linears on the same kernels (gemm_mode f16x3 / f16x4, round 3): an operand row (or the whole X) is multiplied by
+ * 2^e -- a power of two, exact -- so that its largest |value| lands in [2^14, 2^15), then split into hi = RNE_fp16 and
+ * lo = RNE_fp16(remainder): 11 + 11 significand bits + lo's sign = the fp32 value to <= 2^-23 relative for elements within 2^-17
+ * of that maximum, to 2^-40 of the maximum below.  Products hl + lh + hh (nprod = 3; the dropped lo x lo is <= 2^-24 |a b|) or all
+ * four (nprod = 4) on v_mfma_f32_32x32x16_f16, fp32 accumulation; the result is multiplied by 2^-(ex + ew) (exact).
+ * tests/test_gpu_bf16s.py: max and rms error against fp64 <= the exact f32-MFMA kernels' at both AdaptiveMixing shapes.
+ *   sbev_pack_f16s_frags     W [N, ldw] fp32 -> out [ceil(N/32)][K/16][2][64][8] fp16 (sbev_bf16s_image_elems(N, K, 2) elements) and
+ *                            scales: per row [2][N] (2^e, then 2^-e) or, per_tensor = 1, [2] for the whole matrix (one extra pass over
+ *                            it); per_tensor = 2: scales [2] is an input (a power of two from the caller's bound on |W|)
+ *   sbev_linear_f16s_gen     as sbev_linear_bf16s_gen; xscale = X's [2] scales, wdown = W's 2^-e row [N]
+ *   sbev_linear_splitk_f16s  as sbev_linear_splitk_bf16s; X fp32 is multiplied by 2^x_up_log2 inside the kernel (x_is_pairs = 0) -- the caller's bound
+ *                            (|X| 2^x_up_log2 < 65504; an overflow shows as Inf / NaN, never silently); nscale = sbev_f16s_out_scale
+ *   sbev_f16s_out_scale      nscale[n] = wdown[n] 2^-x_up_log2
+ */
+int sbev_pack_f16s_frags(const float* W, int64_t ldw, uint16_t* out, float* scales, int N, int K, int per_tensor, sbev_stream_t stream);
+int sbev_linear_f16s_gen(const uint16_t* Xs, const float* xscale, const uint16_t* Ws, const float* wdown, const float* bias, float* Y,
+                         int64_t M, int N, int K, int64_t ldy, int relu, int nprod, sbev_stream_t stream);
+int sbev_linear_splitk_f16s(const float* X, int x_is_pairs, int x_up_log2, const uint16_t* Wp, const float* nscale, const float* bias, const float* residual,
+                            const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                            int64_t M, int N, int K, int64_t ldx, int relu, int nprod, float* workspace, sbev_stream_t stream);
+int sbev_f16s_out_scale(const float* wdown, int x_up_log2, float* nscale, int N, sbev_stream_t stream);
+/* The pre-split operand: out[i] = (fp16 hi, fp16 lo) of X[i] 2^up_log2 packed in one 32-bit slot (hi in the low half).  With
+ * x_is_pairs = 1 sbev_linear_splitk_f16s takes X in this format (same [M, ldx] geometry) and only de-interleaves it.  The mixing
+ * launches can emit it directly: sbev_adaptive_mixing_pairs_f16 / sbev_sample_mix_pairs_f16 = sbev_adaptive_mixing_f32 /
+ * sbev_sample_mix_f32 with y written as pairs of y 2^up_log2 (what sbev_decoder_forward does in the fp16 GEMM modes). */
+int sbev_f16s_pairs(const float* X, void* out, int64_t n, int up_log2, sbev_stream_t stream);
+int sbev_adaptive_mixing_pairs_f16(const float* x, const float* params, void* y, int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
+                                   int up_log2, sbev_stream_t stream);
+int sbev_sample_mix_pairs_f16(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                              int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                              const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                              const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                              const float* params, void* y, int Pout, float eps, int up_log2, sbev_stream_t stream);
+
 /* dst[i] = (float)src[i] over a contiguous run; src_dtype: 0 fp32, 1 bf16, 2 fp16.  How the online frame ring takes
  * channels-last frames (sparsebev_amd/cache.py); replaces the torch.cat of cached frames, models/sparsebev.py:297-303. */
 int sbev_copy_widen_f32(const void* src, int src_dtype, float* dst, int64_t n, sbev_stream_t stream);
@@ -537,6 +574,11 @@ typedef struct sbev_decoder_weights {
     const float *chain_pack;   /* sbev_decoder_chain_pack image of the small Linears' weights, or NULL (op-by-op launches) */
     const uint16_t *pg_ws;     /* gemm_mode 2 / 3: sbev_pack_bf16s_frags image of pg_w (3 / 2 images); else NULL */
     const uint16_t *op_wp;     /* gemm_mode 2 / 3: sbev_pack_bf16s_frags image of op_w (3 / 2 images); else NULL */
+    /* gemm_mode 4 / 5 (fp16 hi + lo): pg_ws / op_wp are the sbev_pack_f16s_frags images (per-row scales) and */
+    const float *pg_wdown;     /*   the 2^-e row of pg_w's scales [G * (C*C + out_points * T*P)] */
+    const float *op_nscale;    /*   sbev_f16s_out_scale(op_w's 2^-e row, sbev_decoder_mixed_up_log2(cfg)) [embed_dims] */
+    const float *pg_xscale;    /*   {2^e, 2^-e} (device memory) for the generator's input, norm1's output: the largest e with
+                                *   (sqrt(embed_dims - 1) max|norm1_g| + max|norm1_b|) 2^e < 65504 */
 } sbev_decoder_weights;
 
 /*
@@ -557,6 +599,10 @@ int sbev_decoder_row_chain(int enable);
  * (row chains, gather + mixing fusion), -1 on an invalid config: 6 with the row chains, 17 op by op, + 1 for the two-launch gather
  * + mixing, + 1 for the activation split of the split-bf16 GEMM modes. */
 int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights);
+
+/* fp16 GEMM modes: log2 of the power of two the out-projection's input (relu(LayerNorm) over out_points * embed_dims / G elements:
+ * |x| <= sqrt(n - 1)) is multiplied by before its fp16 split inside sbev_decoder_forward: 9 for n = 8192. */
+int sbev_decoder_mixed_up_log2(const sbev_decoder_config* cfg);
 
 /* Bytes of scratch sbev_decoder_forward needs for this config (-1 on an invalid config). */
 int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg);

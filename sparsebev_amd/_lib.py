@@ -79,6 +79,16 @@ SIGNATURES = {
     'sbev_linear_bf16s_gen_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_bf16s_gen': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_decoder_mixed_up_log2': (ctypes.c_int, [_vp]),
+    'sbev_pack_f16s_frags': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_linear_f16s_gen': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                            ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_f16s_pairs': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_adaptive_mixing_pairs_f16': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_float, ctypes.c_int, _vp]),
+    'sbev_linear_splitk_f16s': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'sbev_f16s_out_scale': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     'sbev_linear_bf16s_out_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_bf16s_out_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_splitk_bf16s': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
@@ -114,6 +124,10 @@ SIGNATURES = {
                                            ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,
                                            _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
+    'sbev_sample_mix_pairs_f16': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,
+                                                 _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     'sbev_decoder_fuse_sample_mix': (ctypes.c_int, [ctypes.c_int]),
     'sbev_decoder_chain_pack_floats': (ctypes.c_int64, [_vp]),
     'sbev_decoder_chain_pack': (ctypes.c_int, [_vp, _vp, _vp, _vp]),

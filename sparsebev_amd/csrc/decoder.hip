@@ -7,6 +7,7 @@
 // The launch sequence is static for a given config, which also makes it capturable into a hipGraph by the
 // caller (the stream may be in capture mode: no call in here is capture-illegal).
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include "sbev_common.hpp"
 
@@ -28,7 +29,7 @@ struct Carver {
 
 struct Buffers {
     float *t0, *t1, *x, *x1, *x2, *x3, *qkvt, *att, *so, *wbp, *loc, *sampled, *params, *mixed, *slabs,
-        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s;
+        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc;
     size_t bytes;
 };
 
@@ -62,7 +63,8 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.reg = k.take(BQ * c.code_size);
     b.bbox = k.take(BQ * 10);
     b.x1s = k.take(2 * BQ * D + 64 * (size_t)D);   // x1 as bf16 image fragments (<= 3 images of 2 bytes, rows padded to 32): the
-                                                   // generator's operand in the split-bf16 modes
+                                                   // generator's operand in the split-bf16 / fp16 modes
+    b.xsc = k.take(64);                            // fp16 modes: {2^e, 2^-e} of x1 (written by the pack launch of every layer)
     b.bytes = k.off;
     return b;
 }
@@ -89,7 +91,7 @@ int validate(const sbev_decoder_config* c) {
     // every box kernel (sasa, sampling_front, refine, linear3) reads query_bbox rows with a stride of 10 floats
     SBEV_REQUIRE(c->code_size == 10, "sbev_decoder: code_size %d (the box kernels are built for the 10-wide box code)", c->code_size);
     SBEV_REQUIRE(c->num_layers >= 1 && c->num_classes >= 1 && c->ffn % 4 == 0, "sbev_decoder: head sizes");
-    SBEV_REQUIRE(c->gemm_mode >= SBEV_GEMM_F32 && c->gemm_mode <= SBEV_GEMM_BF16X3S, "sbev_decoder: gemm_mode %d", c->gemm_mode);
+    SBEV_REQUIRE(c->gemm_mode >= SBEV_GEMM_F32 && c->gemm_mode <= SBEV_GEMM_F16X4, "sbev_decoder: gemm_mode %d", c->gemm_mode);
     return SBEV_OK;
 }
 
@@ -146,10 +148,21 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
     const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
                        sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
     const int split = (c.gemm_mode == SBEV_GEMM_BF16X6 || c.gemm_mode == SBEV_GEMM_BF16X3S) ? 1      // x1 -> bf16 image fragments
+                      : (c.gemm_mode == SBEV_GEMM_F16X3 || c.gemm_mode == SBEV_GEMM_F16X4) ? 1      // x1 -> fp16 image fragments
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
     // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
     // op by op: 17 with the fused gather + mixing
     return (chain ? 6 : 17) + (fused ? 0 : 1) + split;
+}
+
+// fp16 modes: the out-projection's input -- relu(LayerNorm without affine over n = out_points * C / G elements), so |x| <= sqrt(n - 1)
+// -- is multiplied by 2^e before its fp16 split: the largest e with sqrt(n) 2^e < 65504 (n = 8192: e = 9)
+extern "C" int sbev_decoder_mixed_up_log2(const sbev_decoder_config* cfg) {
+    if (!cfg || cfg->G < 1 || cfg->out_points < 1 || cfg->D < cfg->G) return 0;
+    const double bound = std::sqrt((double)cfg->out_points * (cfg->D / cfg->G));
+    int e = 0;
+    while (std::ldexp(bound, e + 1) < 65504.0 && e < 15) ++e;
+    return e;
 }
 
 extern "C" int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg) {
@@ -169,8 +182,12 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const sbev::ProfCallScope prof_scope;     // with sbev_profile_stride(n): only every n-th call's launches are bracketed
     SBEV_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sbev_decoder_forward: workspace must be 256-byte aligned");
     SBEV_REQUIRE(cfg->gemm_mode != SBEV_GEMM_BF16X3 || (w->pg_w2 && w->op_w2), "sbev_decoder_forward: gemm_mode bf16x3 needs pg_w2 / op_w2");
-    const int nimg = cfg->gemm_mode == SBEV_GEMM_BF16X6 ? 3 : cfg->gemm_mode == SBEV_GEMM_BF16X3S ? 2 : 0;   // split-bf16 kernels (gemm_bf16s.hip)
+    // split-bf16 / fp16 kernels (gemm_bf16s.hip): their mode code 2 = bf16x3s, 3 = bf16x6, 4 = f16x3, 5 = f16x4
+    const int nimg = cfg->gemm_mode == SBEV_GEMM_BF16X6 ? 3 : cfg->gemm_mode == SBEV_GEMM_BF16X3S ? 2 : cfg->gemm_mode == SBEV_GEMM_F16X3 ? 4
+                     : cfg->gemm_mode == SBEV_GEMM_F16X4 ? 5 : 0;
     SBEV_REQUIRE(nimg == 0 || (w->pg_ws && w->op_wp), "sbev_decoder_forward: gemm_mode %d needs pg_ws / op_wp", cfg->gemm_mode);
+    SBEV_REQUIRE(nimg < 4 || (w->pg_wdown && w->op_nscale && w->pg_xscale), "sbev_decoder_forward: gemm_mode %d needs pg_wdown / op_nscale / pg_xscale", cfg->gemm_mode);
+    const int mixed_up = sbev_decoder_mixed_up_log2(cfg);
     const Buffers b = carve(c, workspace);
     SBEV_REQUIRE((int64_t)b.bytes <= workspace_bytes, "sbev_decoder_forward: workspace too small (%lld < %zu)", (long long)workspace_bytes, b.bytes);
 
@@ -216,9 +233,29 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                  cfg->gemm_mode, (long long)BQ, pgN, D, D, mixN);
     auto generator_bf16s = [&](sbev_stream_t st) -> int {      // x1 -> bf16 image fragments (once per layer) -> Y = X W^T + b
         uint16_t* xs = reinterpret_cast<uint16_t*>(b.x1s);
+        if (nimg >= 4) {                                       // fp16 hi + lo: x1 scaled by one power of two (its maximum -> [2^14, 2^15))
+            // (the power of two comes with the weights: norm1's output is bounded by sqrt(D - 1) max|gamma| + max|beta| -- no pass for a maximum)
+            int e = sbev_pack_f16s_frags(b.x1, D, xs, const_cast<float*>(w->pg_xscale), (int)BQ, D, 2, st);
+            if (e != SBEV_OK) return e;
+            return sbev_linear_f16s_gen(xs, w->pg_xscale, w->pg_ws, w->pg_wdown, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg - 1, st);
+        }
         int e = sbev_pack_bf16s_frags(b.x1, D, xs, (int)BQ, D, nimg, st);
         if (e != SBEV_OK) return e;
         return sbev_linear_bf16s_gen(xs, w->pg_ws, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg, st);
+    };
+
+    // the mixing launches: in the fp16 GEMM modes their epilogue leaves `mixed` as (fp16 hi, fp16 lo) pairs of mixed 2^mixed_up -- the
+    // out-projection's operand, split once per element where the VALU is idle instead of inside the GEMM
+    auto mix_fused = [&](sbev_stream_t st) -> int {
+        if (nimg >= 4)
+            return sbev_sample_mix_pairs_f16(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
+                                             c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, mixed_up, st);
+        return sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
+                                   c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, st);
+    };
+    auto mix_plain = [&](sbev_stream_t st) -> int {
+        if (nimg >= 4) return sbev_adaptive_mixing_pairs_f16(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, mixed_up, st);
+        return sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, st);
     };
 
     const float* bbox = query_bbox;
@@ -244,8 +281,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
                                sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
             if (fused) {
-                TRY(sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
-                                        c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, stream));
+                TRY(mix_fused(stream));
             } else {
                 if (c.n_slots > 0)
                     TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
@@ -253,11 +289,11 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                 else
                     TRY(sbev_msmv_fwd(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
                                       c.G, sbo, Cg, sv, D, b.loc, b.wbp, b.sampled, SBEV_OUT_MIX, c.T, c.G, stream));
-                TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
+                TRY(mix_plain(stream));
             }
             int used = 0;
             if (nimg)
-                TRY(sbev::launch_splitk_slabs_bf16s(b.mixed, w->op_wp, BQ, mixN, mixN, nimg, b.slabs, &used, s_main));
+                TRY(sbev::launch_splitk_slabs_bf16s(b.mixed, w->op_wp, BQ, mixN, mixN, nimg, b.slabs, &used, s_main, mixed_up, w->op_nscale, nimg >= 4));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(sbev::launch_splitk_slabs_bf16x3(b.mixed, w->op_w2, BQ, D, mixN, mixN, splits, b.slabs, &used, s_main));
             else
@@ -319,11 +355,13 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // adaptive mixing + norm2 (join: the generator's output is needed now)  (:171)
         if (fork_pg) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_pg, 0), "hipStreamWaitEvent"));
         if (fused)
-            TRY(sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
-                                    c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, stream));
+            TRY(mix_fused(stream));
         else
-            TRY(sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, stream));
-        if (nimg)
+            TRY(mix_plain(stream));
+        if (nimg >= 4)
+            TRY(sbev_linear_splitk_f16s(b.mixed, 1, mixed_up, w->op_wp, w->op_nscale, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
+                                        0, nimg - 1, b.slabs, stream));
+        else if (nimg)
             TRY(sbev_linear_splitk_bf16s(b.mixed, w->op_wp, w->op_b, b.x1, w->norm2_g, w->norm2_b, eps, b.x2, BQ, D, mixN, mixN,
                                          0, nimg, b.slabs, stream));
         else if (c.gemm_mode == SBEV_GEMM_BF16X3)

@@ -37,7 +37,7 @@
 #ifdef SBEV_EXP_NOMFMA          // keep the fragment reads alive, drop the matrix work
 #define SBEV_MFMA(A, B, C) ([&]() { asm volatile("" ::"v"(A), "v"(B)); return C; }())
 #else
-#define SBEV_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#define SBEV_MFMA(A, B, C) mfma16<PR::F16>(A, B, C)
 #endif
 
 #ifdef SBEV_EXP_TRACE            // per-phase shader-clock stamps of waves 0 and 4 of workgroup 0 (tools/exp/trace_bf16s.py)
@@ -64,6 +64,7 @@ extern "C" int sbev_debug_wgtime_read(unsigned long long* out) {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -93,14 +94,56 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4* out)
     }
 }
 
-// products in the order they are accumulated (small terms first inside a k-step): image of X, image of W
-//   x3: (h,l) (l,h) (h,h)                 x6: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+// fp16 variant (round 3, second half): x * 2^e = hi + lo with hi = RNE_fp16, lo = RNE_fp16(remainder) -- 11 + 11 significand bits +
+// the sign of lo = the fp32 value to <= 2^-23 relative (one bit short of fp32's own 2^-24 half-ulp in the worst case; elements
+// within 2^-17 of the scaled maximum -- below that lo is a subnormal with absolute error 2^-25, i.e. <= 2^-40 of the maximum).  2^e (a power of two: exact) brings the maximum of the row / tensor to
+// [2^14, 2^15) so that fp16's 5-bit exponent covers 29 binades below it; the output is multiplied by 2^-(ex + ew) exactly.
 template <int NIMG>
-struct Prods {
-    static constexpr int N = NIMG == 2 ? 3 : 6;
-    __host__ __device__ static constexpr int ia(int p) { return NIMG == 2 ? (p == 1 ? 1 : 0) : (p == 1 ? 2 : (p == 2 || p == 4) ? 1 : 0); }
-    __host__ __device__ static constexpr int ib(int p) { return NIMG == 2 ? (p == 0 ? 1 : 0) : (p == 0 ? 2 : (p == 2 || p == 3) ? 1 : 0); }
+__device__ __forceinline__ void split8h(const f32x4 a, const f32x4 b, float up, u32x4* out) {
+    float r[8] = {a.x * up, a.y * up, a.z * up, a.w * up, b.x * up, b.y * up, b.z * up, b.w * up};
+#pragma unroll
+    for (int img = 0; img < NIMG; ++img) {
+        unsigned p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const _Float16 h0 = (_Float16)r[2 * i], h1 = (_Float16)r[2 * i + 1];
+            p[i] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            if (img + 1 < NIMG) { r[2 * i] -= (float)h0; r[2 * i + 1] -= (float)h1; }
+        }
+        out[img] = (u32x4){p[0], p[1], p[2], p[3]};
+    }
+}
+
+// MODE: 0 = bf16x3s (2 bf16 images, 3 products), 1 = bf16x6 (3 images, 6 products), 2 = f16x3 (2 fp16 images, 3 products),
+// 3 = f16x4 (2 fp16 images, all 4 products).  Products in the order they are accumulated (small terms first inside a k-step; the
+// last one is hi x hi): image of X, image of W
+//   3 products: (h,l) (l,h) (h,h)     4: (l,l) (h,l) (l,h) (h,h)     6: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+template <int MODE>
+struct Fmt {
+    static constexpr bool F16 = MODE >= 2;
+    static constexpr int NIMG = MODE == 1 ? 3 : 2;
+    static constexpr int N = MODE == 1 ? 6 : MODE == 3 ? 4 : 3;
+    __host__ __device__ static constexpr int ia(int p) {
+        return MODE == 1 ? (p == 1 ? 2 : (p == 2 || p == 4) ? 1 : 0) : MODE == 3 ? ((p == 0 || p == 2) ? 1 : 0) : (p == 1 ? 1 : 0);
+    }
+    __host__ __device__ static constexpr int ib(int p) {
+        return MODE == 1 ? (p == 0 ? 2 : (p == 2 || p == 3) ? 1 : 0) : MODE == 3 ? ((p == 0 || p == 1) ? 1 : 0) : (p == 0 ? 1 : 0);
+    }
 };
+__host__ __device__ constexpr int mode_of(int nimg) { return nimg == 3 ? 1 : nimg == 2 ? 0 : nimg == 4 ? 2 : 3; }     // API code -> MODE
+__host__ __device__ constexpr bool mode_ok(int nimg) { return nimg >= 2 && nimg <= 5; }
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int MODE>
+__device__ __forceinline__ void split8m(const f32x4 a, const f32x4 b, float up, u32x4* out) {
+    if constexpr (Fmt<MODE>::F16) split8h<Fmt<MODE>::NIMG>(a, b, up, out);
+    else split8<Fmt<MODE>::NIMG>(a, b, out);
+}
 
 __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned nb) {
     // workgroup b runs on XCD b % 8: give each XCD a contiguous range of logical ids (bijective for any nb)
@@ -126,8 +169,9 @@ __global__ void split_rows_kernel(const float* x, long long ldx, unsigned short*
 
 // ---- MFMA-ordered fragments [N/32][K/16][NIMG][64 lanes][8 bf16] of W [N, ldw]: lane l holds row 32 nf + (l & 31), k = 16 ks +
 // 8 (l >> 5) + 0..7, i.e. exactly its operand of one v_mfma_f32_32x32x16_bf16 -----------------------------------------------------
-template <int NIMG>
-__global__ void pack_frags_kernel(const float* w, long long ldw, unsigned short* out, int N, int K) {
+template <int MODE>
+__global__ void pack_frags_kernel(const float* w, long long ldw, unsigned short* out, int N, int K, const float* up, int up_stride) {
+    constexpr int NIMG = Fmt<MODE>::NIMG;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int KS = K / 16;
     if (i >= (long long)((N + 31) / 32) * KS * 64) return;
@@ -139,10 +183,51 @@ __global__ void pack_frags_kernel(const float* w, long long ldw, unsigned short*
     row = row < N ? row : N - 1;                     // a ragged last block repeats the last row (its outputs are never stored)
     const float* p = w + (long long)row * ldw + ks * 16 + (lane >> 5) * 8;
     u32x4 im[NIMG];
-    split8<NIMG>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), im);
+    split8m<MODE>(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4), Fmt<MODE>::F16 ? up[(long long)row * up_stride] : 1.f, im);
 #pragma unroll
     for (int img = 0; img < NIMG; ++img)
         *reinterpret_cast<u32x4*>(out + ((f * NIMG + img) * 64 + lane) * 8) = im[img];
+}
+
+// ---- fp16 scales: up = 2^e with max |x| * 2^e in [2^14, 2^15), down = 2^-e; per row (stride 1) or for the whole matrix --------------
+__device__ __forceinline__ void scale_of(float mx, float* up, float* down) {
+    int ex = 0;
+    float e = 0.f;
+    if (mx > 0.f && mx < __builtin_inff()) { (void)frexpf(mx, &ex); e = (float)(15 - ex); }      // mx = m 2^ex, m in [0.5, 1)
+    e = fminf(fmaxf(e, -126.f), 126.f);      // (2^e and 2^-e both normal fp32 numbers)
+    *up = exp2f(e);                       // exact: exp2f of an integer
+    *down = exp2f(-e);
+}
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* w, long long ldw, int N, int K, float* up, float* down) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float mx = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + (long long)row * ldw + k);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) scale_of(mx, up + row, down + row);
+}
+__global__ __launch_bounds__(1024) void tensor_scale_kernel(const float* x, long long ldx, long long rows, int K, float* updown) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    const long long n4 = rows * (K / 4);
+    for (long long i = threadIdx.x; i < n4; i += 1024) {
+        const long long r = i / (K / 4);
+        const int c = (int)(i - r * (K / 4));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c * 4);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+        scale_of(mx, updown, updown + 1);
+    }
 }
 
 // ---- LDS-DMA: 1 KiB per wave-instruction, LDS destination = M0 + 16 lane (lane-linear), source = sbase + voff per lane ----------
@@ -203,6 +288,8 @@ struct GenArgs {
     long long ldy;
     int relu;
     int ntm, base, rem;          // row tiles: the first `rem` have base + 1 fragments of 32 rows, the others `base`
+    const float* colscale;       // fp16 modes: [N] 2^-ew of W's rows (the output columns); null otherwise
+    const float* xscale;         // fp16 modes: {2^ex, 2^-ex} of X (device memory: written by the pack launch before this one)
 };
 
 constexpr int G_COLS = 256;                     // columns of a workgroup tile (8 fragments); rows: 128 or 256 (RF)
@@ -261,17 +348,33 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {          // n wave-uniform
 }
 
 // RF = row fragments (32 rows) per wave: 2 -> 128 x 256 tiles, 4-deep ring, split accumulators; 4 -> 256 x 256 tiles, 3-deep ring
-template <int NIMG, int RF>
+template <int MODE, int RF>
 __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
+    typedef Fmt<MODE> PR;
+    constexpr int NIMG = PR::NIMG;
+    constexpr bool F16 = PR::F16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: its byte address is 0
     constexpr int AF = 2 * RF;                                       // row fragments of a tile (A side); 8 column fragments (B side)
     constexpr int ST_A = AF * 1024, ST_B = 8 * 1024;                 // bytes of one image of one 16-k stage
     constexpr int STAGE = NIMG * (ST_A + ST_B);
-    constexpr int NST = RF == 2 ? 4 : 3;                             // LDS ring depth; loads run NST - 1 stages ahead
+    // LDS ring depth; loads run NST - 1 stages ahead.  256-row tiles: 3 stages of 48 KB with three images; with two images (32 KB) a
+    // fourth fits, and the f16x3 trace wants it: its 24 MFMAs per stage no longer cover the landing of a stage issued 2 stages ago
+    // (380 cycles of vmcnt wait in every FETCH phase, FETCH 1050 > COMPUTE 830)
+    constexpr int NST = RF == 2 ? 4 : 3;        // (a 4th stage for two images x 256 rows fits but measured nothing: 57.2 -> 58.3 us)
+    // Two images x 256-row tiles: the LDS the third image would take carries a per-wave 32 x 32 transpose patch for the epilogue.
+    // The direct epilogue (a lane owns ONE output column: 128 dword stores of two 128-byte lines per wave and tile) held the tile
+    // boundary for 5.3k cycles per phase group -- with the partner group idle at the barrier, 2 x 2 x 5.3k of a 90k-cycle
+    // workgroup (f16x3 trace).  Through the patch a wave stores 32 x dwordx4 (8 full 128-byte row segments per instruction).
+    constexpr bool EPI_LDS = NIMG == 2 && RF == 4;
+    constexpr int EPI_LD = 36;                                       // patch row stride in floats (16-byte aligned rows, 4-bank shift per row)
+    constexpr int EPI_BYTES = EPI_LDS ? 8 * 32 * EPI_LD * 4 : 0;
+    // Experiment kept as a switch: the LDS-DMA requests of the stage NST - 1 ahead issued in the COMPUTE phase, between the MFMAs (they
+    // touch no vector register), instead of in the FETCH phase, because with 24 MFMAs per stage FETCH (issue 380 + reads 190 + wait +
+    // barrier) is longer than COMPUTE (816) and sets the pace.
+    constexpr bool ISSUE_IN_COMPUTE = false;       // (measured: 61 us instead of 56 -- an LDS-DMA instruction holds the wave's issue ~100 cycles, MFMAs wait behind it)
     constexpr bool SPLIT_ACC = RF == 2;                              // second accumulator set for the small products
     constexpr int NBLK = AF + 8;                                     // 32-row blocks per stage (A rows, then B columns): NIMG KiB each
     constexpr int NLMAX = (NBLK + 7) / 8;
-    typedef Prods<NIMG> PR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;                         // wr: row half = phase group (waves w, w + 4 share a SIMD)
@@ -316,7 +419,9 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         const unsigned sb = (unsigned)((lg % NST) * STAGE);
 #pragma unroll
         for (int j = 0; j < NLMAX; ++j) {
+#ifndef SBEV_EXP_NOGLDS
             if (j < nlb) glds16_images<NIMG>(gbase[j], voff, sb + ldst[j]);
+#endif
             gbase[j] += NIMG * 1024;
         }
         ++lg;
@@ -343,7 +448,8 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         auto init_acc = [&](int ti) {                                // tile ti of this workgroup: its bias slice waits in LDS
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
-                const float bv = reinterpret_cast<const float*>(lds + NST * STAGE)[ti * G_COLS + (wc * 2 + fb) * 32 + l31];
+                // (fp16 modes: the accumulators are in scaled units -- bias and the 2^-(ex + ew) factor are applied by store_tile)
+                const float bv = F16 ? 0.f : reinterpret_cast<const float*>(lds + NST * STAGE + EPI_BYTES)[ti * G_COLS + (wc * 2 + fb) * 32 + l31];
 #pragma unroll
                 for (int fa = 0; fa < NFR; ++fa)
 #pragma unroll
@@ -353,8 +459,20 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                     }
             }
         };
-        auto store_tile = [&](int n0) {                              // acc already holds hi x hi + small products
+        auto store_tile = [&](int n0, int tix) {                     // acc already holds hi x hi + small products
             if constexpr (NFA > 0) {
+                if constexpr (F16) {                                 // y = acc 2^-(ex + ew[n]) + b[n]: a lane holds two output columns
+                    const float* bs = reinterpret_cast<const float*>(lds + NST * STAGE + EPI_BYTES) + tix * G_COLS + wc * 64 + l31;
+                    const float* cs = bs + my_tiles * G_COLS;
+                    const float b0 = bs[0], b1 = bs[32], c0 = cs[0], c1 = cs[32];
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            acc[fa][0][e] = fmaf(acc[fa][0][e], c0, b0);
+                            acc[fa][1][e] = fmaf(acc[fa][1][e], c1, b1);
+                        }
+                }
                 if (a.relu) {                                        // one uniform branch, not one per store
 #pragma unroll
                     for (int fa = 0; fa < NFA; ++fa)
@@ -362,6 +480,29 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                         for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
                             for (int e = 0; e < 16; ++e) acc[fa][fb][e] = fmaxf(acc[fa][fb][e], 0.f);
+                }
+                if constexpr (EPI_LDS) {
+                    float* patch = reinterpret_cast<float*>(lds + NST * STAGE) + wave * (32 * EPI_LD);
+                    const int pr = lane >> 3, pc = (lane & 7) * 4;   // read-back: lane -> row pr + 8 i, 4 columns at pc
+#pragma unroll
+                    for (int fa = 0; fa < NFA; ++fa) {
+                        const int r0 = m0 + (wr * RF + fa) * 32;
+#pragma unroll
+                        for (int fb = 0; fb < 2; ++fb) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * lh) * EPI_LD + l31] = acc[fa][fb][e];
+                            __builtin_amdgcn_wave_barrier();         // (wave-private patch: the LDS pipe keeps a wave's accesses in order)
+                            f32x4 v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(patch + (pr + 8 * i) * EPI_LD + pc);
+                            __builtin_amdgcn_wave_barrier();
+                            float* y = a.Y + (long long)(r0 + pr) * a.ldy + n0 + wc * 64 + fb * 32 + pc;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (r0 + pr + 8 * i < M SBEV_EXP_STORE_COND) *reinterpret_cast<f32x4*>(y + (long long)(8 * i) * a.ldy) = v[i];
+                        }
+                    }
+                    return;
                 }
 #pragma unroll
                 for (int fa = 0; fa < NFA; ++fa) {
@@ -396,7 +537,9 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         // make hipcc wait vmcnt(0) in the middle of the LDS-DMA pipeline
         for (int i = tid; i < my_tiles * G_COLS; i += 512) {
             const int t = i / G_COLS, c = i - t * G_COLS;
-            reinterpret_cast<float*>(lds + NST * STAGE)[i] = a.bias ? a.bias[(ct0 + t * cstep) * G_COLS + c] : 0.f;
+            reinterpret_cast<float*>(lds + NST * STAGE + EPI_BYTES)[i] = a.bias ? a.bias[(ct0 + t * cstep) * G_COLS + c] : 0.f;
+            if constexpr (F16)        // behind the bias slices: the columns' output scales 2^-ew[n] 2^-ex
+                reinterpret_cast<float*>(lds + NST * STAGE + EPI_BYTES)[my_tiles * G_COLS + i] = a.colscale[(ct0 + t * cstep) * G_COLS + c] * a.xscale[1];
         }
         __syncthreads();
         init_acc(0);
@@ -420,14 +563,14 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
                 }
             }
             SBEV_TRACE(g, 1)
-            issue_next();
+            if constexpr (!ISSUE_IN_COMPUTE) issue_next();
             SBEV_TRACE(g, 2)
             {
                 const int hi = lg - 1, need = g + 1 < G ? g + 1 : g;
                 wait_vmcnt_n(hi > need ? (hi - need) * nl : 0);
             }
             if (pending) {                                           // the previous tile's stores ride in this phase
-                store_tile(cn0);
+                store_tile(cn0, ti);
                 cn0 += cstep * G_COLS;
                 ++ti;
                 init_acc(ti < my_tiles ? ti : 0);
@@ -437,6 +580,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
             phase_barrier();
             SBEV_TRACE(g, 4)
             // ---- COMPUTE(g): nothing but MFMAs (the partner wave of this SIMD is in its FETCH phase)
+            if constexpr (ISSUE_IN_COMPUTE) issue_next();
             if constexpr (NFA > 0) {
 #pragma unroll
                 for (int p = 0; p < PR::N - 1; ++p)
@@ -468,7 +612,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
             SBEV_TRACE(g, 6)
         }
         if (wr == 0) phase_barrier();
-        if (pending) store_tile(cn0);
+        if (pending) store_tile(cn0, ti);
         SBEV_WGTIME(1)
     };
     if (nfa == RF) run(std::integral_constant<int, RF>{});
@@ -488,6 +632,8 @@ struct OutArgs {
     int M, K;
     long long ldx;
     int nrt, S;                  // row tiles of 64 rows, K chunks
+    float xup;                   // fp16 modes: X is multiplied by this power of two before the split (the caller's bound on |X|)
+    const float* nscale;         // fp16 modes: [256] 2^-ew[n] / xup, applied to the slab values (exact); null otherwise
 };
 
 constexpr int O_IMG = 64 * 64;                  // bytes of one image of one half's stage (64 rows x 32 k)
@@ -499,15 +645,22 @@ constexpr int O_IMG = 64 * 64;                  // bytes of one image of one hal
 // loads four ahead) and a COMPUTE phase (its 48 MFMAs, then the W fragment loads of the next slab, which land during the following
 // FETCH), a barrier after each, and the second K half takes one extra barrier up front: on every SIMD one wave computes while the
 // other fetches.  The halves never touch each other's LDS ring; they meet only in the final fold.
-template <int NIMG>
+// XPRE (fp16 modes): X already holds (fp16 hi, fp16 lo) pairs of x 2^e in its 32-bit slots (the mixing kernel's epilogue made them:
+// sbev_adaptive_mixing_pairs_f16 / sbev_sample_mix_pairs_f16) -- staging a slab is then 8 byte-permutes per thread instead of the
+// ~60 conversion instructions of the split, which the 24 MFMAs of an f16x3 slab no longer hide (trace: COMPUTE 1100 .. 1800 cycles
+// for 792 cycles of matrix work)
+template <int MODE, bool XPRE = false>
 __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
+    typedef Fmt<MODE> PR;
+    static_assert(!XPRE || PR::F16, "pre-split X is the fp16 pair format");
+    constexpr int NIMG = PR::NIMG;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int HSTAGE = NIMG * O_IMG;        // one half's stage
     constexpr int NST = 3;
-    typedef Prods<NIMG> PR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, wc = wave & 3;  // K half of the chunk = phase group, 64-column quarter
+    SBEV_WGTIME(0)
     const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
     const int M = a.M;
@@ -539,7 +692,15 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
     };
     auto stagex = [&](int i, const f32x4 v0, const f32x4 v1) {       // slab i -> ring slot i % 3
         u32x4 im[NIMG];
-        split8<NIMG>(v0, v1, im);
+        if constexpr (XPRE) {
+            const u32x4 p = __builtin_bit_cast(u32x4, v0), q = __builtin_bit_cast(u32x4, v1);
+            im[0] = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
+                            __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u)};
+            im[1] = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
+                            __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u)};
+        } else {
+            split8m<MODE>(v0, v1, a.xup, im);
+        }
         unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) *reinterpret_cast<u32x4*>(st + img * O_IMG) = im[img];
@@ -676,13 +837,215 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
-                        const f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
+                        f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
+                        if constexpr (PR::F16) v *= *reinterpret_cast<const f32x4*>(a.nscale + wc * 64 + 4 * lh + fb * 32 + 8 * g);   // exact: powers of two
+                        *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
+                    }
+            }
+        }
+        SBEV_WGTIME(1)
+    };
+    if (nfa == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
+// ---- out-projection, 128-row tiles (fp16 modes, pre-split X) ---------------------------------------------------------------------
+// Ablation of the kernel above in f16x3 (c2, 66 us): without its MFMAs 63, without MFMAs and stores 58 -- with three products the
+// kernel is bound by operand DELIVERY: every 64-row tile streams its K chunk of all 256 W rows from L2, 15 row tiles x 33.5 MB =
+// 503 MB (+ 118 MB of X) per launch through ~22 B/clk/CU.  Here a workgroup owns up to 128 rows (4 fragments, balanced like the
+// generator's tiles: 900 rows = 5 x 4 + 3 x 3 fragments) x all 256 columns x one K chunk: half the W bytes per MFMA.  A slab is ONE
+// 16-k step (24 MFMAs per wave with 4 row fragments, as before with 2 fragments x 2 k-steps), so a wave holds 128 accumulator
+// registers + one k-step of fragments (32) + two W sets (32); X arrives as (hi, lo) pairs (the mixing kernel's epilogue), staging is
+// 8 byte-permutes per thread.  Same ping-pong of the two K halves, same fixed-order fold: bit-reproducible.
+struct Out4Args {
+    const unsigned* Xp;          // [M, ldx] (fp16 hi, fp16 lo) pairs
+    const unsigned short* Wp;    // [8][K/16][2][64][8] fp16 fragments
+    float* P;                    // [S, M, 256] partial slabs
+    int M, K;
+    long long ldx;
+    int ntm, base, rem, S;       // row tiles: the first `rem` have base + 1 fragments of 32 rows, the others `base`; K chunks
+    const float* nscale;         // [256] 2^-ew[n] 2^-ex
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) {
+    typedef Fmt<MODE> PR;
+    static_assert(PR::F16 && PR::NIMG == 2, "pre-split fp16 operands");
+    constexpr int NIMG = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int IMG = 128 * 32;               // bytes of one image of one half's stage: 128 rows x 16 k
+    constexpr int HSTAGE = NIMG * IMG;
+    constexpr int NST = 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wc = wave & 3;  // K half of the chunk = phase group, 64-column quarter
+    SBEV_WGTIME(0)
+    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(logical / (unsigned)a.ntm), rt = (int)(logical % (unsigned)a.ntm);
+    const int M = a.M;
+    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
+    const int nfa = a.base + (rt < a.rem ? 1 : 0);               // row fragments of this tile: 1 .. 4
+    const int m0 = f0 * 32;
+    const int KS = a.K / 16;
+    const int c0 = (int)((long long)KS * chunk / a.S), c1 = (int)((long long)KS * (chunk + 1) / a.S);
+    const int n_all = c1 - c0, n0h = (n_all + 1) / 2;
+    const int sb = half == 0 ? c0 : c0 + n0h;            // first k-step of this half
+    const int nh = half == 0 ? n0h : n_all - n0h;        // its k-steps (half 0 may have one more)
+
+    const int th = tid & 255;
+    const int srow = th >> 1, skq = th & 1;              // staging: thread -> (row of the tile, 8-k half of the step)
+    int grow = m0 + srow;
+    grow = grow < M ? grow : M - 1;
+    const unsigned* xp = a.Xp + (long long)grow * a.ldx + skq * 8;
+    const unsigned wofs = (unsigned)(srow * 32 + skq * 16);
+    unsigned char* hst = lds + half * (NST * HSTAGE);    // this half's stage ring
+    const int last = nh > 0 ? sb + nh - 1 : c1 - 1;
+    auto loadx = [&](int i, u32x4& v0, u32x4& v1) {      // k-step i of this half (clamped: a dummy past the end)
+        int sl = sb + i;
+        sl = sl < last ? sl : last;
+#ifdef SBEV_EXP_HOTX
+        sl = sl & 7;
+#endif
+        const unsigned* p = xp + (long long)sl * 16;
+#ifdef SBEV_O4_XNT
+        v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + 4));
+#else
+        // (plain loads: a k-step uses 64 of a line's 128 bytes, the next step the rest -- the line has to survive in L2 until then)
+        v0 = *reinterpret_cast<const u32x4*>(p);
+        v1 = *reinterpret_cast<const u32x4*>(p + 4);
+#endif
+    };
+    auto stagex = [&](int i, const u32x4 p, const u32x4 q) {                     // k-step i -> ring slot i % 3: de-interleave hi | lo
+        unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
+        *reinterpret_cast<u32x4*>(st) = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
+                                                __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u)};
+        *reinterpret_cast<u32x4*>(st + IMG) = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
+                                                      __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u)};
+    };
+    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
+    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
+    auto loadw = [&](int i, int fb, bf16x8 (&w)[2][NIMG]) {      // column fragment fb of k-step i of this half (clamped)
+        int sl = sb + i;
+        sl = sl < last ? sl : last;
+#ifdef SBEV_EXP_HOTW
+        sl = sl & 7;
+#endif
+        const long long o = (long long)sl * NIMG * 64 * 8;
+#pragma unroll
+        for (int img = 0; img < NIMG; ++img) w[fb][img] = *reinterpret_cast<const bf16x8*>((fb ? wb1 : wb0) + o + img * 512);
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned fo = (unsigned)l31 * 32u + (unsigned)lh * 16u;       // a fragment = 1 KiB of the image, read as one b128 per lane
+
+    auto run = [&](auto nfa_c) {
+        constexpr int NFA = decltype(nfa_c)::value;
+        f32x16 acc[NFA][2];
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+        u32x4 xa0, xa1, xb0, xb1;                             // X register ring: k-step s + 2 waits in a (s even) / b (s odd)
+        bf16x8 wa[2][NIMG], xf[NFA][NIMG];                    // one W set: the next step's request goes out behind this step's last MFMA
+                                                              // and lands during the partner's COMPUTE phase (a second set spilled)
+        // prologue: k-steps 0 and 1 staged, 2 and 3 requested, W of k-step 0 requested
+        loadx(0, xa0, xa1);
+        loadx(1, xb0, xb1);
+        loadw(0, 0, wa);
+        loadw(0, 1, wa);
+        stagex(0, xa0, xa1);
+        loadx(2, xa0, xa1);
+        stagex(1, xb0, xb1);
+        loadx(3, xb0, xb1);
+        __syncthreads();
+        if (half == 1) phase_barrier();                       // the second K half runs one phase behind
+#define SBEV_O4_STEP(S_, X0, X1)                                                                    \
+        {                                                                                                   \
+            /* FETCH: the step's fragments LDS -> registers */                                              \
+            {                                                                                               \
+                SBEV_TRACE(S_, 0)                                                                           \
+                const unsigned char* A = hst + ((S_) % NST) * HSTAGE + fo;                                  \
+                _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
+                    _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                      \
+                        xf[fa][img] = *reinterpret_cast<const bf16x8*>(A + img * IMG + fa * 1024);          \
+                if ((S_) >= nh) {      /* the unequal last step: this half has none left and multiplies zeros */ \
+                    _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                      \
+                        _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                              \
+                            _Pragma("unroll") for (int e = 0; e < 8; ++e) xf[fa][img][e] = (__bf16)0.f;     \
+                }                                                                                           \
+                SBEV_TRACE(S_, 1)                                                                           \
+                /* the staging of step + 2 and the X request of step + 4 also ride here: this phase otherwise waits ~800 cycles at its */ \
+                /* barrier for the partner's MFMAs, and in the COMPUTE phase every VMEM issue delays the next MFMA                    */ \
+                stagex((S_) + 2, X0, X1);                                                                   \
+                loadx((S_) + 4, X0, X1);                                                                    \
+            }                                                                                               \
+            phase_barrier();                                                                                \
+            SBEV_TRACE(S_, 4)                                                                               \
+            /* COMPUTE: the step's MFMAs and the next step's W requests */                                  \
+            /* column fragment 0 first: its W registers are dead after half of the MFMAs and the next step's request for them goes */ \
+            /* out under the second half (the whole request behind the last MFMA cost ~200 serial cycles per phase)               */ \
+            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
+                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
+                    acc[fa][0] = SBEV_MFMA(wa[0][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][0]);                \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            loadw((S_) + 1, 0, wa);                                                                         \
+            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
+                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
+                    acc[fa][1] = SBEV_MFMA(wa[1][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][1]);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                              \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+            loadw((S_) + 1, 1, wa);                                                                         \
+            SBEV_TRACE(S_, 5)                                                                               \
+            phase_barrier();                                                                                \
+            SBEV_TRACE(S_, 6)                                                                               \
+        }
+        int sl = 0;
+        for (; sl + 1 < n0h; sl += 2) {
+            SBEV_O4_STEP(sl, xa0, xa1)
+            SBEV_O4_STEP(sl + 1, xb0, xb1)
+        }
+        if (sl < n0h) SBEV_O4_STEP(sl, xa0, xa1)
+#undef SBEV_O4_STEP
+        if (half == 0) phase_barrier();
+        // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab
+        __syncthreads();
+        f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * (NFA * 8)) * 64 + lane;       // [wc][fa][fb][g][lane] float4
+        if (half == 1) {
+#pragma unroll
+            for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+        }
+        __syncthreads();
+        if (half == 1) return;
+        float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa) {
+            const int row = m0 + fa * 32 + l31;
+            if (row < M SBEV_EXP_STORE_COND) {
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
+                        f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
+                        v *= *reinterpret_cast<const f32x4*>(a.nscale + wc * 64 + 4 * lh + fb * 32 + 8 * g);   // exact: powers of two
                         *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
                     }
             }
         }
     };
-    if (nfa == 2) run(std::integral_constant<int, 2>{});
+    if (nfa == 4) run(std::integral_constant<int, 4>{});
+    else if (nfa == 3) run(std::integral_constant<int, 3>{});
+    else if (nfa == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
 }
 
@@ -712,9 +1075,28 @@ int out_chunks(long long M, int K) {
     return best;
 }
 
+// the 128-row kernel's plan: row tiles of <= 4 fragments (balanced), K chunks of >= 8 k-steps that fill the CUs in whole rounds
+struct Out4Plan { int ntm, base, rem, S; };
+Out4Plan out4_plan(long long M, int K) {
+    const int nfrag = (int)((M + 31) / 32);
+    Out4Plan p{};
+    p.ntm = (nfrag + 3) / 4;
+    p.base = nfrag / p.ntm;
+    p.rem = nfrag % p.ntm;
+    const int max_s = K / 16 / 8 < 1 ? 1 : K / 16 / 8;
+    p.S = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 64 && s <= max_s; ++s) {
+        const long long wgs = (long long)p.ntm * s;
+        const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; p.S = s; }
+    }
+    return p;
+}
+
 }  // namespace
 
-extern "C" int64_t sbev_bf16s_image_elems(int64_t rows, int K, int nimg) { return (rows + 31) / 32 * 32 * K * nimg; }
+extern "C" int64_t sbev_bf16s_image_elems(int64_t rows, int K, int nimg) { return (rows + 31) / 32 * 32 * K * (nimg == 3 ? 3 : 2); }
 
 extern "C" int sbev_split_bf16s_rows(const float* X, int64_t ldx, uint16_t* out, int64_t rows, int K, int nimg, sbev_stream_t stream) {
     SBEV_REQUIRE(rows >= 0 && K >= 8 && K % 8 == 0 && (nimg == 2 || nimg == 3), "sbev_split_bf16s_rows: K=%d (multiple of 8), nimg=%d (2 or 3)", K, nimg);
@@ -734,9 +1116,23 @@ extern "C" int sbev_pack_bf16s_frags(const float* W, int64_t ldw, uint16_t* out,
     const long long n = (long long)((N + 31) / 32) * (K / 16) * 64;
     const dim3 grid((unsigned)((n + 255) / 256));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (nimg == 3) hipLaunchKernelGGL(pack_frags_kernel<3>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K);
-    else hipLaunchKernelGGL(pack_frags_kernel<2>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K);
+    if (nimg == 3) hipLaunchKernelGGL(pack_frags_kernel<1>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K, (const float*)nullptr, 0);
+    else hipLaunchKernelGGL(pack_frags_kernel<0>, grid, dim3(256), 0, s, W, (long long)ldw, out, N, K, (const float*)nullptr, 0);
     return sbev::check_launch("sbev_pack_bf16s_frags");
+}
+
+// fp16 hi + lo fragments of W [N, ldw] in the same fragment order, scaled by a power of two per row (per_tensor = 0: scales =
+// [2][N], up then down) or by one for the whole matrix (per_tensor = 1: scales = [2]); the scales are computed here (device side).
+// per_tensor = 2: scales [2] is an INPUT (the caller's power of two for a bounded operand: no pass over W for its maximum)
+extern "C" int sbev_pack_f16s_frags(const float* W, int64_t ldw, uint16_t* out, float* scales, int N, int K, int per_tensor, sbev_stream_t stream) {
+    SBEV_REQUIRE(N >= 1 && K >= 16 && K % 16 == 0, "sbev_pack_f16s_frags: N=%d, K=%d (multiple of 16)", N, K);
+    SBEV_REQUIRE(W && out && scales && ldw >= K && ldw % 4 == 0 && (((uintptr_t)W | (uintptr_t)out) & 15) == 0, "sbev_pack_f16s_frags: null / unaligned pointer or bad ldw");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (per_tensor == 1) hipLaunchKernelGGL(tensor_scale_kernel, dim3(1), dim3(1024), 0, s, W, (long long)ldw, (long long)N, K, scales);
+    else if (per_tensor == 0) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, (long long)ldw, N, K, scales, scales + N);
+    const long long n = (long long)((N + 31) / 32) * (K / 16) * 64;
+    hipLaunchKernelGGL(pack_frags_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, (long long)ldw, out, N, K, (const float*)scales, per_tensor ? 0 : 1);
+    return sbev::check_launch("sbev_pack_f16s_frags");
 }
 
 static int ntm_of(int64_t M) { return (int)(((M + 31) / 32 + 7) / 8); }      // row tiles of <= 8 fragments
@@ -746,9 +1142,8 @@ extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {
            ntm_of(M) <= 256;
 }
 
-extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K,
-                                     int64_t ldy, int relu, int nimg, sbev_stream_t stream) {
-    SBEV_REQUIRE(nimg == 2 || nimg == 3, "sbev_linear_bf16s_gen: nimg=%d (2 = bf16x3, 3 = bf16x6)", nimg);
+static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K, int64_t ldy, int relu,
+                      int nimg, const float* xscale, const float* colscale, sbev_stream_t stream) {
     SBEV_REQUIRE(M >= 0 && sbev_linear_bf16s_gen_ok(M > 0 ? M : 1, N, K), "sbev_linear_bf16s_gen: needs N %% 256 == 0, K %% 32 == 0, K <= 4096 (M=%lld N=%d K=%d)", (long long)M, N, K);
     if (M == 0) return SBEV_OK;
     SBEV_REQUIRE(Xs && Ws && Y && ldy >= N && ldy % 4 == 0, "sbev_linear_bf16s_gen: bad pointers / leading dimension");
@@ -760,7 +1155,8 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     const int rf = forced_rf == 2 || forced_rf == 4 ? forced_rf : (nfrag > 4 ? 4 : 2);
     const int tf = 2 * rf;
     const int ntm = (nfrag + tf - 1) / tf;
-    GenArgs a{Xs, Ws, bias, Y, (int)M, N, K, (long long)ldy, relu, ntm, nfrag / ntm, nfrag % ntm};
+    GenArgs a{Xs, Ws, bias, Y, (int)M, N, K, (long long)ldy, relu, ntm, nfrag / ntm, nfrag % ntm, colscale, xscale};
+    const int nim = nimg == 3 ? 3 : 2;          // images per operand
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     static const int cus = [] {
@@ -774,18 +1170,23 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
     // the bias slices of a workgroup's column tiles wait in LDS behind the stage ring: at most 16 tiles (16 KiB) per launch,
     // wider matrices take several launches over column ranges
     const int nct = N / G_COLS;
-    const long long max_ct = per * 16;
+    const int nst = rf == 2 ? 4 : 3;
+    const int ring_bytes = nst * nim * (tf + 8) * 1024 + (nim == 2 && rf == 4 ? 8 * 32 * 36 * 4 : 0);      // + the epilogue's transpose patches
+    int tiles_per_wg = (160 * 1024 - ring_bytes) / (G_COLS * 4 * (nimg >= 4 ? 2 : 1));      // bias (+ scale) slices behind the ring
+    tiles_per_wg = tiles_per_wg > 16 ? 16 : tiles_per_wg;
+    const long long max_ct = per * tiles_per_wg;
     for (long long c0 = 0; c0 < nct; c0 += max_ct) {
         const int nc = (int)(nct - c0 < max_ct ? nct - c0 : max_ct);
         GenArgs ac = a;
-        ac.Ws = Ws + c0 * 8 * (long long)(K / 16) * nimg * 512;      // 8 fragment blocks of 32 columns per tile
+        ac.Ws = Ws + c0 * 8 * (long long)(K / 16) * nim * 512;       // 8 fragment blocks of 32 columns per tile
+        ac.colscale = colscale ? colscale + c0 * G_COLS : nullptr;
         ac.bias = bias ? bias + c0 * G_COLS : nullptr;
         ac.Y = Y + c0 * G_COLS;
         ac.N = nc * G_COLS;
         const long long pc = per < nc ? per : nc;
         const unsigned gridc = (unsigned)(pc * ntm);
-        const int bias_bytes = (int)((nc + pc - 1) / pc) * G_COLS * 4;
-        const int lds = (rf == 2 ? 4 : 3) * nimg * (tf + 8) * 1024 + bias_bytes;
+        const int bias_bytes = (int)((nc + pc - 1) / pc) * G_COLS * 4 * (nimg >= 4 ? 2 : 1);     // (fp16 modes: + the column scales)
+        const int lds = ring_bytes + bias_bytes;
         int st;
         const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
 #define SBEV_LAUNCH_GEN(NI, RFV)                                                                            \
@@ -794,32 +1195,75 @@ extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, con
             if (st != SBEV_OK) return st;                                                                   \
             hipLaunchKernelGGL((gemm_bf16s_gen3_kernel<NI, RFV>), dim3(gridc), dim3(512), lds, s, ac);      \
         }
-        if (nimg == 3 && rf == 4) SBEV_LAUNCH_GEN(3, 4)
-        else if (nimg == 3) SBEV_LAUNCH_GEN(3, 2)
-        else if (rf == 4) SBEV_LAUNCH_GEN(2, 4)
-        else SBEV_LAUNCH_GEN(2, 2)
+        if (nimg == 3 && rf == 4) SBEV_LAUNCH_GEN(1, 4)
+        else if (nimg == 3) SBEV_LAUNCH_GEN(1, 2)
+        else if (nimg == 2 && rf == 4) SBEV_LAUNCH_GEN(0, 4)
+        else if (nimg == 2) SBEV_LAUNCH_GEN(0, 2)
+        else if (nimg == 4 && rf == 4) SBEV_LAUNCH_GEN(2, 4)
+        else if (nimg == 4) SBEV_LAUNCH_GEN(2, 2)
+        else if (rf == 4) SBEV_LAUNCH_GEN(3, 4)
+        else SBEV_LAUNCH_GEN(3, 2)
 #undef SBEV_LAUNCH_GEN
         if (prof) sbev::profile_end(s, e0, e1, 1);
     }
     return sbev::check_launch("sbev_linear_bf16s_gen");
 }
 
+extern "C" int sbev_linear_bf16s_gen(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K,
+                                     int64_t ldy, int relu, int nimg, sbev_stream_t stream) {
+    SBEV_REQUIRE(nimg == 2 || nimg == 3, "sbev_linear_bf16s_gen: nimg=%d (2 = bf16x3, 3 = bf16x6)", nimg);
+    return gen_launch(Xs, Ws, bias, Y, M, N, K, ldy, relu, nimg, nullptr, nullptr, stream);
+}
+
+// fp16 hi + lo images (sbev_pack_f16s_frags): xscale = X's {up, down} (per tensor), wdown = the [N] down-scales of W's rows;
+// nprod = 3 (hl, lh, hh: drops the 2^-24-class lo x lo) or 4
+extern "C" int sbev_linear_f16s_gen(const uint16_t* Xs, const float* xscale, const uint16_t* Ws, const float* wdown, const float* bias, float* Y,
+                                    int64_t M, int N, int K, int64_t ldy, int relu, int nprod, sbev_stream_t stream) {
+    SBEV_REQUIRE(nprod == 3 || nprod == 4, "sbev_linear_f16s_gen: nprod=%d (3 or 4 image products)", nprod);
+    SBEV_REQUIRE(M == 0 || (xscale && wdown), "sbev_linear_f16s_gen: null scale pointer");
+    return gen_launch(Xs, Ws, bias, Y, M, N, K, ldy, relu, nprod + 1, xscale, wdown, stream);
+}
+
 extern "C" int sbev_linear_bf16s_out_ok(int64_t M, int N, int K) {
     return M >= 1 && M <= 0x7fffffffLL / 512 && N == 256 && K >= 256 && K % 32 == 0;
 }
 
-extern "C" int sbev_linear_bf16s_out_plan(int64_t M, int N, int K) {
+extern "C" int sbev_linear_bf16s_out_plan(int64_t M, int N, int K) {      // slabs to provide: the larger of the two kernels' plans
     if (!sbev_linear_bf16s_out_ok(M, N, K)) return 0;
-    return out_chunks(M, K);
+    const int a = out_chunks(M, K), b = out4_plan(M, K).S;
+    return a > b ? a : b;
 }
 
 namespace sbev {
 // the GEMM half: *used partial slabs [used, M, 256] (to be summed by sbev_splitk_reduce_f32 or the row-chain tail)
 int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
-                              hipStream_t s) {
+                              hipStream_t s, int x_up_log2, const float* nscale, bool x_pairs) {
+    SBEV_REQUIRE(nimg < 4 || nscale, "sbev_linear_splitk_f16s: null scale pointer");
+    if (x_pairs) {                              // fp16 modes with the pre-split operand: 128-row tiles
+        SBEV_REQUIRE(nimg >= 4, "sbev_linear_splitk_f16s: pre-split X needs an fp16 mode");
+        const Out4Plan pl = out4_plan(M, K);
+        *used = pl.S;
+        Out4Args a4{reinterpret_cast<const unsigned*>(X), Wp, slabs, (int)M, K, (long long)ldx, pl.ntm, pl.base, pl.rem, pl.S, nscale};
+        const long long wgs4 = (long long)pl.ntm * pl.S;
+        SBEV_REQUIRE(wgs4 <= 0x7fffffffLL, "sbev_linear_splitk_f16s: too many workgroups");
+        constexpr int LDS4 = 128 * 1024;        // 4 column quarters x 4 fragments x 8 KiB of fold buffer (>= the 48 KiB of stages)
+        hipEvent_t f0, f1;
+        int st4;
+#define SBEV_LAUNCH_OUT4(KERN)                                                                   \
+        {                                                                                        \
+            st4 = reserve_lds(KERN, LDS4, "sbev_linear_splitk_f16s");                            \
+            if (st4 != SBEV_OK) return st4;                                                      \
+            const bool prof = profile_begin(s, &f0, &f1, 2);                                     \
+            hipLaunchKernelGGL(KERN, dim3((unsigned)wgs4), dim3(512), LDS4, s, a4);              \
+            if (prof) profile_end(s, f0, f1, 2);                                                 \
+        }
+        if (nimg == 4) SBEV_LAUNCH_OUT4(gemm_bf16s_out4_kernel<2>) else SBEV_LAUNCH_OUT4(gemm_bf16s_out4_kernel<3>)
+#undef SBEV_LAUNCH_OUT4
+        return check_launch("sbev_linear_splitk_f16s (gemm, 128-row tiles)");
+    }
     const int S = out_chunks(M, K);
     *used = S;
-    OutArgs a{X, Wp, slabs, (int)M, K, (long long)ldx, (int)((M + 63) / 64), S};
+    OutArgs a{X, Wp, slabs, (int)M, K, (long long)ldx, (int)((M + 63) / 64), S, ldexpf(1.f, x_up_log2), nscale};
     const long long wgs = (long long)a.nrt * S;
     SBEV_REQUIRE(wgs <= 0x7fffffffLL, "sbev_linear_splitk_bf16s: too many workgroups");
     hipEvent_t e0, e1;
@@ -834,7 +1278,10 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
         hipLaunchKernelGGL(KERN, dim3((unsigned)wgs), dim3(512), LDSB, s, a);                    \
         if (prof) profile_end(s, e0, e1, 2);                                                     \
     }
-    if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<3>, LDS3) else SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<2>, LDS2)
+    if (nimg == 3) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<1>, LDS3)
+    else if (nimg == 2) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<0>, LDS2)
+    else if (nimg == 4) SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<2>, LDS2)
+    else SBEV_LAUNCH_OUT(gemm_bf16s_out3_kernel<3>, LDS2)
 #undef SBEV_LAUNCH_OUT
     return check_launch("sbev_linear_splitk_bf16s (gemm)");
 }
@@ -850,7 +1297,56 @@ extern "C" int sbev_linear_splitk_bf16s(const float* X, const uint16_t* Wp, cons
     SBEV_REQUIRE(X && Wp && Y && workspace && ldx % 4 == 0 && ldx >= K, "sbev_linear_splitk_bf16s: bad pointers");
     SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)workspace) & 15) == 0, "sbev_linear_splitk_bf16s: 16-byte alignment");
     int used = 0;
-    const int st = sbev::launch_splitk_slabs_bf16s(X, Wp, M, K, ldx, nimg, workspace, &used, reinterpret_cast<hipStream_t>(stream));
+    const int st = sbev::launch_splitk_slabs_bf16s(X, Wp, M, K, ldx, nimg, workspace, &used, reinterpret_cast<hipStream_t>(stream), 0, nullptr, false);
     if (st != SBEV_OK) return st;
     return sbev_splitk_reduce_f32(workspace, used, bias, residual, ln_w, ln_b, ln_eps, Y, M, N, relu, stream);
+}
+
+// fp16 hi + lo: X (fp32) is multiplied by 2^x_up_log2 and split in the kernel -- the CALLER guarantees |X| 2^x_up_log2 < 65504 (an
+// overflow shows as Inf / NaN in Y, never silently); nscale = [256] 2^-ew[n] 2^-x_up_log2 (sbev_f16s_out_scale).
+// x_is_pairs: X already holds the (hi, lo) pairs of x 2^x_up_log2 in its 32-bit slots (sbev_f16s_pairs, the *_pairs_f16 mixing launches)
+extern "C" int sbev_linear_splitk_f16s(const float* X, int x_is_pairs, int x_up_log2, const uint16_t* Wp, const float* nscale, const float* bias, const float* residual,
+                                       const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                       int64_t M, int N, int K, int64_t ldx, int relu, int nprod, float* workspace, sbev_stream_t stream) {
+    SBEV_REQUIRE(nprod == 3 || nprod == 4, "sbev_linear_splitk_f16s: nprod=%d (3 or 4 image products)", nprod);
+    SBEV_REQUIRE(x_up_log2 >= -100 && x_up_log2 <= 100, "sbev_linear_splitk_f16s: x_up_log2=%d", x_up_log2);
+    SBEV_REQUIRE(M >= 0 && sbev_linear_bf16s_out_ok(M > 0 ? M : 1, N, K), "sbev_linear_splitk_f16s: needs N == 256, K %% 32 == 0, K >= 256 (N=%d K=%d)", N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && Wp && Y && workspace && nscale && ldx % 4 == 0 && ldx >= K, "sbev_linear_splitk_f16s: bad pointers");
+    SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)workspace | (uintptr_t)nscale) & 15) == 0, "sbev_linear_splitk_f16s: 16-byte alignment");
+    int used = 0;
+    const int st = sbev::launch_splitk_slabs_bf16s(X, Wp, M, K, ldx, nprod + 1, workspace, &used, reinterpret_cast<hipStream_t>(stream), x_up_log2, nscale,
+                                                   x_is_pairs != 0);
+    if (st != SBEV_OK) return st;
+    return sbev_splitk_reduce_f32(workspace, used, bias, residual, ln_w, ln_b, ln_eps, Y, M, N, relu, stream);
+}
+
+// nscale[n] = wdown[n] 2^-x_up_log2 (exact), the per-column factor of the fp16 out-projection's slabs
+namespace {
+__global__ void out_scale_kernel(const float* wdown, float f, float* out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = wdown[i] * f;
+}
+__global__ void pairs_kernel(const float* x, unsigned* out, long long n, float up) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i] * up;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    out[i] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+}
+// out[i] = (fp16 hi, fp16 lo) of x[i] 2^up_log2 in one 32-bit slot (hi in the low half): the pre-split operand format
+extern "C" int sbev_f16s_pairs(const float* X, void* out, int64_t n, int up_log2, sbev_stream_t stream) {
+    SBEV_REQUIRE(n >= 0 && up_log2 >= -100 && up_log2 <= 100, "sbev_f16s_pairs: bad arguments");
+    if (n == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && out, "sbev_f16s_pairs: null pointer");
+    hipLaunchKernelGGL(pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, static_cast<unsigned*>(out),
+                       (long long)n, ldexpf(1.f, up_log2));
+    return sbev::check_launch("sbev_f16s_pairs");
+}
+extern "C" int sbev_f16s_out_scale(const float* wdown, int x_up_log2, float* nscale, int N, sbev_stream_t stream) {
+    SBEV_REQUIRE(wdown && nscale && N >= 1 && x_up_log2 >= -100 && x_up_log2 <= 100, "sbev_f16s_out_scale: bad arguments");
+    hipLaunchKernelGGL(out_scale_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), wdown, ldexpf(1.f, -x_up_log2), nscale, N);
+    return sbev::check_launch("sbev_f16s_out_scale");
 }

@@ -34,6 +34,8 @@ struct MixArgs {
     long long n_items;    // BQ * G
     int Pin;
     float eps;
+    float out_up;         // 0: y is fp32.  2^e: y holds (fp16 hi, fp16 lo) PAIRS of y 2^e in each 32-bit slot -- the operand format of
+                          // the fp16 out-projection (gemm_bf16s.hip: hi = RNE(y 2^e), lo = RNE(y 2^e - hi)), split here once per element
 };
 
 #include "msmv_common.hpp"
@@ -55,6 +57,7 @@ struct SampleMixArgs {
     long long n_items;
     int Pin;
     float eps;
+    float out_up;
     MsmvArgs s;           // sampler descriptors: s.loc [B*T*G, Q, P, 3], s.w [B*G*T, Q, P, L]; s.Q, s.T, s.G, s.P (== 4), s.N
 };
 template <int SL>
@@ -100,6 +103,13 @@ __device__ __forceinline__ void block_mean_rstd(float s_w, float m2_w, float n_w
         m2 += red[4 + w] + n_w * d * d;
     }
     rstd = rsqrtf(m2 / n + eps);
+}
+
+// (fp16 hi, fp16 lo) of a scaled value in one 32-bit slot: hi = RNE_fp16(x), lo = RNE_fp16(x - hi) (the subtraction is exact)
+__device__ __forceinline__ float f16_pair(float x) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    return __uint_as_float((unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16));
 }
 
 // RT = ceil(Pin / 16) row tiles of matmul 1; WIDE: Pin % 16 == 0 (b128 A reads in matmul 2); L > 0: fused sampler with L
@@ -391,10 +401,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             Yo[(r * 16 + fk * 4 + e) * LDY + cw + fi] = fmaxf((acc2[r][e] - mean2) * rstd2, 0.f);
     __syncthreads();
     float* yg = a.y + item * POUT * C;
+    const float up = a.out_up;
 #pragma unroll
     for (int i = tid; i < POUT * (C / 4); i += 256) {
         const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
-        *reinterpret_cast<float4*>(yg + r * C + c4) = *reinterpret_cast<const float4*>(&Yo[r * LDY + c4]);
+        float4 v = *reinterpret_cast<const float4*>(&Yo[r * LDY + c4]);
+        if (up != 0.f) { v.x = f16_pair(v.x * up); v.y = f16_pair(v.y * up); v.z = f16_pair(v.z * up); v.w = f16_pair(v.w * up); }
+        *reinterpret_cast<float4*>(yg + r * C + c4) = v;
     }
 }
 
@@ -454,16 +467,15 @@ int launch_sample_mix_rt(const SampleMixArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
-                                        int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
-                                        sbev_stream_t stream) {
+static int adaptive_mixing_impl(const float* x, const float* params, float* y, int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
+                                float out_up, sbev_stream_t stream) {
     SBEV_REQUIRE(BQ >= 0 && G >= 1, "sbev_adaptive_mixing_f32: bad sizes");
     SBEV_REQUIRE(Cg == C && Pout == POUT, "sbev_adaptive_mixing_f32: built for C=64 channels per group and 128 out points (got %d, %d)", Cg, Pout);
     SBEV_REQUIRE(Pin >= 4 && Pin % 4 == 0 && Pin <= 120, "sbev_adaptive_mixing_f32: in_points=%d must be a multiple of 4 in 4..120 (LDS budget)", Pin);
     if (BQ == 0) return SBEV_OK;
     SBEV_REQUIRE(x && params && y, "sbev_adaptive_mixing_f32: null pointer");
     SBEV_REQUIRE(BQ * G <= 0x7fffffffLL, "sbev_adaptive_mixing_f32: too many items");
-    MixArgs a{x, params, y, BQ * G, Pin, eps};
+    MixArgs a{x, params, y, BQ * G, Pin, eps, out_up};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch ((Pin + 15) / 16) {
         case 1: return launch_mix<1>(a, s);
@@ -477,17 +489,32 @@ extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, flo
     }
 }
 
+extern "C" int sbev_adaptive_mixing_f32(const float* x, const float* params, float* y,
+                                        int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
+                                        sbev_stream_t stream) {
+    return adaptive_mixing_impl(x, params, y, BQ, G, Pin, Cg, Pout, eps, 0.f, stream);
+}
+
+// the same, y as (fp16 hi, fp16 lo) pairs of y 2^up_log2 in the fp32 slots: the fp16 out-projection's operand (sbev_linear_splitk_f16s
+// with x_is_pairs), split here instead of inside the GEMM.  |y| 2^up_log2 must stay below 65504 (sbev_decoder_mixed_up_log2)
+extern "C" int sbev_adaptive_mixing_pairs_f16(const float* x, const float* params, void* y,
+                                              int64_t BQ, int G, int Pin, int Cg, int Pout, float eps, int up_log2,
+                                              sbev_stream_t stream) {
+    SBEV_REQUIRE(up_log2 >= -100 && up_log2 <= 100, "sbev_adaptive_mixing_pairs_f16: up_log2=%d", up_log2);
+    return adaptive_mixing_impl(x, params, static_cast<float*>(y), BQ, G, Pin, Cg, Pout, eps, ldexpf(1.f, up_log2), stream);
+}
+
 extern "C" int sbev_sample_mix_supported(int L, int C, int P, int T, int gdiv, int G) {
     // T * P in 4 .. 64 (row tiles 1 .. 4) or 113 .. 120 (8 row tiles: the 15-frame, 8-point configuration); P = 4 or 8 points per chunked frame
     const int pin = T * P;
     return (L == 4 || L == 5) && C == 64 && (P == 4 || P == 8) && gdiv == G && T >= 1 && (pin <= 64 || (pin > 112 && pin <= 120));
 }
 
-extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
-                                   int64_t B, int N, int Q, int T, int G, int P, int Cg,
-                                   const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
-                                   const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
-                                   const float* params, float* y, int Pout, float eps, sbev_stream_t stream) {
+static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                           int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                           const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                           const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                           const float* params, float* y, int Pout, float eps, float out_up, sbev_stream_t stream) {
     SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_sample_mix_f32: null descriptor array");
     SBEV_REQUIRE(sbev_sample_mix_supported(L, Cg, P, T, G, G), "sbev_sample_mix_f32: needs L in {4,5}, C = 64, P in {4,8}, T*P in 4..64 or 116..120 (got L=%d C=%d P=%d T=%d)", L, Cg, P, T);
     SBEV_REQUIRE(Pout == POUT, "sbev_sample_mix_f32: built for 128 out points");
@@ -498,7 +525,7 @@ extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, 
     SBEV_REQUIRE(loc && weights && params && y, "sbev_sample_mix_f32: null pointer");
     SBEV_REQUIRE(B * Q * G <= 0x7fffffffLL && B * (int64_t)T * G * Q <= 0x7fffffffLL, "sbev_sample_mix_f32: too many items");
     SampleMixArgs a{};
-    a.params = params; a.y = y; a.n_items = B * Q * G; a.Pin = T * P; a.eps = eps;
+    a.params = params; a.y = y; a.n_items = B * Q * G; a.Pin = T * P; a.eps = eps; a.out_up = out_up;
     MsmvArgs& m = a.s;
     for (int l = 0; l < L; ++l) {
         SBEV_REQUIRE(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_sample_mix_f32: level %d", l);
@@ -524,4 +551,24 @@ extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (feat_dtype == SBEV_F32) return L == 4 ? launch_sample_mix_rt<4, float>(a, s) : launch_sample_mix_rt<5, float>(a, s);
     return L == 4 ? launch_sample_mix_rt<4, unsigned short>(a, s) : launch_sample_mix_rt<5, unsigned short>(a, s);
+}
+
+extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                   int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                                   const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                   const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                   const float* params, float* y, int Pout, float eps, sbev_stream_t stream) {
+    return sample_mix_impl(feats, hw, L, feat_dtype, B, N, Q, T, G, P, Cg, stride_bo, stride_g, stride_v, stride_px, loc, weights, frame_slots, n_slots,
+                           params, y, Pout, eps, 0.f, stream);
+}
+
+// the same, y as (fp16 hi, fp16 lo) pairs of y 2^up_log2 (see sbev_adaptive_mixing_pairs_f16)
+extern "C" int sbev_sample_mix_pairs_f16(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                         int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                                         const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                         const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                         const float* params, void* y, int Pout, float eps, int up_log2, sbev_stream_t stream) {
+    SBEV_REQUIRE(up_log2 >= -100 && up_log2 <= 100, "sbev_sample_mix_pairs_f16: up_log2=%d", up_log2);
+    return sample_mix_impl(feats, hw, L, feat_dtype, B, N, Q, T, G, P, Cg, stride_bo, stride_g, stride_v, stride_px, loc, weights, frame_slots, n_slots,
+                           params, static_cast<float*>(y), Pout, eps, ldexpf(1.f, up_log2), stream);
 }

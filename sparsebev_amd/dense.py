@@ -157,6 +157,72 @@ def linear_splitk_bf16s(x, w_frags, b, nimg=3, residual=None, ln=None, relu=Fals
     return y.reshape(*x.shape[:-1], N)
 
 
+# ---- fp16 hi + lo Linears (csrc/gemm_bf16s.hip, MODE 2 / 3): x 2^e = hi + lo (two fp16 images), 3 or 4 image products --------------
+def pack_f16s_frags(w, per_tensor=False):
+    """fp32 [N, K] -> (int16 [ceil(N/32), K/16, 2, 64, 8] fp16 hi / lo images of W * 2^e in MFMA operand order, scales): e per row
+    (scales = [2, N]: 2^e, 2^-e) or one for the matrix (per_tensor: scales = [2]), chosen so that the scaled maximum is in [2^14, 2^15)."""
+    _dev(w)
+    w = w.reshape(-1, w.shape[-1]).contiguous()
+    N, K = w.shape
+    out = torch.empty((N + 31) // 32, K // 16, 2, 64, 8, device=w.device, dtype=torch.int16)
+    scales = torch.empty(2 if per_tensor else 2 * N, device=w.device, dtype=torch.float32)
+    st = _lib.load().sbev_pack_f16s_frags(_p(w), K, _p(out), _p(scales), N, K, int(per_tensor), _stream())
+    _lib.check(st, 'sbev_pack_f16s_frags')
+    return out, (scales if per_tensor else scales.reshape(2, N))
+
+
+def linear_f16s_gen(x, w_frags, w_scales, b, nprod=3, relu=False):
+    """y = act(x @ W.T + b) with (w_frags, w_scales) = pack_f16s_frags(W); x fp32 [.., K] is scaled (per tensor), split and packed
+    here.  N % 256 == 0, K % 32 == 0 (the parameter generator's shape)."""
+    _dev(x, w_frags)
+    K, N = x.shape[-1], w_frags.shape[0] * 32
+    xs, xsc = pack_f16s_frags(x, per_tensor=True)
+    M = x.numel() // K
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    st = _lib.load().sbev_linear_f16s_gen(_p(xs), _p(xsc), _p(w_frags), _p(w_scales[1]), _p(b), _p(y), M, N, K, N, int(relu), nprod, _stream())
+    _lib.check(st, 'sbev_linear_f16s_gen')
+    return y.reshape(*x.shape[:-1], N)
+
+
+def f16s_pairs(x, up_log2):
+    """fp32 -> int32 of the same shape: (fp16 hi, fp16 lo) of x * 2^up_log2 packed in one 32-bit slot (hi in the low half)"""
+    _dev(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.int32)
+    _lib.check(_lib.load().sbev_f16s_pairs(_p(x), _p(out), x.numel(), int(up_log2), _stream()), 'sbev_f16s_pairs')
+    return out
+
+
+def linear_splitk_f16s(x, w_frags, w_scales, b, nprod=3, residual=None, ln=None, relu=False, x_up_log2=None, x_is_pairs=False):
+    """y = LayerNorm?(act(x @ W.T + b) + residual), N == 256, with (w_frags, w_scales) = pack_f16s_frags(W); x stays fp32 and is
+    multiplied by 2^x_up_log2 and split inside the kernel (default: from max |x|, one host sync -- the decoder passes its bound);
+    x_is_pairs: x is f16s_pairs(x_fp32, x_up_log2) (int32), only de-interleaved inside the kernel."""
+    _dev(x, w_frags)
+    K = x.shape[-1]
+    N = w_frags.shape[0] * 32
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    lib = _lib.load()
+    plan = lib.sbev_linear_bf16s_out_plan(M, N, K)
+    if plan <= 0:
+        raise RuntimeError('sbev_linear_splitk_f16s does not cover M=%d N=%d K=%d' % (M, N, K))
+    if x_up_log2 is None:
+        import math
+        mx = float(x2.abs().max())
+        x_up_log2 = 15 - math.frexp(mx)[1] if mx > 0 and math.isfinite(mx) else 0
+    nscale = torch.empty(N, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sbev_f16s_out_scale(_p(w_scales[1]), int(x_up_log2), _p(nscale), N, _stream()), 'sbev_f16s_out_scale')
+    ws = _ws(plan * M * N * 4, x.device)
+    res2 = residual.reshape(-1, N).contiguous() if residual is not None else None
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    st = lib.sbev_linear_splitk_f16s(_p(x2), int(x_is_pairs), int(x_up_log2), _p(w_frags), _p(nscale), _p(b), _p(res2), _p(ln[0] if ln else None),
+                                     _p(ln[1] if ln else None), 1e-5, _p(y), M, N, K, K, int(relu), nprod, _p(ws), _stream())
+    _lib.check(st, 'sbev_linear_splitk_f16s')
+    return y.reshape(*x.shape[:-1], N)
+
+
 class _LinearProblem(ctypes.Structure):
     """struct sbev_linear_problem (include/sbev_hip.h)"""
     _fields_ = [('X', ctypes.c_void_p), ('W', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('residual', ctypes.c_void_p),

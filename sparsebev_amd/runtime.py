@@ -7,8 +7,8 @@ import torch
 from . import _lib
 
 MAX_LEVELS = 5
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_BF16X3S = 0, 1, 2, 3      # sbev_gemm_mode
-GEMM_MODES = {'f32': GEMM_F32, 'bf16x3': GEMM_BF16X3, 'bf16x6': GEMM_BF16X6, 'bf16x3s': GEMM_BF16X3S}
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_BF16X3S, GEMM_F16X3, GEMM_F16X4 = 0, 1, 2, 3, 4, 5      # sbev_gemm_mode
+GEMM_MODES = {'f32': GEMM_F32, 'bf16x3': GEMM_BF16X3, 'bf16x6': GEMM_BF16X6, 'bf16x3s': GEMM_BF16X3S, 'f16x3': GEMM_F16X3, 'f16x4': GEMM_F16X4}
 _f = ctypes.c_void_p
 
 
@@ -26,7 +26,7 @@ _WEIGHT_FIELDS = ['pe0_w', 'pe0_b', 'pe1_g', 'pe1_b', 'pe3_w', 'pe3_b', 'pe4_g',
                   'pg_w', 'pg_b', 'op_w', 'op_b', 'pg_w2', 'op_w2', 'ffn0_w', 'ffn0_b', 'ffn1_w', 'ffn1_b',
                   'norm1_g', 'norm1_b', 'norm2_g', 'norm2_b', 'norm3_g', 'norm3_b',
                   'cls0_w', 'cls0_b', 'cls1_g', 'cls1_b', 'cls3_w', 'cls3_b', 'cls4_g', 'cls4_b', 'cls6_w', 'cls6_b',
-                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b', 'chain_pack', 'pg_ws', 'op_wp']
+                  'reg0_w', 'reg0_b', 'reg2_w', 'reg2_b', 'reg4_w', 'reg4_b', 'chain_pack', 'pg_ws', 'op_wp', 'pg_wdown', 'op_nscale', 'pg_xscale']
 
 
 class DecoderWeights(ctypes.Structure):
@@ -124,6 +124,22 @@ class DecoderRuntime:
             nimg = 3 if self.gemm_mode == GEMM_BF16X6 else 2
             keep['pg_ws'] = dense.pack_bf16s_frags(keep['pg_w'], nimg)
             keep['op_wp'] = dense.pack_bf16s_frags(keep['op_w'], nimg)
+        if self.gemm_mode in (GEMM_F16X3, GEMM_F16X4):         # scaled fp16 hi + lo images (csrc/gemm_bf16s.hip), one power of two per weight row
+            from . import dense
+            lib = _lib.load()
+            keep['pg_ws'], pg_sc = dense.pack_f16s_frags(keep['pg_w'])
+            keep['op_wp'], op_sc = dense.pack_f16s_frags(keep['op_w'])
+            keep['pg_wdown'] = pg_sc[1].contiguous()
+            c0 = DecoderConfig()
+            c0.G, c0.D, c0.out_points = smp.num_groups, D, mix.out_points
+            # the generator's input is norm1's output: |LayerNorm(x) g + b| <= sqrt(D - 1) max|g| + max|b| -> its power of two, fixed per bind
+            import math
+            bound = math.sqrt(D - 1) * float(keep['norm1_g'].abs().max()) + float(keep['norm1_b'].abs().max())
+            e = 0 if not (bound > 0 and math.isfinite(bound)) else max(-100, min(100, math.floor(math.log2(65504.0 / bound) - 1e-9)))
+            keep['pg_xscale'] = torch.tensor([2.0 ** e, 2.0 ** -e], device=pg_sc.device, dtype=torch.float32)
+            keep['op_nscale'] = torch.empty(D, device=pg_sc.device, dtype=torch.float32)
+            _lib.check(lib.sbev_f16s_out_scale(_ptr(op_sc[1].contiguous()), lib.sbev_decoder_mixed_up_log2(ctypes.byref(c0)), _ptr(keep['op_nscale']), D,
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'sbev_f16s_out_scale')
         w = DecoderWeights()
         for k in _WEIGHT_FIELDS:
             setattr(w, k, keep[k].data_ptr() if k in keep else None)

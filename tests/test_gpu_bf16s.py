@@ -163,7 +163,9 @@ def test_shape_guards():
     assert lib.sbev_linear_bf16s_gen_ok(900, 32768, 250) == 0
     assert lib.sbev_linear_bf16s_out_ok(900, 256, 32768) == 1 and lib.sbev_linear_bf16s_out_ok(900, 512, 32768) == 0
     plan = lib.sbev_linear_bf16s_out_plan(900, 256, 32768)
-    assert 1 <= plan <= 64 and 240 <= plan * 15 <= 256        # 15 row tiles x plan chunks: one near-full round of the 256 CUs
+    # the larger of the two kernels' plans: 15 tiles of 64 rows x 17 chunks (bf16 modes) / 8 tiles of <= 128 rows x 32 chunks (fp16 modes,
+    # pre-split X) -- each one near-full round of the 256 CUs
+    assert plan == 32
     assert lib.sbev_linear_bf16s_out_plan(900, 512, 32768) == 0
     x = torch.zeros(4, 256, device=DEV)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -171,3 +173,129 @@ def test_shape_guards():
     assert lib.sbev_linear_bf16s_gen(p(x), p(x), None, p(x), 4, 100, 256, 100, 0, 3, st) == -1
     assert lib.sbev_linear_bf16s_gen(p(x), p(x), None, p(x), 4, 256, 256, 256, 0, 4, st) == -1
     assert b'nimg' in lib.sbev_last_error()
+
+
+# ---- fp16 hi + lo modes (f16x3 / f16x4): scaled split, 3 or 4 products -----------------------------------------------------------
+def _f16_images(frags):
+    """int16 [.., 2, 64, 8] fp16 bit patterns -> fp32 values"""
+    return frags.view(torch.float16).float()
+
+
+def test_f16_split_is_scaled_hi_plus_lo():
+    """pack_f16s_frags: 2^e per row with the row maximum in [2^14, 2^15); hi = RNE_fp16(x 2^e), lo = RNE_fp16(x 2^e - hi); the pair
+    reproduces x to 2^-23 relative (11 + 11 significand bits and lo's sign) for elements within 2^-17 of the row maximum, to 2^-25 in scaled units below."""
+    N, K = 77, 96
+    w = _rand((N, K), 21, wide=True)
+    w[3] = 0.0                                                   # an all-zero row: scale 1
+    w[5, :4] = torch.tensor([3.0e38, -1.0e30, 1.0e-30, 0.0], device=DEV)
+    frags, sc = dense.pack_f16s_frags(w)
+    assert frags.shape == ((N + 31) // 32, K // 16, 2, 64, 8) and sc.shape == (2, N)
+    up, down = sc[0], sc[1]
+    assert torch.equal(up * down, torch.ones_like(up)) and torch.equal(torch.exp2(torch.log2(up).round()), up)      # exact powers of two
+    mx = w.abs().amax(1) * up
+    nz = w.abs().amax(1) > 0
+    assert bool(((mx[nz] >= 2.0 ** 14) & (mx[nz] < 2.0 ** 15)).all()) and float(up[3]) == 1.0
+    img = _f16_images(frags)                                     # [nf, ks, 2, 64, 8]
+    lane = torch.arange(64, device=DEV)
+    for nf in range((N + 31) // 32):
+        rows = (nf * 32 + (lane & 31)).clamp_max(N - 1)
+        for ks in range(K // 16):
+            k0 = ks * 16 + (lane >> 5) * 8
+            xs = torch.stack([w[rows, k0 + j] for j in range(8)], dim=1) * up[rows, None]
+            hi = xs.to(torch.float16).float()
+            lo = (xs - hi).to(torch.float16).float()
+            assert torch.equal(img[nf, ks, 0], hi) and torch.equal(img[nf, ks, 1], lo)
+            err = (hi.double() + lo.double() - xs.double()).abs()
+            assert bool((err <= torch.maximum(xs.double().abs() * 2.0 ** -23, torch.full_like(err, 2.0 ** -25))).all())
+    # per tensor: one power of two for the whole matrix
+    frags_t, sc_t = dense.pack_f16s_frags(w[:3], per_tensor=True)
+    assert sc_t.shape == (2,) and 2.0 ** 14 <= float(w[:3].abs().max() * sc_t[0]) < 2.0 ** 15
+
+
+@pytest.mark.parametrize('nprod', [3, 4])
+def test_generator_f16_not_narrower_than_f32_mfma(nprod):
+    """(900, 32768, 256): max and rms error against fp64 of the fp16 hi + lo modes <= those of gemm_nt_f32_strip_kernel, on unit-scale
+    inputs AND on inputs whose elements span 12 binades."""
+    M, N, K = 900, 32768, 256
+    for wide in (False, True):
+        x, w, b = _rand((M, K), 3, wide=wide), _rand((N, K), 4, K ** -0.5, wide=wide), _rand((N,), 5)
+        wf, wsc = dense.pack_f16s_frags(w)
+        y = dense.linear_f16s_gen(x, wf, wsc, b, nprod=nprod)
+        yf = dense.linear(x, w, b)
+        ref = x.double() @ w.double().t() + b.double()
+        e, r = _errs(y, ref)
+        ef, rf = _errs(yf, ref)
+        print('generator f16x%d wide=%s  max/rms err vs fp64: %.3e %.3e   f32-mfma %.3e %.3e' % (nprod, wide, e, r, ef, rf))
+        assert e <= ef and r <= rf, ('fp16 hi + lo is narrower than the f32 MFMA kernel', e, r, ef, rf)
+        del ref
+
+
+@pytest.mark.parametrize('nprod', [3, 4])
+@pytest.mark.parametrize('pairs', [False, True])
+def test_out_projection_f16_not_narrower_than_f32_mfma(nprod, pairs):
+    """(900, 256, 32768) split-K: X split inside the kernel (64-row tiles) or handed over as (hi, lo) pairs (128-row tiles)."""
+    M, N, K = 900, 256, 32768
+    import math
+    for wide in (False, True):
+        x = _rand((M, K), 6, wide=wide).clamp_min(0)
+        w, b = _rand((N, K), 7, K ** -0.5, wide=wide), _rand((N,), 8)
+        up = 15 - math.frexp(float(x.abs().max()))[1]
+        wf, wsc = dense.pack_f16s_frags(w)
+        xin = dense.f16s_pairs(x, up) if pairs else x
+        y = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=nprod, x_up_log2=up, x_is_pairs=pairs)
+        yf = dense.linear(x, w, b)
+        ref = x.double() @ w.double().t() + b.double()
+        e, r = _errs(y, ref)
+        ef, rf = _errs(yf, ref)
+        print('out-proj f16x%d pairs=%s wide=%s  max/rms err vs fp64: %.3e %.3e   f32-mfma %.3e %.3e' % (nprod, pairs, wide, e, r, ef, rf))
+        assert e <= ef and r <= rf, ('fp16 hi + lo is narrower than the f32 MFMA kernel', e, r, ef, rf)
+        # bit-reproducible (fixed summation order, no atomics)
+        assert torch.equal(y, dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=nprod, x_up_log2=up, x_is_pairs=pairs))
+        del ref
+    # fused epilogue: + residual, LayerNorm
+    res, gam, bet = _rand((M, N), 9), _rand((N,), 10), _rand((N,), 11)
+    yl = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=nprod, residual=res, ln=(gam, bet), x_up_log2=up, x_is_pairs=pairs)
+    ref = torch.nn.functional.layer_norm(x.double() @ w.double().t() + b.double() + res.double(), (N,), gam.double(), bet.double(), 1e-5)
+    assert (yl.double() - ref).abs().max().item() < 5e-3         # (12-binade inputs: outputs of O(100))
+
+
+@pytest.mark.parametrize('M', [1, 31, 33, 97, 129, 900, 1600, 3600])
+@pytest.mark.parametrize('N,K,relu,use_bias', [(512, 256, False, True), (256, 32, True, True), (1024, 96, False, False), (77824, 256, False, True)])
+def test_generator_f16_ragged_rows(M, N, K, relu, use_bias):
+    x, w = _rand((M, K), M + N), _rand((N, K), M + K, K ** -0.5)
+    b = _rand((N,), 12) if use_bias else None
+    wf, wsc = dense.pack_f16s_frags(w)
+    y = dense.linear_f16s_gen(x, wf, wsc, b, nprod=3, relu=relu)
+    ref = x.double() @ w.double().t() + (b.double() if use_bias else 0.0)
+    if relu:
+        ref = ref.clamp_min(0)
+    assert (y.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('pairs', [False, True])
+@pytest.mark.parametrize('M,K', [(1, 256), (33, 512), (64, 1024), (65, 2048), (97, 4096), (100, 32768), (129, 2048), (3200, 4096), (7, 32768 + 32)])
+def test_out_projection_f16_ragged(M, K, pairs):
+    """1 .. 4 row fragments per tile, odd k-step counts per chunk (the two wave quartets of a workgroup get unequal halves)."""
+    N = 256
+    x, w, b = _rand((M, K), M + K), _rand((N, K), K, K ** -0.5), _rand((N,), 13)
+    wf, wsc = dense.pack_f16s_frags(w)
+    xin = dense.f16s_pairs(x, 11) if pairs else x
+    y = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=3, x_up_log2=11, x_is_pairs=pairs)
+    ref = x.double() @ w.double().t() + b.double()
+    assert (y.double() - ref).abs().max().item() < 3e-6
+
+
+def test_mixing_kernels_emit_the_pair_format():
+    """sbev_adaptive_mixing_pairs_f16 == f16s_pairs(sbev_adaptive_mixing_f32): the split moved into the producer's epilogue, bit for bit"""
+    BQ, G, Pin, C, Pout = 50, 4, 32, 64, 128
+    x = _rand((BQ, G, Pin, C), 31)
+    prm = _rand((BQ, G, C * C + Pout * Pin), 32, 0.3)
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.empty(BQ, G * Pout * C, device=DEV)
+    yp = torch.empty(BQ, G * Pout * C, device=DEV, dtype=torch.int32)
+    assert lib.sbev_adaptive_mixing_f32(p(x), p(prm), p(y), BQ, G, Pin, C, Pout, 1e-5, st) == 0
+    assert lib.sbev_adaptive_mixing_pairs_f16(p(x), p(prm), p(yp), BQ, G, Pin, C, Pout, 1e-5, 9, st) == 0
+    assert torch.equal(yp, dense.f16s_pairs(y, 9))
+    assert float(y.max()) * 2 ** 9 < 65504                      # the LayerNorm bound the decoder's 2^9 rests on: |y| <= sqrt(8191)

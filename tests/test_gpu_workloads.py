@@ -18,7 +18,7 @@ from sparsebev_amd.transformer import SparseBEVTransformer
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 DEV = 'cuda:0'
-GEMM_MODES_UNDER_TEST = ('bf16x6', 'bf16x3s', 'bf16x3')      # besides the exact f32 default
+GEMM_MODES_UNDER_TEST = ('f16x3', 'bf16x6', 'f16x4', 'bf16x3s', 'bf16x3')      # besides the exact f32 default
 PREFIX = 'decoder.decoder_layer.'
 
 # name: (pyramid, Q, T, per-GPU batch, feature dtype) -- bench.py's CONFIGS, BASELINE.json configs[1..4]

@@ -9,9 +9,15 @@ st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 M, N, K, nimg = 900, 32768, 256, 3
 x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') / 16; b = torch.randn(N, device='cuda')
 y = torch.empty(M, N, device='cuda')
-ws = dense.pack_bf16s_frags(w, nimg); xs = dense.pack_bf16s_frags(x, nimg)
-for _ in range(3):
-    lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, 0, nimg, st)
+mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16x6'
+if mode == 'f16x3':
+    wf, wsc = dense.pack_f16s_frags(w); xf, xsc = dense.pack_f16s_frags(x, per_tensor=True)
+    for _ in range(3):
+        lib.sbev_linear_f16s_gen(p(xf), p(xsc), p(wf), p(wsc[1]), p(b), p(y), M, N, K, N, 0, 3, st)
+else:
+    ws = dense.pack_bf16s_frags(w, nimg); xs = dense.pack_bf16s_frags(x, nimg)
+    for _ in range(3):
+        lib.sbev_linear_bf16s_gen(p(xs), p(ws), p(b), p(y), M, N, K, N, 0, nimg, st)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (2 * 512 * 8))()
 raw = ctypes.CDLL(_lib.LIB_PATH)
@@ -43,3 +49,6 @@ print('lifetime realtime ticks: min %d median %d max %d ; shader-counter ticks: 
       % (life_rt.min(), np.median(life_rt), life_rt.max(), life_ck.min(), np.median(life_ck), life_ck.max(), np.median(life_ck / np.maximum(life_rt, 1))))
 order = np.argsort(w[:, 2])
 print('slowest workgroups (index, lifetime rt):', [(int(i), int(life_rt[i])) for i in order[-6:]], ' fastest:', [(int(i), int(life_rt[i])) for i in order[:6]])
+us = (w[:, 2] - w[:, 0]) / 100.0
+cyc = w[:, 3] - w[:, 1]
+print('workgroup lifetime us: median %.1f min %.1f max %.1f; %.2f GHz' % (np.median(us), us.min(), us.max(), np.median(cyc / us) / 1e3))

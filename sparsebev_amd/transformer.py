@@ -420,13 +420,26 @@ class SparseBEVTransformerDecoder(_Base):
                                     # classification branch aside): measured -3 % samples/s at c2 -- the big kernels fill every CU, and
                                     # the forked path cannot use the grouped branch launches
         self.static_graph = os.environ.get('SBEV_NO_GRAPH') != '1'      # replay a captured hipGraph for repeated identical (pointer-wise) calls
-        self.gemm_mode = 0          # the two big mixing GEMMs: 0 / 'f32' = exact f32-input MFMA (default); 2 / 'bf16x6' = fp32-class split on
-                                    # the bf16 matrix core (hi + mid + lo images, 6 products); 1 / 'bf16x3', 3 / 'bf16x3s' = 3 products
+        # the two big mixing GEMMs (runtime.GEMM_MODES).  Default 'f16x3': fp32 operands as scaled fp16 hi + lo images, 3 products,
+        # fp32 accumulation on the 16-bit matrix core -- fp32-class: max and rms error against fp64 BELOW the exact f32-input MFMA
+        # kernels' at both GEMM shapes, also on inputs spanning 12 binades (tests/test_gpu_bf16s.py), and generator + out-projection
+        # within the review's 2 x 60 us at config 2.  'f32' = the exact f32-input MFMA kernels (the default of
+        # rounds 1-2; SBEV_GEMM_MODE=f32 selects it process-wide); 'bf16x6' = hi + mid + lo bf16 images, 6 products; 'f16x4' = all four
+        # fp16 products; 'bf16x3' / 'bf16x3s' = the 2^-16-class modes.  Shapes the split kernels do not cover (embed_dims != 256) run 'f32'.
+        self.gemm_mode = os.environ.get('SBEV_GEMM_MODE') or 'f16x3'
         self.value_forcing = None   # tests only: (bbox per layer, feat per layer) recorded from the reference; the differentiable path then
                                     # evaluates layer i+1 AT those values (x + (x_ref - x).detach()) with the autograd graph intact, so that
                                     # multi-layer gradients can be compared at 1e-4 although fp32 rounding noise grows ~5x per layer
         self.decoder_layer = SparseBEVTransformerDecoderLayer(embed_dims, num_frames, num_points, num_levels,
                                                               num_classes, code_size, pc_range=pc_range)
+
+    def _split_gemm_covers(self, rows):
+        """whether csrc/gemm_bf16s.hip covers this layer's generator / out-projection shapes (N % 256 == 0, K % 32 == 0, 256 columns out)"""
+        from . import _lib
+        mix = self.decoder_layer.mixing
+        pg, op = mix.parameter_generator.weight, mix.out_proj.weight
+        lib = _lib.load()
+        return bool(lib.sbev_linear_bf16s_gen_ok(rows, pg.shape[0], pg.shape[1]) and lib.sbev_linear_bf16s_out_ok(rows, op.shape[0], op.shape[1]))
 
     @torch.no_grad()
     def init_weights(self):
@@ -456,6 +469,10 @@ class SparseBEVTransformerDecoder(_Base):
         if inference and not (layerwise or DUMP.enabled):
             from .runtime import DecoderRuntime, GEMM_MODES
             mode = GEMM_MODES.get(self.gemm_mode, self.gemm_mode)
+            if mode not in GEMM_MODES.values():
+                raise ValueError('gemm_mode %r: expected one of %s' % (self.gemm_mode, sorted(GEMM_MODES)))
+            if mode >= 2 and not self._split_gemm_covers(B * query_bbox.shape[1]):
+                mode = 0                        # shapes outside the split kernels' coverage: the exact kernels (same arithmetic class)
             if self._runtime is None or self._runtime.gemm_mode != mode or self._runtime.overlap != self.overlap:
                 self._runtime = DecoderRuntime(self, mode, self.overlap)
             if self.static_graph and query_bbox.dtype == torch.float32 and query_feat.dtype == torch.float32:

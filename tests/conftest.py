@@ -56,9 +56,19 @@ def op_by_op_runtime():
         runtime.row_chain(True)
 
 
-def runtime_op_by_op(model, *args, **kw):
-    with op_by_op_runtime():
-        return model(*args, **kw)
+def runtime_op_by_op(model, *args, exact_gemm=False, **kw):
+    """the C++ runtime with one launch per op.  exact_gemm: in the 'f32' mode of the two mixing GEMMs -- the kernels the layer-by-layer
+    Python path (layerwise=True, a debugging path) launches, so that the two can be compared bit for bit; the default mode (fp16 hi + lo
+    split) is compared with the oracle / the recordings instead."""
+    dec = getattr(model, 'decoder', model)
+    mode = dec.gemm_mode
+    if exact_gemm:
+        dec.gemm_mode = 'f32'
+    try:
+        with op_by_op_runtime():
+            return model(*args, **kw)
+    finally:
+        dec.gemm_mode = mode
 
 
 @pytest.fixture(autouse=True)

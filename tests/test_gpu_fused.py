@@ -99,5 +99,5 @@ def test_decoder_runtime_fused_equals_unfused(T, L, pyr, P):
     lw = m(bbox, feat, list(feats), None, copy.deepcopy(metas), layerwise=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     from conftest import runtime_op_by_op
-    c = runtime_op_by_op(m, bbox, feat, list(feats), None, copy.deepcopy(metas))
+    c = runtime_op_by_op(m, bbox, feat, list(feats), None, copy.deepcopy(metas), exact_gemm=True)
     assert torch.equal(c[0], lw[0]) and torch.equal(c[1], lw[1])

@@ -104,7 +104,7 @@ def test_new_tensors_weight_updates_and_switches_never_hit_a_stale_graph():
     assert torch.equal(g(bbox, feat, list(feats), None, metas)[0], e(bbox, feat, list(feats), None, metas)[0])
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'bf16x3s'])
+@pytest.mark.parametrize('mode', ['f16x3', 'f32', 'bf16x6', 'bf16x3s', 'f16x4'])
 def test_graph_replay_in_every_gemm_mode_and_with_nhwc_inputs(mode):
     feats, bbox, feat, metas, L = inputs(Q=100, T=8, pyr='tiny', seed=9)
     g, e = build(8, L, 13), build(8, L, 13, graph=False)

@@ -32,6 +32,17 @@ from sparsebev_amd.transformer import SparseBEVTransformer         # noqa: E402
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_COPY_GBPS = 6290.0      # best measured device copy rate in the same guide (SURVEY.md section 8d asks for both)
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA dense peak (same guide, matrix-core table)
+MFMA_16BIT_PEAK_TFLOPS = 2500.0   # fp16 / bf16 dense MFMA peak (same table; the 2:1-sparsity figure is not used)
+GEMM_WHAT = {
+    'f16x3': 'fp32-class (default): fp32 operands as scaled fp16 hi + lo images, 3 products (hl, lh, hh), f32 accumulate on the 16-bit matrix core '
+             '(csrc/gemm_bf16s.hip); max and rms error vs fp64 below the exact f32 MFMA kernels (tests/test_gpu_bf16s.py); mixing generator + out-projection only',
+    'f16x4': 'the same with all 4 fp16 image products',
+    'f32': 'exact f32-input MFMA kernels (gemm.hip / gemm_regtile.hip): the default of rounds 1-2',
+    'bf16x6': 'fp32-class: hi + mid + lo bf16 images, 6 products, f32 accumulate (csrc/gemm_bf16s.hip)',
+    'bf16x3s': '3 x bf16 split products (2^-16 class) on the gemm_bf16s.hip kernels',
+    'bf16x3': '3 x bf16 split products, f32 accumulate (sbev_linear_bf16x3, round-2 kernels)'}
+GEMM_PRODUCTS = {'f16x3': 3, 'f16x4': 4, 'bf16x6': 6, 'bf16x3s': 3, 'bf16x3': 3}
+DEFAULT_GEMM = os.environ.get('SBEV_GEMM_MODE') or 'f16x3'
 
 
 def pmc_profile(config, kernel='msmv_fwd_kernel'):
@@ -293,9 +304,9 @@ def main():
     ap.add_argument('--detector', action='store_true', help='force the detector figure for other configs too: also report a LABELLED detector-level samples/s: stock-PyTorch ResNet-50 + FPN stand-in (tools/backbone_standin.py, fp16) on the 6 new images -> frame ring -> SparseBEVHead -> NMS-free decode (online mode, like the reference FPS)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
     ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
-    ap.add_argument('--gemm', default='f32', choices=sorted(runtime.GEMM_MODES),
-                    help='the two big mixing GEMMs: f32 = exact f32-input MFMA (default); bf16x6 = fp32-class split on the bf16 matrix core '
-                         '(hi + mid + lo images, 6 products); bf16x3s / bf16x3 = 3 products (2^-16 class; new / round-2 kernels)')
+    ap.add_argument('--gemm', default=DEFAULT_GEMM, choices=sorted(runtime.GEMM_MODES),
+                    help='the two big mixing GEMMs: f16x3 = fp32-class scaled fp16 hi + lo split, 3 products (default); f32 = exact f32-input MFMA; '
+                         'bf16x6 = hi + mid + lo bf16 images, 6 products; f16x4 = 4 fp16 products; bf16x3s / bf16x3 = 3 bf16 products (2^-16 class)')
     args = ap.parse_args()
 
     torch.set_grad_enabled(False)     # inference benchmark, like the reference's timing.py / val.py (with grad enabled the
@@ -396,14 +407,13 @@ def main():
     runtime.profile_sampler(False)
     checksum = float(cls.double().abs().sum().item() + box.double().abs().sum().item())
 
-    # secondary measurement (rank 0, N = 1 only): the same steps with the opt-in 3 x bf16 split for the two big
-    # mixing GEMMs; reported next to -- never instead of -- the exact-fp32 `value`
+    # secondary measurements (rank 0, N = 1 only): the same steps in the other modes of the two big mixing GEMMs -- first of all the
+    # exact f32-input MFMA kernels -- reported next to, never instead of, `value` (which is the mode of --gemm, by default the library's)
     alt = None
-    if world == 1 and args.gemm == 'f32' and not args.no_alt:
+    if world == 1 and args.gemm == DEFAULT_GEMM and not args.no_alt:
         alt = {}
-        for mode, what in (('bf16x6', 'fp32-class: hi + mid + lo bf16 images, 6 products, f32 accumulate (csrc/gemm_bf16s.hip), mixing generator + out-proj only'),
-                           ('bf16x3s', '3 x bf16 split products (2^-16 class) on the gemm_bf16s.hip kernels'),
-                           ('bf16x3', '3 x bf16 split products, f32 accumulate (sbev_linear_bf16x3, round-2 kernels)')):
+        for mode in [m for m in ('f32', 'f16x3', 'bf16x6', 'bf16x3s', 'bf16x3') if m != args.gemm]:
+            what = GEMM_WHAT[mode]
             model.decoder.gemm_mode = mode
             try:
                 for _ in range(3):
@@ -422,11 +432,11 @@ def main():
                 runtime.profile_sampler(False)
                 alt[mode] = {'gemm': what, 'value': round(args.steps * B / dt3, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt3 / args.steps, 4),
                              'generator_us': round(1e3 * sum(g_ms[0]) / max(len(g_ms[0]), 1), 2), 'out_proj_us': round(1e3 * sum(g_ms[1]) / max(len(g_ms[1]), 1), 2),
-                             'max_abs_dev_vs_exact_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
+                             'max_abs_dev_vs_default_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
             except Exception as e:      # noqa: BLE001  (a secondary figure must never take the metric line down)
                 alt[mode] = {'error': repr(e)[:300]}
             finally:
-                model.decoder.gemm_mode = 'f32'
+                model.decoder.gemm_mode = args.gemm
 
     detector = None
     if world == 1 and (args.detector or (args.config == 'c2' and not args.no_detector and not args.online)):
@@ -466,7 +476,7 @@ def main():
             'ms_per_step': round(1e3 * elapsed_max / args.steps, 4),
             'host_issue_ms_per_step': round(1e3 * host_issue, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + ('' if args.gemm == 'f32' else ' (mixing GEMMs: %s split on the bf16 matrix core, f32 accumulate)' % args.gemm),
+            'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + ('' if args.gemm == 'f32' else ' (the two mixing GEMMs: %s = %s)' % (args.gemm, GEMM_WHAT[args.gemm])),
             'data': 'synthetic',
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
                                    '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
@@ -513,6 +523,22 @@ def main():
                                      'event_sampling': 'HIP events around the fused launches of every %dth of the eager steps run right after the timed region (which replays a captured graph)' % PROFILE_EVERY}
         # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event
         # measurement, priced against the f32-input MFMA peak; PMC MFMA-pipe utilisation from profiles/ when present
+        if args.gemm != 'f32' and all(gemm_ms):
+            # the split-operand kernels: arithmetic done = nprod image products on the 16-bit matrix core; `fp32_equiv` prices the GEMM itself
+            D_, Pin_, Pout_ = 256, T * P_, 128
+            npr = GEMM_PRODUCTS[args.gemm]
+            fl_g = 2.0 * B * Q * D_ * (G_ * (Cg_ * Cg_ + Pin_ * Pout_))
+            fl_o = 2.0 * B * Q * D_ * (G_ * Pout_ * Cg_)
+            g_us, o_us = (sum(ms) / len(ms) * 1e3 for ms in gemm_ms)
+            out['roofline_mfma'] = [
+                {'kernel': name, 'bound': 'mfma', 'achieved': round(npr * fl / (us * 1e-6) / 1e12, 1), 'peak': MFMA_16BIT_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                 'frac': round(npr * fl / (us * 1e-6) / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4), 'image_products': npr,
+                 'fp32_equiv_tflops': round(fl / (us * 1e-6) / 1e12, 1), 'launches': len(ms), 'avg_us': round(us, 2), 'algorithmic_flop_per_launch': fl}
+                for name, fl, us, ms in (('gemm_bf16s_gen3_kernel (mixing parameter generator, %s)' % args.gemm, fl_g, g_us, gemm_ms[0]),
+                                         ('gemm_bf16s_out%s_kernel (mixing out-projection, split-K, %s)' % ('4' if args.gemm.startswith('f16') else '3', args.gemm), fl_o, o_us, gemm_ms[1]))]
+            # the fp32-class emulation may be the default once generator + out-projection <= 2 x 60 us at config 2
+            out['gemm_gate'] = {'generator_us': round(g_us, 2), 'out_proj_us': round(o_us, 2), 'sum_us': round(g_us + o_us, 2),
+                                'measured': 'HIP events around the two launches of 10 eager steps right after the timed region', 'config': args.config}
         if args.gemm == 'f32' and all(gemm_ms):
             D_, Pin_, Pout_ = 256, T * P_, 128
             flops = 2.0 * B * Q * D_ * (G_ * (Cg_ * Cg_ + Pin_ * Pout_))          # generator; the out-projection has G*Pout*Cg*D = the same at Pin = 32

@@ -135,6 +135,9 @@ __host__ __device__ constexpr bool mode_ok(int nimg) { return nimg >= 2 && nimg 
 
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+#ifdef SBEV_EXP_F16_AS_BF16          // timing experiment only (wrong numbers): does the fp16 multiplier array cost clock / power?
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -923,17 +926,32 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
         *reinterpret_cast<u32x4*>(st + IMG) = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
                                                       __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u)};
     };
-    const unsigned short* wb0 = a.Wp + ((long long)(2 * wc) * KS * NIMG * 64 + lane) * 8;
-    const unsigned short* wb1 = a.Wp + ((long long)(2 * wc + 1) * KS * NIMG * 64 + lane) * 8;
-    auto loadw = [&](int i, int fb, bf16x8 (&w)[2][NIMG]) {      // column fragment fb of k-step i of this half (clamped)
+    // W: this wave's two column fragments of a k-step (2 x 2 KiB, hi | lo images adjacent) travel global -> LDS by LDS-DMA into a
+    // wave-private 3-slot ring, requested in the FETCH phase two steps ahead, and are read into registers in the step's own FETCH
+    // phase: no vector register is in flight for W and the COMPUTE phase is nothing but MFMAs.  (W requests between the MFMAs cost
+    // ~200 cycles per phase -- every VMEM issue delays the next MFMA; requested at the start of the FETCH phase straight into
+    // registers their L2 latency did not fit the phase: 69 us instead of 62.)
+    constexpr int WSLOT = 2 * NIMG * 1024;               // one step of one wave: 2 column fragments x 2 images
+    constexpr int WRING0 = 2 * NST * HSTAGE;             // behind the two halves' X stages
+    const unsigned wring = (unsigned)(WRING0 + wave * (NST * WSLOT));
+    const unsigned char* wg0 = reinterpret_cast<const unsigned char*>(a.Wp) + (long long)(2 * wc) * KS * (NIMG * 1024);
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue_w = [&](int i) {                          // k-step i of this half (clamped) -> ring slot i % 3
         int sl = sb + i;
         sl = sl < last ? sl : last;
 #ifdef SBEV_EXP_HOTW
         sl = sl & 7;
 #endif
-        const long long o = (long long)sl * NIMG * 64 * 8;
+        const unsigned dst = wring + (unsigned)((i % NST) * WSLOT);
+        glds16_images<NIMG>(wg0 + (long long)sl * (NIMG * 1024), voff, dst);
+        glds16_images<NIMG>(wg0 + ((long long)KS + sl) * (NIMG * 1024), voff, dst + NIMG * 1024);
+    };
+    auto readw = [&](int i, bf16x8 (&w)[2][NIMG]) {
+        const unsigned char* src = lds + wring + (i % NST) * WSLOT + voff;
 #pragma unroll
-        for (int img = 0; img < NIMG; ++img) w[fb][img] = *reinterpret_cast<const bf16x8*>((fb ? wb1 : wb0) + o + img * 512);
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int img = 0; img < NIMG; ++img) w[fb][img] = *reinterpret_cast<const bf16x8*>(src + (fb * NIMG + img) * 1024);
     };
     const int l31 = lane & 31, lh = lane >> 5;
     const unsigned fo = (unsigned)l31 * 32u + (unsigned)lh * 16u;       // a fragment = 1 KiB of the image, read as one b128 per lane
@@ -950,15 +968,17 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
         u32x4 xa0, xa1, xb0, xb1;                             // X register ring: k-step s + 2 waits in a (s even) / b (s odd)
         bf16x8 wa[2][NIMG], xf[NFA][NIMG];                    // one W set: the next step's request goes out behind this step's last MFMA
                                                               // and lands during the partner's COMPUTE phase (a second set spilled)
-        // prologue: k-steps 0 and 1 staged, 2 and 3 requested, W of k-step 0 requested
+        // prologue: k-steps 0 and 1 staged, X of 2 and 3 and W of 0 and 1 requested -- and landed: the counted waits below then
+        // start from "nothing outstanding" (per step a wave issues 4 W requests, then 2 X requests)
         loadx(0, xa0, xa1);
         loadx(1, xb0, xb1);
-        loadw(0, 0, wa);
-        loadw(0, 1, wa);
+        issue_w(0);
+        issue_w(1);
         stagex(0, xa0, xa1);
         loadx(2, xa0, xa1);
         stagex(1, xb0, xb1);
         loadx(3, xb0, xb1);
+        wait_vmcnt_imm<0>();
         __syncthreads();
         if (half == 1) phase_barrier();                       // the second K half runs one phase behind
 #define SBEV_O4_STEP(S_, X0, X1)                                                                    \
@@ -966,6 +986,10 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
             /* FETCH: the step's fragments LDS -> registers */                                              \
             {                                                                                               \
                 SBEV_TRACE(S_, 0)                                                                           \
+                /* W of this step (requested two steps ago) has landed once at most the 8 younger requests are outstanding: X of */ \
+                /* step + 2 (2), W of step + 1 (4), X of step + 3 (2) -- vector memory operations complete in order             */ \
+                wait_vmcnt_imm<8>();                                                                        \
+                readw((S_), wa);                                                                            \
                 const unsigned char* A = hst + ((S_) % NST) * HSTAGE + fo;                                  \
                 _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
                     _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                      \
@@ -979,27 +1003,17 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
                 /* the staging of step + 2 and the X request of step + 4 also ride here: this phase otherwise waits ~800 cycles at its */ \
                 /* barrier for the partner's MFMAs, and in the COMPUTE phase every VMEM issue delays the next MFMA                    */ \
                 stagex((S_) + 2, X0, X1);                                                                   \
+                __builtin_amdgcn_sched_barrier(0);     /* (the W requests stay behind the staging: the compiler's wait for X counts only its own loads) */ \
+                issue_w((S_) + 2);                                                                          \
                 loadx((S_) + 4, X0, X1);                                                                    \
             }                                                                                               \
             phase_barrier();                                                                                \
             SBEV_TRACE(S_, 4)                                                                               \
-            /* COMPUTE: the step's MFMAs and the next step's W requests */                                  \
-            /* column fragment 0 first: its W registers are dead after half of the MFMAs and the next step's request for them goes */ \
-            /* out under the second half (the whole request behind the last MFMA cost ~200 serial cycles per phase)               */ \
+            /* COMPUTE: the step's MFMAs, nothing else */                                                   \
             _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
                 _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
-                    acc[fa][0] = SBEV_MFMA(wa[0][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][0]);                \
-            __builtin_amdgcn_sched_barrier(0);                                                              \
-            loadw((S_) + 1, 0, wa);                                                                         \
-            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
-                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
-                    acc[fa][1] = SBEV_MFMA(wa[1][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][1]);                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                              \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                              \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                              \
-            loadw((S_) + 1, 1, wa);                                                                         \
+                    _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
+                        acc[fa][fb] = SBEV_MFMA(wa[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);         \
             SBEV_TRACE(S_, 5)                                                                               \
             phase_barrier();                                                                                \
             SBEV_TRACE(S_, 6)                                                                               \
@@ -1012,9 +1026,14 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
         if (sl < n0h) SBEV_O4_STEP(sl, xa0, xa1)
 #undef SBEV_O4_STEP
         if (half == 0) phase_barrier();
-        // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab
+        // fold the two K halves (fixed order: bit-reproducible) and write the chunk's slab -- through an [m][n] image of the whole tile in
+        // LDS: K half 1 writes its accumulators there (a lane holds one output ROW m and 4-column pieces), half 0 adds its own in
+        // place, then all 8 waves read whole rows back and store 1 KiB per instruction.  (Storing from the accumulator layout wrote
+        // 32-byte pieces of 32 rows per instruction: 19k of a workgroup's 83k cycles went into the fold + stores -- f16x3 trace.)
+        wait_vmcnt_imm<0>();                                   // the last (dummy, clamped) W requests still write LDS this image reuses
         __syncthreads();
-        f32x4* fold = reinterpret_cast<f32x4*>(lds) + (wc * (NFA * 8)) * 64 + lane;       // [wc][fa][fb][g][lane] float4
+        constexpr int FLD = 256 + 4;                           // image row stride in floats
+        float* img = reinterpret_cast<float*>(lds);
         if (half == 1) {
 #pragma unroll
             for (int fa = 0; fa < NFA; ++fa)
@@ -1022,26 +1041,33 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
                 for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        fold[((fa * 2 + fb) * 4 + g) * 64] = (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(img + (fa * 32 + l31) * FLD + wc * 64 + fb * 32 + 8 * g + 4 * lh) =
+                            (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
         }
         __syncthreads();
-        if (half == 1) return;
-        float* out = a.P + (long long)chunk * M * 256 + wc * 64 + 4 * lh;
+        if (half == 0) {
 #pragma unroll
-        for (int fa = 0; fa < NFA; ++fa) {
-            const int row = m0 + fa * 32 + l31;
-            if (row < M SBEV_EXP_STORE_COND) {
+            for (int fa = 0; fa < NFA; ++fa)
 #pragma unroll
                 for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
-                        f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
-                        v *= *reinterpret_cast<const f32x4*>(a.nscale + wc * 64 + 4 * lh + fb * 32 + 8 * g);   // exact: powers of two
-                        *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
+                        f32x4* q = reinterpret_cast<f32x4*>(img + (fa * 32 + l31) * FLD + wc * 64 + fb * 32 + 8 * g + 4 * lh);
+                        const f32x4 o = *q;
+                        *q = (f32x4){acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
                     }
+        }
+        __syncthreads();
+        {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + lane * 4);          // a lane owns 4 fixed columns: exact powers of two
+            float* out = a.P + (long long)chunk * M * 256 + lane * 4;
+            for (int r = wave; r < NFA * 32; r += 8) {
+                const int row = m0 + r;
+                if (row < M SBEV_EXP_STORE_COND)
+                    *reinterpret_cast<f32x4*>(out + (long long)row * 256) = *reinterpret_cast<const f32x4*>(img + r * FLD + lane * 4) * sc;
             }
         }
+        SBEV_WGTIME(1)
     };
     if (nfa == 4) run(std::integral_constant<int, 4>{});
     else if (nfa == 3) run(std::integral_constant<int, 3>{});
@@ -1246,7 +1272,7 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
         Out4Args a4{reinterpret_cast<const unsigned*>(X), Wp, slabs, (int)M, K, (long long)ldx, pl.ntm, pl.base, pl.rem, pl.S, nscale};
         const long long wgs4 = (long long)pl.ntm * pl.S;
         SBEV_REQUIRE(wgs4 <= 0x7fffffffLL, "sbev_linear_splitk_f16s: too many workgroups");
-        constexpr int LDS4 = 128 * 1024;        // 4 column quarters x 4 fragments x 8 KiB of fold buffer (>= the 48 KiB of stages)
+        constexpr int LDS4 = 144 * 1024;        // 48 KiB of X stages + 8 waves x 12 KiB of W ring (the 128 KiB fold buffer reuses them)
         hipEvent_t f0, f1;
         int st4;
 #define SBEV_LAUNCH_OUT4(KERN)                                                                   \

@@ -36,8 +36,11 @@ for grp in (0, 1):
 wt = (ctypes.c_ulonglong * (1024 * 4))()
 raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p]
 if raw.sbev_debug_wgtime_read(wt) == 0:
-    a = np.array(wt, dtype=np.uint64).reshape(1024, 4).astype(np.int64)[:255]
+    a = np.array(wt, dtype=np.uint64).reshape(1024, 4).astype(np.int64)[:256]
+    a = a[a[:, 2] > 0]
     if a[:, 2].max() > 0:
         us = (a[:, 2] - a[:, 0]) / 100.0
         cyc = a[:, 3] - a[:, 1]
-        print('workgroup lifetime us: median %.1f min %.1f max %.1f; shader clocks %.0f -> %.2f GHz; launch span %.1f us' % (np.median(us), us.min(), us.max(), np.median(cyc), np.median(cyc / us) / 1e3, (a[:, 2].max() - a[:, 0].min()) / 100.0))
+        print('workgroup lifetime us: median %.1f min %.1f max %.1f; shader clocks %.0f -> %.2f GHz; launch span %.1f us; start skew %.1f us' % (np.median(us), us.min(), us.max(), np.median(cyc), np.median(cyc / us) / 1e3, (a[:, 2].max() - a[:, 0].min()) / 100.0, (a[:, 0].max() - a[:, 0].min()) / 100.0))
+        first = t[0, 0, 0]
+        print('workgroup 0: start -> first FETCH stamp %d cycles; last stamp -> end %d cycles' % (first - a[0, 1], a[0, 3] - t[0, 29, 6]))

@@ -66,6 +66,42 @@ def pmc_profile(config, kernel='msmv_fwd_kernel'):
     return best
 
 
+def live_kernel_stats(config, gemm, timeout=120):
+    """Average kernel durations of THIS run's decoder step by `rocprofv3 --kernel-trace --stats` (no counters: durations are not
+    disturbed by counter collection), measured now: bench.py re-runs itself for 20 steps under the tracer and the stats CSV is
+    parsed.  Returns {short kernel name: avg_us} or None (same guards as live_pmc)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get('SBEV_BENCH_CHILD') == '1' or shutil.which('rocprofv3') is None:
+        return None
+    if any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTX', 'ROCTRACER')) or k == 'HSA_TOOLS_LIB' for k in os.environ):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_summary
+    tmp = tempfile.mkdtemp(prefix='sbev_kt_', dir='/tmp')
+    env = dict(os.environ, SBEV_BENCH_CHILD='1', TMPDIR='/tmp')
+    try:
+        cmd = ['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '-o', 'b', '--',
+               sys.executable, os.path.join(ROOT, 'bench.py'), '--config', config, '--gemm', gemm, '--steps', '20', '--warmup', '3',
+               '--no-cpu-baseline', '--no-alt', '--no-detector', '--no-live-pmc']
+        r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
+        csvs = [os.path.join(d, f) for d, _, fs in os.walk(tmp) for f in fs if f.endswith('kernel_stats.csv')]
+        if r.returncode != 0 or not csvs:
+            return None
+        res = {}
+        for row in csv.DictReader(open(csvs[0])):
+            sh = pmc_summary.short(row['Name'])
+            if sh is not None and sh not in res:
+                res[sh] = round(float(row['AverageNs']) / 1e3, 2)
+        return res or None
+    except Exception:      # noqa: BLE001  (a measurement aid must never take the metric line down)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def live_pmc(config, timeout=90):
     """HBM-side byte counters of THIS run's kernels, measured now: bench.py re-runs itself for a few steps under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes -- the two do not fit one; --kernel-trace only beside
@@ -538,7 +574,14 @@ def main():
                                          ('gemm_bf16s_out%s_kernel (mixing out-projection, split-K, %s)' % ('4' if args.gemm.startswith('f16') else '3', args.gemm), fl_o, o_us, gemm_ms[1]))]
             # the fp32-class emulation may be the default once generator + out-projection <= 2 x 60 us at config 2
             out['gemm_gate'] = {'generator_us': round(g_us, 2), 'out_proj_us': round(o_us, 2), 'sum_us': round(g_us + o_us, 2),
-                                'measured': 'HIP events around the two launches of 10 eager steps right after the timed region', 'config': args.config}
+                                'measured': 'HIP events around the two launches of 10 eager steps right after the timed region (an upper bound: the records '
+                                            'include the launch gap)', 'config': args.config}
+            kt = live_kernel_stats(args.config, args.gemm) if (world == 1 and not args.no_live_pmc) else None
+            if kt and 'gemm_bf16s_gen3_kernel' in kt:
+                ok = kt.get('gemm_bf16s_out4_kernel', kt.get('gemm_bf16s_out3_kernel'))
+                out['gemm_gate'].update({'generator_us_rocprof': kt['gemm_bf16s_gen3_kernel'], 'out_proj_us_rocprof': ok,
+                                         'sum_us_rocprof': round(kt['gemm_bf16s_gen3_kernel'] + ok, 2) if ok else None,
+                                         'rocprof': 'rocprofv3 --kernel-trace --stats of 23 steps of this command re-run now on this box: AverageNs of the two kernels'})
         if args.gemm == 'f32' and all(gemm_ms):
             D_, Pin_, Pout_ = 256, T * P_, 128
             flops = 2.0 * B * Q * D_ * (G_ * (Cg_ * Cg_ + Pin_ * Pout_))          # generator; the out-projection has G*Pout*Cg*D = the same at Pin = 32

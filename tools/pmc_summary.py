@@ -25,13 +25,13 @@ def short(name):
     m = re.search(r'adaptive_mixing_kernel<\d+, (true|false), (\d+)', name)
     if m:                      # the fused gather + mixing instantiations (L > 0) vs the plain mixing kernel
         return 'adaptive_mixing_kernel' if m.group(2) != '0' else 'adaptive_mixing_kernel_plain'
-    m = re.search(r'row_chain_kernel<(\d)>', name)
+    m = re.search(r'row_chain_kernel<(\d)(?:, \d)?>', name)
     if m:                      # the three row chains (csrc/row_chain.hip): 0 tail (+ next front), 1 layer-0 front, 2 attention chain
         return 'row_chain_kernel_' + {'0': 'tail', '1': 'front', '2': 'attention'}[m.group(1)]
     for key in ('msmv_fwd_kernel', 'adaptive_mixing_kernel', 'transpose_tiles_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
                 'gemm_nt_f32_small_kernel', 'gemm_group_small_kernel', 'gemm_nt_f32_strip_kernel', 'gemm_nt_f32_regtile_kernel',
                 'sample_project_kernel', 'sampling_front_kernel', 'ffn_fused_kernel', 'branch_chain_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3',
-                'gemm_bf16s_gen3_kernel', 'gemm_bf16s_out3_kernel', 'pack_frags_kernel'):
+                'gemm_bf16s_gen3_kernel', 'gemm_bf16s_out3_kernel', 'gemm_bf16s_out4_kernel', 'pack_frags_kernel'):
         if key in name:
             return key
     return None

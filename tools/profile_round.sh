@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile recipe (run on the GPU box through gpurun):  tools/profile_round.sh r2
-# bench line (default command), rocprofv3 kernel stats of the same workload (exact fp32 and the opt-in bf16x3 mode), the
+# bench line (default command), rocprofv3 kernel stats of the same workload (default f16x3 GEMM mode, exact f32 MFMA, bf16x6), the
 # MFMA-busy counter pass, the other configs' bench lines, one training step's kernel stats.  PMC byte counters per config:
 # tools/profile_pmc.sh.  Everything lands in gpurun_out/prof_<round>/; copy what is to be judged into profiles/.
 set -u
@@ -12,16 +12,19 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
 tail -1 $OUT/bench_line.json | cut -c1-400
 Q="--no-cpu-baseline --no-alt --no-detector --no-live-pmc"
+# kernel stats of the same workload: the default mode of the two mixing GEMMs (f16x3), the exact f32-MFMA kernels, bf16x6
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py $Q --steps 20 > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_f32 -o bench -- python $R/bench.py $Q --steps 20 --gemm f32 > $OUT/kt_f32.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt6 -o bench -- python $R/bench.py $Q --steps 20 --gemm bf16x6 > $OUT/kt6.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o bench -- python $R/bench.py $Q --steps 20 --gemm bf16x3s > $OUT/kt3.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma6 -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 --gemm bf16x6 > $OUT/pmc_mfma6.log 2>&1
-python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma6 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma6 -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary_bf16x6.json | head -6
-rm -f $(find $OUT/pmc_mfma6 -name "*counter_collection.csv")
+# MFMA-busy counter pass (its own run, --kernel-trace only beside it): default mode, then the exact kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 > $OUT/pmc_mfma.log 2>&1
-python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary.json | head -12
+python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary.json | head -8
 rm -f $(find $OUT/pmc_mfma -name "*counter_collection.csv")
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_f32 -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 --gemm f32 > $OUT/pmc_mfma_f32.log 2>&1
+python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma_f32 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma_f32 -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary_f32.json | head -6
+rm -f $(find $OUT/pmc_mfma_f32 -name "*counter_collection.csv")
 for c in c1 c3 c4 c5 c6; do python $R/bench.py --config $c $Q --steps 30 2>/dev/null | tail -1 > $OUT/bench_$c.json; cut -c1-220 $OUT/bench_$c.json; done
+for c in c3 c4 c6; do python $R/bench.py --config $c $Q --steps 30 --gemm f32 2>/dev/null | tail -1 > $OUT/bench_${c}_f32.json; cut -c1-200 $OUT/bench_${c}_f32.json; done
 python $R/bench.py --nhwc $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_nhwc.json; cut -c1-200 $OUT/bench_nhwc.json
 python $R/bench.py --online $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_online.json; cut -c1-200 $OUT/bench_online.json
 SBEV_NO_SAMPLE_MIX=1 python $R/bench.py $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_unfused.json; cut -c1-200 $OUT/bench_unfused.json

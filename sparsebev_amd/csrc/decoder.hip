@@ -148,7 +148,7 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
     const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
                        sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
     const int split = (c.gemm_mode == SBEV_GEMM_BF16X6 || c.gemm_mode == SBEV_GEMM_BF16X3S) ? 1      // x1 -> bf16 image fragments
-                      : (c.gemm_mode == SBEV_GEMM_F16X3 || c.gemm_mode == SBEV_GEMM_F16X4) ? 1      // x1 -> fp16 image fragments
+                      : (c.gemm_mode == SBEV_GEMM_F16X3 || c.gemm_mode == SBEV_GEMM_F16X4) ? (chain ? 0 : 1)      // x1 -> fp16 image fragments (the attention chain writes them)
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
     // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
     // op by op: 17 with the fused gather + mixing
@@ -231,8 +231,10 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     SBEV_REQUIRE(nimg == 0 || (sbev_linear_bf16s_gen_ok(BQ, pgN, D) && sbev_linear_bf16s_out_ok(BQ, D, mixN)),
                  "sbev_decoder_forward: gemm_mode %d does not cover this shape (rows %lld, generator %d x %d, out-projection %d x %d)",
                  cfg->gemm_mode, (long long)BQ, pgN, D, D, mixN);
-    auto generator_bf16s = [&](sbev_stream_t st) -> int {      // x1 -> bf16 image fragments (once per layer) -> Y = X W^T + b
+    auto generator_bf16s = [&](sbev_stream_t st, bool packed = false) -> int {      // x1 -> image fragments (once per layer) -> Y = X W^T + b
         uint16_t* xs = reinterpret_cast<uint16_t*>(b.x1s);
+        if (nimg >= 4 && packed)                               // (the attention chain already wrote the fragments)
+            return sbev_linear_f16s_gen(xs, w->pg_xscale, w->pg_ws, w->pg_wdown, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg - 1, st);
         if (nimg >= 4) {                                       // fp16 hi + lo: x1 scaled by one power of two (its maximum -> [2^14, 2^15))
             // (the power of two comes with the weights: norm1's output is bounded by sqrt(D - 1) max|gamma| + max|beta| -- no pass for a maximum)
             int e = sbev_pack_f16s_frags(b.x1, D, xs, const_cast<float*>(w->pg_xscale), (int)BQ, D, 2, st);
@@ -271,9 +273,11 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         float* box_l = bbox_out + (int64_t)layer * BQ * c.code_size;
         if (chain) {
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
-            TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main));
+            // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
+            TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
+                                        nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr));
             if (nimg)
-                TRY(generator_bf16s(stream));
+                TRY(generator_bf16s(stream, true));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(generator_bf16x3(stream));
             else

@@ -92,6 +92,8 @@ struct ChainArgs {
     float* qkvt; int attn_in_rows;
     const float* att;            // PRE_ATT: [M, 256]
     float* x1_out;               // [M, 256]
+    unsigned short* x1_frag;     // fp16 GEMM modes: x1 also as the generator's operand -- scaled fp16 hi | lo images in MFMA fragment order
+    const float* x1_scale;       //   (gemm_bf16s.hip: [M/32][16 k-steps][2][64 lanes][8]), scaled by x1_scale[0] = 2^e; null otherwise
     float* so; int soN;          // so: null when the sample points are projected in here (proj.loc_bp set)
     sbev_ops::SamplePointArgs proj;
     float eps;
@@ -664,6 +666,28 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a.x1_out[g * DM + lane + 64 * c] = v[c];
                 }
+                if (a.x1_frag && live) {
+                    // the generator's operand, saving its pack launch (5 us per layer): lane = (image, 8-k piece) reads the piece's 8
+                    // values of the row just written to LDS (same wave: the LDS pipe keeps its accesses in order) and stores 16 bytes
+                    // at the piece's place in fragment (g / 32, k-step): row g % 32 is "lane" g % 32 + 32 (k-half) of that fragment
+                    __builtin_amdgcn_wave_barrier();
+                    const int k8 = lane & 31, im = lane >> 5;
+                    const float up = a.x1_scale[0];
+                    const float4 p0 = *reinterpret_cast<const float4*>(smem + OFF_X3 + row * LDX + 8 * k8);
+                    const float4 p1 = *reinterpret_cast<const float4*>(smem + OFF_X3 + row * LDX + 8 * k8 + 4);
+                    const float f[8] = {p0.x * up, p0.y * up, p0.z * up, p0.w * up, p1.x * up, p1.y * up, p1.z * up, p1.w * up};
+                    unsigned w4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const _Float16 h0 = (_Float16)f[2 * i], h1 = (_Float16)f[2 * i + 1];
+                        const _Float16 l0 = (_Float16)(f[2 * i] - (float)h0), l1 = (_Float16)(f[2 * i + 1] - (float)h1);
+                        const _Float16 e0 = im ? l0 : h0, e1 = im ? l1 : h1;
+                        w4[i] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+                    }
+                    const long long frag = ((g >> 5) * (DM / 16) + (k8 >> 1)) * 2 + im;            // [row block][k-step][image]
+                    uint4* dst = reinterpret_cast<uint4*>(a.x1_frag + frag * 512 + (((int)(g & 31) + 32 * (k8 & 1)) * 8));
+                    *dst = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
             } break;
             case EPI_SAMP: {     // sampling_offset | scale_weights Linear -> so (kept in LDS for the projection below)
                 if (side) break;
@@ -775,7 +799,11 @@ int pieces(int rg, int cgs, int K) {
 }
 
 // rows per workgroup = 4 rg: the smallest of 4, 8, 16 that covers the rows with one round of workgroups (256 CUs)
-int row_groups(long long rows) { return rows <= 256 * 4 ? 1 : rows <= 256 * 8 ? 2 : 4; }
+int row_groups(long long rows) {
+    static const int forced = getenv("SBEV_CHAIN_RG") ? atoi(getenv("SBEV_CHAIN_RG")) : 0;      // A/B: 1, 2 or 4 row groups whatever the row count
+    if ((forced == 1 && rows <= 256 * 4) || (forced == 2 && rows <= 256 * 8) || forced == 4) return forced;
+    return rows <= 256 * 4 ? 1 : rows <= 256 * 8 ? 2 : 4;
+}
 Offs offs(int rg) { return rg == 1 ? offs_of<1>() : rg == 2 ? offs_of<2>() : offs_of<4>(); }
 
 }  // namespace
@@ -902,12 +930,13 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
 // attention out-projection + residual + norm1 -> x1, sampling Linear -> sample points -> projection (loc, level weights)
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
                       const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
-                      hipStream_t s) {
+                      hipStream_t s, uint16_t* x1_frag, const float* x1_scale) {
     const PackMap m = pack_map(c);
     ChainArgs a{};
     fill_common(a, c, eps);
     a.pre = PRE_ATT;
     a.att = att; a.x = const_cast<float*>(x); a.x1_out = x1; a.so = nullptr;
+    a.x1_frag = x1_frag; a.x1_scale = x1_scale;
     a.proj = sbev_ops::sample_point_args(bbox, time_diff, lidar2img, c.pc_range, c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w,
                                          c.eps_homo, loc_bp, w_bp);
     const int rg = row_groups(a.M);

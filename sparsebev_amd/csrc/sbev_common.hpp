@@ -56,7 +56,7 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
                        float* qkvt, float eps, hipStream_t s);
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
                       const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
-                      hipStream_t s);
+                      hipStream_t s, uint16_t* x1_frag = nullptr, const float* x1_scale = nullptr);
 int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* slabs, int splits, const float* x1,
                       const float* bbox, const float* vel_div, float* x3, float* cls_out, float* box_out, int with_front, float* x,
                       float* qkvt, float eps, hipStream_t s);

@@ -57,6 +57,7 @@ def invalidate_caches():
     detected through ``_version`` and need nothing.  ``SparseBEVTransformerDecoder.invalidate_caches()`` calls this and
     re-binds the inference runtime's packed weight images."""
     _WT_CACHE.clear()
+    _F16_CACHE.clear()
 
 
 def _transposed(w):
@@ -84,6 +85,35 @@ def _transposed(w):
                 del _WT_CACHE[k]
         _WT_CACHE[id(w)] = (weakref.ref(w), w._version, wt)
     return wt
+
+
+_F16_CACHE = {}     # (id(parameter), transposed) -> (weak reference, version, fragments, scales): pack_f16s_frags of W or W^T
+
+
+def _f16_frags(w, transposed=False):
+    """The fp16 hi + lo fragment image (dense.pack_f16s_frags) of a Linear weight [N, K] -- or of W^T, the operand of grad_x = grad_y . W
+    as a generator-shaped GEMM -- cached until the weight is modified in place (like _transposed: one pack per weight update)."""
+    key = (id(w), bool(transposed))
+    hit = _F16_CACHE.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:
+        return hit[2], hit[3]
+    src = _transposed(w) if transposed else _c(w.detach())
+    frags, scales = dense.pack_f16s_frags(src)
+    if w.is_leaf:
+        if len(_F16_CACHE) >= 64:
+            for k in [k for k, v in _F16_CACHE.items() if v[0]() is None]:
+                del _F16_CACHE[k]
+        _F16_CACHE[key] = (weakref.ref(w), w._version, frags, scales)
+    return frags, scales
+
+
+def _mixed_up_log2(n):
+    """largest e with sqrt(n) 2^e < 65504: the fp16 scale of relu(LayerNorm over n elements, no affine) (csrc: sbev_decoder_mixed_up_log2)"""
+    import math
+    e = 0
+    while math.sqrt(n) * 2.0 ** (e + 1) < 65504.0 and e < 15:
+        e += 1
+    return e
 
 
 def _linear_grads(gy2, x2, w, need_x, need_w):
@@ -259,11 +289,27 @@ class AdaptiveMixing(torch.autograd.Function):
     parameters [B*Q, 32768] and the mixed activations [B*Q, 32768] and saves the two re-runs (183 us per layer)."""
 
     @staticmethod
-    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points, recompute):
+    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points, recompute, gemm_f16=False):
         B, Q, G, Pin, C = x.shape
         D = query.shape[-1]
         BQ = B * Q
         ctx.out_points, ctx.recompute = out_points, bool(recompute)
+        lib = _lib.load()
+        # gemm_f16 (the decoder's default GEMM mode, DESIGN 9.7): generator, out-projection and grad_mixed on the fp16 hi + lo kernels --
+        # three of the six 15-GFLOP GEMMs of a layer's forward + backward (grad_params . W_pg would need a device-side bound of the
+        # gradient's magnitude and the two grad_W GEMMs reduce over the rows: those stay on the exact kernels)
+        ctx.f16 = bool(gemm_f16) and not recompute and bool(lib.sbev_linear_bf16s_gen_ok(BQ, pg_w.shape[0], pg_w.shape[1])) and \
+            bool(lib.sbev_linear_bf16s_out_ok(BQ, op_w.shape[0], op_w.shape[1])) and bool(lib.sbev_linear_bf16s_gen_ok(BQ, op_w.shape[1], op_w.shape[0]))
+        if ctx.f16:
+            x = _c(x)
+            params = dense.linear_f16s_gen(_c(query).reshape(BQ, D), *_f16_frags(pg_w), pg_b)
+            mixed = torch.empty(BQ, G * out_points * C, device=x.device, dtype=torch.float32)
+            _lib.check(lib.sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, out_points, _EPS, _stream()),
+                       'sbev_adaptive_mixing_f32')
+            y = dense.linear_splitk_f16s(mixed, *_f16_frags(op_w), op_b, residual=_c(query).reshape(BQ, D),
+                                         x_up_log2=_mixed_up_log2(out_points * C)).reshape(query.shape)
+            ctx.save_for_backward(x, query, pg_w, pg_b, op_w, op_b, params, mixed)
+            return y
         if recompute:
             y = dense.adaptive_mixing(x, query, pg_w, pg_b, op_w, op_b, out_points)       # = query + out_proj(mix)
             ctx.save_for_backward(x, query, pg_w, pg_b, op_w, op_b)
@@ -298,7 +344,11 @@ class AdaptiveMixing(torch.autograd.Function):
                        'sbev_adaptive_mixing_f32')
         # out-projection backward
         _, gb_op = _bias_relu_bwd(gy2, None, True)
-        gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, True)
+        if ctx.f16:      # grad_mixed = grad_y . W_op: generator-shaped (K = 256 -> 32768 columns) with the fragments of W_op^T
+            gmixed = dense.linear_f16s_gen(gy2, *_f16_frags(op_w, transposed=True), None)
+            _, gw_op = _linear_grads(gy2, mixed, _c(op_w), False, True)
+        else:
+            gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, True)
         del mixed
         # mixing core backward
         gx = torch.empty_like(x)
@@ -311,7 +361,7 @@ class AdaptiveMixing(torch.autograd.Function):
         _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
         # grad_query = grad_y (the `query +` residual) + grad_params . W_pg: the forward split-K Linear with W_pg^T, residual fused
         gq = dense.linear(gparams, _transposed(pg_w), None, residual=gy2).reshape(query.shape)
-        return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None
+        return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None, None
 
 
 class FeatureTap(torch.autograd.Function):

@@ -213,11 +213,16 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* w, long lon
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) scale_of(mx, up + row, down + row);
 }
-__global__ __launch_bounds__(1024) void tensor_scale_kernel(const float* x, long long ldx, long long rows, int K, float* updown) {
-    __shared__ float red[16];
+// one power of two for a whole matrix: up to 64 blocks each reduce a slice to a partial maximum, the block that draws the last
+// ticket reduces the partials (a maximum: order-free) and writes {2^e, 2^-e}.  (One 1024-thread block for 900 x 256 values: 26 us.)
+__device__ float g_scale_part[64];
+__device__ unsigned g_scale_ticket;
+__global__ __launch_bounds__(256) void tensor_scale_kernel(const float* x, long long ldx, long long rows, int K, float* updown) {
+    __shared__ float red[4];
+    __shared__ int is_last;
     float mx = 0.f;
     const long long n4 = rows * (K / 4);
-    for (long long i = threadIdx.x; i < n4; i += 1024) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const long long r = i / (K / 4);
         const int c = (int)(i - r * (K / 4));
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c * 4);
@@ -228,9 +233,19 @@ __global__ __launch_bounds__(1024) void tensor_scale_kernel(const float* x, long
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
-        scale_of(mx, updown, updown + 1);
+        g_scale_part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __threadfence();
+        const unsigned t = atomicAdd(&g_scale_ticket, 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) g_scale_ticket = 0u;
     }
+    __syncthreads();
+    if (!is_last || threadIdx.x >= 64) return;
+    __threadfence();
+    float m = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&g_scale_part[threadIdx.x]) : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) scale_of(m, updown, updown + 1);
 }
 
 // ---- LDS-DMA: 1 KiB per wave-instruction, LDS destination = M0 + 16 lane (lane-linear), source = sbase + voff per lane ----------
@@ -1154,7 +1169,11 @@ extern "C" int sbev_pack_f16s_frags(const float* W, int64_t ldw, uint16_t* out, 
     SBEV_REQUIRE(N >= 1 && K >= 16 && K % 16 == 0, "sbev_pack_f16s_frags: N=%d, K=%d (multiple of 16)", N, K);
     SBEV_REQUIRE(W && out && scales && ldw >= K && ldw % 4 == 0 && (((uintptr_t)W | (uintptr_t)out) & 15) == 0, "sbev_pack_f16s_frags: null / unaligned pointer or bad ldw");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (per_tensor == 1) hipLaunchKernelGGL(tensor_scale_kernel, dim3(1), dim3(1024), 0, s, W, (long long)ldw, (long long)N, K, scales);
+    if (per_tensor == 1) {
+        const long long n4 = (long long)N * (K / 4);
+        const unsigned nb = (unsigned)(n4 / 1024 < 1 ? 1 : n4 / 1024 > 64 ? 64 : n4 / 1024);
+        hipLaunchKernelGGL(tensor_scale_kernel, dim3(nb), dim3(256), 0, s, W, (long long)ldw, (long long)N, K, scales);
+    }
     else if (per_tensor == 0) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, (long long)ldw, N, K, scales, scales + N);
     const long long n = (long long)((N + 31) / 32) * (K / 16) * 64;
     hipLaunchKernelGGL(pack_frags_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, (long long)ldw, out, N, K, (const float*)scales, per_tensor ? 0 : 1);

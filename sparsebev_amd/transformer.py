@@ -228,7 +228,8 @@ class SparseBEVTransformerDecoderLayer(_Base):
         sampled = AG.Sampling.apply(query_bbox, both, feats, ctx, cfg, feat_token)     # feat_token: AG.feature_token (None: frozen features)
         # adaptive mixing (+ identity), norm2
         x = AG.layer_norm(AG.AdaptiveMixing.apply(sampled, x, mix.parameter_generator.weight, mix.parameter_generator.bias,
-                                                  mix.out_proj.weight, mix.out_proj.bias, mix.out_points, self.recompute_mixing),
+                                                  mix.out_proj.weight, mix.out_proj.bias, mix.out_points, self.recompute_mixing,
+                                                  getattr(self, 'train_gemm_f16', False)),
                           self.norm2.weight, self.norm2.bias)
         # FFN (+ identity), norm3
         f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]
@@ -510,6 +511,8 @@ class SparseBEVTransformerDecoder(_Base):
         orig = [f for f in mlvl_feats if torch.is_tensor(f)] if isinstance(mlvl_feats, (list, tuple)) else []
         token = AG.feature_token(feats, orig)       # ONE node hands the shared feature-gradient buffers to autograd (or None)
         layer = self.decoder_layer
+        from .runtime import GEMM_MODES, GEMM_F16X3, GEMM_F16X4
+        layer.train_gemm_f16 = GEMM_MODES.get(self.gemm_mode, self.gemm_mode) in (GEMM_F16X3, GEMM_F16X4)     # autograd.AdaptiveMixing
         saved = (layer.self_attn.attn_drop, layer.ffn_drop)
         if not self.training:
             layer.self_attn.attn_drop, layer.ffn_drop = 0.0, 0.0

@@ -1,29 +1,30 @@
-// Split-bf16 Linears for the two 15-GFLOP GEMMs of adaptive mixing on the bf16 matrix core (round 3):
-//   NIMG = 3  "bf16x6": x = hi + mid + lo (three RNE bf16 images, 8 + 8 + 8 significand bits = an exact split of an fp32
-//             value), Y = sum of the SIX image products whose weight is >= 2^-16 (hh, hm, mh, mm, hl, lh), fp32 accumulation
-//             on v_mfma_f32_32x32x16_bf16.  Dropped: ml, lm, ll <= 2^-23 |a b| per product -- below the rounding an fp32 fma
-//             chain commits per step, so the result is fp32-class ("not narrower than fp32": tests/test_gpu_bf16s.py compares
-//             both against fp64).  6 x 15.1 GFLOP at the 2.5 PF bf16 peak = 36 us, against a 96 us floor on the f32 MFMA.
-//   NIMG = 2  "bf16x3": hi + lo, three products (2^-16 class), the opt-in fast mode of rounds 1-2 on the same kernels.
+// Split-operand Linears for the two 15-GFLOP GEMMs of adaptive mixing on the 16-bit matrix core (round 3): fp32 operands as two or
+// three 16-bit images, the image products that matter, fp32 accumulation.  MODE (template; API code `nimg` / `nprod + 1`):
+//   f16x3   (code 4, the decoder's default): x 2^e = hi + lo, two RNE fp16 images of the operand scaled by a
+//           power of two per row / tensor (11 + 11 significand bits + lo's sign: the fp32 value to <= 2^-23), products hl + lh + hh
+//           on v_mfma_f32_32x32x16_f16; the dropped lo x lo is <= 2^-24 |a b|.  Max and rms error against fp64 BELOW the exact
+//           f32-MFMA kernels' at both shapes, also on 12-binade inputs (tests/test_gpu_bf16s.py).   f16x4 (code 5): + lo x lo.
+//   bf16x6  (code 3): x = hi + mid + lo, three RNE bf16 images (8 + 8 + 8 bits = an exact split), the SIX products of weight >= 2^-16
+//           (hh, hm, mh, mm, hl, lh) on v_mfma_f32_32x32x16_bf16; dropped ml, lm, ll <= 2^-23 |a b|.  fp32-class too, twice the matrix work.
+//   bf16x3s (code 2): hi + lo bf16, three products (2^-16 class), the opt-in fast mode of rounds 1-2 on the same kernels.
 // Replaces nothing in the reference (torch.nn.Linear, models/sparsebev_transformer.py:358,378); same semantics as
 // sbev_linear_f32 / sbev_linear_splitk_f32.
 //
 // Why these kernels and not gemm_bf16x3.hip's: a 16-byte-per-lane VGPR write-back (global load or ds_read_b128) costs the issuing
 // wave ~85 matrix-pipe cycles when it is alone on its SIMD and 23-38 with a partner wave, so the
-// one-wave-per-SIMD register-stationary strips that win for 32-cycle-per-16x16x4 f32 MFMAs are load-issue-bound at bf16 rates
-// (72 us for 45 GFLOP = 25 % of peak).  Here every workgroup is 8 waves = two per SIMD, operands are read as whole 1-KiB
-// fragments, and a wave owns a 64 x 64 output tile so that one fragment read feeds 2 (x3) ... 6 (x6) MFMAs of 32 cycles.
+// one-wave-per-SIMD register-stationary strips that win for 32-cycle-per-16x16x4 f32 MFMAs are load-issue-bound at 16-bit rates
+// (72 us for 45 GFLOP = 25 % of peak).  Here every workgroup is 8 waves = two per SIMD running as two PHASE GROUPS one barrier phase
+// apart (one fetches while the other multiplies), operands are pre-ordered as whole 1-KiB MFMA fragments that an LDS-DMA
+// instruction copies verbatim and a ds_read_b128 at lane x 16 reads back conflict-free.
 //
-//   generator  Y[M, N] = X[M, K] W[N, K]^T + b   (K = 256, N = 32768 ...):  workgroup tile <= 128 rows x 256 columns, K slabs of
-//              32 through a double-buffered LDS stage filled by global_load_lds_dwordx4 (both operands pre-split into row-major
-//              bf16 planes: X once per layer by sbev_split_bf16s_rows, W once per weight update), 16-B chunks XOR-swizzled on
-//              the SOURCE address so that the lane-linear LDS image is conflict-free for ds_read_b128 fragments.  Row tiles
-//              are 3 or 4 fragments of 32 rows, balanced (900 rows = 5 x 4 + 3 x 3 fragments: 3 % padding instead of 12 %).
-//   out-proj   slabs[S, M, 256] = X[M, K] W[256, K]^T over S K-chunks (K = 32768): workgroup = 64 rows x all 256 columns x one
-//              chunk, its two wave quartets take the two halves of the chunk and fold through LDS (S slabs instead of 2 S).
-//              X (fp32, the mixing kernel's output) is split in the kernel -- each element exactly once -- into an LDS stage;
-//              W fragments come pre-packed in MFMA order (sbev_pack_bf16s_frags: 1 KiB per (32 columns, 16 k, image)), straight
-//              from L2 into registers (no sharing between waves to exploit: every wave owns its own 64 columns).
+//   generator  Y[M, N] = X[M, K] W[N, K]^T + b  (K = 256, N = 32768 ...): gemm_bf16s_gen3_kernel -- persistent workgroups, one
+//              256 x 256 (or 128 x 256) tile at a time, 16-k stages in a 3 / 4-deep LDS-DMA ring; two images: epilogue through
+//              per-wave 32 x 32 LDS transpose patches (whole 128-byte row segments per store).
+//   out-proj   slabs[S, M, 256] = X[M, K] W[256, K]^T over S K-chunks (K = 32768), summed by the row-chain tail / sbev_splitk_reduce:
+//              gemm_bf16s_out3_kernel -- 64 rows x 256 columns x one chunk, X (fp32) split inside the kernel (bf16 modes; fp16 with a
+//              caller-supplied power of two);  gemm_bf16s_out4_kernel (fp16 modes, the decoder's path) -- <= 128 rows x 256 columns
+//              x one chunk, X handed over as (fp16 hi, fp16 lo) PAIRS by the mixing kernel's epilogue (sbev_*_pairs_f16), W through
+//              a wave-private LDS-DMA ring, the two K halves folded through an [m][n] image of the tile in LDS.
 #include <cstdlib>
 #include <type_traits>
 #include "sbev_common.hpp"

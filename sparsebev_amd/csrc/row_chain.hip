@@ -475,9 +475,9 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         }
     }
     if (PRE == PRE_SLABS) {
-        // mixing.out_proj: sum of the split-K slabs -- 16 independent loads in flight per wave (all of its rows' together), added in
+        // mixing.out_proj: sum of the split-K slabs -- up to 32 independent loads in flight per wave (all of its rows' together), added in
         // slab order; lane = 4 columns.  A dead row reads the last row's slabs (no branch: hipcc sinks loads into branches) x 0.
-        constexpr int NB = 16 / RPW;
+        constexpr int NB = 32 / RPW;             // (32 slabs = the fp16 out-projection's plan at 900 rows: one batch, one latency)
         for (int z0 = 0; z0 < a.splits; z0 += NB) {
             float4 q[RPW][NB];
 #pragma unroll

@@ -540,6 +540,12 @@ def main():
                                             'the timed region (inside it the gather runs fused with the mixing kernel: roofline_fused)' % (PROFILE_EVERY, min(20, 2 * args.steps)))
                                            if fused_ms else 'HIP events around the sampler launches of every %dth of the eager steps run right after the timed region (which replays a captured graph)' % PROFILE_EVERY},
         }
+        # the tracer's view of the same kernels (no event records, no launch gaps): this command re-run now under rocprofv3 --kernel-trace --stats
+        kt = live_kernel_stats(args.config, args.gemm) if (world == 1 and not args.no_live_pmc) else None
+        if kt and 'msmv_fwd_kernel' in kt:
+            out['roofline']['avg_us_rocprof'] = kt['msmv_fwd_kernel']
+            if traffic:
+                out['roofline']['frac_rocprof'] = round(traffic / (kt['msmv_fwd_kernel'] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
         if fused_ms:
             # the launch the timed steps really run: gather + adaptive mixing in one kernel.  Algorithmic bytes = the sampler's
             # gather reads (no [B,Q,G,T*P,C] write any more) + the item's dynamic parameters + its mixed output
@@ -557,6 +563,8 @@ def main():
                                      'achieved_algorithmic': round(f_alg / (f_avg * 1e-3) / 1e9, 1), 'algorithmic_bytes_per_launch': f_alg,
                                      'launches': len(fused_ms), 'avg_us': round(f_avg * 1e3, 2),
                                      'event_sampling': 'HIP events around the fused launches of every %dth of the eager steps run right after the timed region (which replays a captured graph)' % PROFILE_EVERY}
+            if kt and 'adaptive_mixing_kernel' in kt:
+                out['roofline_fused']['avg_us_rocprof'] = kt['adaptive_mixing_kernel']
         # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event
         # measurement, priced against the f32-input MFMA peak; PMC MFMA-pipe utilisation from profiles/ when present
         if args.gemm != 'f32' and all(gemm_ms):
@@ -576,7 +584,6 @@ def main():
             out['gemm_gate'] = {'generator_us': round(g_us, 2), 'out_proj_us': round(o_us, 2), 'sum_us': round(g_us + o_us, 2),
                                 'measured': 'HIP events around the two launches of 10 eager steps right after the timed region (an upper bound: the records '
                                             'include the launch gap)', 'config': args.config}
-            kt = live_kernel_stats(args.config, args.gemm) if (world == 1 and not args.no_live_pmc) else None
             if kt and 'gemm_bf16s_gen3_kernel' in kt:
                 ok = kt.get('gemm_bf16s_out4_kernel', kt.get('gemm_bf16s_out3_kernel'))
                 out['gemm_gate'].update({'generator_us_rocprof': kt['gemm_bf16s_gen3_kernel'], 'out_proj_us_rocprof': ok,

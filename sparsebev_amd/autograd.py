@@ -67,10 +67,11 @@ def _transposed(w):
     instead of a 128 x 128-tile split-K launch + slab sum: 33 us), the strip kernel for grad_mixed (K = 256 -> 32 768 columns),
     the register-tile split-K kernel for the generator's input gradient (K = 32 768).  Costs one 2 x 33.5 MB transpose per
     big weight and optimizer step (12 us each)."""
-    # cached for leaf tensors only (parameters), keyed by id() with a weak reference to the tensor OBJECT beside it (a
-    # WeakKeyDictionary would compare tensors with ==): the cache never keeps a parameter alive, a recycled id never matches; temporaries (the packed q | k | v | tau weight)
-    # are transposed each time.  Writes through ``.data`` do not bump ``_version``: see invalidate_caches().
-    cacheable = w.is_leaf
+    # keyed by id() with a weak reference to the tensor OBJECT beside it (a WeakKeyDictionary would compare tensors with ==): the
+    # cache never keeps a tensor alive, a recycled id never matches.  Parameters live across steps; the packed q | k | v | tau and
+    # sampling weights are one tensor per decoder call shared by its layers (layer.packed_train_weights) and hit here from the second
+    # layer's backward on.  Writes through ``.data`` do not bump ``_version``: see invalidate_caches().
+    cacheable = True
     if cacheable:
         hit = _WT_CACHE.get(id(w))
         if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2].device == w.device:

@@ -483,6 +483,12 @@ int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, float* db, in
 int64_t sbev_layer_norm_bwd_workspace(int64_t M, int N);
 int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
                         float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, sbev_stream_t stream);
+/* sbev_bias_relu_bwd / sbev_layer_norm_bwd with the parameter gradients (db; dgamma, dbeta) ADDED to their buffers when accumulate != 0:
+ * a parameter shared by the layers of a decoder call collects its gradient in one buffer, no separate summation launches. */
+int sbev_bias_relu_bwd_acc(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
+                           float* workspace, int accumulate, sbev_stream_t stream);
+int sbev_layer_norm_bwd_acc(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                            float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, int accumulate, sbev_stream_t stream);
 
 /* sbev_linear3_ln_relu_f32 that also stores the Linear's pre-LayerNorm output `pre` [M,N] (may be NULL). */
 int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const float* w, const float* b,

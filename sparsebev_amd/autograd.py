@@ -88,6 +88,51 @@ def _transposed(w):
     return wt
 
 
+class Tap:
+    """Gradient collector of the parameters a decoder call's layers SHARE (the reference stacks ONE layer six times,
+    models/sparsebev_transformer.py:47-50): every backward node ADDS its parameter gradient to the parameter's one buffer in the
+    epilogue of the kernel that computes it (sbev_gemm_f32 accumulate, sbev_bias_relu_bwd_acc, sbev_layer_norm_bwd_acc) and returns
+    None to autograd; ``ParamTap`` -- one node per call, which autograd runs after every node holding its token -- hands the buffers
+    over.  Replaces 5 torch `add` launches per parameter and step (48 parameters: 240 of a step's launches), and
+    an ``AccumulateGrad`` hook (DDP) sees each parameter once, complete.  Like FeatureTap there is no forward-time counter: partial
+    losses and repeated backward passes work."""
+
+    def __init__(self, params):
+        self.ids = {id(p) for p in params if p.requires_grad}
+        self.bufs = {}
+        self.token = ParamTap.apply(self, *params) if self.ids else None
+        self._empty = None
+
+    def has(self, pid):
+        return self.token is not None and pid in self.ids
+
+    def token_grad(self):
+        if self._empty is None:
+            self._empty = self.token.new_empty(0)
+        return self._empty
+
+
+class ParamTap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tap, *params):
+        ctx.tap, ctx.pids = tap, [id(p) for p in params]
+        return params[0].new_empty(0)
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        bufs = ctx.tap.bufs
+        return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
+
+
+def _tap_gemm(tap, pid, *gemm_args):
+    """grad_W (+)= into the tapped parameter's buffer; gemm_args as for gemm() without out / ldc / accumulate"""
+    buf = tap.bufs.get(pid)
+    if buf is None:
+        tap.bufs[pid] = gemm(*gemm_args)
+    else:
+        gemm(*gemm_args, out=buf, ldc=gemm_args[7], accumulate=True)
+
+
 _F16_CACHE = {}     # (id(parameter), transposed) -> (weak reference, version, fragments, scales): pack_f16s_frags of W or W^T
 
 
@@ -131,17 +176,23 @@ def _linear_grads(gy2, x2, w, need_x, need_w):
     return gx, gw
 
 
-def _bias_relu_bwd(gy2, y2, want_db):
-    """(masked grad, bias grad): gy * (y > 0) when y2 is the ReLU output (else gy itself) and its column sums."""
+def _bias_relu_bwd(gy2, y2, want_db, tap=None, pid=None):
+    """(masked grad, bias grad): gy * (y > 0) when y2 is the ReLU output (else gy itself) and its column sums.  With a Tap holding the
+    bias (pid) the sums are added to its buffer and None is returned for them."""
     M, N = gy2.shape
     if y2 is None and not want_db:
         return gy2, None
     gz = torch.empty_like(gy2) if y2 is not None else None
-    db = torch.empty(N, device=gy2.device, dtype=torch.float32) if want_db else None
+    tapped = want_db and tap is not None and tap.has(pid)
+    acc = tapped and pid in tap.bufs
+    db = (tap.bufs[pid] if acc else torch.empty(N, device=gy2.device, dtype=torch.float32)) if want_db else None
     lib = _lib.load()
     ws = torch.empty(max(lib.sbev_colsum_workspace(M, N) // 4, 1), device=gy2.device, dtype=torch.float32) if want_db else None
-    st = lib.sbev_bias_relu_bwd(_p(gy2), _p(y2), _p(gz), _p(db), M, N, N, _p(ws), _stream())
+    st = lib.sbev_bias_relu_bwd_acc(_p(gy2), _p(y2), _p(gz), _p(db), M, N, N, _p(ws), int(acc), _stream())
     _lib.check(st, 'sbev_bias_relu_bwd')
+    if tapped:
+        tap.bufs[pid] = db
+        db = None
     return (gz if gz is not None else gy2), db
 
 
@@ -149,7 +200,7 @@ class Linear(torch.autograd.Function):
     """y = act(x W^T + b) (+ residual): forward = dense.linear (gemm.hip), backward = gemm_any.hip + bias_relu_bwd."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu, residual):
+    def forward(ctx, x, w, b, relu, residual, tap=None, token=None):
         # the ReLU mask is read off the output, which a residual would shift; the decoder layer never combines the two
         if relu and residual is not None:
             raise RuntimeError('autograd.Linear: relu together with a residual is not supported')
@@ -158,20 +209,28 @@ class Linear(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_b = b is not None
+        ctx.tap, ctx.w_id, ctx.b_id = tap, id(w), id(b)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         N, K = w.shape
+        tap = ctx.tap
         gy2 = _c(gy).reshape(-1, N)
         x2 = _c(x).reshape(-1, K)
-        gz, db = _bias_relu_bwd(gy2, y.reshape(-1, N) if ctx.relu else None, ctx.has_b and ctx.needs_input_grad[2])
-        gx, gw = _linear_grads(gz, x2, _c(w), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return (gx.reshape(x.shape) if gx is not None else None, gw, db, None, gy if ctx.has_res and ctx.needs_input_grad[4] else None)
+        gz, db = _bias_relu_bwd(gy2, y.reshape(-1, N) if ctx.relu else None, ctx.has_b and ctx.needs_input_grad[2], tap, ctx.b_id)
+        w_tapped = ctx.needs_input_grad[1] and tap is not None and tap.has(ctx.w_id)
+        gx, gw = _linear_grads(gz, x2, _c(w), ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not w_tapped)
+        if w_tapped:
+            _tap_gemm(tap, ctx.w_id, gz, True, N, x2, True, K, N, K, gz.shape[0])
+        return (gx.reshape(x.shape) if gx is not None else None, gw, db, None, gy if ctx.has_res and ctx.needs_input_grad[4] else None,
+                None, tap.token_grad() if (tap is not None and tap.token is not None) else None)
 
 
-def linear(x, w, b, relu=False, residual=None):
+def linear(x, w, b, relu=False, residual=None, tap=None):
+    if tap is not None and tap.token is not None:
+        return Linear.apply(x, w, b, relu, residual, tap, tap.token)
     return Linear.apply(x, w, b, relu, residual)
 
 
@@ -179,11 +238,12 @@ class LayerNorm(torch.autograd.Function):
     """relu?(LayerNorm(x)) (+ add_after): forward = dense.layer_norm, backward = sbev_layer_norm_bwd."""
 
     @staticmethod
-    def forward(ctx, x, g, b, relu, add_after):
+    def forward(ctx, x, g, b, relu, add_after, tap=None, token=None):
         y = dense.layer_norm(x, g, b, relu=relu, add_after=add_after)
         ctx.relu = bool(relu)
         ctx.has_add = add_after is not None
         ctx.save_for_backward(x, g, b)
+        ctx.tap, ctx.g_id, ctx.b_id = tap, id(g), id(b)
         return y
 
     @staticmethod
@@ -193,15 +253,24 @@ class LayerNorm(torch.autograd.Function):
         gy2, x2 = _c(gy).reshape(-1, N), _c(x).reshape(-1, N)
         M = x2.shape[0]
         gx = torch.empty_like(x2)
-        dg, dbeta = torch.empty_like(g), torch.empty_like(b)
+        tap = ctx.tap
+        tapped = tap is not None and tap.has(ctx.g_id) and tap.has(ctx.b_id)
+        acc = tapped and ctx.g_id in tap.bufs and ctx.b_id in tap.bufs
+        dg, dbeta = (tap.bufs[ctx.g_id], tap.bufs[ctx.b_id]) if acc else (torch.empty_like(g), torch.empty_like(b))
         stats = torch.empty(max(_lib.load().sbev_layer_norm_bwd_workspace(M, N) // 4, 1), device=x.device, dtype=torch.float32)
-        st = _lib.load().sbev_layer_norm_bwd(_p(gy2), _p(x2), _p(_c(g)), _p(_c(b)), _EPS, int(ctx.relu), _p(gx), _p(dg), _p(dbeta),
-                                             _p(stats), M, N, _stream())
+        st = _lib.load().sbev_layer_norm_bwd_acc(_p(gy2), _p(x2), _p(_c(g)), _p(_c(b)), _EPS, int(ctx.relu), _p(gx), _p(dg), _p(dbeta),
+                                                 _p(stats), M, N, int(acc), _stream())
         _lib.check(st, 'sbev_layer_norm_bwd')
-        return gx.reshape(x.shape), dg, dbeta, None, gy if ctx.has_add and ctx.needs_input_grad[4] else None
+        if tapped:
+            tap.bufs[ctx.g_id], tap.bufs[ctx.b_id] = dg, dbeta
+            dg = dbeta = None
+        return (gx.reshape(x.shape), dg, dbeta, None, gy if ctx.has_add and ctx.needs_input_grad[4] else None,
+                None, tap.token_grad() if (tap is not None and tap.token is not None) else None)
 
 
-def layer_norm(x, g, b, relu=False, add_after=None):
+def layer_norm(x, g, b, relu=False, add_after=None, tap=None):
+    if tap is not None and tap.token is not None:
+        return LayerNorm.apply(x, g, b, relu, add_after, tap, tap.token)
     return LayerNorm.apply(x, g, b, relu, add_after)
 
 
@@ -209,7 +278,8 @@ class Linear3LnRelu(torch.autograd.Function):
     """relu(LayerNorm(bbox[..., :3] W^T + b)) -- position_encoder[0..2] (models/sparsebev_transformer.py:116-119)."""
 
     @staticmethod
-    def forward(ctx, bbox, w, b, lnw, lnb):
+    def forward(ctx, bbox, w, b, lnw, lnb, tap=None, token=None):
+        ctx.tap, ctx.pids = tap, (id(w), id(b), id(lnw), id(lnb))
         N = w.shape[0]
         ld = bbox.shape[-1]
         x2 = _c(bbox).reshape(-1, ld)
@@ -229,19 +299,30 @@ class Linear3LnRelu(torch.autograd.Function):
         M, ld = x2.shape
         gy2 = _c(gy).reshape(-1, N)
         gpre = torch.empty_like(pre)
-        dg, dbeta = torch.empty_like(lnw), torch.empty_like(lnb)
+        tap = ctx.tap
+        w_id, b_id, g_id, be_id = ctx.pids
+        ln_tapped = tap is not None and tap.has(g_id) and tap.has(be_id)
+        acc = ln_tapped and g_id in tap.bufs and be_id in tap.bufs
+        dg, dbeta = (tap.bufs[g_id], tap.bufs[be_id]) if acc else (torch.empty_like(lnw), torch.empty_like(lnb))
         lib = _lib.load()
         stats = torch.empty(max(lib.sbev_layer_norm_bwd_workspace(M, N) // 4, 1), device=gy.device, dtype=torch.float32)
-        _lib.check(lib.sbev_layer_norm_bwd(_p(gy2), _p(pre), _p(_c(lnw)), _p(_c(lnb)), _EPS, 1, _p(gpre), _p(dg), _p(dbeta), _p(stats),
-                                           M, N, _stream()), 'sbev_layer_norm_bwd')
-        _, db = _bias_relu_bwd(gpre, None, True)
-        gw = gemm(gpre, True, N, x2, True, ld, N, 3, M)                    # grad_pre^T [N,M] . bbox[:, :3]
+        _lib.check(lib.sbev_layer_norm_bwd_acc(_p(gy2), _p(pre), _p(_c(lnw)), _p(_c(lnb)), _EPS, 1, _p(gpre), _p(dg), _p(dbeta), _p(stats),
+                                               M, N, int(acc), _stream()), 'sbev_layer_norm_bwd')
+        if ln_tapped:
+            tap.bufs[g_id], tap.bufs[be_id] = dg, dbeta
+            dg = dbeta = None
+        _, db = _bias_relu_bwd(gpre, None, True, tap, b_id)
+        if tap is not None and tap.has(w_id):
+            _tap_gemm(tap, w_id, gpre, True, N, x2, True, ld, N, 3, M)
+            gw = None
+        else:
+            gw = gemm(gpre, True, N, x2, True, ld, N, 3, M)                # grad_pre^T [N,M] . bbox[:, :3]
         gb = None
         if ctx.needs_input_grad[0]:
             gb = torch.zeros(M, ld, device=gy.device, dtype=torch.float32)
             gemm(gpre, False, N, _c(w), True, 3, M, 3, N, out=gb, ldc=ld)  # grad_pre . W -> columns 0..2 of the box grad
             gb = gb.reshape(ctx.bshape)
-        return gb, gw, db, dg, dbeta
+        return gb, gw, db, dg, dbeta, None, tap.token_grad() if (tap is not None and tap.token is not None) else None
 
 
 class SasaCore(torch.autograd.Function):
@@ -290,7 +371,8 @@ class AdaptiveMixing(torch.autograd.Function):
     parameters [B*Q, 32768] and the mixed activations [B*Q, 32768] and saves the two re-runs (183 us per layer)."""
 
     @staticmethod
-    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points, recompute, gemm_f16=False):
+    def forward(ctx, x, query, pg_w, pg_b, op_w, op_b, out_points, recompute, gemm_f16=False, tap=None, token=None):
+        ctx.tap, ctx.pids = tap, (id(pg_w), id(pg_b), id(op_w), id(op_b))
         B, Q, G, Pin, C = x.shape
         D = query.shape[-1]
         BQ = B * Q
@@ -343,13 +425,21 @@ class AdaptiveMixing(torch.autograd.Function):
             mixed = torch.empty(BQ, G * ctx.out_points * C, device=x.device, dtype=torch.float32)
             _lib.check(lib.sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, ctx.out_points, _EPS, _stream()),
                        'sbev_adaptive_mixing_f32')
+        tap = ctx.tap
+        pgw_id, pgb_id, opw_id, opb_id = ctx.pids
+        opw_tapped = tap is not None and tap.has(opw_id)
+        pgw_tapped = tap is not None and tap.has(pgw_id)
         # out-projection backward
-        _, gb_op = _bias_relu_bwd(gy2, None, True)
+        _, gb_op = _bias_relu_bwd(gy2, None, True, tap, opb_id)
         if ctx.f16:      # grad_mixed = grad_y . W_op: generator-shaped (K = 256 -> 32768 columns) with the fragments of W_op^T
             gmixed = dense.linear_f16s_gen(gy2, *_f16_frags(op_w, transposed=True), None)
-            _, gw_op = _linear_grads(gy2, mixed, _c(op_w), False, True)
+            gw_op = None
+            if not opw_tapped:
+                _, gw_op = _linear_grads(gy2, mixed, _c(op_w), False, True)
         else:
-            gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, True)
+            gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, not opw_tapped)
+        if opw_tapped:
+            _tap_gemm(tap, opw_id, gy2, True, D, mixed, True, mixed.shape[1], D, mixed.shape[1], BQ)
         del mixed
         # mixing core backward
         gx = torch.empty_like(x)
@@ -358,11 +448,16 @@ class AdaptiveMixing(torch.autograd.Function):
                                                     _EPS, _stream()), 'sbev_adaptive_mixing_bwd_f32')
         del gmixed, params
         # parameter generator backward
-        _, gb_pg = _bias_relu_bwd(gparams, None, True)
-        _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
+        _, gb_pg = _bias_relu_bwd(gparams, None, True, tap, pgb_id)
+        gw_pg = None
+        if pgw_tapped:
+            _tap_gemm(tap, pgw_id, gparams, True, gparams.shape[1], q2, True, D, gparams.shape[1], D, BQ)
+        else:
+            _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
         # grad_query = grad_y (the `query +` residual) + grad_params . W_pg: the forward split-K Linear with W_pg^T, residual fused
         gq = dense.linear(gparams, _transposed(pg_w), None, residual=gy2).reshape(query.shape)
-        return gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None, None
+        return (gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None, None, None,
+                tap.token_grad() if (tap is not None and tap.token is not None) else None)
 
 
 class FeatureTap(torch.autograd.Function):

@@ -23,6 +23,7 @@ struct ColArgs {
     float* part;         // [chunks, N] or null (no column sums wanted)
     long long M, ld;
     int N;
+    int accumulate;      // column sums are ADDED to db (the shared parameters' gradients of a decoder call: autograd.ParamTap)
 };
 
 __global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const ColArgs a) {
@@ -83,20 +84,20 @@ __global__ __launch_bounds__(1024) void bias_relu_bwd_onepass_kernel(const ColAr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][c];
-        db[n] = t;
+        db[n] = a.accumulate ? db[n] + t : t;
     }
 }
 
 // out[k][n] = sum_chunks part[k][chunk][n]  for K stacked partial sets (K = 1: bias; K = 2: dgamma, dbeta)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                                        int chunks, int N) {
+                                                        int chunks, int N, int accumulate = 0) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float* out = blockIdx.y == 0 ? out0 : out1;
     const float* p = part + (long long)blockIdx.y * chunks * N;
     float s = 0.f;
     for (int c = 0; c < chunks; ++c) s += p[(long long)c * N + n];
-    out[n] = s;
+    out[n] = accumulate ? out[n] + s : s;
 }
 
 // ---- LayerNorm backward ---------------------------------------------------------------------------------------------
@@ -116,6 +117,7 @@ struct LnBwdArgs {
     long long M;
     int N, relu;
     float eps;
+    int accumulate;      // dgamma / dbeta are added to
 };
 
 __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const LnBwdArgs a) {
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(1024) void ln_bwd_cols_onepass_kernel(const LnBwdAr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[rg][k][c];
-        (rg == 0 ? a.dgamma : a.dbeta)[n] = t;
+        float* o = (rg == 0 ? a.dgamma : a.dbeta) + n;
+        *o = a.accumulate ? *o + t : t;
     }
 }
 
@@ -470,30 +473,40 @@ extern "C" int64_t sbev_colsum_workspace(int64_t M, int N) {
     return ((M + ROW_CHUNK - 1) / ROW_CHUNK) * (int64_t)N * (int64_t)sizeof(float);
 }
 
-extern "C" int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
-                                  float* workspace, sbev_stream_t stream) {
+static int bias_relu_bwd_impl(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
+                              float* workspace, int accumulate, sbev_stream_t stream) {
     SBEV_REQUIRE(M >= 0 && N >= 0 && ld >= N, "sbev_bias_relu_bwd: bad sizes");
     if (N == 0) return SBEV_OK;
     SBEV_REQUIRE(dY != nullptr && (!db || workspace), "sbev_bias_relu_bwd: null grad / workspace");
     const int chunks = (int)((M + ROW_CHUNK - 1) / ROW_CHUNK);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (db && M > 0 && M <= ONE_PASS_ROWS) {
-        ColArgs a{dY, Y, dZ, nullptr, M, ld, N};
+        ColArgs a{dY, Y, dZ, nullptr, M, ld, N, accumulate};
         hipLaunchKernelGGL(bias_relu_bwd_onepass_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s, a, db);
         return sbev::check_launch("sbev_bias_relu_bwd");
     }
     if (chunks > 0) {
         SBEV_REQUIRE(chunks <= 65535, "sbev_bias_relu_bwd: too many rows");
-        ColArgs a{dY, Y, dZ, db ? workspace : nullptr, M, ld, N};
+        ColArgs a{dY, Y, dZ, db ? workspace : nullptr, M, ld, N, 0};
         hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, s, a);
         int st = sbev::check_launch("sbev_bias_relu_bwd");
         if (st != SBEV_OK) return st;
     }
     if (db) {
-        hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((N + 255) / 256), 1), dim3(256), 0, s, workspace, db, db, chunks, N);
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((N + 255) / 256), 1), dim3(256), 0, s, workspace, db, db, chunks, N, accumulate);
         return sbev::check_launch("sbev_bias_relu_bwd (sum)");
     }
     return SBEV_OK;
+}
+
+extern "C" int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
+                                  float* workspace, sbev_stream_t stream) {
+    return bias_relu_bwd_impl(dY, Y, dZ, db, M, N, ld, workspace, 0, stream);
+}
+// the same with the column sums ADDED to db (accumulate != 0): one parameter used by several layers of a call
+extern "C" int sbev_bias_relu_bwd_acc(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
+                                      float* workspace, int accumulate, sbev_stream_t stream) {
+    return bias_relu_bwd_impl(dY, Y, dZ, db, M, N, ld, workspace, accumulate, stream);
 }
 
 extern "C" int64_t sbev_layer_norm_bwd_workspace(int64_t M, int N) {
@@ -501,11 +514,11 @@ extern "C" int64_t sbev_layer_norm_bwd_workspace(int64_t M, int N) {
     return (2 * M + 2 * ((M + ROW_CHUNK - 1) / ROW_CHUNK) * (int64_t)N) * (int64_t)sizeof(float);
 }
 
-extern "C" int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
-                                   float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, sbev_stream_t stream) {
+static int layer_norm_bwd_impl(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                               float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, int accumulate, sbev_stream_t stream) {
     SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024, "sbev_layer_norm_bwd: N=%d must be a multiple of 4 in 4..1024", N);
     SBEV_REQUIRE(dY && X && gamma && dX && dgamma && dbeta && workspace && (!relu || beta), "sbev_layer_norm_bwd: null pointer");
-    LnBwdArgs a{dY, X, gamma, beta, dX, workspace, dgamma, dbeta, M, N, relu, eps};
+    LnBwdArgs a{dY, X, gamma, beta, dX, workspace, dgamma, dbeta, M, N, relu, eps, accumulate};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int chunks = (int)((M + ROW_CHUNK - 1) / ROW_CHUNK);
     SBEV_REQUIRE(chunks <= 65535, "sbev_layer_norm_bwd: too many rows");
@@ -521,8 +534,19 @@ extern "C" int sbev_layer_norm_bwd(const float* dY, const float* X, const float*
         st = sbev::check_launch("sbev_layer_norm_bwd (columns)");
         if (st != SBEV_OK) return st;
     }
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, workspace + 2 * M, dgamma, dbeta, chunks, N);
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((N + 255) / 256), 2), dim3(256), 0, s, workspace + 2 * M, dgamma, dbeta, chunks, N, accumulate);
     return sbev::check_launch("sbev_layer_norm_bwd (sum)");
+}
+
+extern "C" int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                                   float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, sbev_stream_t stream) {
+    return layer_norm_bwd_impl(dY, X, gamma, beta, eps, relu, dX, dgamma, dbeta, workspace, M, N, 0, stream);
+}
+// the same with dgamma / dbeta ADDED to (accumulate != 0)
+extern "C" int sbev_layer_norm_bwd_acc(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                                       float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, int accumulate,
+                                       sbev_stream_t stream) {
+    return layer_norm_bwd_impl(dY, X, gamma, beta, eps, relu, dX, dgamma, dbeta, workspace, M, N, accumulate, stream);
 }
 
 extern "C" int sbev_refine_bbox_bwd(const float* grad_out, const float* out, const float* query_bbox, const float* vel_div,

@@ -215,7 +215,7 @@ class SparseBEVTransformerDecoderLayer(_Base):
         samp_b = torch.cat([smp.sampling_offset.bias, smp.scale_weights.bias], 0)
         return in_w, in_b, samp_w, samp_b
 
-    def forward_train(self, query_bbox, query_feat, feats, attn_mask, ctx, feat_token=None, packed=None):
+    def forward_train(self, query_bbox, query_feat, feats, attn_mask, ctx, feat_token=None, packed=None, tap=None):
         """The same layer with every op as a differentiable node (sparsebev_amd.autograd: HIP forward + HIP backward),
         unfused where a fused inference launch would hide an activation the backward needs.  Dropout (attention
         probabilities 0.1, the two FFN dropouts 0.1 -- mmcv defaults the reference's layer is built with,
@@ -224,39 +224,40 @@ class SparseBEVTransformerDecoderLayer(_Base):
         pe, sa, smp, mix = self.position_encoder, self.self_attn, self.sampling, self.mixing
         att = sa.attention.attn
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (sa.attn_drop > 0 or self.ffn_drop > 0) else 0
-        pos = AG.Linear3LnRelu.apply(query_bbox, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias)
-        x = AG.layer_norm(AG.linear(pos, pe[3].weight, pe[3].bias), pe[4].weight, pe[4].bias, relu=True, add_after=query_feat)
+        tk = (tap, tap.token) if (tap is not None and tap.token is not None) else ()
+        pos = AG.Linear3LnRelu.apply(query_bbox, pe[0].weight, pe[0].bias, pe[1].weight, pe[1].bias, *tk)
+        x = AG.layer_norm(AG.linear(pos, pe[3].weight, pe[3].bias, tap=tap), pe[4].weight, pe[4].bias, relu=True, add_after=query_feat, tap=tap)
         # self attention (+ identity), norm1
         D, H = self.embed_dims, sa.num_heads
         in_w, in_b, samp_w, samp_b = packed if packed is not None else self.packed_train_weights()
-        qkvt = AG.linear(x, in_w, in_b)
+        qkvt = AG.linear(x, in_w, in_b, tap=tap)
         mask = attn_mask.to(device=x.device, dtype=torch.uint8).contiguous() if attn_mask is not None else None
         a = AG.SasaCore.apply(qkvt, query_bbox, mask, tuple(sa.pc_range), H, sa.attn_drop, seed)
-        x = AG.layer_norm(AG.linear(a, att.out_proj.weight, att.out_proj.bias, residual=x), self.norm1.weight, self.norm1.bias)
+        x = AG.layer_norm(AG.linear(a, att.out_proj.weight, att.out_proj.bias, residual=x, tap=tap), self.norm1.weight, self.norm1.bias, tap=tap)
         # adaptive spatio-temporal sampling
-        both = AG.linear(x, samp_w, samp_b)
+        both = AG.linear(x, samp_w, samp_b, tap=tap)
         cfg = (smp.num_frames, smp.num_groups, smp.num_points, smp.num_levels, tuple(smp.pc_range))
         sampled = AG.Sampling.apply(query_bbox, both, feats, ctx, cfg, feat_token)     # feat_token: AG.feature_token (None: frozen features)
         # adaptive mixing (+ identity), norm2
         x = AG.layer_norm(AG.AdaptiveMixing.apply(sampled, x, mix.parameter_generator.weight, mix.parameter_generator.bias,
                                                   mix.out_proj.weight, mix.out_proj.bias, mix.out_points, self.recompute_mixing,
-                                                  getattr(self, 'train_gemm_f16', False)),
-                          self.norm2.weight, self.norm2.bias)
+                                                  getattr(self, 'train_gemm_f16', False), *tk),
+                          self.norm2.weight, self.norm2.bias, tap=tap)
         # FFN (+ identity), norm3
         f0, f1 = self.ffn.layers[0][0], self.ffn.layers[1]
-        h = AG.dropout(AG.linear(x, f0.weight, f0.bias, relu=True), self.ffn_drop, seed + 1)
+        h = AG.dropout(AG.linear(x, f0.weight, f0.bias, relu=True, tap=tap), self.ffn_drop, seed + 1)
         if self.ffn_drop > 0:
             # the torch add below is the `identity +` of mmcv's FFN around a dropped-out branch (autograd plumbing)
-            x = AG.layer_norm(x + AG.dropout(AG.linear(h, f1.weight, f1.bias), self.ffn_drop, seed + 2), self.norm3.weight, self.norm3.bias)
+            x = AG.layer_norm(x + AG.dropout(AG.linear(h, f1.weight, f1.bias, tap=tap), self.ffn_drop, seed + 2), self.norm3.weight, self.norm3.bias, tap=tap)
         else:
-            x = AG.layer_norm(AG.linear(h, f1.weight, f1.bias, residual=x), self.norm3.weight, self.norm3.bias)
+            x = AG.layer_norm(AG.linear(h, f1.weight, f1.bias, residual=x, tap=tap), self.norm3.weight, self.norm3.bias, tap=tap)
         cb, rb = self.cls_branch, self.reg_branch
-        c = AG.layer_norm(AG.linear(x, cb[0].weight, cb[0].bias), cb[1].weight, cb[1].bias, relu=True)
-        c = AG.layer_norm(AG.linear(c, cb[3].weight, cb[3].bias), cb[4].weight, cb[4].bias, relu=True)
-        cls_score = AG.linear(c, cb[6].weight, cb[6].bias)
-        r = AG.linear(x, rb[0].weight, rb[0].bias, relu=True)
-        r = AG.linear(r, rb[2].weight, rb[2].bias, relu=True)
-        reg = AG.linear(r, rb[4].weight, rb[4].bias)
+        c = AG.layer_norm(AG.linear(x, cb[0].weight, cb[0].bias, tap=tap), cb[1].weight, cb[1].bias, relu=True, tap=tap)
+        c = AG.layer_norm(AG.linear(c, cb[3].weight, cb[3].bias, tap=tap), cb[4].weight, cb[4].bias, relu=True, tap=tap)
+        cls_score = AG.linear(c, cb[6].weight, cb[6].bias, tap=tap)
+        r = AG.linear(x, rb[0].weight, rb[0].bias, relu=True, tap=tap)
+        r = AG.linear(r, rb[2].weight, rb[2].bias, relu=True, tap=tap)
+        reg = AG.linear(r, rb[4].weight, rb[4].bias, tap=tap)
         bbox_pred = AG.RefineBbox.apply(query_bbox, reg, ctx.vel_div)
         return x, cls_score, bbox_pred
 
@@ -431,6 +432,7 @@ class SparseBEVTransformerDecoder(_Base):
         self.overlap = False        # opt-in two-stream fork/join in the C++ runtime (1: generator GEMM || sampling chain, 2: only the
                                     # classification branch aside): measured -3 % samples/s at c2 -- the big kernels fill every CU, and
                                     # the forked path cannot use the grouped branch launches
+        self.tap_param_grads = os.environ.get('SBEV_NO_PARAM_TAP') != '1'     # training: parameter gradients collected per call (autograd.Tap)
         self.static_graph = os.environ.get('SBEV_NO_GRAPH') != '1'      # replay a captured hipGraph for repeated identical (pointer-wise) calls
         # the two big mixing GEMMs (runtime.GEMM_MODES).  Default 'f16x3': fp32 operands as scaled fp16 hi + lo images, 3 products,
         # fp32 accumulation on the 16-bit matrix core -- fp32-class: max and rms error against fp64 BELOW the exact f32-input MFMA
@@ -530,8 +532,10 @@ class SparseBEVTransformerDecoder(_Base):
         try:
             cls_scores, bbox_preds = [], []
             packed = layer.packed_train_weights()
+            # the layers share their parameters: ONE gradient buffer per parameter and call, added to in the kernels' epilogues (AG.Tap)
+            tap = AG.Tap([p for p in layer.parameters()]) if self.tap_param_grads else None
             for i in range(self.num_layers):
-                query_feat, cls_score, bbox_pred = layer.forward_train(query_bbox, query_feat, feats, attn_mask, ctx, token, packed)
+                query_feat, cls_score, bbox_pred = layer.forward_train(query_bbox, query_feat, feats, attn_mask, ctx, token, packed, tap)
                 query_bbox = bbox_pred.detach()
                 cls_scores.append(cls_score)
                 bbox_preds.append(bbox_pred)

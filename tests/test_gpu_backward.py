@@ -388,6 +388,43 @@ def test_feature_gradient_with_partial_layer_loss_and_repeated_backward():
 
 
 @torch.enable_grad()
+def test_shared_parameter_gradients_collected_per_call_equal_autograd_accumulation():
+    """autograd.Tap / ParamTap (round 3): the parameters the layers share collect their gradient in one buffer per call, added to in the
+    kernels' epilogues, and reach ``.grad`` through ONE node -- the same numbers as autograd's own accumulation (SBEV tap off) to
+    summation-order rounding; every parameter gets a gradient; a loss on layer 0 only equals the 1-layer module's gradients; two backward
+    passes under retain_graph give twice the gradient."""
+    B, Q, T, L = 1, 36, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=26)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=27)]
+
+    def run(num_layers, tap, loss_of=lambda c, b: c.sum() + b.pow(2).sum(), passes=1):
+        model = build(T, L, 25, num_layers).eval()
+        model.decoder.tap_param_grads = tap
+        cls, box = model(bbox, feat.clone().requires_grad_(True), list(feats), None, copy.deepcopy(metas))
+        loss = loss_of(cls, box)
+        for i in range(passes):
+            loss.backward(retain_graph=i + 1 < passes)
+        return {n: p.grad for n, p in model.named_parameters()}
+
+    a, b = run(3, True), run(3, False)
+    assert all(g is not None for g in a.values()) and set(a) == set(b)
+    for n in a:
+        assert (a[n] - b[n]).abs().max() <= 2e-5 * max(b[n].abs().max().item(), 1e-3), n
+    first = lambda c, bx: c[0].sum() + bx[0].pow(2).sum()
+    part, one = run(2, True, first), run(1, True, first)
+    for n in part:
+        if one[n] is None:
+            assert part[n] is None or float(part[n].abs().max()) == 0.0, n
+        else:
+            assert (part[n] - one[n]).abs().max() <= 2e-5 * max(one[n].abs().max().item(), 1e-3), n
+    twice = run(3, True, passes=2)
+    for n in a:
+        assert (twice[n] - 2 * a[n]).abs().max() <= 2e-5 * max(a[n].abs().max().item(), 1e-3), n
+
+
+@torch.enable_grad()
 def test_eval_mode_with_grad_is_differentiable_and_matches_the_inference_runtime():
     """Grad enabled + something requires grad -> the module is differentiable like the reference's (no silent detached
     outputs); its forward values equal the fused inference runtime's to rounding; under no_grad the runtime runs."""

@@ -470,6 +470,13 @@ int64_t sbev_gemm_f32_workspace(int64_t M, int N, int64_t K);
 int sbev_gemm_f32(const float* A, int a_kmajor, int64_t lda, const float* B, int b_kmajor, int64_t ldb,
                   float* C, int64_t ldc, int64_t M, int N, int64_t K, int accumulate,
                   float* workspace, sbev_stream_t stream);
+/* The same reduction over up to 8 operand pairs of identical layout and shape in ONE launch (+ the slab sum): C (+)= sum_s A_s B_s --
+ * the weight gradient of a Linear shared by several decoder layers.  A / B: host arrays of nseg device pointers;
+ * workspace: sbev_gemm_f32_multi_workspace(M, N, K, nseg) bytes (always needed).  Bit-reproducible. */
+int64_t sbev_gemm_f32_multi_workspace(int64_t M, int N, int64_t K, int nseg);
+int sbev_gemm_f32_multi(const float* const* A, int a_kmajor, int64_t lda, const float* const* B, int b_kmajor, int64_t ldb,
+                        int nseg, float* C, int64_t ldc, int64_t M, int N, int64_t K, int accumulate,
+                        float* workspace, sbev_stream_t stream);
 
 /* dZ = dY * (Y > 0) (Y = a ReLU's forward output, NULL: dZ = dY; dZ may be NULL or alias dY) and db[n] = sum_m dZ[m,n]
  * (NULL: skipped).  Rows have stride ld.  workspace: sbev_colsum_workspace(M, N) bytes (needed when db != NULL);

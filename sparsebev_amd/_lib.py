@@ -137,6 +137,9 @@ SIGNATURES = {
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
     'sbev_colsum_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
     'sbev_layer_norm_bwd_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int]),
+    'sbev_gemm_f32_multi_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
+    'sbev_gemm_f32_multi': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int64, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int64,
+                                           ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
     'sbev_bias_relu_bwd_acc': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp]),
     'sbev_layer_norm_bwd_acc': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp, _vp,
                                                ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),

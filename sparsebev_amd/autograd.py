@@ -100,6 +100,7 @@ class Tap:
     def __init__(self, params):
         self.ids = {id(p) for p in params if p.requires_grad}
         self.bufs = {}
+        self.deferred = {}          # id(weight) -> [(grad_y [M, N], x [M, K]), ...]: small weight gradients, reduced in one launch at the end
         self.token = ParamTap.apply(self, *params) if self.ids else None
         self._empty = None
 
@@ -120,12 +121,45 @@ class ParamTap(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gtoken):
-        bufs = ctx.tap.bufs
+        tap = ctx.tap
+        for pid, segs in tap.deferred.items():
+            _multi_wgrad(tap, pid, segs)
+        tap.deferred = {}
+        bufs = tap.bufs
         return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
 
 
+def _multi_wgrad(tap, pid, segs):
+    """grad_W [N, K] = sum over the layers' (grad_y, x) pairs of grad_y^T . x -- one sbev_gemm_f32_multi launch per <= 8 pairs"""
+    lib = _lib.load()
+    gy0, x0 = segs[0]
+    M, N = gy0.shape
+    K = x0.shape[1]
+    for s0 in range(0, len(segs), 8):
+        part = segs[s0:s0 + 8]
+        n = len(part)
+        buf = tap.bufs.get(pid)
+        acc = buf is not None
+        if buf is None:
+            buf = torch.empty(N, K, device=gy0.device, dtype=torch.float32)
+        A = (ctypes.c_void_p * n)(*[g.data_ptr() for g, _ in part])
+        Bp = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in part])
+        ws = torch.empty(max(lib.sbev_gemm_f32_multi_workspace(N, K, M, n) // 4, 1), device=gy0.device, dtype=torch.float32)
+        st = lib.sbev_gemm_f32_multi(A, 1, N, Bp, 1, K, n, _p(buf), K, N, K, M, int(acc), _p(ws), _stream())
+        _lib.check(st, 'sbev_gemm_f32_multi')
+        tap.bufs[pid] = buf
+
+
+_DEFER_MAX = 1 << 18      # weight gradients up to 512 x 512 wait for the end of the call (their operands are < 2 MB per layer)
+
+
 def _tap_gemm(tap, pid, *gemm_args):
-    """grad_W (+)= into the tapped parameter's buffer; gemm_args as for gemm() without out / ldc / accumulate"""
+    """grad_W (+)= into the tapped parameter's buffer; gemm_args as for gemm() without out / ldc / accumulate.  Small gradients
+    (grad_y^T . x with both operands k-major) are only recorded here: ParamTap reduces all layers' pairs in one launch."""
+    A, a_km, lda, B, b_km, ldb, M, N, K = gemm_args
+    if a_km and b_km and M * N <= _DEFER_MAX and lda == M and ldb == N and K % 4 == 0 and K == A.shape[0] and (not tap.deferred.get(pid) or tap.deferred[pid][0][0].shape == A.shape):
+        tap.deferred.setdefault(pid, []).append((A, B))
+        return
     buf = tap.bufs.get(pid)
     if buf is None:
         tap.bufs[pid] = gemm(*gemm_args)

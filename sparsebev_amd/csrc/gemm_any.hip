@@ -37,6 +37,11 @@ struct AnyArgs {
     long long lda, ldb, ldc;
     long long k_per_split;   // multiple of TK
     int accumulate;
+    // multi-segment reduction (sbev_gemm_f32_multi): C = sum over segments of A_s B_s, every segment with the same layout / M / N / K;
+    // split z = segment * splits_per_seg + sub-split of that segment's K range.  nseg = 0: the single (A, B) above.
+    int nseg, splits_per_seg;
+    const float* Aseg[8];
+    const float* Bseg[8];
 };
 
 // Stage one operand tile (128 "outer" x 32 k) from global memory into registers.  OUTER = rows of C this operand indexes
@@ -107,7 +112,16 @@ __global__ __launch_bounds__(256, 2) void gemm_any_kernel(const AnyArgs a) {
     const unsigned tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const long long m0 = (long long)tm * TM;
     const long long n0 = (long long)tn * TN;
-    const long long kbeg = SPLIT ? (long long)blockIdx.z * a.k_per_split : 0;
+    const float* Aop = a.A;
+    const float* Bop = a.B;
+    unsigned zk = blockIdx.z;
+    if (SPLIT && a.nseg > 0) {
+        const unsigned seg = blockIdx.z / (unsigned)a.splits_per_seg;
+        zk = blockIdx.z - seg * (unsigned)a.splits_per_seg;
+        Aop = a.Aseg[seg];
+        Bop = a.Bseg[seg];
+    }
+    const long long kbeg = SPLIT ? (long long)zk * a.k_per_split : 0;
     const long long kend = SPLIT ? (kbeg + a.k_per_split < a.K ? kbeg + a.k_per_split : a.K) : a.K;
     const int nk = (int)((kend - kbeg + TK - 1) / TK);
 
@@ -121,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void gemm_any_kernel(const AnyArgs a) {
 
     float4 ra[4], rb[4];
     if (nk > 0) {
-        stage_load<AK, VEC>(a.A, a.lda, a.M, kend, m0, kbeg, tid, ra);
-        stage_load<BKM, VEC>(a.B, a.ldb, a.N, kend, n0, kbeg, tid, rb);
+        stage_load<AK, VEC>(Aop, a.lda, a.M, kend, m0, kbeg, tid, ra);
+        stage_load<BKM, VEC>(Bop, a.ldb, a.N, kend, n0, kbeg, tid, rb);
         stage_store<AK>(lds, tid, ra);
         stage_store<BKM>(lds + OPER_FLOATS, tid, rb);
     }
@@ -130,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void gemm_any_kernel(const AnyArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
-            stage_load<AK, VEC>(a.A, a.lda, a.M, kend, m0, kbeg + (long long)(kt + 1) * TK, tid, ra);
-            stage_load<BKM, VEC>(a.B, a.ldb, a.N, kend, n0, kbeg + (long long)(kt + 1) * TK, tid, rb);
+            stage_load<AK, VEC>(Aop, a.lda, a.M, kend, m0, kbeg + (long long)(kt + 1) * TK, tid, ra);
+            stage_load<BKM, VEC>(Bop, a.ldb, a.N, kend, n0, kbeg + (long long)(kt + 1) * TK, tid, rb);
         }
         const float* As = lds + buf * 2 * OPER_FLOATS;
         const float* Bs = As + OPER_FLOATS;
@@ -257,4 +271,48 @@ extern "C" int sbev_gemm_f32(const float* A, int a_kmajor, int64_t lda, const fl
     }
     a.k_per_split = K;
     return vec ? launch_layout<true>(a, a_kmajor, b_kmajor, 1, s) : launch_layout<false>(a, a_kmajor, b_kmajor, 1, s);
+}
+
+// C[M,N] (+)= sum_s sum_k A_s(m,k) B_s(k,n): nseg <= 8 operand pairs of identical layout and shape reduced in ONE launch (+ the slab
+// sum) -- the weight gradient of a Linear that several layers of a decoder call share (training: 6 x (GEMM + slab sum + add) -> 2
+// launches).  workspace: sbev_gemm_f32_multi_workspace(M, N, K, nseg) bytes.  Slabs are added segment by segment, split by split:
+// bit-reproducible.
+static int multi_splits(int64_t M, int N, int64_t K, int nseg) {
+    const long long tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    long long s = 256 / (tiles * nseg);
+    const long long max_s = K / 64 < 1 ? 1 : K / 64;
+    if (s > max_s) s = max_s;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : (int)s;
+}
+extern "C" int64_t sbev_gemm_f32_multi_workspace(int64_t M, int N, int64_t K, int nseg) {
+    if (M < 0 || N < 0 || K < 0 || nseg < 1 || nseg > 8) return -1;
+    return (int64_t)nseg * multi_splits(M, N, K, nseg) * M * N * (int64_t)sizeof(float);
+}
+extern "C" int sbev_gemm_f32_multi(const float* const* A, int a_kmajor, int64_t lda, const float* const* B, int b_kmajor, int64_t ldb,
+                                   int nseg, float* C, int64_t ldc, int64_t M, int N, int64_t K, int accumulate,
+                                   float* workspace, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nseg >= 1 && nseg <= 8, "sbev_gemm_f32_multi: bad sizes (1 .. 8 segments)");
+    if (M == 0 || N == 0) return SBEV_OK;
+    SBEV_REQUIRE(A && B && C && workspace, "sbev_gemm_f32_multi: null pointer");
+    SBEV_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N, "sbev_gemm_f32_multi: leading dimension too small");
+    AnyArgs a{};
+    a.A = A[0]; a.B = B[0]; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.accumulate = 0;
+    bool vec = lda % 4 == 0 && ldb % 4 == 0 && (a_kmajor ? M % 4 == 0 : K % 4 == 0) && (b_kmajor ? N % 4 == 0 : K % 4 == 0);
+    for (int i = 0; i < nseg; ++i) {
+        SBEV_REQUIRE(A[i] && B[i], "sbev_gemm_f32_multi: null segment pointer");
+        a.Aseg[i] = A[i]; a.Bseg[i] = B[i];
+        vec = vec && (reinterpret_cast<uintptr_t>(A[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(B[i]) & 15) == 0;
+    }
+    int sps = multi_splits(M, N, K, nseg);
+    a.k_per_split = ((K + sps - 1) / sps + TK - 1) / TK * TK;
+    sps = (int)((K + a.k_per_split - 1) / a.k_per_split);
+    a.nseg = nseg; a.splits_per_seg = sps;
+    a.C = workspace; a.ldc = N;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int st = vec ? launch_layout<true>(a, a_kmajor, b_kmajor, nseg * sps, s) : launch_layout<false>(a, a_kmajor, b_kmajor, nseg * sps, s);
+    if (st != SBEV_OK) return st;
+    const long long n = M * N;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, workspace, C, M, N, ldc, nseg * sps, accumulate);
+    return sbev::check_launch("sbev_gemm_f32_multi (slab sum)");
 }

@@ -101,6 +101,7 @@ class Tap:
         self.ids = {id(p) for p in params if p.requires_grad}
         self.bufs = {}
         self.deferred = {}          # id(weight) -> [(grad_y [M, N], x [M, K]), ...]: small weight gradients, reduced in one launch at the end
+        self.deferred_bias = {}     # id(bias) -> id(weight): bias gradient = column sums of that weight's recorded grad_y matrices
         self.token = ParamTap.apply(self, *params) if self.ids else None
         self._empty = None
 
@@ -122,11 +123,43 @@ class ParamTap(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtoken):
         tap = ctx.tap
+        _group_bias_grads(tap)
         for pid, segs in tap.deferred.items():
             _multi_wgrad(tap, pid, segs)
-        tap.deferred = {}
+        tap.deferred, tap.deferred_bias = {}, {}
         bufs = tap.bufs
         return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
+
+
+def _group_bias_grads(tap):
+    """the recorded biases' gradients: column sums over all layers' grad_y matrices, <= 16 biases per sbev_colsum_group launch"""
+    if not tap.deferred_bias:
+        return
+    lib = _lib.load()
+    by_rows = {}
+    for b_id, w_id in tap.deferred_bias.items():
+        segs = tap.deferred.get(w_id)
+        if segs:
+            by_rows.setdefault(segs[0][0].shape[0], []).append((b_id, [g for g, _ in segs]))
+    for M, items in by_rows.items():
+        jobs = []                       # (bias id, <= 8 matrices, accumulate)
+        for b_id, gs in items:
+            for s0 in range(0, len(gs), 8):
+                jobs.append((b_id, gs[s0:s0 + 8], s0 > 0 or b_id in tap.bufs))
+        for j0 in range(0, len(jobs), 16):
+            part = jobs[j0:j0 + 16]
+            ng = len(part)
+            segs = (ctypes.c_void_p * (ng * 8))()
+            outs = (ctypes.c_void_p * ng)()
+            Ns, nsegs, accs = (ctypes.c_int32 * ng)(), (ctypes.c_int32 * ng)(), (ctypes.c_int32 * ng)()
+            for i, (b_id, gs, acc) in enumerate(part):
+                N = gs[0].shape[1]
+                if b_id not in tap.bufs:
+                    tap.bufs[b_id] = torch.empty(N, device=gs[0].device, dtype=torch.float32)
+                for k, g in enumerate(gs):
+                    segs[i * 8 + k] = g.data_ptr()
+                outs[i], Ns[i], nsegs[i], accs[i] = tap.bufs[b_id].data_ptr(), N, len(gs), int(acc)
+            _lib.check(lib.sbev_colsum_group(segs, outs, Ns, nsegs, accs, ng, M, _stream()), 'sbev_colsum_group')
 
 
 def _multi_wgrad(tap, pid, segs):
@@ -153,11 +186,16 @@ def _multi_wgrad(tap, pid, segs):
 _DEFER_MAX = 1 << 18      # weight gradients up to 512 x 512 wait for the end of the call (their operands are < 2 MB per layer)
 
 
+def _defers(tap, pid, A, a_km, lda, b_km, ldb, M, N, K):
+    return bool(a_km and b_km and M * N <= _DEFER_MAX and lda == M and ldb == N and K % 4 == 0 and K == A.shape[0] and A.is_contiguous()
+                and (not tap.deferred.get(pid) or tap.deferred[pid][0][0].shape == A.shape))
+
+
 def _tap_gemm(tap, pid, *gemm_args):
     """grad_W (+)= into the tapped parameter's buffer; gemm_args as for gemm() without out / ldc / accumulate.  Small gradients
     (grad_y^T . x with both operands k-major) are only recorded here: ParamTap reduces all layers' pairs in one launch."""
     A, a_km, lda, B, b_km, ldb, M, N, K = gemm_args
-    if a_km and b_km and M * N <= _DEFER_MAX and lda == M and ldb == N and K % 4 == 0 and K == A.shape[0] and (not tap.deferred.get(pid) or tap.deferred[pid][0][0].shape == A.shape):
+    if _defers(tap, pid, A, a_km, lda, b_km, ldb, M, N, K):
         tap.deferred.setdefault(pid, []).append((A, B))
         return
     buf = tap.bufs.get(pid)
@@ -253,8 +291,14 @@ class Linear(torch.autograd.Function):
         tap = ctx.tap
         gy2 = _c(gy).reshape(-1, N)
         x2 = _c(x).reshape(-1, K)
-        gz, db = _bias_relu_bwd(gy2, y.reshape(-1, N) if ctx.relu else None, ctx.has_b and ctx.needs_input_grad[2], tap, ctx.b_id)
         w_tapped = ctx.needs_input_grad[1] and tap is not None and tap.has(ctx.w_id)
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
+        if (w_tapped and want_db and not ctx.relu and tap.has(ctx.b_id) and ctx.b_id not in tap.bufs
+                and _defers(tap, ctx.w_id, gy2, True, N, True, K, N, K, gy2.shape[0])):
+            tap.deferred_bias[ctx.b_id] = ctx.w_id          # column sums of the grad_y matrices recorded for the weight, at the end
+            gz, db = gy2, None
+        else:
+            gz, db = _bias_relu_bwd(gy2, y.reshape(-1, N) if ctx.relu else None, want_db, tap, ctx.b_id)
         gx, gw = _linear_grads(gz, x2, _c(w), ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not w_tapped)
         if w_tapped:
             _tap_gemm(tap, ctx.w_id, gz, True, N, x2, True, K, N, K, gz.shape[0])

@@ -88,6 +88,51 @@ __global__ __launch_bounds__(1024) void bias_relu_bwd_onepass_kernel(const ColAr
     }
 }
 
+// Grouped column sums: the bias gradients of up to 16 Linears, each the sum over up to 8 [M, N_b] gradient matrices (the layers of a
+// decoder call that share the bias), in ONE launch -- block = 64 columns of one bias x 16 row lanes, walking all segments' rows 8 at a
+// time; lane-ordered LDS sum: deterministic.  (Per layer and bias this was one 10 us launch: 66 of a training step's launches.)
+struct ColGroup {
+    const float* seg[8];
+    float* out;
+    int N, nseg, blk0, accumulate;
+};
+struct ColGroupArgs {
+    ColGroup g[16];
+    int ng;
+    long long M;
+};
+__global__ __launch_bounds__(1024) void colsum_group_kernel(const ColGroupArgs a) {
+    __shared__ float red[16][64];
+    int gi = 0;
+    for (int i = 1; i < a.ng; ++i)
+        if ((int)blockIdx.x >= a.g[i].blk0) gi = i;
+    const ColGroup& g = a.g[gi];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = ((int)blockIdx.x - g.blk0) * 64 + c;
+    float s = 0.f;
+    if (n < g.N) {
+        for (int sgi = 0; sgi < g.nseg; ++sgi) {
+            const float* p = g.seg[sgi] + n;
+            long long m = rg;
+            for (; m + 112 < a.M; m += 128) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = p[(m + 16 * i) * g.N];
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; m < a.M; m += 16) s += p[m * g.N];
+        }
+    }
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < g.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][c];
+        g.out[n] = g.accumulate ? g.out[n] + t : t;
+    }
+}
+
 // out[k][n] = sum_chunks part[k][chunk][n]  for K stacked partial sets (K = 1: bias; K = 2: dgamma, dbeta)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
                                                         int chunks, int N, int accumulate = 0) {
@@ -507,6 +552,29 @@ extern "C" int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, fl
 extern "C" int sbev_bias_relu_bwd_acc(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
                                       float* workspace, int accumulate, sbev_stream_t stream) {
     return bias_relu_bwd_impl(dY, Y, dZ, db, M, N, ld, workspace, accumulate, stream);
+}
+
+// out_b[n] (+)= sum over the nseg_b matrices seg_b[s] [M, N_b] (row-major, contiguous) of their column sums, for ng <= 16 groups b:
+// segs = host array of ng * 8 device pointers (row b: its nseg_b pointers first), outs / Ns / nsegs / accumulate = host arrays [ng]
+extern "C" int sbev_colsum_group(const float* const* segs, float* const* outs, const int32_t* Ns, const int32_t* nsegs,
+                                 const int32_t* accumulate, int ng, int64_t M, sbev_stream_t stream) {
+    SBEV_REQUIRE(ng >= 0 && ng <= 16 && M >= 0, "sbev_colsum_group: at most 16 groups");
+    if (ng == 0) return SBEV_OK;
+    SBEV_REQUIRE(segs && outs && Ns && nsegs && accumulate, "sbev_colsum_group: null pointer");
+    ColGroupArgs a{};
+    a.ng = ng; a.M = M;
+    int blk = 0;
+    for (int b = 0; b < ng; ++b) {
+        SBEV_REQUIRE(Ns[b] >= 1 && nsegs[b] >= 1 && nsegs[b] <= 8 && outs[b], "sbev_colsum_group: group %d", b);
+        a.g[b].N = Ns[b]; a.g[b].nseg = nsegs[b]; a.g[b].out = outs[b]; a.g[b].blk0 = blk; a.g[b].accumulate = accumulate[b];
+        for (int s = 0; s < nsegs[b]; ++s) {
+            SBEV_REQUIRE(segs[b * 8 + s], "sbev_colsum_group: null segment");
+            a.g[b].seg[s] = segs[b * 8 + s];
+        }
+        blk += (Ns[b] + 63) / 64;
+    }
+    hipLaunchKernelGGL(colsum_group_kernel, dim3((unsigned)blk), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_colsum_group");
 }
 
 extern "C" int64_t sbev_layer_norm_bwd_workspace(int64_t M, int N) {

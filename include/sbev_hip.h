@@ -492,6 +492,15 @@ int sbev_layer_norm_bwd(const float* dY, const float* X, const float* gamma, con
                         float* dX, float* dgamma, float* dbeta, float* workspace, int64_t M, int N, sbev_stream_t stream);
 /* sbev_bias_relu_bwd / sbev_layer_norm_bwd with the parameter gradients (db; dgamma, dbeta) ADDED to their buffers when accumulate != 0:
  * a parameter shared by the layers of a decoder call collects its gradient in one buffer, no separate summation launches. */
+/* LayerNorm backward in two halves for parameters shared by several layers: sbev_layer_norm_bwd_rows = dX and the [M, 2] (mean, rstd)
+ * rows (workspace >= 2 M floats); sbev_layer_norm_param_group = dgamma / dbeta of ng <= 8 LayerNorms, each summed over <= 8
+ * (dY, X, stats) triples, in ONE launch.  Pointer tables are host arrays [ng][8]; the per-LayerNorm arrays [ng]. */
+int sbev_layer_norm_bwd_rows(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                             float* dX, float* workspace, int64_t M, int N, sbev_stream_t stream);
+int sbev_layer_norm_param_group(const float* const* dYs, const float* const* Xs, const float* const* stats,
+                                const float* const* gammas, const float* const* betas, float* const* dgammas, float* const* dbetas,
+                                const int32_t* Ns, const int32_t* nsegs, const int32_t* relus, const int32_t* accumulate,
+                                int ng, int64_t M, sbev_stream_t stream);
 /* Grouped bias gradients: out_b[n] (+)= sum_s colsum(seg_b[s] [M, N_b]) for ng <= 16 biases with <= 8 gradient matrices each (the
  * layers of a call sharing the bias) in ONE launch.  segs: host array [ng][8] of device pointers; outs / Ns / nsegs / accumulate: [ng]. */
 int sbev_colsum_group(const float* const* segs, float* const* outs, const int32_t* Ns, const int32_t* nsegs,

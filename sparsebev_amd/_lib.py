@@ -140,6 +140,8 @@ SIGNATURES = {
     'sbev_gemm_f32_multi_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     'sbev_gemm_f32_multi': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int64, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int64,
                                            ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
+    'sbev_layer_norm_bwd_rows': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_layer_norm_param_group': (ctypes.c_int, [ctypes.POINTER(_vp)] * 7 + [_c_i32p] * 4 + [ctypes.c_int, ctypes.c_int64, _vp]),
     'sbev_colsum_group': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _c_i32p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int64, _vp]),
     'sbev_bias_relu_bwd_acc': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp]),
     'sbev_layer_norm_bwd_acc': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, _vp, _vp, _vp,

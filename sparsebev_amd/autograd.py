@@ -12,6 +12,7 @@ PyTorch is used for what it is here for -- device memory, streams, and the autog
 math kernel computes anything on this path except the parameter ``cat`` / output ``stack`` / ``nan_to_num`` plumbing.
 """
 import ctypes
+import os
 
 import torch
 
@@ -102,6 +103,7 @@ class Tap:
         self.bufs = {}
         self.deferred = {}          # id(weight) -> [(grad_y [M, N], x [M, K]), ...]: small weight gradients, reduced in one launch at the end
         self.deferred_bias = {}     # id(bias) -> id(weight): bias gradient = column sums of that weight's recorded grad_y matrices
+        self.deferred_ln = {}       # (id(gamma), id(beta)) -> [gamma, beta, relu, [(grad_y, x, row statistics), ...]]
         self.token = ParamTap.apply(self, *params) if self.ids else None
         self._empty = None
 
@@ -124,9 +126,10 @@ class ParamTap(torch.autograd.Function):
     def backward(ctx, gtoken):
         tap = ctx.tap
         _group_bias_grads(tap)
+        _group_ln_grads(tap)
         for pid, segs in tap.deferred.items():
             _multi_wgrad(tap, pid, segs)
-        tap.deferred, tap.deferred_bias = {}, {}
+        tap.deferred, tap.deferred_bias, tap.deferred_ln = {}, {}, {}
         bufs = tap.bufs
         return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
 
@@ -160,6 +163,40 @@ def _group_bias_grads(tap):
                     segs[i * 8 + k] = g.data_ptr()
                 outs[i], Ns[i], nsegs[i], accs[i] = tap.bufs[b_id].data_ptr(), N, len(gs), int(acc)
             _lib.check(lib.sbev_colsum_group(segs, outs, Ns, nsegs, accs, ng, M, _stream()), 'sbev_colsum_group')
+
+
+_LN_GROUP = os.environ.get('SBEV_NO_LN_GROUP', '0') != '1'   # A/B switch: LayerNorm parameter gradients per layer (1) or grouped per call
+
+
+def _group_ln_grads(tap):
+    """the recorded LayerNorms' dgamma / dbeta: sums over all layers' (grad_y, x, statistics), <= 8 LayerNorms per launch"""
+    if not tap.deferred_ln:
+        return
+    lib = _lib.load()
+    jobs = []
+    for (g_id, b_id), (g, b, relu, segs) in tap.deferred_ln.items():
+        for s0 in range(0, len(segs), 8):
+            jobs.append((g_id, b_id, g, b, relu, segs[s0:s0 + 8], s0 > 0 or g_id in tap.bufs))
+    by_rows = {}
+    for j in jobs:
+        by_rows.setdefault(j[5][0][0].shape[0], []).append(j)
+    VP = ctypes.c_void_p
+    for M, items in by_rows.items():
+        for j0 in range(0, len(items), 8):
+            part = items[j0:j0 + 8]
+            ng = len(part)
+            dYs, Xs, Ss = (VP * (ng * 8))(), (VP * (ng * 8))(), (VP * (ng * 8))()
+            gam, bet, dgs, dbs = (VP * ng)(), (VP * ng)(), (VP * ng)(), (VP * ng)()
+            Ns, nsegs, relus, accs = [(ctypes.c_int32 * ng)() for _ in range(4)]
+            for i, (g_id, b_id, g, b, relu, segs, acc) in enumerate(part):
+                if g_id not in tap.bufs:
+                    tap.bufs[g_id], tap.bufs[b_id] = torch.empty_like(g), torch.empty_like(b)
+                for k, (gy, x, st) in enumerate(segs):
+                    dYs[i * 8 + k], Xs[i * 8 + k], Ss[i * 8 + k] = gy.data_ptr(), x.data_ptr(), st.data_ptr()
+                gam[i], bet[i], dgs[i], dbs[i] = g.data_ptr(), b.data_ptr(), tap.bufs[g_id].data_ptr(), tap.bufs[b_id].data_ptr()
+                Ns[i], nsegs[i], relus[i], accs[i] = g.shape[0], len(segs), int(relu), int(acc)
+            _lib.check(lib.sbev_layer_norm_param_group(dYs, Xs, Ss, gam, bet, dgs, dbs, Ns, nsegs, relus, accs, ng, M, _stream()),
+                       'sbev_layer_norm_param_group')
 
 
 def _multi_wgrad(tap, pid, segs):
@@ -333,6 +370,13 @@ class LayerNorm(torch.autograd.Function):
         gx = torch.empty_like(x2)
         tap = ctx.tap
         tapped = tap is not None and tap.has(ctx.g_id) and tap.has(ctx.b_id)
+        if tapped and _LN_GROUP and ctx.g_id not in tap.bufs and g.is_contiguous() and b.is_contiguous():
+            # shared LayerNorm: dX and the row statistics now, dgamma / dbeta of all layers in one grouped launch at the end of the call
+            stats = torch.empty(2 * M, device=x.device, dtype=torch.float32)
+            st = _lib.load().sbev_layer_norm_bwd_rows(_p(gy2), _p(x2), _p(g), _p(b), _EPS, int(ctx.relu), _p(gx), _p(stats), M, N, _stream())
+            _lib.check(st, 'sbev_layer_norm_bwd_rows')
+            tap.deferred_ln.setdefault((ctx.g_id, ctx.b_id), [g, b, ctx.relu, []])[3].append((gy2, x2, stats))
+            return (gx.reshape(x.shape), None, None, None, gy if ctx.has_add and ctx.needs_input_grad[4] else None, None, tap.token_grad())
         acc = tapped and ctx.g_id in tap.bufs and ctx.b_id in tap.bufs
         dg, dbeta = (tap.bufs[ctx.g_id], tap.bufs[ctx.b_id]) if acc else (torch.empty_like(g), torch.empty_like(b))
         stats = torch.empty(max(_lib.load().sbev_layer_norm_bwd_workspace(M, N) // 4, 1), device=x.device, dtype=torch.float32)

@@ -300,6 +300,76 @@ __global__ __launch_bounds__(1024) void ln_bwd_cols_onepass_kernel(const LnBwdAr
     }
 }
 
+// Grouped LayerNorm parameter gradients: dgamma / dbeta of up to 8 LayerNorms, each summed over up to 8 (dY, X, row statistics)
+// triples -- the layers of a decoder call sharing the LayerNorm -- in ONE launch (block = 64 columns of one LayerNorm x 16 row lanes;
+// the statistics are the [M, 2] (mean, rstd) rows sbev_layer_norm_bwd_acc leaves at the start of its workspace).
+struct LnGroup {
+    const float* dY[8];
+    const float* X[8];
+    const float* stats[8];
+    const float* gamma;
+    const float* beta;
+    float* dgamma;
+    float* dbeta;
+    int N, nseg, blk0, relu, accumulate;
+};
+struct LnGroupArgs {
+    LnGroup g[8];
+    int ng;
+    long long M;
+};
+__global__ __launch_bounds__(1024) void ln_param_group_kernel(const LnGroupArgs a) {
+    __shared__ float red[2][16][64];
+    int gi = 0;
+    for (int i = 1; i < a.ng; ++i)
+        if ((int)blockIdx.x >= a.g[i].blk0) gi = i;
+    const LnGroup& g = a.g[gi];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = ((int)blockIdx.x - g.blk0) * 64 + c;
+    float sg = 0.f, sb = 0.f;
+    if (n < g.N) {
+        const float w = g.gamma[n], bt = g.relu ? g.beta[n] : 0.f;
+        for (int sgi = 0; sgi < g.nseg; ++sgi) {
+            const float* dY = g.dY[sgi] + n;
+            const float* X = g.X[sgi] + n;
+            const float* st = g.stats[sgi];
+            long long m = rg;
+            for (; m + 48 < a.M; m += 64) {
+                float h[4], gr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long long r = m + 16 * i;
+                    h[i] = (X[r * g.N] - st[r * 2]) * st[r * 2 + 1];
+                    gr[i] = dY[r * g.N];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (g.relu && !(h[i] * w + bt > 0.f)) gr[i] = 0.f;
+                    sg += gr[i] * h[i];
+                    sb += gr[i];
+                }
+            }
+            for (; m < a.M; m += 16) {
+                const float hh = (X[m * g.N] - st[m * 2]) * st[m * 2 + 1];
+                float gg = dY[m * g.N];
+                if (g.relu && !(hh * w + bt > 0.f)) gg = 0.f;
+                sg += gg * hh;
+                sb += gg;
+            }
+        }
+    }
+    red[0][rg][c] = sg;
+    red[1][rg][c] = sb;
+    __syncthreads();
+    if (rg < 2 && n < g.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[rg][k][c];
+        float* o = (rg == 0 ? g.dgamma : g.dbeta) + n;
+        *o = g.accumulate ? *o + t : t;
+    }
+}
+
 // ---- refine_bbox backward (models/sparsebev_transformer.py:155-160,179-183; models/utils.py:87-102) ----------------
 struct RefineBwdArgs {
     const float* gout;     // [BQ,10]  grad of the refined box
@@ -552,6 +622,46 @@ extern "C" int sbev_bias_relu_bwd(const float* dY, const float* Y, float* dZ, fl
 extern "C" int sbev_bias_relu_bwd_acc(const float* dY, const float* Y, float* dZ, float* db, int64_t M, int N, int64_t ld,
                                       float* workspace, int accumulate, sbev_stream_t stream) {
     return bias_relu_bwd_impl(dY, Y, dZ, db, M, N, ld, workspace, accumulate, stream);
+}
+
+// dX and the row statistics only (no dgamma / dbeta): the first half of sbev_layer_norm_bwd, for callers that sum the parameter
+// gradients later with sbev_layer_norm_param_group.  workspace: >= 2 M floats, receives [M, 2] (mean, rstd).
+extern "C" int sbev_layer_norm_bwd_rows(const float* dY, const float* X, const float* gamma, const float* beta, float eps, int relu,
+                                        float* dX, float* workspace, int64_t M, int N, sbev_stream_t stream) {
+    SBEV_REQUIRE(M >= 0 && N >= 4 && N % 4 == 0 && N <= 1024, "sbev_layer_norm_bwd_rows: N=%d must be a multiple of 4 in 4..1024", N);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(dY && X && gamma && dX && workspace && (!relu || beta), "sbev_layer_norm_bwd_rows: null pointer");
+    LnBwdArgs a{dY, X, gamma, beta, dX, workspace, nullptr, nullptr, M, N, relu, eps, 0};
+    hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_layer_norm_bwd_rows");
+}
+
+// dgamma_b / dbeta_b (+)= sums over the nseg_b (dY, X, stats) triples of LayerNorm b, ng <= 8 LayerNorms in one launch.
+// dYs / Xs / stats: host arrays [ng][8] of device pointers; gammas / betas / dgammas / dbetas: [ng]; Ns / nsegs / relus / accumulate: [ng]
+extern "C" int sbev_layer_norm_param_group(const float* const* dYs, const float* const* Xs, const float* const* stats,
+                                           const float* const* gammas, const float* const* betas, float* const* dgammas, float* const* dbetas,
+                                           const int32_t* Ns, const int32_t* nsegs, const int32_t* relus, const int32_t* accumulate,
+                                           int ng, int64_t M, sbev_stream_t stream) {
+    SBEV_REQUIRE(ng >= 0 && ng <= 8 && M >= 0, "sbev_layer_norm_param_group: at most 8 groups");
+    if (ng == 0) return SBEV_OK;
+    SBEV_REQUIRE(dYs && Xs && stats && gammas && betas && dgammas && dbetas && Ns && nsegs && relus && accumulate, "sbev_layer_norm_param_group: null pointer");
+    LnGroupArgs a{};
+    a.ng = ng; a.M = M;
+    int blk = 0;
+    for (int b = 0; b < ng; ++b) {
+        SBEV_REQUIRE(Ns[b] >= 1 && nsegs[b] >= 1 && nsegs[b] <= 8 && gammas[b] && dgammas[b] && dbetas[b] && (!relus[b] || betas[b]),
+                     "sbev_layer_norm_param_group: group %d", b);
+        LnGroup& g = a.g[b];
+        g.N = Ns[b]; g.nseg = nsegs[b]; g.blk0 = blk; g.relu = relus[b]; g.accumulate = accumulate[b];
+        g.gamma = gammas[b]; g.beta = betas[b]; g.dgamma = dgammas[b]; g.dbeta = dbetas[b];
+        for (int s = 0; s < nsegs[b]; ++s) {
+            SBEV_REQUIRE(dYs[b * 8 + s] && Xs[b * 8 + s] && stats[b * 8 + s], "sbev_layer_norm_param_group: null segment");
+            g.dY[s] = dYs[b * 8 + s]; g.X[s] = Xs[b * 8 + s]; g.stats[s] = stats[b * 8 + s];
+        }
+        blk += (Ns[b] + 63) / 64;
+    }
+    hipLaunchKernelGGL(ln_param_group_kernel, dim3((unsigned)blk), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_layer_norm_param_group");
 }
 
 // out_b[n] (+)= sum over the nseg_b matrices seg_b[s] [M, N_b] (row-major, contiguous) of their column sums, for ng <= 16 groups b:

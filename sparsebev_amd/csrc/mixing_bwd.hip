@@ -14,7 +14,15 @@
 // v_mfma_f32_16x16x4_f32 (exact fp32), wave w owning the 16-column slab w of every 64-wide result (two 16-row tiles of dS):
 // 288 MFMAs per wave.  The first version did them with plain FMAs fed by LDS broadcasts: 1.05 ms per layer at config 2 (150
 // us per workgroup); this one is bounded by its 112 KiB of HBM traffic per item (x, params, g_out in; g_x, g_params out).
+//
+// FAST (in_points == 32, the decoder's T * P = 8 * 4): every global operand of the item is requested in the first instructions of
+// the kernel -- x and S as float4 into LDS (S [128][36]: 16 KiB read once per workgroup instead of once per wave per product), the
+// wave's slabs of M, M^T and g_out into registers -- and the workgroup synchronises on LDS traffic only (s_waitcnt lgkmcnt(0) +
+// s_barrier: __syncthreads' vmcnt(0) made every LayerNorm reduction wait for the gradient stores of the product before it).
+// The generic path exposes one L2 / HBM round trip per product and per 8-step operand batch (~16 per workgroup, 39 us per
+// workgroup at 2 workgroups per CU: 274 us per layer at config 2); FAST exposes one.  LDS 76.7 KiB: still 2 workgroups per CU.
 #include "sbev_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -31,11 +39,21 @@ struct MixBwdArgs {
     float eps;
 };
 
+// workgroup barrier for data exchanged through LDS only (global loads / stores of this wave stay in flight across it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool FAST>
+__device__ __forceinline__ void wg_sync() {
+    if constexpr (FAST) lds_barrier();
+    else __syncthreads();
+}
+
+template <bool FAST>
 __device__ __forceinline__ float block_sum(float v, float* red, int wave, int lane) {
     v = sbev::wave_sum_dpp(v);
-    __syncthreads();
+    wg_sync<FAST>();
     if (lane == 0) red[wave] = v;
-    __syncthreads();
+    wg_sync<FAST>();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
@@ -44,8 +62,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_16x16x4_f32 operand convention used below: lane = (fi = lane & 15, fk = lane >> 4);
 //   A operand: A[i = fi][k = 4s + fk];  B operand: B[k = 4s + fk][j = fi];  C/D: rows fk*4 + e (e = 0..3), column fi.
-template <int RT>      // RT = ceil(Pin / 16) row tiles of the Pin-row matrices (rows Pin..16*RT-1 are zero padding in LDS)
+constexpr int LDS_S = 36;   // FAST: row stride of S in LDS (floats): 16-byte rows, row- and column-walking fragment reads conflict-free per half wave
+
+template <int RT, bool FAST>      // RT = ceil(Pin / 16) row tiles of the Pin-row matrices (rows Pin..16*RT-1 are zero padding in LDS)
 __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
+    static_assert(!FAST || RT == 2, "FAST is the in_points == 32 instance");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
     constexpr int PR = RT * 16;
@@ -54,6 +75,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     float* d1 = h1 + PR * LD;            // [PR][LD]   dy1
     float* y2 = d1 + PR * LD;            // [POUT][LD] dy2
     float* red = y2 + POUT * LD;         // [8]
+    float* sl = red + 8;                 // FAST: S [POUT][LDS_S]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, fk = lane >> 4;
@@ -69,17 +91,50 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     float* __restrict__ gx = a.gx + item * Pin * C;
     const float n1cnt = (float)(Pin * C), n2cnt = (float)(POUT * C);
 
-    for (int i = tid; i < PR * C; i += 256) xs[(i >> 6) * LD + (i & 63)] = (i >> 6) < Pin ? x[i] : 0.f;
-    __syncthreads();
+    float mB[C / 4], mT[C / 4];
+    f32x4 gor[POUT / 16];
+    if constexpr (FAST) {        // all global operands of the item, in the order they are consumed
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(Sg);
+        f32x4 xr[2], sr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xr[i] = x4[tid + 256 * i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sr[i] = s4[tid + 256 * i];
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) mB[q] = Mg[(4 * q + fk) * C + cw + fi];
+#pragma unroll
+        for (int r = 0; r < POUT / 16; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gor[r][e] = go[(r * 16 + fk * 4 + e) * C + cw + fi];
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) mT[q] = Mg[(cw + fi) * C + 4 * q + fk];        // B[k = co][j = ci] = M[ci][co]
+        __builtin_amdgcn_sched_barrier(0);       // every request is out before the first wait (the LDS writes of x)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e0 = (tid + 256 * i) * 4;
+            float* d = xs + (e0 >> 6) * LD + (e0 & 63);
+            d[0] = xr[i][0]; d[1] = xr[i][1]; d[2] = xr[i][2]; d[3] = xr[i][3];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e0 = (tid + 256 * i) * 4;
+            *reinterpret_cast<f32x4*>(sl + (e0 >> 5) * LDS_S + (e0 & 31)) = sr[i];
+        }
+    } else {
+        for (int i = tid; i < PR * C; i += 256) xs[(i >> 6) * LD + (i & 63)] = (i >> 6) < Pin ? x[i] : 0.f;
+    }
+    wg_sync<FAST>();
     // ---- (1) y1 = x M, LayerNorm statistics, h1 -> LDS ----------------------------------------------------------------
     f32x4 acc1[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // operands that come from global memory are requested as ONE batch of independent loads per product (a load inside the
     // MFMA chain made every MFMA wait for its own L2 round trip: 47 us per workgroup for 4 us of matrix-core work)
-    float mB[C / 4];
+    if constexpr (!FAST) {
 #pragma unroll
-    for (int s4 = 0; s4 < C / 4; ++s4) mB[s4] = Mg[(4 * s4 + fk) * C + cw + fi];
+        for (int s4 = 0; s4 < C / 4; ++s4) mB[s4] = Mg[(4 * s4 + fk) * C + cw + fi];
+    }
 #pragma unroll
     for (int s4 = 0; s4 < C / 4; ++s4) {
 #pragma unroll
@@ -90,7 +145,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += (r * 16 + fk * 4 + e) < Pin ? acc1[r][e] : 0.f;
-    const float mean1 = block_sum(s, red, wave, lane) / n1cnt;
+    const float mean1 = block_sum<FAST>(s, red, wave, lane) / n1cnt;
     s = 0.f;
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -99,7 +154,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
             const float d = acc1[r][e] - mean1;
             s += (r * 16 + fk * 4 + e) < Pin ? d * d : 0.f;
         }
-    const float rstd1 = rsqrtf(block_sum(s, red + 4, wave, lane) / n1cnt + a.eps);
+    const float rstd1 = rsqrtf(block_sum<FAST>(s, red + 4, wave, lane) / n1cnt + a.eps);
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -107,12 +162,19 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
             const int row = r * 16 + fk * 4 + e;
             h1[row * LD + cw + fi] = row < Pin ? (acc1[r][e] - mean1) * rstd1 : 0.f;
         }
-    __syncthreads();
+    wg_sync<FAST>();
     // ---- (2) y2 = S relu(h1), LayerNorm statistics, dy2 -> LDS -------------------------------------------------------
     f32x4 acc2[POUT / 16];
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (FAST) {
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const float bq = fmaxf(h1[(4 * s4 + fk) * LD + cw + fi], 0.f);
+#pragma unroll
+            for (int r = 0; r < POUT / 16; ++r) acc2[r] = MFMA16(sl[(r * 16 + fi) * LDS_S + 4 * s4 + fk], bq, acc2[r]);
+        }
+    } else {
         float sA[POUT / 16], sN[POUT / 16];
 #pragma unroll
         for (int r = 0; r < POUT / 16; ++r) sA[r] = Sg[(r * 16 + fi) * Pin + fk];
@@ -133,7 +195,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     for (int r = 0; r < POUT / 16; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s += acc2[r][e];
-    const float mean2 = block_sum(s, red, wave, lane) / n2cnt;
+    const float mean2 = block_sum<FAST>(s, red, wave, lane) / n2cnt;
     s = 0.f;
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r)
@@ -142,7 +204,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
             const float d = acc2[r][e] - mean2;
             s += d * d;
         }
-    const float rstd2 = rsqrtf(block_sum(s, red + 4, wave, lane) / n2cnt + a.eps);
+    const float rstd2 = rsqrtf(block_sum<FAST>(s, red + 4, wave, lane) / n2cnt + a.eps);
     f32x4 g2[POUT / 16];
     float sg = 0.f, sgh = 0.f;
 #pragma unroll
@@ -151,18 +213,21 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
         for (int e = 0; e < 4; ++e) {
             const float h = (acc2[r][e] - mean2) * rstd2;
             acc2[r][e] = h;
-            const float g = h > 0.f ? go[(r * 16 + fk * 4 + e) * C + cw + fi] : 0.f;
+            float gq;
+            if constexpr (FAST) gq = gor[r][e];
+            else gq = go[(r * 16 + fk * 4 + e) * C + cw + fi];
+            const float g = h > 0.f ? gq : 0.f;
             g2[r][e] = g;
             sg += g;
             sgh += g * h;
         }
-    const float mg2 = block_sum(sg, red, wave, lane) / n2cnt;
-    const float mgh2 = block_sum(sgh, red + 4, wave, lane) / n2cnt;
+    const float mg2 = block_sum<FAST>(sg, red, wave, lane) / n2cnt;
+    const float mgh2 = block_sum<FAST>(sgh, red + 4, wave, lane) / n2cnt;
 #pragma unroll
     for (int r = 0; r < POUT / 16; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) y2[(r * 16 + fk * 4 + e) * LD + cw + fi] = rstd2 * (g2[r][e] - mg2 - acc2[r][e] * mgh2);
-    __syncthreads();
+    wg_sync<FAST>();
     // ---- (3) dS = dy2 n1^T : wave w owns the 16-row tiles w and w + 4 of the 128 output rows -----------------------------
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -186,7 +251,14 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     f32x4 acc4[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc4[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (FAST) {
+#pragma unroll 8
+        for (int s4 = 0; s4 < POUT / 4; ++s4) {
+            const float bq = y2[(4 * s4 + fk) * LD + cw + fi];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc4[r] = MFMA16(sl[(4 * s4 + fk) * LDS_S + r * 16 + fi], bq, acc4[r]);
+        }
+    } else {
         constexpr int AHEAD = 8;                                  // steps of S^T operands requested together
         float tA[AHEAD][RT];
         for (int s0 = 0; s0 < POUT / 4; s0 += AHEAD) {
@@ -218,8 +290,8 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
             sg += g;
             sgh += g * h;
         }
-    const float mg1 = block_sum(sg, red, wave, lane) / n1cnt;
-    const float mgh1 = block_sum(sgh, red + 4, wave, lane) / n1cnt;
+    const float mg1 = block_sum<FAST>(sg, red, wave, lane) / n1cnt;
+    const float mgh1 = block_sum<FAST>(sgh, red + 4, wave, lane) / n1cnt;
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -227,7 +299,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
             const int row = r * 16 + fk * 4 + e;
             d1[row * LD + cw + fi] = row < Pin ? rstd1 * (acc4[r][e] - mg1 - hh[r][e] * mgh1) : 0.f;
         }
-    __syncthreads();
+    wg_sync<FAST>();
     // ---- (5) dM = x^T dy1 : wave w owns output columns [cw, cw + 16), the four 16-row tiles of ci ------------------------
     {
         f32x4 acc[4];
@@ -248,9 +320,10 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
         f32x4 acc[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float mT[C / 4];
+        if constexpr (!FAST) {
 #pragma unroll
-        for (int s4 = 0; s4 < C / 4; ++s4) mT[s4] = Mg[(cw + fi) * C + 4 * s4 + fk];    // B[k = co][j = ci] = M[ci][co]
+            for (int s4 = 0; s4 < C / 4; ++s4) mT[s4] = Mg[(cw + fi) * C + 4 * s4 + fk];    // B[k = co][j = ci] = M[ci][co]
+        }
 #pragma unroll
         for (int s4 = 0; s4 < C / 4; ++s4) {
 #pragma unroll
@@ -266,10 +339,10 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     }
 }
 
-template <int RT>
+template <int RT, bool FAST = false>
 int launch_mix_bwd(const MixBwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)((3 * RT * 16 + POUT) * LD + 8) * sizeof(float);
-    auto k = mixing_bwd_kernel<RT>;
+    const size_t lds = (size_t)((3 * RT * 16 + POUT) * LD + 8 + (FAST ? POUT * LDS_S : 0)) * sizeof(float);
+    auto k = mixing_bwd_kernel<RT, FAST>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
@@ -296,7 +369,12 @@ extern "C" int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch ((Pin + 15) / 16) {
         case 1: return launch_mix_bwd<1>(a, s);
-        case 2: return launch_mix_bwd<2>(a, s);
+        case 2:
+        {
+            static const bool generic = getenv("SBEV_MIX_BWD_GENERIC") != nullptr;      // A/B switch: the per-product operand loads
+            if (Pin == 32 && (((uintptr_t)x) & 15) == 0 && !generic) return launch_mix_bwd<2, true>(a, s);
+        }
+            return launch_mix_bwd<2>(a, s);
         case 3: return launch_mix_bwd<3>(a, s);
         case 4: return launch_mix_bwd<4>(a, s);
         case 5: return launch_mix_bwd<5>(a, s);

@@ -424,6 +424,8 @@ int sbev_f16s_out_scale(const float* wdown, int x_up_log2, float* nscale, int N,
  * launches can emit it directly: sbev_adaptive_mixing_pairs_f16 / sbev_sample_mix_pairs_f16 = sbev_adaptive_mixing_f32 /
  * sbev_sample_mix_f32 with y written as pairs of y 2^up_log2 (what sbev_decoder_forward does in the fp16 GEMM modes). */
 int sbev_f16s_pairs(const float* X, void* out, int64_t n, int up_log2, sbev_stream_t stream);
+/* updown[0..1] = {2^e, 2^-e} with max |X| 2^e in [2^14, 2^15) over X [rows, ldx] (K columns): the operand scale of sbev_gemm_tn_f16s */
+int sbev_f16s_tensor_scale(const float* X, int64_t ldx, int64_t rows, int K, float* updown, sbev_stream_t stream);
 int sbev_adaptive_mixing_pairs_f16(const float* x, const float* params, void* y, int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
                                    int up_log2, sbev_stream_t stream);
 int sbev_sample_mix_pairs_f16(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
@@ -478,6 +480,15 @@ int sbev_gemm_f32_multi(const float* const* A, int a_kmajor, int64_t lda, const 
                         int nseg, float* C, int64_t ldc, int64_t M, int N, int64_t K, int accumulate,
                         float* workspace, sbev_stream_t stream);
 
+/* grad_W-shaped product on the fp16 matrix core (gemm_tn_f16s.hip): C[M,N] (+)= sum_k A[k*lda + m] B[k*ldb + n], both operands
+ * k-major (grad_W = grad_y^T . x of a Linear, reduced over the B*Q rows; replaces sbev_gemm_f32(a_kmajor = b_kmajor = 1) where
+ * sbev_gemm_tn_f16s_ok: M, N multiples of 4 and >= 256 tiles of 128 x 128).  Operands are multiplied by a_scale[0] / b_scale[0]
+ * (device, {2^e, 2^-e}: sbev_f16s_tensor_scale or a caller's bound), split into fp16 hi + lo inside the kernel, 3 products
+ * (hl, lh, hh), fp32 accumulation, result times a_scale[1] b_scale[1].  Error vs fp64 <= the exact f32-MFMA kernel's. */
+int sbev_gemm_tn_f16s_ok(int64_t M, int64_t N, int64_t K);
+int sbev_gemm_tn_f16s(const float* A, int64_t lda, const float* a_scale, const float* B, int64_t ldb, const float* b_scale,
+                      float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, sbev_stream_t stream);
+
 /* dZ = dY * (Y > 0) (Y = a ReLU's forward output, NULL: dZ = dY; dZ may be NULL or alias dY) and db[n] = sum_m dZ[m,n]
  * (NULL: skipped).  Rows have stride ld.  workspace: sbev_colsum_workspace(M, N) bytes (needed when db != NULL);
  * column sums are added in a fixed order (bit-reproducible). */
@@ -519,6 +530,10 @@ int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const float* w, con
  * grad_x [BQ,G,Pin,C], grad_params [BQ,G,C*C+Pout*Pin]. */
 int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
                                  int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
+/* the same, also writing item_max[BQ*G] = max |grad_params| of each (row, group): sbev_f16s_tensor_scale of that array is the
+ * fp16 scale of grad_params without another pass over its 118 MB */
+int sbev_adaptive_mixing_bwd_max_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
+                                     float* item_max, int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
 
 /* Training forward of sbev_sasa_f32 with attention dropout (mmcv MultiheadAttention attn_drop; keep decisions are a
  * hash of (seed, b, h, i, j)), and the backward of either forward: grad_out [B,Q,H*32] -> grad_qkvt [B,Q,ld]

@@ -84,6 +84,12 @@ SIGNATURES = {
     'sbev_linear_f16s_gen': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                             ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_f16s_pairs': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_f16s_tensor_scale': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp, _vp]),
+    'sbev_gemm_tn_f16s_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    'sbev_gemm_tn_f16s': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _vp]),
+    'sbev_adaptive_mixing_bwd_max_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_float, _vp]),
     'sbev_adaptive_mixing_pairs_f16': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                       ctypes.c_float, ctypes.c_int, _vp]),
     'sbev_linear_splitk_f16s': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,

@@ -271,6 +271,33 @@ def _mixed_up_log2(n):
     return e
 
 
+_SCALE_CONST = {}    # (device, e) -> fp32 [2] {2^e, 2^-e}
+
+
+def _const_scale(device, e):
+    """a caller-side bound as the device scale pair the fp16 GEMMs take"""
+    key = (str(device), int(e))
+    t = _SCALE_CONST.get(key)
+    if t is None:
+        t = _SCALE_CONST[key] = torch.tensor([2.0 ** e, 2.0 ** -e], device=device, dtype=torch.float32)
+    return t
+
+
+_WGRAD_F16 = os.environ.get('SBEV_NO_WGRAD_F16', '0') != '1'    # A/B switch: the two big grad_W GEMMs on the fp16 kernel (gemm_tn_f16s.hip)
+
+
+def _wgrad_tn_f16(tap, pid, tapped, A, lda, a_scale, B, ldb, b_scale, M, N, K):
+    """grad_W [M, N] = A^T B on the fp16 hi + lo kernel: into the tapped parameter's buffer (returns None) or as a new tensor"""
+    if not tapped:
+        return dense.gemm_tn_f16s(A, lda, a_scale, B, ldb, b_scale, M, N, K)
+    buf = tap.bufs.get(pid)
+    if buf is None:
+        tap.bufs[pid] = dense.gemm_tn_f16s(A, lda, a_scale, B, ldb, b_scale, M, N, K)
+    else:
+        dense.gemm_tn_f16s(A, lda, a_scale, B, ldb, b_scale, M, N, K, out=buf, ldc=N, accumulate=True)
+    return None
+
+
 def _linear_grads(gy2, x2, w, need_x, need_w):
     """gy2 [M,N], x2 [M,K], w [N,K] -> (grad_x [M,K] | None, grad_w [N,K] | None)"""
     M, N = gy2.shape
@@ -501,13 +528,13 @@ class AdaptiveMixing(torch.autograd.Function):
         ctx.out_points, ctx.recompute = out_points, bool(recompute)
         lib = _lib.load()
         # gemm_f16 (the decoder's default GEMM mode): generator, out-projection and grad_mixed on the fp16 hi + lo kernels --
-        # three of the six 15-GFLOP GEMMs of a layer's forward + backward (grad_params . W_pg would need a device-side bound of the
-        # gradient's magnitude and the two grad_W GEMMs reduce over the rows: those stay on the exact kernels)
+        # three of the six 15-GFLOP GEMMs of a layer's forward + backward; the two grad_W GEMMs (reduced over the rows) run on
+        # gemm_tn_f16s.hip's in-kernel split; grad_params . W_pg stays on the exact split-K kernel
         ctx.f16 = bool(gemm_f16) and not recompute and bool(lib.sbev_linear_bf16s_gen_ok(BQ, pg_w.shape[0], pg_w.shape[1])) and \
             bool(lib.sbev_linear_bf16s_out_ok(BQ, op_w.shape[0], op_w.shape[1])) and bool(lib.sbev_linear_bf16s_gen_ok(BQ, op_w.shape[1], op_w.shape[0]))
         if ctx.f16:
             x = _c(x)
-            params = dense.linear_f16s_gen(_c(query).reshape(BQ, D), *_f16_frags(pg_w), pg_b)
+            params, ctx.q_scale = dense.linear_f16s_gen(_c(query).reshape(BQ, D), *_f16_frags(pg_w), pg_b, return_scale=True)
             mixed = torch.empty(BQ, G * out_points * C, device=x.device, dtype=torch.float32)
             _lib.check(lib.sbev_adaptive_mixing_f32(_p(x), _p(params), _p(mixed), BQ, G, Pin, C, out_points, _EPS, _stream()),
                        'sbev_adaptive_mixing_f32')
@@ -553,26 +580,39 @@ class AdaptiveMixing(torch.autograd.Function):
         pgw_tapped = tap is not None and tap.has(pgw_id)
         # out-projection backward
         _, gb_op = _bias_relu_bwd(gy2, None, True, tap, opb_id)
+        NM, NP = mixed.shape[1], params.shape[1]
+        # the two big grad_W products (15 GFLOP each) on the fp16 hi + lo kernel: operand scales from what the fp16 forward / backward
+        # GEMMs computed anyway (grad_y, query), the LayerNorm bound (mixed) and the mixing backward's per-item maxima (grad_params)
+        wg_f16 = ctx.f16 and _WGRAD_F16 and bool(lib.sbev_gemm_tn_f16s_ok(D, NM, BQ)) and bool(lib.sbev_gemm_tn_f16s_ok(NP, D, BQ)) and (BQ * G) % 4 == 0
         if ctx.f16:      # grad_mixed = grad_y . W_op: generator-shaped (K = 256 -> 32768 columns) with the fragments of W_op^T
-            gmixed = dense.linear_f16s_gen(gy2, *_f16_frags(op_w, transposed=True), None)
+            gmixed, gy_scale = dense.linear_f16s_gen(gy2, *_f16_frags(op_w, transposed=True), None, return_scale=True)
             gw_op = None
-            if not opw_tapped:
+            if wg_f16:
+                gw_op = _wgrad_tn_f16(tap, opw_id, opw_tapped, gy2, D, gy_scale, mixed, NM, _const_scale(x.device, _mixed_up_log2(ctx.out_points * C)), D, NM, BQ)
+            elif not opw_tapped:
                 _, gw_op = _linear_grads(gy2, mixed, _c(op_w), False, True)
         else:
             gmixed, gw_op = _linear_grads(gy2, mixed, _c(op_w), True, not opw_tapped)
-        if opw_tapped:
-            _tap_gemm(tap, opw_id, gy2, True, D, mixed, True, mixed.shape[1], D, mixed.shape[1], BQ)
+        if opw_tapped and not wg_f16:
+            _tap_gemm(tap, opw_id, gy2, True, D, mixed, True, NM, D, NM, BQ)
         del mixed
         # mixing core backward
         gx = torch.empty_like(x)
         gparams = torch.empty_like(params)
-        _lib.check(lib.sbev_adaptive_mixing_bwd_f32(_p(x), _p(params), _p(gmixed), _p(gx), _p(gparams), BQ, G, Pin, C, ctx.out_points,
-                                                    _EPS, _stream()), 'sbev_adaptive_mixing_bwd_f32')
+        if wg_f16:
+            item_max = torch.empty(BQ * G, device=x.device, dtype=torch.float32)
+            _lib.check(lib.sbev_adaptive_mixing_bwd_max_f32(_p(x), _p(params), _p(gmixed), _p(gx), _p(gparams), _p(item_max), BQ, G, Pin, C,
+                                                            ctx.out_points, _EPS, _stream()), 'sbev_adaptive_mixing_bwd_max_f32')
+        else:
+            _lib.check(lib.sbev_adaptive_mixing_bwd_f32(_p(x), _p(params), _p(gmixed), _p(gx), _p(gparams), BQ, G, Pin, C, ctx.out_points,
+                                                        _EPS, _stream()), 'sbev_adaptive_mixing_bwd_f32')
         del gmixed, params
         # parameter generator backward
         _, gb_pg = _bias_relu_bwd(gparams, None, True, tap, pgb_id)
         gw_pg = None
-        if pgw_tapped:
+        if wg_f16:
+            gw_pg = _wgrad_tn_f16(tap, pgw_id, pgw_tapped, gparams, NP, dense.f16s_tensor_scale(item_max), q2, D, ctx.q_scale, NP, D, BQ)
+        elif pgw_tapped:
             _tap_gemm(tap, pgw_id, gparams, True, gparams.shape[1], q2, True, D, gparams.shape[1], D, BQ)
         else:
             _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)

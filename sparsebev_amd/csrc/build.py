@@ -23,6 +23,7 @@ UNITS = {
     'gemm_bf16x3.hip': [],
     'gemm_bf16s.hip': [],                # split-bf16 (bf16x6 / bf16x3) Linears, 8-wave workgroups on v_mfma_f32_32x32x16_bf16
     'gemm_any.hip': [],                  # layout-generic GEMM: grad_x / grad_W of every Linear (training)
+    'gemm_tn_f16s.hip': [],              # grad_W of AdaptiveMixing's two big Linears: fp16 hi + lo split on the way into LDS
     'mixing_bwd.hip': [],
     'attention_bwd.hip': [],
     'attention_bwd_mfma.hip': [],

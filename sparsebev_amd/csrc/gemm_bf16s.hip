@@ -1181,6 +1181,16 @@ extern "C" int sbev_pack_f16s_frags(const float* W, int64_t ldw, uint16_t* out, 
     return sbev::check_launch("sbev_pack_f16s_frags");
 }
 
+// {2^e, 2^-e} of a whole fp32 matrix [rows, ldx] (K columns used): the scale sbev_gemm_tn_f16s takes for an operand
+extern "C" int sbev_f16s_tensor_scale(const float* X, int64_t ldx, int64_t rows, int K, float* updown, sbev_stream_t stream) {
+    SBEV_REQUIRE(X && updown && rows >= 1 && K >= 4 && K % 4 == 0 && ldx >= K && ldx % 4 == 0 && (((uintptr_t)X) & 15) == 0,
+                 "sbev_f16s_tensor_scale: rows=%lld, K=%d (multiple of 4), ldx=%lld (multiple of 4), X 16-byte aligned", (long long)rows, K, (long long)ldx);
+    const long long n4 = (long long)rows * (K / 4);
+    const unsigned nb = (unsigned)(n4 / 1024 < 1 ? 1 : n4 / 1024 > 64 ? 64 : n4 / 1024);
+    hipLaunchKernelGGL(tensor_scale_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, (long long)ldx, (long long)rows, K, updown);
+    return sbev::check_launch("sbev_f16s_tensor_scale");
+}
+
 static int ntm_of(int64_t M) { return (int)(((M + 31) / 32 + 7) / 8); }      // row tiles of <= 8 fragments
 
 extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {

@@ -1,0 +1,210 @@
+// Weight gradients of AdaptiveMixing's two big Linears on the fp16 matrix core (training; gfx950).
+//
+//   C[M,N] (+)= sum_k A[k*lda + m] * B[k*ldb + n]          both operands k-major: grad_W = grad_y^T . x, reduced over the B*Q rows
+//
+// models/sparsebev_transformer.py:358-379 leaves these to autograd / cuBLAS.  At config 2 they are [256 x 32768] and [32768 x 256]
+// over K = 900 rows: 15.1 GFLOP each, 174 us on gemm_any.hip's exact v_mfma_f32_32x32x2_f32 tiles (99 us of matrix-core time at
+// 2 workgroups per CU).  Here every fp32 operand value is multiplied by the caller's power of two (max |x| 2^e in [2^14, 2^15), see
+// gemm_bf16s.hip) and split into fp16 hi + lo ON THE WAY INTO LDS; the products hl + lh + hh run on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation (18.6 us of matrix-core time for the same tile plan), the result is multiplied by 2^-(ea + eb).  Error against
+// fp64: below the exact f32-MFMA kernel's (tests/test_gpu_backward.py), as for the forward GEMMs.
+//
+// 128 x 128 x 32 tiles, 2 x 2 waves x 2 x 2 MFMA tiles, register-staged, double-buffered LDS, one barrier per K step (the plan
+// of gemm_any.hip).  A thread stages a 4 (outer) x 4 (k) block: four float4 loads along the contiguous outer index (512 B per
+// wave and k row), then per outer index one 8-byte LDS write of 4 consecutive k per image.  LDS image: [128 outer][32 k] fp16,
+// rows of 72 bytes, row m stored at physical row  (m & ~31) | (((m >> 2) + 8 (m & 3)) & 31):  the 32 lanes of a staging write
+// (rows 4 o4 + e, o4 = 0..31) and the 32 lanes of a fragment read (rows base + 0..31) both land on 32 distinct even banks.
+// K is zero-filled to a multiple of 32 on the way in (K = 900).
+#include "sbev_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TM = 128, TN = 128, TK = 32;
+constexpr int ROWB = 72;                 // bytes per LDS row: 32 fp16 + 8 pad
+constexpr int IMG = TM * ROWB;           // one image (hi or lo) of one operand tile
+constexpr int OPER = 2 * IMG;            // hi, lo
+constexpr int BUF = 2 * OPER;            // A, B
+constexpr int LDS_BYTES = 2 * BUF;       // double buffer: 73,728
+
+struct TnArgs {
+    const float* A;
+    const float* B;
+    const float* a_scale;    // [2]: 2^ea, 2^-ea
+    const float* b_scale;
+    float* C;
+    long long M, N, K;
+    long long lda, ldb, ldc;
+    int accumulate;
+};
+
+__device__ __forceinline__ int phys_row(int m) { return (m & ~31) | (((m >> 2) + 8 * (m & 3)) & 31); }
+
+__device__ __forceinline__ void stage_load(const float* __restrict__ P, long long ld, long long outer, long long K, long long o0,
+                                           long long k0, int o4, int kq, f32x4 (&r)[4]) {
+    const long long o = o0 + 4 * o4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long k = k0 + 4 * kq + i;
+        const bool ok = k < K && o < outer;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P + (ok ? k * ld + o : 0));     // unconditional load: counted vmcnt waits
+        r[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// r[i][e] = value at (k = 4 kq + i, outer = 4 o4 + e)  ->  hi / lo images, 4 consecutive k (8 bytes) per outer index
+__device__ __forceinline__ void stage_store(unsigned char* S, int o4, int kq, const f32x4 (&r)[4], float up) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = r[i][e] * up;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            h[i] = __builtin_bit_cast(unsigned short, hi);
+            l[i] = __builtin_bit_cast(unsigned short, lo);
+        }
+        const int prow = (o4 >> 3) * 32 + ((o4 + 8 * e) & 31);       // = phys_row(4 o4 + e)
+        unsigned char* d = S + prow * ROWB + kq * 8;
+        *reinterpret_cast<u32x2*>(d) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+        *reinterpret_cast<u32x2*>(d + IMG) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+    }
+}
+
+// operand of v_mfma_f32_32x32x16_f16: lane (fr, fh) supplies (row fr, k = 8 fh .. 8 fh + 7) of the 16-k step
+__device__ __forceinline__ f16x8 frag(const unsigned char* S, int row_off, int ks, int fh) {
+    const u32x2* p = reinterpret_cast<const u32x2*>(S + row_off + ks * 32 + fh * 16);
+    const u32x2 a = p[0], b = p[1];
+    return __builtin_bit_cast(f16x8, (u32x4){a.x, a.y, b.x, b.y});
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int o4 = tid & 31, kq = tid >> 5;
+    // the dimension with fewer tiles varies slowest: the workgroups that share a tile of the long operand are a multiple of 8
+    // apart (256 tiles along the long side) and run on the same XCD / L2
+    const unsigned tiles_m = (unsigned)((a.M + TM - 1) / TM), tiles_n = (unsigned)((a.N + TN - 1) / TN);
+    unsigned tm, tn;
+    if (tiles_n < tiles_m) { tn = blockIdx.x / tiles_m; tm = blockIdx.x % tiles_m; }
+    else { tm = blockIdx.x / tiles_n; tn = blockIdx.x % tiles_n; }
+    const long long m0 = (long long)tm * TM, n0 = (long long)tn * TN;
+    const int nk = (int)((a.K + TK - 1) / TK);
+    const float upa = a.a_scale[0], upb = a.b_scale[0];
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int arow[2], brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = phys_row(wr * 64 + i * 32 + fr) * ROWB;
+        brow[i] = phys_row(wc * 64 + i * 32 + fr) * ROWB;
+    }
+
+    f32x4 ra[4], rb[4];
+    stage_load(a.A, a.lda, a.M, a.K, m0, 0, o4, kq, ra);
+    stage_load(a.B, a.ldb, a.N, a.K, n0, 0, o4, kq, rb);
+    stage_store(lds, o4, kq, ra, upa);
+    stage_store(lds + OPER, o4, kq, rb, upb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            stage_load(a.A, a.lda, a.M, a.K, m0, (long long)(kt + 1) * TK, o4, kq, ra);
+            stage_load(a.B, a.ldb, a.N, a.K, n0, (long long)(kt + 1) * TK, o4, kq, rb);
+        }
+        const unsigned char* As = lds + buf * BUF;
+        const unsigned char* Bs = As + OPER;
+#pragma unroll
+        for (int ks = 0; ks < TK / 16; ++ks) {
+            f16x8 fa[2][2], fb[2][2];       // [tile][image]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int img = 0; img < 2; ++img) {
+                    fa[i][img] = frag(As + img * IMG, arow[i], ks, fh);
+                    fb[i][img] = frag(Bs + img * IMG, brow[i], ks, fh);
+                }
+            // small terms first, hi x hi last (the order of gemm_bf16s.hip's 3-product mode)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            unsigned char* An = lds + (buf ^ 1) * BUF;
+            stage_store(An, o4, kq, ra, upa);
+            stage_store(An + OPER, o4, kq, rb, upb);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    const float down = a.a_scale[1] * a.b_scale[1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wc * 64 + j * 32 + fr;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (m >= a.M) continue;
+                float* p = a.C + m * a.ldc + n;
+                const float v = acc[i][j][e] * down;
+                *p = a.accumulate ? *p + v : v;
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int sbev_gemm_tn_f16s_ok(int64_t M, int64_t N, int64_t K) {
+    // enough tiles to fill the chip without a split of K (else: sbev_gemm_f32 and its split-K plan)
+    return M >= 4 && N >= 4 && M % 4 == 0 && N % 4 == 0 && K >= 1 && ((M + TM - 1) / TM) * ((N + TN - 1) / TN) >= 256 &&
+           ((M + TM - 1) / TM) * ((N + TN - 1) / TN) <= 0x7fffffffLL;
+}
+
+extern "C" int sbev_gemm_tn_f16s(const float* A, int64_t lda, const float* a_scale, const float* B, int64_t ldb, const float* b_scale,
+                                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, sbev_stream_t stream) {
+    SBEV_REQUIRE(sbev_gemm_tn_f16s_ok(M, N, K), "sbev_gemm_tn_f16s: M=%lld, N=%lld (multiples of 4, >= 256 tiles of 128 x 128), K=%lld",
+                 (long long)M, (long long)N, (long long)K);
+    SBEV_REQUIRE(A && B && C && a_scale && b_scale, "sbev_gemm_tn_f16s: null pointer");
+    SBEV_REQUIRE(lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+                 "sbev_gemm_tn_f16s: leading dimensions must cover the operands and be multiples of 4, A and B 16-byte aligned");
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f16s_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+    if (!attr_ok) {
+        (void)hipGetLastError();
+        sbev::set_error("sbev_gemm_tn_f16s: cannot reserve %d bytes of LDS", LDS_BYTES);
+        return SBEV_ELAUNCH;
+    }
+    const TnArgs a{A, B, a_scale, b_scale, C, M, N, K, lda, ldb, ldc, accumulate};
+    const long long tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    hipLaunchKernelGGL(gemm_tn_f16s_kernel, dim3((unsigned)tiles), dim3(256), LDS_BYTES, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_gemm_tn_f16s");
+}

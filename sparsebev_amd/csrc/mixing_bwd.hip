@@ -34,6 +34,7 @@ struct MixBwdArgs {
     const float* gout;     // [BQ, G, Pout, C]
     float* gx;             // [BQ, G, Pin, C]
     float* gparams;        // [BQ, G, C*C + Pout*Pin]
+    float* item_max;       // [BQ * G] max |gparams| of each item (the fp16 GEMM's scale of grad_params comes from these), or NULL
     long long n_items;
     int Pin;
     float eps;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y2[(r * 16 + fk * 4 + e) * LD + cw + fi] = rstd2 * (g2[r][e] - mg2 - acc2[r][e] * mgh2);
     wg_sync<FAST>();
+    float gmx = 0.f;
     // ---- (3) dS = dy2 n1^T : wave w owns the 16-row tiles w and w + 4 of the 128 output rows -----------------------------
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -245,7 +247,10 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
         for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (ct * 16 + fi < Pin) gS[(rt * 16 + fk * 4 + e) * Pin + ct * 16 + fi] = acc[ct][e];
+                if (ct * 16 + fi < Pin) {
+                    gS[(rt * 16 + fk * 4 + e) * Pin + ct * 16 + fi] = acc[ct][e];
+                    gmx = fmaxf(gmx, fabsf(acc[ct][e]));
+                }
     }
     // ---- (4) dn1 = S^T dy2, ReLU mask, LayerNorm-1 backward -> dy1 in LDS ------------------------------------------------
     f32x4 acc4[RT];
@@ -313,7 +318,10 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gM[(ct * 16 + fk * 4 + e) * C + cw + fi] = acc[ct][e];
+            for (int e = 0; e < 4; ++e) {
+                gM[(ct * 16 + fk * 4 + e) * C + cw + fi] = acc[ct][e];
+                gmx = fmaxf(gmx, fabsf(acc[ct][e]));
+            }
     }
     // ---- (6) dx = dy1 M^T : wave w owns the input-channel slab ci in [cw, cw + 16) ---------------------------------------
     {
@@ -337,6 +345,14 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
                 if (row < Pin) gx[row * C + cw + fi] = acc[r][e];
             }
     }
+    if (a.item_max) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, o));
+        wg_sync<FAST>();
+        if (lane == 0) red[wave] = gmx;
+        wg_sync<FAST>();
+        if (tid == 0) a.item_max[item] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
 }
 
 template <int RT, bool FAST = false>
@@ -356,8 +372,8 @@ int launch_mix_bwd(const MixBwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
-                                            int64_t BQ, int G, int Pin, int Cg, int Pout, float eps, sbev_stream_t stream) {
+static int mixing_bwd(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params, float* item_max,
+                      int64_t BQ, int G, int Pin, int Cg, int Pout, float eps, sbev_stream_t stream) {
     SBEV_REQUIRE(BQ >= 0 && G >= 1, "sbev_adaptive_mixing_bwd_f32: bad sizes");
     SBEV_REQUIRE(Cg == C && Pout == POUT, "sbev_adaptive_mixing_bwd_f32: built for C=64 channels per group and 128 out points (got %d, %d)", Cg, Pout);
     SBEV_REQUIRE(Pin >= 4 && Pin % 4 == 0 && Pin <= 120, "sbev_adaptive_mixing_bwd_f32: in_points=%d must be a multiple of 4 in 4..120 (as the forward)", Pin);
@@ -365,7 +381,7 @@ extern "C" int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params,
     SBEV_REQUIRE(x && params && grad_y && grad_x && grad_params, "sbev_adaptive_mixing_bwd_f32: null pointer");
     SBEV_REQUIRE(BQ * G <= 0x7fffffffLL, "sbev_adaptive_mixing_bwd_f32: too many items");
     SBEV_REQUIRE((((uintptr_t)params) & 15) == 0 && (Pin * Pout) % 4 == 0, "sbev_adaptive_mixing_bwd_f32: params must be 16-byte aligned");
-    MixBwdArgs a{x, params, grad_y, grad_x, grad_params, BQ * G, Pin, eps};
+    MixBwdArgs a{x, params, grad_y, grad_x, grad_params, item_max, BQ * G, Pin, eps};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch ((Pin + 15) / 16) {
         case 1: return launch_mix_bwd<1>(a, s);
@@ -382,4 +398,15 @@ extern "C" int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params,
         case 7: return launch_mix_bwd<7>(a, s);
         default: return launch_mix_bwd<8>(a, s);
     }
+}
+
+extern "C" int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
+                                            int64_t BQ, int G, int Pin, int Cg, int Pout, float eps, sbev_stream_t stream) {
+    return mixing_bwd(x, params, grad_y, grad_x, grad_params, nullptr, BQ, G, Pin, Cg, Pout, eps, stream);
+}
+
+extern "C" int sbev_adaptive_mixing_bwd_max_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
+                                                float* item_max, int64_t BQ, int G, int Pin, int Cg, int Pout, float eps, sbev_stream_t stream) {
+    SBEV_REQUIRE(item_max || BQ == 0, "sbev_adaptive_mixing_bwd_max_f32: null item_max");
+    return mixing_bwd(x, params, grad_y, grad_x, grad_params, item_max, BQ, G, Pin, Cg, Pout, eps, stream);
 }

@@ -171,9 +171,9 @@ def pack_f16s_frags(w, per_tensor=False):
     return out, (scales if per_tensor else scales.reshape(2, N))
 
 
-def linear_f16s_gen(x, w_frags, w_scales, b, nprod=3, relu=False):
+def linear_f16s_gen(x, w_frags, w_scales, b, nprod=3, relu=False, return_scale=False):
     """y = act(x @ W.T + b) with (w_frags, w_scales) = pack_f16s_frags(W); x fp32 [.., K] is scaled (per tensor), split and packed
-    here.  N % 256 == 0, K % 32 == 0 (the parameter generator's shape)."""
+    here.  N % 256 == 0, K % 32 == 0 (the parameter generator's shape).  return_scale: also x's {2^e, 2^-e} (device, [2])."""
     _dev(x, w_frags)
     K, N = x.shape[-1], w_frags.shape[0] * 32
     xs, xsc = pack_f16s_frags(x, per_tensor=True)
@@ -181,7 +181,32 @@ def linear_f16s_gen(x, w_frags, w_scales, b, nprod=3, relu=False):
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     st = _lib.load().sbev_linear_f16s_gen(_p(xs), _p(xsc), _p(w_frags), _p(w_scales[1]), _p(b), _p(y), M, N, K, N, int(relu), nprod, _stream())
     _lib.check(st, 'sbev_linear_f16s_gen')
-    return y.reshape(*x.shape[:-1], N)
+    y = y.reshape(*x.shape[:-1], N)
+    return (y, xsc) if return_scale else y
+
+
+def f16s_tensor_scale(x):
+    """{2^e, 2^-e} (device fp32 [2]) with max |x| 2^e in [2^14, 2^15): the operand scale gemm_tn_f16s takes.  x: fp32, contiguous,
+    numel % 4 == 0."""
+    _dev(x)
+    x = x.contiguous()
+    n = x.numel()
+    K = x.shape[-1] if x.dim() >= 2 and x.shape[-1] % 4 == 0 else n
+    out = torch.empty(2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().sbev_f16s_tensor_scale(_p(x), K, n // K, K, _p(out), _stream()), 'sbev_f16s_tensor_scale')
+    return out
+
+
+def gemm_tn_f16s(A, lda, a_scale, B, ldb, b_scale, M, N, K, out=None, ldc=None, accumulate=False):
+    """C[M,N] (+)= sum_k A[k*lda + m] B[k*ldb + n] (grad_W = grad_y^T . x) on the fp16 hi + lo kernels; a_scale / b_scale: device
+    {2^e, 2^-e} of the operands (f16s_tensor_scale or a bound).  See sbev_gemm_tn_f16s."""
+    _dev(A, B)
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        ldc = N
+    st = _lib.load().sbev_gemm_tn_f16s(_p(A), lda, _p(a_scale), _p(B), ldb, _p(b_scale), _p(out), ldc, M, N, K, int(accumulate), _stream())
+    _lib.check(st, 'sbev_gemm_tn_f16s')
+    return out
 
 
 def f16s_pairs(x, up_log2):

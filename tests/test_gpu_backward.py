@@ -24,6 +24,61 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 32768, 900), (32768, 256, 900), (260, 16384, 37), (4096, 1028, 64)])
+@pytest.mark.parametrize('wide', [False, True])
+def test_gemm_tn_f16s_vs_fp64_not_worse_than_the_exact_kernel(M, N, K, wide):
+    """grad_W-shaped product on the fp16 hi + lo kernel (sbev_gemm_tn_f16s): error against fp64 <= the exact f32-MFMA kernel's
+    (sbev_gemm_f32, same layouts) -- also with operands spread over 12 binades -- ragged M / N / K, accumulation into a strided
+    destination, and scales from sbev_f16s_tensor_scale."""
+    from sparsebev_amd import dense
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Bm = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g) / K ** 0.5
+    if wide:
+        A = A * torch.exp2(torch.randint(-12, 1, A.shape, generator=g).float())
+        Bm = Bm * torch.exp2(torch.randint(-12, 1, Bm.shape, generator=g).float())
+    ref = A.double().t() @ Bm.double()
+    Ad, Bd = A.to(DEV), Bm.to(DEV)
+    sa, sb = dense.f16s_tensor_scale(Ad), dense.f16s_tensor_scale(Bd)
+    for t, sc in ((A, sa), (Bm, sb)):
+        up, down = sc.cpu().tolist()
+        assert up * down == 1.0 and 2.0 ** 14 <= t.abs().max().item() * up < 2.0 ** 15
+    out = dense.gemm_tn_f16s(Ad, M, sa, Bd, N, sb, M, N, K)
+    exact = AG.gemm(Ad, True, M, Bd, True, N, M, N, K)
+    e16 = (out.cpu().double() - ref).abs()
+    e32 = (exact.cpu().double() - ref).abs()
+    assert e16.max() <= 1.05 * e32.max() + 1e-12, (e16.max().item(), e32.max().item())
+    assert e16.pow(2).mean().sqrt() <= 1.05 * e32.pow(2).mean().sqrt() + 1e-12
+    assert e16.max() < 3e-6 * max(1.0, ref.abs().max().item())
+    # accumulate into a strided destination; a caller-side bound instead of the measured scale (any 2^e with max |x| 2^e < 65504)
+    C0 = torch.randn(M, N + 4, generator=g)
+    dst = C0.to(DEV)
+    e = int(torch.log2(60000.0 / A.abs().max()).floor().item())
+    dense.gemm_tn_f16s(Ad, M, torch.tensor([2.0 ** e, 2.0 ** -e], device=DEV), Bd, N, sb, M, N, K, out=dst, ldc=N + 4, accumulate=True)
+    ref2 = C0.double()
+    ref2[:, :N] += ref
+    assert (dst.cpu().double() - ref2).abs().max() < 3e-6 * max(1.0, ref.abs().max().item()) + 1e-6
+    assert torch.equal(dst[:, N:].cpu(), C0[:, N:])
+
+
+def test_mixing_backward_item_maxima_are_the_maxima_of_grad_params():
+    g = torch.Generator().manual_seed(5)
+    BQ, G, Pin, C, Pout = 37, 4, 32, 64, 128
+    NP = C * C + Pout * Pin
+    x = torch.randn(BQ, G, Pin, C, generator=g).to(DEV)
+    params = (torch.randn(BQ, G * NP, generator=g) * 0.2).to(DEV)
+    gy = (torch.randn(BQ, G * Pout * C, generator=g) * torch.exp2(torch.randint(-6, 6, (BQ, 1), generator=g).float())).to(DEV)
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    gx0, gp0 = torch.empty_like(x), torch.empty_like(params)
+    gx1, gp1 = torch.empty_like(x), torch.empty_like(params)
+    imax = torch.empty(BQ * G, device=DEV)
+    assert lib.sbev_adaptive_mixing_bwd_f32(p(x), p(params), p(gy), p(gx0), p(gp0), BQ, G, Pin, C, Pout, 1e-5, None) == 0
+    assert lib.sbev_adaptive_mixing_bwd_max_f32(p(x), p(params), p(gy), p(gx1), p(gp1), p(imax), BQ, G, Pin, C, Pout, 1e-5, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gx0, gx1) and torch.equal(gp0, gp1)
+    assert torch.equal(imax, gp1.reshape(BQ * G, NP).abs().amax(dim=1))
+
+
 @pytest.mark.parametrize('M,N,K', [(900, 256, 256), (900, 256, 32768), (256, 32768, 900), (32768, 256, 900), (900, 32768, 256),
                                    (37, 10, 256), (256, 3, 72), (130, 129, 33), (1, 5, 7), (3600, 256, 8192)])
 def test_gemm_any_all_layouts_vs_fp64(M, N, K):

@@ -419,6 +419,11 @@ int sbev_linear_splitk_f16s(const float* X, int x_is_pairs, int x_up_log2, const
                             const float* ln_w, const float* ln_b, float ln_eps, float* Y,
                             int64_t M, int N, int K, int64_t ldx, int relu, int nprod, float* workspace, sbev_stream_t stream);
 int sbev_f16s_out_scale(const float* wdown, int x_up_log2, float* nscale, int N, sbev_stream_t stream);
+/* sbev_linear_splitk_f16s with X's scale in device memory (x_scale = {2^e, 2^-e}, e.g. sbev_f16s_tensor_scale) instead of a host-side
+ * bound; wdown = W's [N] down-scales (sbev_pack_f16s_frags scales + N).  X fp32 only. */
+int sbev_linear_splitk_f16s_xdev(const float* X, const float* x_scale, const uint16_t* Wp, const float* wdown, const float* bias,
+                                 const float* residual, const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                 int64_t M, int N, int K, int64_t ldx, int relu, int nprod, float* workspace, sbev_stream_t stream);
 /* The pre-split operand: out[i] = (fp16 hi, fp16 lo) of X[i] 2^up_log2 packed in one 32-bit slot (hi in the low half).  With
  * x_is_pairs = 1 sbev_linear_splitk_f16s takes X in this format (same [M, ldx] geometry) and only de-interleaves it.  The mixing
  * launches can emit it directly: sbev_adaptive_mixing_pairs_f16 / sbev_sample_mix_pairs_f16 = sbev_adaptive_mixing_f32 /
@@ -530,8 +535,8 @@ int sbev_linear3_ln_relu_ex_f32(const float* x, int64_t ldx, const float* w, con
  * grad_x [BQ,G,Pin,C], grad_params [BQ,G,C*C+Pout*Pin]. */
 int sbev_adaptive_mixing_bwd_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
                                  int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
-/* the same, also writing item_max[BQ*G] = max |grad_params| of each (row, group): sbev_f16s_tensor_scale of that array is the
- * fp16 scale of grad_params without another pass over its 118 MB */
+/* the same, also writing item_max[BQ*G][4]: four partial maxima of |grad_params| per (row, group), their maximum = that item's
+ * maximum: sbev_f16s_tensor_scale of the array is the fp16 scale of grad_params without another pass over its 118 MB */
 int sbev_adaptive_mixing_bwd_max_f32(const float* x, const float* params, const float* grad_y, float* grad_x, float* grad_params,
                                      float* item_max, int64_t BQ, int G, int Pin, int C, int Pout, float eps, sbev_stream_t stream);
 

@@ -95,6 +95,8 @@ SIGNATURES = {
     'sbev_linear_splitk_f16s': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'sbev_f16s_out_scale': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    'sbev_linear_splitk_f16s_xdev': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'sbev_linear_bf16s_out_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_bf16s_out_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_splitk_bf16s': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, ctypes.c_int64, ctypes.c_int,

@@ -286,6 +286,9 @@ def _const_scale(device, e):
 _WGRAD_F16 = os.environ.get('SBEV_NO_WGRAD_F16', '0') != '1'    # A/B switch: the two big grad_W GEMMs on the fp16 kernel (gemm_tn_f16s.hip)
 
 
+_GQ_F16 = os.environ.get('SBEV_NO_GQ_F16', '0') != '1'          # A/B switch: grad_query = grad_params . W_pg on the fp16 split-K kernel
+
+
 def _wgrad_tn_f16(tap, pid, tapped, A, lda, a_scale, B, ldb, b_scale, M, N, K):
     """grad_W [M, N] = A^T B on the fp16 hi + lo kernel: into the tapped parameter's buffer (returns None) or as a new tensor"""
     if not tapped:
@@ -529,7 +532,7 @@ class AdaptiveMixing(torch.autograd.Function):
         lib = _lib.load()
         # gemm_f16 (the decoder's default GEMM mode): generator, out-projection and grad_mixed on the fp16 hi + lo kernels --
         # three of the six 15-GFLOP GEMMs of a layer's forward + backward; the two grad_W GEMMs (reduced over the rows) run on
-        # gemm_tn_f16s.hip's in-kernel split; grad_params . W_pg stays on the exact split-K kernel
+        # gemm_tn_f16s.hip's in-kernel split and grad_params . W_pg on the split-K kernel with a device-side scale: all six
         ctx.f16 = bool(gemm_f16) and not recompute and bool(lib.sbev_linear_bf16s_gen_ok(BQ, pg_w.shape[0], pg_w.shape[1])) and \
             bool(lib.sbev_linear_bf16s_out_ok(BQ, op_w.shape[0], op_w.shape[1])) and bool(lib.sbev_linear_bf16s_gen_ok(BQ, op_w.shape[1], op_w.shape[0]))
         if ctx.f16:
@@ -583,7 +586,7 @@ class AdaptiveMixing(torch.autograd.Function):
         NM, NP = mixed.shape[1], params.shape[1]
         # the two big grad_W products (15 GFLOP each) on the fp16 hi + lo kernel: operand scales from what the fp16 forward / backward
         # GEMMs computed anyway (grad_y, query), the LayerNorm bound (mixed) and the mixing backward's per-item maxima (grad_params)
-        wg_f16 = ctx.f16 and _WGRAD_F16 and bool(lib.sbev_gemm_tn_f16s_ok(D, NM, BQ)) and bool(lib.sbev_gemm_tn_f16s_ok(NP, D, BQ)) and (BQ * G) % 4 == 0
+        wg_f16 = ctx.f16 and _WGRAD_F16 and bool(lib.sbev_gemm_tn_f16s_ok(D, NM, BQ)) and bool(lib.sbev_gemm_tn_f16s_ok(NP, D, BQ))
         if ctx.f16:      # grad_mixed = grad_y . W_op: generator-shaped (K = 256 -> 32768 columns) with the fragments of W_op^T
             gmixed, gy_scale = dense.linear_f16s_gen(gy2, *_f16_frags(op_w, transposed=True), None, return_scale=True)
             gw_op = None
@@ -600,7 +603,7 @@ class AdaptiveMixing(torch.autograd.Function):
         gx = torch.empty_like(x)
         gparams = torch.empty_like(params)
         if wg_f16:
-            item_max = torch.empty(BQ * G, device=x.device, dtype=torch.float32)
+            item_max = torch.empty(BQ * G * 4, device=x.device, dtype=torch.float32)     # four partial maxima per item
             _lib.check(lib.sbev_adaptive_mixing_bwd_max_f32(_p(x), _p(params), _p(gmixed), _p(gx), _p(gparams), _p(item_max), BQ, G, Pin, C,
                                                             ctx.out_points, _EPS, _stream()), 'sbev_adaptive_mixing_bwd_max_f32')
         else:
@@ -611,13 +614,17 @@ class AdaptiveMixing(torch.autograd.Function):
         _, gb_pg = _bias_relu_bwd(gparams, None, True, tap, pgb_id)
         gw_pg = None
         if wg_f16:
-            gw_pg = _wgrad_tn_f16(tap, pgw_id, pgw_tapped, gparams, NP, dense.f16s_tensor_scale(item_max), q2, D, ctx.q_scale, NP, D, BQ)
+            gp_scale = dense.f16s_tensor_scale(item_max)
+            gw_pg = _wgrad_tn_f16(tap, pgw_id, pgw_tapped, gparams, NP, gp_scale, q2, D, ctx.q_scale, NP, D, BQ)
         elif pgw_tapped:
             _tap_gemm(tap, pgw_id, gparams, True, gparams.shape[1], q2, True, D, gparams.shape[1], D, BQ)
         else:
             _, gw_pg = _linear_grads(gparams, q2, _c(pg_w), False, True)
         # grad_query = grad_y (the `query +` residual) + grad_params . W_pg: the forward split-K Linear with W_pg^T, residual fused
-        gq = dense.linear(gparams, _transposed(pg_w), None, residual=gy2).reshape(query.shape)
+        if wg_f16 and _GQ_F16 and bool(lib.sbev_linear_bf16s_out_ok(BQ, D, NP)):       # the same product on the fp16 split-K kernel, scale from the maxima
+            gq = dense.linear_splitk_f16s(gparams, *_f16_frags(pg_w, transposed=True), None, residual=gy2, x_scale=gp_scale).reshape(query.shape)
+        else:
+            gq = dense.linear(gparams, _transposed(pg_w), None, residual=gy2).reshape(query.shape)
         return (gx, gq, gw_pg, gb_pg, gw_op, gb_op, None, None, None, None,
                 tap.token_grad() if (tap is not None and tap.token is not None) else None)
 

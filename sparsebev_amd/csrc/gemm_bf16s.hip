@@ -653,6 +653,7 @@ struct OutArgs {
     int nrt, S;                  // row tiles of 64 rows, K chunks
     float xup;                   // fp16 modes: X is multiplied by this power of two before the split (the caller's bound on |X|)
     const float* nscale;         // fp16 modes: [256] 2^-ew[n] / xup, applied to the slab values (exact); null otherwise
+    const float* xdev;           // fp16 modes, optional: X's {2^e, 2^-e} in device memory (replaces xup; the slabs are also multiplied by 2^-e)
 };
 
 constexpr int O_IMG = 64 * 64;                  // bytes of one image of one half's stage (64 rows x 32 k)
@@ -709,6 +710,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
         v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));         // streamed once: keep L2 for W
         v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
     };
+    const float xup = a.xdev ? a.xdev[0] : a.xup;
     auto stagex = [&](int i, const f32x4 v0, const f32x4 v1) {       // slab i -> ring slot i % 3
         u32x4 im[NIMG];
         if constexpr (XPRE) {
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
             im[1] = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
                             __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u)};
         } else {
-            split8m<MODE>(v0, v1, a.xup, im);
+            split8m<MODE>(v0, v1, xup, im);
         }
         unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
 #pragma unroll
@@ -857,7 +859,10 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 o = fold[((fa * 2 + fb) * 4 + g) * 64];
                         f32x4 v = {acc[fa][fb][4 * g] + o[0], acc[fa][fb][4 * g + 1] + o[1], acc[fa][fb][4 * g + 2] + o[2], acc[fa][fb][4 * g + 3] + o[3]};
-                        if constexpr (PR::F16) v *= *reinterpret_cast<const f32x4*>(a.nscale + wc * 64 + 4 * lh + fb * 32 + 8 * g);   // exact: powers of two
+                        if constexpr (PR::F16) {      // exact: powers of two
+                            v *= *reinterpret_cast<const f32x4*>(a.nscale + wc * 64 + 4 * lh + fb * 32 + 8 * g);
+                            if (a.xdev) v *= a.xdev[1];
+                        }
                         *reinterpret_cast<f32x4*>(out + (long long)row * 256 + fb * 32 + 8 * g) = v;
                     }
             }
@@ -1293,8 +1298,9 @@ extern "C" int sbev_linear_bf16s_out_plan(int64_t M, int N, int K) {      // sla
 namespace sbev {
 // the GEMM half: *used partial slabs [used, M, 256] (to be summed by sbev_splitk_reduce_f32 or the row-chain tail)
 int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
-                              hipStream_t s, int x_up_log2, const float* nscale, bool x_pairs) {
+                              hipStream_t s, int x_up_log2, const float* nscale, bool x_pairs, const float* xdev) {
     SBEV_REQUIRE(nimg < 4 || nscale, "sbev_linear_splitk_f16s: null scale pointer");
+    SBEV_REQUIRE(!xdev || (nimg >= 4 && !x_pairs), "sbev_linear_splitk_f16s: a device-side X scale needs an fp16 mode and fp32 X");
     if (x_pairs) {                              // fp16 modes with the pre-split operand: 128-row tiles
         SBEV_REQUIRE(nimg >= 4, "sbev_linear_splitk_f16s: pre-split X needs an fp16 mode");
         const Out4Plan pl = out4_plan(M, K);
@@ -1319,7 +1325,7 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
     }
     const int S = out_chunks(M, K);
     *used = S;
-    OutArgs a{X, Wp, slabs, (int)M, K, (long long)ldx, (int)((M + 63) / 64), S, ldexpf(1.f, x_up_log2), nscale};
+    OutArgs a{X, Wp, slabs, (int)M, K, (long long)ldx, (int)((M + 63) / 64), S, ldexpf(1.f, x_up_log2), nscale, xdev};
     const long long wgs = (long long)a.nrt * S;
     SBEV_REQUIRE(wgs <= 0x7fffffffLL, "sbev_linear_splitk_bf16s: too many workgroups");
     hipEvent_t e0, e1;
@@ -1373,6 +1379,23 @@ extern "C" int sbev_linear_splitk_f16s(const float* X, int x_is_pairs, int x_up_
     int used = 0;
     const int st = sbev::launch_splitk_slabs_bf16s(X, Wp, M, K, ldx, nprod + 1, workspace, &used, reinterpret_cast<hipStream_t>(stream), x_up_log2, nscale,
                                                    x_is_pairs != 0);
+    if (st != SBEV_OK) return st;
+    return sbev_splitk_reduce_f32(workspace, used, bias, residual, ln_w, ln_b, ln_eps, Y, M, N, relu, stream);
+}
+
+// The same with X's scale in DEVICE memory (x_scale = {2^e, 2^-e}: sbev_f16s_tensor_scale or the maxima a producer kernel left):
+// no host-side bound needed -- grad_x = grad_y . W of the parameter generator in training, whose grad_y has no a-priori magnitude.
+// wdown = W's [N] down-scales (sbev_pack_f16s_frags scales + N); the kernel applies 2^-e itself.  X fp32 only.
+extern "C" int sbev_linear_splitk_f16s_xdev(const float* X, const float* x_scale, const uint16_t* Wp, const float* wdown, const float* bias,
+                                            const float* residual, const float* ln_w, const float* ln_b, float ln_eps, float* Y,
+                                            int64_t M, int N, int K, int64_t ldx, int relu, int nprod, float* workspace, sbev_stream_t stream) {
+    SBEV_REQUIRE(nprod == 3 || nprod == 4, "sbev_linear_splitk_f16s_xdev: nprod=%d (3 or 4 image products)", nprod);
+    SBEV_REQUIRE(M >= 0 && sbev_linear_bf16s_out_ok(M > 0 ? M : 1, N, K), "sbev_linear_splitk_f16s_xdev: needs N == 256, K %% 32 == 0, K >= 256 (N=%d K=%d)", N, K);
+    if (M == 0) return SBEV_OK;
+    SBEV_REQUIRE(X && x_scale && Wp && Y && workspace && wdown && ldx % 4 == 0 && ldx >= K, "sbev_linear_splitk_f16s_xdev: bad pointers");
+    SBEV_REQUIRE((((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)workspace | (uintptr_t)wdown) & 15) == 0, "sbev_linear_splitk_f16s_xdev: 16-byte alignment");
+    int used = 0;
+    const int st = sbev::launch_splitk_slabs_bf16s(X, Wp, M, K, ldx, nprod + 1, workspace, &used, reinterpret_cast<hipStream_t>(stream), 0, wdown, false, x_scale);
     if (st != SBEV_OK) return st;
     return sbev_splitk_reduce_f32(workspace, used, bias, residual, ln_w, ln_b, ln_eps, Y, M, N, relu, stream);
 }

@@ -16,6 +16,7 @@
 // (rows 4 o4 + e, o4 = 0..31) and the 32 lanes of a fragment read (rows base + 0..31) both land on 32 distinct even banks.
 // K is zero-filled to a multiple of 32 on the way in (K = 900).
 #include "sbev_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -43,28 +44,43 @@ struct TnArgs {
     int accumulate;
 };
 
+// workgroup barrier for the LDS tiles only: the global loads of the next two K steps stay in flight across it (__syncthreads waits
+// for vmcnt(0))
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int phys_row(int m) { return (m & ~31) | (((m >> 2) + 8 * (m & 3)) & 31); }
 
-__device__ __forceinline__ void stage_load(const float* __restrict__ P, long long ld, long long outer, long long K, long long o0,
-                                           long long k0, int o4, int kq, f32x4 (&r)[4]) {
-    const long long o = o0 + 4 * o4;
+// Request a 4 (k) x 4 (outer) block of K step `kt`.  Addressing is 32-bit per lane on a wave-uniform 64-bit base (one v_min + one
+// v_mad_u24 per load; 64-bit per-lane address arithmetic and compares were a third of the loop's instructions): the tile index is
+// clamped to the last tile that has rows, the row inside the tile to its last row, the column block to the last one inside the
+// matrix -- every load is in bounds and UNCONDITIONAL (a load under a branch makes every later wait a vmcnt(0)); what was clamped
+// is zeroed by stage_store.
+__device__ __forceinline__ void stage_load(const float* __restrict__ P, unsigned ld4, long long K, int nk, int kt, unsigned col4, int kq,
+                                           u32x4 (&r)[4]) {
+    const int ktc = kt < nk ? kt : nk - 1;                                     // (uniform)
+    const long long rows = K - (long long)ktc * TK;
+    const int last = (int)(rows < TK ? rows : TK) - 1;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(P) + (unsigned long long)ktc * TK * ld4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long long k = k0 + 4 * kq + i;
-        const bool ok = k < K && o < outer;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(P + (ok ? k * ld + o : 0));     // unconditional load: counted vmcnt waits
-        r[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int row = min(4 * kq + i, last);
+        r[i] = *reinterpret_cast<const u32x4*>(base + (__umul24((unsigned)row, ld4) + col4));
     }
 }
 
-// r[i][e] = value at (k = 4 kq + i, outer = 4 o4 + e)  ->  hi / lo images, 4 consecutive k (8 bytes) per outer index
-__device__ __forceinline__ void stage_store(unsigned char* S, int o4, int kq, const f32x4 (&r)[4], float up) {
+// r[i][e] = value at (k = k0 + 4 kq + i, outer = 4 o4 + e)  ->  hi / lo images, 4 consecutive k (8 bytes) per outer index.
+// upk[i]: the operand's scale, or 0 for a row past K.  Only A's rows are zeroed (B's clamped rows then multiply zeros), and clamped
+// columns are not zeroed at all (their outputs are never stored): a clamped element is a copy of an element of the same column
+// of the same operand, so a non-finite copy can only reach outputs that the original already makes non-finite.  No branch here:
+// a conditional block that touches the staging registers makes the statically inserted waits drain the prefetch.
+__device__ __forceinline__ void stage_store(unsigned char* S, int o4, int kq, const u32x4 (&r)[4], const float (&upk)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         unsigned short h[4], l[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float v = r[i][e] * up;
+            const unsigned bits = r[i][e];       // (an rvalue: __builtin_bit_cast of the element lvalue r[i][e] reads element 0)
+            const float v = __builtin_bit_cast(float, bits) * upk[i];
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)(v - (float)hi);
             h[i] = __builtin_bit_cast(unsigned short, hi);
@@ -116,19 +132,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
         brow[i] = phys_row(wc * 64 + i * 32 + fr) * ROWB;
     }
 
-    f32x4 ra[4], rb[4];
-    stage_load(a.A, a.lda, a.M, a.K, m0, 0, o4, kq, ra);
-    stage_load(a.B, a.ldb, a.N, a.K, n0, 0, o4, kq, rb);
-    stage_store(lds, o4, kq, ra, upa);
-    stage_store(lds + OPER, o4, kq, rb, upb);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            stage_load(a.A, a.lda, a.M, a.K, m0, (long long)(kt + 1) * TK, o4, kq, ra);
-            stage_load(a.B, a.ldb, a.N, a.K, n0, (long long)(kt + 1) * TK, o4, kq, rb);
-        }
-        const unsigned char* As = lds + buf * BUF;
+    // operand tiles are requested TWO K steps ahead (register sets 0 / 1): a K step is ~0.6 us of matrix-core + conversion work per
+    // wave, the loads' round trip under load is several times that (one step ahead: 102 us per launch at config 2)
+    u32x4 ra[2][4], rb[2][4];
+    const bool a_ok = m0 + 4 * o4 < a.M, b_ok = n0 + 4 * o4 < a.N;
+    const unsigned lda4 = (unsigned)a.lda * 4u, ldb4 = (unsigned)a.ldb * 4u;
+    const unsigned acol4 = (unsigned)(a_ok ? m0 + 4 * o4 : a.M - 4) * 4u, bcol4 = (unsigned)(b_ok ? n0 + 4 * o4 : a.N - 4) * 4u;
+    stage_load(a.A, lda4, a.K, nk, 0, acol4, kq, ra[0]);
+    stage_load(a.B, ldb4, a.K, nk, 0, bcol4, kq, rb[0]);
+    stage_load(a.A, lda4, a.K, nk, 1, acol4, kq, ra[1]);
+    stage_load(a.B, ldb4, a.K, nk, 1, bcol4, kq, rb[1]);
+    const float upb4[4] = {upb, upb, upb, upb};
+    auto store_tile = [&](unsigned char* Sn, const u32x4 (&xa)[4], const u32x4 (&xb)[4], long long krem) {
+        float upa4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) upa4[i] = 4 * kq + i < krem ? upa : 0.f;
+        stage_store(Sn, o4, kq, xa, upa4);
+        stage_store(Sn + OPER, o4, kq, xb, upb4);
+    };
+    store_tile(lds, ra[0], rb[0], a.K);
+    lds_barrier();
+    // step kt: LDS buffer kt & 1 holds tile kt, register set (kt + 1) & 1 tile kt + 1 (in flight), register set kt & 1 is free
+    auto step = [&](auto par, int kt) {
+        constexpr int P = decltype(par)::value;
+        stage_load(a.A, lda4, a.K, nk, kt + 2, acol4, kq, ra[P]);
+        stage_load(a.B, ldb4, a.K, nk, kt + 2, bcol4, kq, rb[P]);
+        __builtin_amdgcn_sched_barrier(0);      // (the conversion of tile kt + 1 below must not be hoisted to here: its loads
+        const unsigned char* As = lds + P * BUF;      // would be waited for a whole K step early)
         const unsigned char* Bs = As + OPER;
 #pragma unroll
         for (int ks = 0; ks < TK / 16; ++ks) {
@@ -154,12 +184,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            unsigned char* An = lds + (buf ^ 1) * BUF;
-            stage_store(An, o4, kq, ra, upa);
-            stage_store(An + OPER, o4, kq, rb, upb);
-        }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // (unconditional, as is the second step of a pair below: a skipped conversion or step would leave its register set "pending"
+        // on one path into the loop head and the statically inserted waits would drain the prefetch on every iteration; past K the
+        // tiles are zero)
+        unsigned char* An = lds + (P ^ 1) * BUF;
+        store_tile(An, ra[P ^ 1], rb[P ^ 1], a.K - (long long)(kt + 1) * TK);      // rows of tile kt + 1 inside K (<= 0: a zero tile)
+        lds_barrier();
+    };
+    // tile 1 has landed before the loop is entered: otherwise the registers the prologue's loads target count as pending at the
+    // loop head on every iteration (static s_waitcnt insertion) and the loop waits for its loads a K step early
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -194,8 +232,9 @@ extern "C" int sbev_gemm_tn_f16s(const float* A, int64_t lda, const float* a_sca
     SBEV_REQUIRE(sbev_gemm_tn_f16s_ok(M, N, K), "sbev_gemm_tn_f16s: M=%lld, N=%lld (multiples of 4, >= 256 tiles of 128 x 128), K=%lld",
                  (long long)M, (long long)N, (long long)K);
     SBEV_REQUIRE(A && B && C && a_scale && b_scale, "sbev_gemm_tn_f16s: null pointer");
-    SBEV_REQUIRE(lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
-                 "sbev_gemm_tn_f16s: leading dimensions must cover the operands and be multiples of 4, A and B 16-byte aligned");
+    SBEV_REQUIRE(lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && lda < (1 << 22) && ldb < (1 << 22) &&
+                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+                 "sbev_gemm_tn_f16s: leading dimensions must cover the operands, be multiples of 4 and < 2^22; A and B 16-byte aligned");
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f16s_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     if (!attr_ok) {

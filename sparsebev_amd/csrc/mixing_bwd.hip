@@ -34,7 +34,7 @@ struct MixBwdArgs {
     const float* gout;     // [BQ, G, Pout, C]
     float* gx;             // [BQ, G, Pin, C]
     float* gparams;        // [BQ, G, C*C + Pout*Pin]
-    float* item_max;       // [BQ * G] max |gparams| of each item (the fp16 GEMM's scale of grad_params comes from these), or NULL
+    float* item_max;       // [BQ * G][4] partial maxima of |gparams| per item (one per wave; the fp16 GEMMs' scale of grad_params comes from these), or NULL
     long long n_items;
     int Pin;
     float eps;
@@ -345,13 +345,10 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
                 if (row < Pin) gx[row * C + cw + fi] = acc[r][e];
             }
     }
-    if (a.item_max) {
+    if (a.item_max) {       // one partial maximum per wave: no workgroup barrier at the end of the kernel
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) gmx = fmaxf(gmx, __shfl_xor(gmx, o));
-        wg_sync<FAST>();
-        if (lane == 0) red[wave] = gmx;
-        wg_sync<FAST>();
-        if (tid == 0) a.item_max[item] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (lane == 0) a.item_max[item * 4 + wave] = gmx;
     }
 }
 

@@ -47,7 +47,7 @@ int launch_splitk_slabs_bf16x3(const float* X, const uint16_t* W2, int64_t M, in
 
 // gemm_bf16s.hip: the GEMM half of sbev_linear_splitk_bf16s (*used partial slabs [used, M, 256], not reduced)
 int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
-                              hipStream_t s, int x_up_log2 = 0, const float* nscale = nullptr, bool x_pairs = false);
+                              hipStream_t s, int x_up_log2 = 0, const float* nscale = nullptr, bool x_pairs = false, const float* xdev = nullptr);
 
 // row_chain.hip: the row-local op chains of a decoder layer as single launches (weights pre-packed: sbev_decoder_chain_pack)
 bool row_chain_supported(const sbev_decoder_config& c);

@@ -218,10 +218,11 @@ def f16s_pairs(x, up_log2):
     return out
 
 
-def linear_splitk_f16s(x, w_frags, w_scales, b, nprod=3, residual=None, ln=None, relu=False, x_up_log2=None, x_is_pairs=False):
+def linear_splitk_f16s(x, w_frags, w_scales, b, nprod=3, residual=None, ln=None, relu=False, x_up_log2=None, x_is_pairs=False, x_scale=None):
     """y = LayerNorm?(act(x @ W.T + b) + residual), N == 256, with (w_frags, w_scales) = pack_f16s_frags(W); x stays fp32 and is
     multiplied by 2^x_up_log2 and split inside the kernel (default: from max |x|, one host sync -- the decoder passes its bound);
-    x_is_pairs: x is f16s_pairs(x_fp32, x_up_log2) (int32), only de-interleaved inside the kernel."""
+    x_is_pairs: x is f16s_pairs(x_fp32, x_up_log2) (int32), only de-interleaved inside the kernel;
+    x_scale: device {2^e, 2^-e} of x (f16s_tensor_scale) instead of a host-side exponent -- no sync, no bound."""
     _dev(x, w_frags)
     K = x.shape[-1]
     N = w_frags.shape[0] * 32
@@ -233,15 +234,20 @@ def linear_splitk_f16s(x, w_frags, w_scales, b, nprod=3, residual=None, ln=None,
     plan = lib.sbev_linear_bf16s_out_plan(M, N, K)
     if plan <= 0:
         raise RuntimeError('sbev_linear_splitk_f16s does not cover M=%d N=%d K=%d' % (M, N, K))
+    ws = _ws(plan * M * N * 4, x.device)
+    res2 = residual.reshape(-1, N).contiguous() if residual is not None else None
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    if x_scale is not None:
+        st = lib.sbev_linear_splitk_f16s_xdev(_p(x2), _p(x_scale), _p(w_frags), _p(w_scales[1]), _p(b), _p(res2), _p(ln[0] if ln else None),
+                                              _p(ln[1] if ln else None), 1e-5, _p(y), M, N, K, K, int(relu), nprod, _p(ws), _stream())
+        _lib.check(st, 'sbev_linear_splitk_f16s_xdev')
+        return y.reshape(*x.shape[:-1], N)
     if x_up_log2 is None:
         import math
         mx = float(x2.abs().max())
         x_up_log2 = 15 - math.frexp(mx)[1] if mx > 0 and math.isfinite(mx) else 0
     nscale = torch.empty(N, device=x.device, dtype=torch.float32)
     _lib.check(lib.sbev_f16s_out_scale(_p(w_scales[1]), int(x_up_log2), _p(nscale), N, _stream()), 'sbev_f16s_out_scale')
-    ws = _ws(plan * M * N * 4, x.device)
-    res2 = residual.reshape(-1, N).contiguous() if residual is not None else None
-    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     st = lib.sbev_linear_splitk_f16s(_p(x2), int(x_is_pairs), int(x_up_log2), _p(w_frags), _p(nscale), _p(b), _p(res2), _p(ln[0] if ln else None),
                                      _p(ln[1] if ln else None), 1e-5, _p(y), M, N, K, K, int(relu), nprod, _p(ws), _stream())
     _lib.check(st, 'sbev_linear_splitk_f16s')

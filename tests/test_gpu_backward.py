@@ -71,12 +71,12 @@ def test_mixing_backward_item_maxima_are_the_maxima_of_grad_params():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     gx0, gp0 = torch.empty_like(x), torch.empty_like(params)
     gx1, gp1 = torch.empty_like(x), torch.empty_like(params)
-    imax = torch.empty(BQ * G, device=DEV)
+    imax = torch.empty(BQ * G * 4, device=DEV)           # four partial maxima per item
     assert lib.sbev_adaptive_mixing_bwd_f32(p(x), p(params), p(gy), p(gx0), p(gp0), BQ, G, Pin, C, Pout, 1e-5, None) == 0
     assert lib.sbev_adaptive_mixing_bwd_max_f32(p(x), p(params), p(gy), p(gx1), p(gp1), p(imax), BQ, G, Pin, C, Pout, 1e-5, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(gx0, gx1) and torch.equal(gp0, gp1)
-    assert torch.equal(imax, gp1.reshape(BQ * G, NP).abs().amax(dim=1))
+    assert torch.equal(imax.reshape(BQ * G, 4).amax(dim=1), gp1.reshape(BQ * G, NP).abs().amax(dim=1))
 
 
 @pytest.mark.parametrize('M,N,K', [(900, 256, 256), (900, 256, 32768), (256, 32768, 900), (32768, 256, 900), (900, 32768, 256),

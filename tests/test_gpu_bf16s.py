@@ -285,6 +285,27 @@ def test_out_projection_f16_ragged(M, K, pairs):
     assert (y.double() - ref).abs().max().item() < 3e-6
 
 
+@pytest.mark.parametrize('M,K,mag', [(900, 32768, 1.0), (900, 32768, 3e-7), (97, 4096, 5e4), (1, 256, 1.0)])
+def test_out_projection_f16_device_side_scale(M, K, mag):
+    """sbev_linear_splitk_f16s_xdev: X's power of two comes from device memory (sbev_f16s_tensor_scale) -- operands of any
+    magnitude (a gradient), no host sync; the result equals the host-exponent path bit for bit and is not narrower than the exact kernel."""
+    import math
+    N = 256
+    x, w, b = _rand((M, K), M + K + 1, mag, wide=True), _rand((N, K), K + 2, K ** -0.5), _rand((N,), 14, mag)
+    res = _rand((M, N), 15, mag)
+    wf, wsc = dense.pack_f16s_frags(w)
+    xs = dense.f16s_tensor_scale(x)
+    up = 15 - math.frexp(float(x.abs().max()))[1]
+    assert xs.cpu().tolist() == [2.0 ** up, 2.0 ** -up]
+    y = dense.linear_splitk_f16s(x, wf, wsc, b, residual=res, x_scale=xs)
+    assert torch.equal(y, dense.linear_splitk_f16s(x, wf, wsc, b, residual=res, x_up_log2=up))
+    ref = x.double() @ w.double().t() + b.double() + res.double()
+    e, r = _errs(y, ref)
+    ef, rf = _errs(dense.linear(x, w, b, residual=res), ref)
+    slack = 1.02 if M >= 97 else 1.5          # (a maximum over a single row is one sample of the error distribution)
+    assert e <= slack * ef + 1e-30 and r <= 1.02 * rf + 1e-30, (e, r, ef, rf)
+
+
 def test_mixing_kernels_emit_the_pair_format():
     """sbev_adaptive_mixing_pairs_f16 == f16s_pairs(sbev_adaptive_mixing_f32): the split moved into the producer's epilogue, bit for bit"""
     BQ, G, Pin, C, Pout = 50, 4, 32, 64, 128

@@ -12,8 +12,11 @@
 // 128 x 128 x 32 tiles, 2 x 2 waves x 2 x 2 MFMA tiles, register-staged, double-buffered LDS, one barrier per K step (the plan
 // of gemm_any.hip).  A thread stages a 4 (outer) x 4 (k) block: four float4 loads along the contiguous outer index (512 B per
 // wave and k row), then per outer index one 8-byte LDS write of 4 consecutive k per image.  LDS image: [128 outer][32 k] fp16,
-// rows of 72 bytes, row m stored at physical row  (m & ~31) | (((m >> 2) + 8 (m & 3)) & 31):  the 32 lanes of a staging write
-// (rows 4 o4 + e, o4 = 0..31) and the 32 lanes of a fragment read (rows base + 0..31) both land on 32 distinct even banks.
+// rows of 72 bytes (18 banks), row m stored at physical row  m ^ ((m >> 4) & 3).  Both the staging writes (ds_write2st64_b64) and the
+// fragment reads (ds_read2_b64) are serviced in groups of 16 consecutive lanes on 32 banks, 8 bytes per lane: conflict-free iff the 16
+// rows of a group are distinct mod 16 -- a write group is rows 4 o4 + e over 16 consecutive o4 (bits 2..5 of m vary), a read group
+// rows base + 0..15 (bits 0..3 vary); the XOR moves bits 4..5 into bits 0..1, so both are.  (The first layout was conflict-free for
+// 32-lane groups on 64 banks -- ds_read_b64's rule -- but the compiler fuses the two halves of a fragment into ds_read2_b64.)
 // K is zero-filled to a multiple of 32 on the way in (K = 900).
 #include "sbev_common.hpp"
 #include <type_traits>
@@ -48,7 +51,7 @@ struct TnArgs {
 // for vmcnt(0))
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ int phys_row(int m) { return (m & ~31) | (((m >> 2) + 8 * (m & 3)) & 31); }
+__device__ __forceinline__ int phys_row(int m) { return m ^ ((m >> 4) & 3); }
 
 // Request a 4 (k) x 4 (outer) block of K step `kt`.  Addressing is 32-bit per lane on a wave-uniform 64-bit base (one v_min + one
 // v_mad_u24 per load; 64-bit per-lane address arithmetic and compares were a third of the loop's instructions): the tile index is
@@ -86,7 +89,7 @@ __device__ __forceinline__ void stage_store(unsigned char* S, int o4, int kq, co
             h[i] = __builtin_bit_cast(unsigned short, hi);
             l[i] = __builtin_bit_cast(unsigned short, lo);
         }
-        const int prow = (o4 >> 3) * 32 + ((o4 + 8 * e) & 31);       // = phys_row(4 o4 + e)
+        const int prow = phys_row(4 * o4 + e);
         unsigned char* d = S + prow * ROWB + kq * 8;
         *reinterpret_cast<u32x2*>(d) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
         *reinterpret_cast<u32x2*>(d + IMG) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};

@@ -53,46 +53,46 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ int phys_row(int m) { return m ^ ((m >> 4) & 3); }
 
-// Request a 4 (k) x 4 (outer) block of K step `kt`.  Addressing is 32-bit per lane on a wave-uniform 64-bit base (one v_min + one
-// v_mad_u24 per load; 64-bit per-lane address arithmetic and compares were a third of the loop's instructions): the tile index is
-// clamped to the last tile that has rows, the row inside the tile to its last row, the column block to the last one inside the
-// matrix -- every load is in bounds and UNCONDITIONAL (a load under a branch makes every later wait a vmcnt(0)); what was clamped
-// is zeroed by stage_store.
-__device__ __forceinline__ void stage_load(const float* __restrict__ P, unsigned ld4, long long K, int nk, int kt, unsigned col4, int kq,
-                                           u32x4 (&r)[4]) {
-    const int ktc = kt < nk ? kt : nk - 1;                                     // (uniform)
-    const long long rows = K - (long long)ktc * TK;
-    const int last = (int)(rows < TK ? rows : TK) - 1;
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(P) + (unsigned long long)ktc * TK * ld4;
+// Request a 4 (k) x 4 (outer) block of K step `kt`: buffer loads -- the matrix's descriptor and the tile's row offset in SGPRs, a
+// per-lane 32-bit offset that does not change over the loop (64-bit per-lane address arithmetic was a third of the loop's instructions, and by the PMC model of these GEMMs --
+// wave cycles = a + 12.5 cycles x VALU instructions -- instructions are what the kernel's time is made of).  The LAST tile is
+// shifted back to rows K - 32 .. K - 1 (tiles past K too): every load is in bounds and UNCONDITIONAL (a load under a branch makes
+// every later wait a vmcnt(0)); store_tile zeroes the rows below kt * 32 that the shift brought in again.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void stage_load(rsrc_t P, unsigned ld4, int K, int kt, const unsigned (&voff)[4], u32x4 (&r)[4]) {
+    const int k0 = kt * TK < K - TK ? kt * TK : K - TK;                                          // (uniform)
+    const unsigned soff = (unsigned)k0 * ld4;                                                    // SGPR offset of the tile's first row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = min(4 * kq + i, last);
-        r[i] = *reinterpret_cast<const u32x4*>(base + (__umul24((unsigned)row, ld4) + col4));
-    }
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(P, (int)voff[i], (int)soff, 0));
 }
 
-// r[i][e] = value at (k = k0 + 4 kq + i, outer = 4 o4 + e)  ->  hi / lo images, 4 consecutive k (8 bytes) per outer index.
-// upk[i]: the operand's scale, or 0 for a row past K.  Only A's rows are zeroed (B's clamped rows then multiply zeros), and clamped
-// columns are not zeroed at all (their outputs are never stored): a clamped element is a copy of an element of the same column
-// of the same operand, so a non-finite copy can only reach outputs that the original already makes non-finite.  No branch here:
-// a conditional block that touches the staging registers makes the statically inserted waits drain the prefetch.
+// (f16(a.x * s.x), f16(a.y * s.y)) packed, and the same of the remainders a * s - hi: v_fma_mix{lo,hi}_f16 round fma(a, s, c) to
+// fp16 once and write one half of the destination -- 2 instructions per value, no separate multiply, convert-back, subtract or pack
+// (the compiler's own selection for the C expression: 3.4 per value).  a * s is exact (s a power of two), a * s - hi is exact
+// in the fma: the images are bit for bit those of (_Float16)(a s), (_Float16)(a s - hi).
+__device__ __forceinline__ void split_pair(unsigned a0, unsigned a1, float s0, float s1, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a0), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(a1), "v"(s1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a0), "v"(s0), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(a1), "v"(s1), "v"(hi));
+}
+
+// r[i][e] = value at (k row 4 kq + i of the tile, outer = 4 o4 + e)  ->  hi / lo images, 4 consecutive k (8 bytes) per outer index.
+// upk[i]: the operand's scale, or 0 for a row that is not this tile's.  Only A's rows are zeroed (B's then multiply zeros), and
+// clamped columns are not zeroed at all (their outputs are never stored): such an element is a copy of an element of the same
+// column of the same operand, so a non-finite copy can only reach outputs that the original already makes non-finite.  No branch
+// here: a conditional block that touches the staging registers makes the statically inserted waits drain the prefetch.
 __device__ __forceinline__ void stage_store(unsigned char* S, int o4, int kq, const u32x4 (&r)[4], const float (&upk)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        unsigned short h[4], l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned bits = r[i][e];       // (an rvalue: __builtin_bit_cast of the element lvalue r[i][e] reads element 0)
-            const float v = __builtin_bit_cast(float, bits) * upk[i];
-            const _Float16 hi = (_Float16)v;
-            const _Float16 lo = (_Float16)(v - (float)hi);
-            h[i] = __builtin_bit_cast(unsigned short, hi);
-            l[i] = __builtin_bit_cast(unsigned short, lo);
-        }
+        const unsigned b0 = r[0][e], b1 = r[1][e], b2 = r[2][e], b3 = r[3][e];
+        unsigned h01, l01, h23, l23;
+        split_pair(b0, b1, upk[0], upk[1], h01, l01);
+        split_pair(b2, b3, upk[2], upk[3], h23, l23);
         const int prow = phys_row(4 * o4 + e);
         unsigned char* d = S + prow * ROWB + kq * 8;
-        *reinterpret_cast<u32x2*>(d) = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-        *reinterpret_cast<u32x2*>(d + IMG) = (u32x2){(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+        *reinterpret_cast<u32x2*>(d) = (u32x2){h01, h23};
+        *reinterpret_cast<u32x2*>(d + IMG) = (u32x2){l01, l23};
     }
 }
 
@@ -141,25 +141,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
     const bool a_ok = m0 + 4 * o4 < a.M, b_ok = n0 + 4 * o4 < a.N;
     const unsigned lda4 = (unsigned)a.lda * 4u, ldb4 = (unsigned)a.ldb * 4u;
     const unsigned acol4 = (unsigned)(a_ok ? m0 + 4 * o4 : a.M - 4) * 4u, bcol4 = (unsigned)(b_ok ? n0 + 4 * o4 : a.N - 4) * 4u;
-    stage_load(a.A, lda4, a.K, nk, 0, acol4, kq, ra[0]);
-    stage_load(a.B, ldb4, a.K, nk, 0, bcol4, kq, rb[0]);
-    stage_load(a.A, lda4, a.K, nk, 1, acol4, kq, ra[1]);
-    stage_load(a.B, ldb4, a.K, nk, 1, bcol4, kq, rb[1]);
+    unsigned voa[4], vob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        voa[i] = (unsigned)(4 * kq + i) * lda4 + acol4;
+        vob[i] = (unsigned)(4 * kq + i) * ldb4 + bcol4;
+    }
+    const int K = (int)a.K;
+    const rsrc_t Ad = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)((unsigned)K * lda4), 0x00020000);
+    const rsrc_t Bd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, (int)((unsigned)K * ldb4), 0x00020000);
+    stage_load(Ad, lda4, K, 0, voa, ra[0]);
+    stage_load(Bd, ldb4, K, 0, vob, rb[0]);
+    stage_load(Ad, lda4, K, 1, voa, ra[1]);
+    stage_load(Bd, ldb4, K, 1, vob, rb[1]);
     const float upb4[4] = {upb, upb, upb, upb};
-    auto store_tile = [&](unsigned char* Sn, const u32x4 (&xa)[4], const u32x4 (&xb)[4], long long krem) {
+    const int kend = (int)a.K - TK;                  // first row of the shifted last tile
+    auto store_tile = [&](unsigned char* Sn, const u32x4 (&xa)[4], const u32x4 (&xb)[4], int kt) {
+        const int skip = kt * TK - (kt * TK < kend ? kt * TK : kend);      // (uniform) rows of the tile that belong to earlier tiles; >= 32 past K
         float upa4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) upa4[i] = 4 * kq + i < krem ? upa : 0.f;
+        for (int i = 0; i < 4; ++i) upa4[i] = 4 * kq + i >= skip ? upa : 0.f;
         stage_store(Sn, o4, kq, xa, upa4);
         stage_store(Sn + OPER, o4, kq, xb, upb4);
     };
-    store_tile(lds, ra[0], rb[0], a.K);
+    store_tile(lds, ra[0], rb[0], 0);
     lds_barrier();
     // step kt: LDS buffer kt & 1 holds tile kt, register set (kt + 1) & 1 tile kt + 1 (in flight), register set kt & 1 is free
     auto step = [&](auto par, int kt) {
         constexpr int P = decltype(par)::value;
-        stage_load(a.A, lda4, a.K, nk, kt + 2, acol4, kq, ra[P]);
-        stage_load(a.B, ldb4, a.K, nk, kt + 2, bcol4, kq, rb[P]);
+        stage_load(Ad, lda4, K, kt + 2, voa, ra[P]);
+        stage_load(Bd, ldb4, K, kt + 2, vob, rb[P]);
         __builtin_amdgcn_sched_barrier(0);      // (the conversion of tile kt + 1 below must not be hoisted to here: its loads
         const unsigned char* As = lds + P * BUF;      // would be waited for a whole K step early)
         const unsigned char* Bs = As + OPER;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
         // on one path into the loop head and the statically inserted waits would drain the prefetch on every iteration; past K the
         // tiles are zero)
         unsigned char* An = lds + (P ^ 1) * BUF;
-        store_tile(An, ra[P ^ 1], rb[P ^ 1], a.K - (long long)(kt + 1) * TK);      // rows of tile kt + 1 inside K (<= 0: a zero tile)
+        store_tile(An, ra[P ^ 1], rb[P ^ 1], kt + 1);
         lds_barrier();
     };
     // tile 1 has landed before the loop is entered: otherwise the registers the prologue's loads target count as pending at the
@@ -226,18 +237,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
 
 extern "C" int sbev_gemm_tn_f16s_ok(int64_t M, int64_t N, int64_t K) {
     // enough tiles to fill the chip without a split of K (else: sbev_gemm_f32 and its split-K plan)
-    return M >= 4 && N >= 4 && M % 4 == 0 && N % 4 == 0 && K >= 1 && ((M + TM - 1) / TM) * ((N + TN - 1) / TN) >= 256 &&
+    return M >= 4 && N >= 4 && M % 4 == 0 && N % 4 == 0 && K >= TK && K < (1LL << 26) && ((M + TM - 1) / TM) * ((N + TN - 1) / TN) >= 256 &&
            ((M + TM - 1) / TM) * ((N + TN - 1) / TN) <= 0x7fffffffLL;
 }
 
 extern "C" int sbev_gemm_tn_f16s(const float* A, int64_t lda, const float* a_scale, const float* B, int64_t ldb, const float* b_scale,
                                  float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int accumulate, sbev_stream_t stream) {
-    SBEV_REQUIRE(sbev_gemm_tn_f16s_ok(M, N, K), "sbev_gemm_tn_f16s: M=%lld, N=%lld (multiples of 4, >= 256 tiles of 128 x 128), K=%lld",
+    SBEV_REQUIRE(sbev_gemm_tn_f16s_ok(M, N, K), "sbev_gemm_tn_f16s: M=%lld, N=%lld (multiples of 4, >= 256 tiles of 128 x 128), K=%lld (>= 32)",
                  (long long)M, (long long)N, (long long)K);
     SBEV_REQUIRE(A && B && C && a_scale && b_scale, "sbev_gemm_tn_f16s: null pointer");
-    SBEV_REQUIRE(lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && lda < (1 << 22) && ldb < (1 << 22) &&
+    SBEV_REQUIRE(lda >= M && ldb >= N && ldc >= N && lda % 4 == 0 && ldb % 4 == 0 && K * lda < (1LL << 29) && K * ldb < (1LL << 29) &&
                      (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
-                 "sbev_gemm_tn_f16s: leading dimensions must cover the operands, be multiples of 4 and < 2^22; A and B 16-byte aligned");
+                 "sbev_gemm_tn_f16s: leading dimensions must cover the operands and be multiples of 4, an operand < 2 GiB (32-bit buffer offsets); A and B 16-byte aligned");
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f16s_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     if (!attr_ok) {

@@ -176,6 +176,26 @@ __global__ __launch_bounds__(256, 2) void gemm_any_kernel(const AnyArgs a) {
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): the 32 lanes of a
     // half-wave store 32 consecutive floats of one row.
     float* C = SPLIT ? a.C + (long long)blockIdx.z * a.M * a.ldc : a.C;
+    if (!SPLIT && a.accumulate) {      // all 64 old values requested together (clamped addresses): element-wise load + add + store
+        float old[2][2][16];           // was 64 serialised round trips per lane (30 us of the big grad_W launches)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const long long n = n0 + wc * 64 + j * 32 + fr, nc = n < a.N ? n : a.N - 1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long long m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, mc = m < a.M ? m : a.M - 1;
+                    old[i][j][e] = C[mc * a.ldc + nc];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += old[i][j][e];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -185,9 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_any_kernel(const AnyArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long long m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (m >= a.M) continue;
-                float* p = C + m * a.ldc + n;
-                *p = (!SPLIT && a.accumulate) ? *p + acc[i][j][e] : acc[i][j][e];
+                if (m < a.M) C[m * a.ldc + n] = acc[i][j][e];
             }
         }
 }

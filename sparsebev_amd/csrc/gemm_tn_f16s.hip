@@ -65,12 +65,26 @@ __device__ __forceinline__ void stage_load(rsrc_t P, unsigned ld4, int K, int kt
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(P, (int)voff[i], (int)soff, 0));
 }
+#ifdef SBEV_TN_NO_LOAD
+#define SBEV_TN_LOOP_LOAD(...)
+#else
+#define SBEV_TN_LOOP_LOAD(...) stage_load(__VA_ARGS__)
+#endif
+#ifdef SBEV_TN_NO_MFMA
+#define SBEV_TN_MFMA(A_, B_, C_) ([&]() { asm volatile("" ::"v"(A_), "v"(B_)); return C_; }())
+#else
+#define SBEV_TN_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0)
+#endif
 
 // (f16(a.x * s.x), f16(a.y * s.y)) packed, and the same of the remainders a * s - hi: v_fma_mix{lo,hi}_f16 round fma(a, s, c) to
 // fp16 once and write one half of the destination -- 2 instructions per value, no separate multiply, convert-back, subtract or pack
 // (the compiler's own selection for the C expression: 3.4 per value).  a * s is exact (s a power of two), a * s - hi is exact
 // in the fma: the images are bit for bit those of (_Float16)(a s), (_Float16)(a s - hi).
 __device__ __forceinline__ void split_pair(unsigned a0, unsigned a1, float s0, float s1, unsigned& hi, unsigned& lo) {
+#ifdef SBEV_TN_NO_CONV            // ablations (tools/exp/ablate_tn.py): timing only, wrong numbers
+    hi = a0 ^ __builtin_bit_cast(unsigned, s0); lo = a1 ^ __builtin_bit_cast(unsigned, s1);
+    return;
+#endif
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a0), "v"(s0));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(a1), "v"(s1));
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a0), "v"(s0), "v"(hi));
@@ -82,22 +96,32 @@ __device__ __forceinline__ void split_pair(unsigned a0, unsigned a1, float s0, f
 // clamped columns are not zeroed at all (their outputs are never stored): such an element is a copy of an element of the same
 // column of the same operand, so a non-finite copy can only reach outputs that the original already makes non-finite.  No branch
 // here: a conditional block that touches the staging registers makes the statically inserted waits drain the prefetch.
+__device__ __forceinline__ void stage_store_e(unsigned char* S, int o4, int kq, const u32x4 (&r)[4], const float (&upk)[4], int e) {
+    const unsigned b0 = r[0][e], b1 = r[1][e], b2 = r[2][e], b3 = r[3][e];
+    unsigned h01, l01, h23, l23;
+    split_pair(b0, b1, upk[0], upk[1], h01, l01);
+    split_pair(b2, b3, upk[2], upk[3], h23, l23);
+    const int prow = phys_row(4 * o4 + e);
+    unsigned char* d = S + prow * ROWB + kq * 8;
+#ifdef SBEV_TN_NO_LDSW
+    asm volatile("" ::"v"(h01), "v"(h23), "v"(l01), "v"(l23), "v"(d));
+#else
+    *reinterpret_cast<u32x2*>(d) = (u32x2){h01, h23};
+    *reinterpret_cast<u32x2*>(d + IMG) = (u32x2){l01, l23};
+#endif
+}
 __device__ __forceinline__ void stage_store(unsigned char* S, int o4, int kq, const u32x4 (&r)[4], const float (&upk)[4]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const unsigned b0 = r[0][e], b1 = r[1][e], b2 = r[2][e], b3 = r[3][e];
-        unsigned h01, l01, h23, l23;
-        split_pair(b0, b1, upk[0], upk[1], h01, l01);
-        split_pair(b2, b3, upk[2], upk[3], h23, l23);
-        const int prow = phys_row(4 * o4 + e);
-        unsigned char* d = S + prow * ROWB + kq * 8;
-        *reinterpret_cast<u32x2*>(d) = (u32x2){h01, h23};
-        *reinterpret_cast<u32x2*>(d + IMG) = (u32x2){l01, l23};
-    }
+    for (int e = 0; e < 4; ++e) stage_store_e(S, o4, kq, r, upk, e);
 }
 
 // operand of v_mfma_f32_32x32x16_f16: lane (fr, fh) supplies (row fr, k = 8 fh .. 8 fh + 7) of the 16-k step
 __device__ __forceinline__ f16x8 frag(const unsigned char* S, int row_off, int ks, int fh) {
+#ifdef SBEV_TN_NO_LDSR
+    unsigned q = (unsigned)(unsigned long long)S + row_off + ks + fh;
+    asm volatile("" : "+v"(q));
+    return __builtin_bit_cast(f16x8, (u32x4){q, q, q, q});
+#endif
     const u32x2* p = reinterpret_cast<const u32x2*>(S + row_off + ks * 32 + fh * 16);
     const u32x2 a = p[0], b = p[1];
     return __builtin_bit_cast(f16x8, (u32x4){a.x, a.y, b.x, b.y});
@@ -110,12 +134,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
     const int o4 = tid & 31, kq = tid >> 5;
-    // the dimension with fewer tiles varies slowest: the workgroups that share a tile of the long operand are a multiple of 8
-    // apart (256 tiles along the long side) and run on the same XCD / L2
+    // Workgroup b runs on XCD b % 8.  Give each XCD a CONTIGUOUS range of logical tile ids, the short side of the tile grid
+    // fastest: the (two) workgroups that share a tile of the long operand are dispatched back to back into the same L2, and the
+    // 32 consecutive long-side tiles of an XCD read one contiguous 16 KiB piece of every row of the long operand at about the same
+    // time (first version: id % tiles along the long side -- neighbouring 512-byte pieces of a row went to eight different L2s;
+    // in the training step, operands coming from HBM: 88 us against 64 us with the operands hot in the 256 MB cache)
     const unsigned tiles_m = (unsigned)((a.M + TM - 1) / TM), tiles_n = (unsigned)((a.N + TN - 1) / TN);
+    const unsigned nb = gridDim.x, full = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7;
+    const unsigned lid = xcd * full + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     unsigned tm, tn;
-    if (tiles_n < tiles_m) { tn = blockIdx.x / tiles_m; tm = blockIdx.x % tiles_m; }
-    else { tm = blockIdx.x / tiles_n; tn = blockIdx.x % tiles_n; }
+    if (tiles_n < tiles_m) { tm = lid / tiles_n; tn = lid % tiles_n; }
+    else { tn = lid / tiles_m; tm = lid % tiles_m; }
     const long long m0 = (long long)tm * TM, n0 = (long long)tn * TN;
     const int nk = (int)((a.K + TK - 1) / TK);
     const float upa = a.a_scale[0], upb = a.b_scale[0];
@@ -169,41 +198,48 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
     // step kt: LDS buffer kt & 1 holds tile kt, register set (kt + 1) & 1 tile kt + 1 (in flight), register set kt & 1 is free
     auto step = [&](auto par, int kt) {
         constexpr int P = decltype(par)::value;
-        stage_load(Ad, lda4, K, kt + 2, voa, ra[P]);
-        stage_load(Bd, ldb4, K, kt + 2, vob, rb[P]);
-        __builtin_amdgcn_sched_barrier(0);      // (the conversion of tile kt + 1 below must not be hoisted to here: its loads
-        const unsigned char* As = lds + P * BUF;      // would be waited for a whole K step early)
+        SBEV_TN_LOOP_LOAD(Ad, lda4, K, kt + 2, voa, ra[P]);
+        SBEV_TN_LOOP_LOAD(Bd, ldb4, K, kt + 2, vob, rb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* As = lds + P * BUF;
         const unsigned char* Bs = As + OPER;
+        unsigned char* An = lds + (P ^ 1) * BUF;
+        // all fragments of the K step first, then six groups of four MFMAs (2 k-steps x 3 products; small terms first, hi x hi last:
+        // the order of gemm_bf16s.hip's 3-product mode), each followed by its share of the conversion of tile kt + 1 into the other
+        // buffer (8 chunks: 4 outer indices x 2 operands).  The conversion's VALU work issues in the shadow of the MFMAs before
+        // it; with everything of one kind in one block (first version) the waves of a workgroup -- barrier-synchronised -- were
+        // all reading LDS, then all on the matrix core, then all converting: the three pipes' busy times ADDED up to the K step's
+        // duration (PMC: LDS 34 %, MFMA 28 %, VALU 13-25 %).  The conversion is unconditional (a skipped one would leave its
+        // register set "pending" on one path into the loop head and the static waits would drain the prefetch); past K the
+        // tiles are zero.
+        f16x8 fa[2][2][2], fb[2][2][2];       // [k-step][tile][image]
 #pragma unroll
-        for (int ks = 0; ks < TK / 16; ++ks) {
-            f16x8 fa[2][2], fb[2][2];       // [tile][image]
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int img = 0; img < 2; ++img) {
-                    fa[i][img] = frag(As + img * IMG, arow[i], ks, fh);
-                    fb[i][img] = frag(Bs + img * IMG, brow[i], ks, fh);
+                    fa[ks][i][img] = frag(As + img * IMG, arow[i], ks, fh);
+                    fb[ks][i][img] = frag(Bs + img * IMG, brow[i], ks, fh);
                 }
-            // small terms first, hi x hi last (the order of gemm_bf16s.hip's 3-product mode)
+        const int skip = (kt + 1) * TK - ((kt + 1) * TK < kend ? (kt + 1) * TK : kend);   // (uniform) rows of tile kt + 1 that belong to earlier tiles; >= 32 past K
+        float upa4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) upa4[i] = 4 * kq + i >= skip ? upa : 0.f;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int ks = g / 3, pr = g % 3, ia = pr == 1 ? 1 : 0, ib = pr == 0 ? 1 : 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = SBEV_TN_MFMA(fa[ks][i][ia], fb[ks][j][ib], acc[i][j]);
+            if (g < 4) stage_store_e(An, o4, kq, ra[P ^ 1], upa4, g);
+            else {
+                stage_store_e(An + OPER, o4, kq, rb[P ^ 1], upb4, 2 * (g - 4));
+                stage_store_e(An + OPER, o4, kq, rb[P ^ 1], upb4, 2 * (g - 4) + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // (unconditional, as is the second step of a pair below: a skipped conversion or step would leave its register set "pending"
-        // on one path into the loop head and the statically inserted waits would drain the prefetch on every iteration; past K the
-        // tiles are zero)
-        unsigned char* An = lds + (P ^ 1) * BUF;
-        store_tile(An, ra[P ^ 1], rb[P ^ 1], kt + 1);
         lds_barrier();
     };
     // tile 1 has landed before the loop is entered: otherwise the registers the prologue's loads target count as pending at the
@@ -214,8 +250,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
         step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
-    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
+    // accumulate: ALL 64 old values are requested before the first is needed (clamped addresses, unconditional loads) -- a
+    // load + add + store per element was 64 serialised round trips, 30 us of a 90 us launch.
     const float down = a.a_scale[1] * a.b_scale[1];
+    if (a.accumulate) {
+        float old[2][2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const long long n = n0 + wc * 64 + j * 32 + fr, nc = n < a.N ? n : a.N - 1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long long m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, mc = m < a.M ? m : a.M - 1;
+                    old[i][j][e] = a.C[mc * a.ldc + nc];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = old[i][j][e] + acc[i][j][e] * down;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= down;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -225,10 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f16s_kernel(const TnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long long m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (m >= a.M) continue;
-                float* p = a.C + m * a.ldc + n;
-                const float v = acc[i][j][e] * down;
-                *p = a.accumulate ? *p + v : v;
+                if (m < a.M) a.C[m * a.ldc + n] = acc[i][j][e];
             }
         }
 }

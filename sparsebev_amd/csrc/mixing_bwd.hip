@@ -69,7 +69,7 @@ template <int RT, bool FAST>      // RT = ceil(Pin / 16) row tiles of the Pin-ro
 __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
     static_assert(!FAST || RT == 2, "FAST is the in_points == 32 instance");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Pin = a.Pin;
+    const int Pin = FAST ? 32 : a.Pin;       // FAST: a compile-time constant (store addresses by shifts, no per-element bounds branches)
     constexpr int PR = RT * 16;
     float* xs = smem;                    // [PR][LD]
     float* h1 = xs + PR * LD;            // [PR][LD]   h1 = LN(y1) (pre-ReLU; pad rows 0)
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void mixing_bwd_kernel(const MixBwdArgs a) {
         for (int ct = 0; ct < RT; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (ct * 16 + fi < Pin) {
+                if (FAST || ct * 16 + fi < Pin) {
                     gS[(rt * 16 + fk * 4 + e) * Pin + ct * 16 + fi] = acc[ct][e];
                     gmx = fmaxf(gmx, fabsf(acc[ct][e]));
                 }

@@ -258,6 +258,39 @@ def test_adaptive_mixing_function_vs_oracle_autograd(T):
 
 
 @torch.enable_grad()
+def test_adaptive_mixing_fp16_gemms_full_size_without_a_tap_match_the_exact_path():
+    """autograd.AdaptiveMixing at config 2's size (900 queries: the grad_W products qualify for sbev_gemm_tn_f16s) with gemm_f16=True and
+    NO ParamTap -- the gradients are returned as new tensors -- against the same node on the exact f32-MFMA kernels, and with a gradient
+    of tiny magnitude (the scales are measured on the device: nothing may underflow)."""
+    g = torch.Generator().manual_seed(77)
+    B, Q, G, T, P, C = 1, 900, 4, 8, 4, 64
+    params = S.make_params(31, embed_dims=256, num_frames=T, num_points=P, num_levels=4)
+    names = ['mixing.parameter_generator.weight', 'mixing.parameter_generator.bias', 'mixing.out_proj.weight', 'mixing.out_proj.bias']
+    x = torch.randn(B, Q, G, T * P, C, generator=g).to(DEV)
+    query = torch.randn(B, Q, 256, generator=g).to(DEV)
+    for mag in (1.0, 1e-9):
+        gy = (torch.randn(B, Q, 256, generator=g) * mag).to(DEV)
+        grads = []
+        for f16 in (False, True):
+            dv = [x.clone().requires_grad_(True), query.clone().requires_grad_(True)] + [params[n].to(DEV).requires_grad_(True) for n in names]
+            y = AG.AdaptiveMixing.apply(*dv, 128, False, f16)
+            y.backward(gy)
+            grads.append([y.detach()] + [d.grad for d in dv])
+        for k, (a, b) in enumerate(zip(*grads)):
+            assert torch.isfinite(b).all()
+            if k == 0:
+                assert rel(b, a) < 2e-5, (mag, rel(b, a))          # the forward output
+                continue
+            # gradients: the two forwards differ in the last bits, so a handful of the 37 M ReLU decisions of the mixing core flip and
+            # move their (query, group) block through its LayerNorm statistics (measured: 7 of 3600 blocks) -- norm-wise agreement, and
+            # all but a small fraction element-wise
+            d = (b.double() - a.double()).abs()
+            l2 = (d.pow(2).sum() / a.double().pow(2).sum()).sqrt().item()
+            off = (d > 2e-5 * a.abs().max().double()).double().mean().item()
+            assert l2 < 2e-3 and (k != 1 or off < 1e-2), (mag, k, a.shape, l2, off)      # (element-wise: grad_x only; the others sum over blocks)
+
+
+@torch.enable_grad()
 @pytest.mark.parametrize('T,L,pyr', [(2, 4, 'tiny'), (4, 5, 'tiny5')])
 def test_sampling_function_vs_oracle_autograd(T, L, pyr):
     """sample points -> projection / view select -> gather, differentiated: grads wrt the box (centre, dims, yaw), the packed

@@ -145,12 +145,12 @@ def _group_bias_grads(tap):
         if segs:
             by_rows.setdefault(segs[0][0].shape[0], []).append((b_id, [g for g, _ in segs]))
     for M, items in by_rows.items():
-        jobs = []                       # (bias id, <= 8 matrices, accumulate)
-        for b_id, gs in items:
+        rounds = {}                     # chunk index -> [(bias id, <= 8 matrices, accumulate)]: the second chunk of a bias (more than 8
+        for b_id, gs in items:          # layers) adds to what the first one wrote, so it goes into a LATER launch
             for s0 in range(0, len(gs), 8):
-                jobs.append((b_id, gs[s0:s0 + 8], s0 > 0 or b_id in tap.bufs))
-        for j0 in range(0, len(jobs), 16):
-            part = jobs[j0:j0 + 16]
+                rounds.setdefault(s0, []).append((b_id, gs[s0:s0 + 8], s0 > 0 or b_id in tap.bufs))
+        parts = [jobs[j0:j0 + 16] for _, jobs in sorted(rounds.items()) for j0 in range(0, len(jobs), 16)]
+        for part in parts:
             ng = len(part)
             segs = (ctypes.c_void_p * (ng * 8))()
             outs = (ctypes.c_void_p * ng)()
@@ -176,19 +176,19 @@ def _group_ln_grads(tap):
     jobs = []
     for (g_id, b_id), (g, b, relu, segs) in tap.deferred_ln.items():
         for s0 in range(0, len(segs), 8):
-            jobs.append((g_id, b_id, g, b, relu, segs[s0:s0 + 8], s0 > 0 or g_id in tap.bufs))
-    by_rows = {}
-    for j in jobs:
-        by_rows.setdefault(j[5][0][0].shape[0], []).append(j)
+            jobs.append((g_id, b_id, g, b, relu, segs[s0:s0 + 8], s0 > 0 or g_id in tap.bufs, s0))
+    by_rows = {}                        # (chunk index, rows) -> jobs: a LayerNorm's second chunk (more than 8 layers) accumulates into what
+    for j in jobs:                      # its first one wrote and must run in a later launch
+        by_rows.setdefault((j[7], j[5][0][0].shape[0]), []).append(j)
     VP = ctypes.c_void_p
-    for M, items in by_rows.items():
+    for (_, M), items in sorted(by_rows.items(), key=lambda kv: kv[0]):
         for j0 in range(0, len(items), 8):
             part = items[j0:j0 + 8]
             ng = len(part)
             dYs, Xs, Ss = (VP * (ng * 8))(), (VP * (ng * 8))(), (VP * (ng * 8))()
             gam, bet, dgs, dbs = (VP * ng)(), (VP * ng)(), (VP * ng)(), (VP * ng)()
             Ns, nsegs, relus, accs = [(ctypes.c_int32 * ng)() for _ in range(4)]
-            for i, (g_id, b_id, g, b, relu, segs, acc) in enumerate(part):
+            for i, (g_id, b_id, g, b, relu, segs, acc, _) in enumerate(part):
                 if g_id not in tap.bufs:
                     tap.bufs[g_id], tap.bufs[b_id] = torch.empty_like(g), torch.empty_like(b)
                 for k, (gy, x, st) in enumerate(segs):

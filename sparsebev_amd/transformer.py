@@ -533,7 +533,8 @@ class SparseBEVTransformerDecoder(_Base):
             cls_scores, bbox_preds = [], []
             packed = layer.packed_train_weights()
             # the layers share their parameters: ONE gradient buffer per parameter and call, added to in the kernels' epilogues (AG.Tap)
-            tap = AG.Tap([p for p in layer.parameters()]) if self.tap_param_grads else None
+            # (the packed q | k | v | tau and sampling tensors too: their gradient reaches the parameters through the one cat node each)
+            tap = AG.Tap([p for p in layer.parameters()] + [t for t in packed if t.requires_grad]) if self.tap_param_grads else None
             for i in range(self.num_layers):
                 query_feat, cls_score, bbox_pred = layer.forward_train(query_bbox, query_feat, feats, attn_mask, ctx, token, packed, tap)
                 query_bbox = bbox_pred.detach()

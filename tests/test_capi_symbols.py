@@ -159,6 +159,36 @@ def test_round2_entry_points_validate_without_gpu(lib):
     assert lib.sbev_copy_widen_f32(one, 3, one, 4, None) == -1
 
 
+def test_round3_training_entry_points_validate_without_gpu(lib):
+    """The grouped parameter-gradient launches and the fp16 hi + lo training GEMMs refuse what they do not cover before any HIP call."""
+    one = ctypes.c_void_p(16)
+    VP = ctypes.c_void_p
+    # grad_W on the fp16 kernel: shape coverage (>= 256 tiles of 128 x 128, K >= 32, multiples of 4), 32-bit buffer offsets
+    assert lib.sbev_gemm_tn_f16s_ok(256, 32768, 900) == 1 and lib.sbev_gemm_tn_f16s_ok(32768, 256, 900) == 1
+    assert lib.sbev_gemm_tn_f16s_ok(256, 256, 900) == 0 and lib.sbev_gemm_tn_f16s_ok(256, 32768, 16) == 0 and lib.sbev_gemm_tn_f16s_ok(258, 32768, 900) == 0
+    assert lib.sbev_gemm_tn_f16s(one, 256, one, one, 32768, one, one, 32768, 256, 256, 900, 0, None) == -1               # too few tiles
+    assert lib.sbev_gemm_tn_f16s(one, 256, None, one, 32768, one, one, 32768, 256, 32768, 900, 0, None) == -1            # null scale
+    assert lib.sbev_gemm_tn_f16s(one, 128, one, one, 32768, one, one, 32768, 256, 32768, 900, 0, None) == -1             # lda < M
+    assert lib.sbev_gemm_tn_f16s(one, 256, one, one, 1 << 22, one, one, 32768, 256, 32768, 900, 0, None) == -1 and b'2 GiB' in lib.sbev_last_error()
+    assert lib.sbev_f16s_tensor_scale(one, 6, 4, 6, one, None) == -1                                                    # K % 4
+    # split-K Linear with the operand scale in device memory: same shape contract as sbev_linear_splitk_f16s, fp32 X only
+    assert lib.sbev_linear_splitk_f16s_xdev(one, one, one, one, None, None, None, None, 1e-5, one, 4, 128, 256, 256, 0, 3, one, None) == -1   # N != 256
+    assert lib.sbev_linear_splitk_f16s_xdev(one, None, one, one, None, None, None, None, 1e-5, one, 4, 256, 256, 256, 0, 3, one, None) == -1  # null scale
+    assert lib.sbev_linear_splitk_f16s_xdev(None, None, None, None, None, None, None, None, 1e-5, None, 0, 256, 256, 256, 0, 3, None, None) == 0
+    # mixing backward that also writes the partial maxima
+    assert lib.sbev_adaptive_mixing_bwd_max_f32(one, one, one, one, one, None, 4, 4, 32, 64, 128, 1e-5, None) == -1     # null item_max
+    assert lib.sbev_adaptive_mixing_bwd_max_f32(None, None, None, None, None, None, 0, 4, 32, 64, 128, 1e-5, None) == 0  # empty
+    # grouped reductions: group / segment limits
+    i32 = lambda *v: (ctypes.c_int32 * len(v))(*v)
+    ptrs = lambda n: (VP * n)(*([16] * n))
+    assert lib.sbev_colsum_group(ptrs(17 * 8), ptrs(17), i32(*[4] * 17), i32(*[1] * 17), i32(*[0] * 17), 17, 8, None) == -1      # > 16 groups
+    assert lib.sbev_colsum_group(ptrs(8), ptrs(1), i32(4), i32(9), i32(0), 1, 8, None) == -1                                      # > 8 segments
+    assert lib.sbev_layer_norm_param_group(ptrs(72), ptrs(72), ptrs(72), ptrs(9), ptrs(9), ptrs(9), ptrs(9), i32(*[4] * 9), i32(*[1] * 9),
+                                           i32(*[0] * 9), i32(*[0] * 9), 9, 8, None) == -1                                        # > 8 groups
+    assert lib.sbev_layer_norm_bwd_rows(one, one, one, one, 1e-5, 0, one, one, 4, 6, None) == -1                                  # N % 4
+    assert lib.sbev_gemm_f32_multi_workspace(256, 256, 900, 6) > 0 and lib.sbev_gemm_f32_multi_workspace(256, 256, 900, 9) == -1
+
+
 def test_chain_pack_size_is_a_pure_host_function(lib):
     """sbev_decoder_chain_pack_floats: the size of the lane-ordered weight image of the row-chain kernels for the
     reference's layer shape, 0 for shapes the kernels do not cover; the pack call validates its arguments on the host."""

@@ -116,6 +116,13 @@ int sbev_msmv_fwd_ring(const void* const* feats, const int32_t* hw, int L, int f
                        const float* loc, const float* weights, float* out,
                        int out_layout, int T, int G, const int32_t* frame_slots, int n_slots, sbev_stream_t stream);
 
+/* sbev_msmv_fwd / _ring gather through raw BUFFER loads whenever every level's (sample-batch) slab is below 2 GiB: an out-of-map
+ * bilinear corner is an out-of-range buffer offset, answered with zeros by the hardware and never read -- the reference's semantics
+ * (msmv_sampling_forward.cu:47-66) also for Inf / NaN border pixels.  Larger slabs take 64-bit global loads + a select (same
+ * results).  sbev_msmv_buffer_taps(0) forces that path (tests, A/B; env SBEV_MSMV_NO_BUF=1); returns the previous setting. */
+int sbev_msmv_buffer_taps(int enable);
+
+
 /*
  * Multi-scale multi-view bilinear sampling, backward (fp32 features).
  * Replaces: _ms_deform_attn_cuda_c2345_backward / _c23456_backward (models/csrc/msmv_sampling/msmv_sampling.cpp:212-360,
@@ -454,6 +461,10 @@ int sbev_copy_widen_f32(const void* src, int src_dtype, float* dst, int64_t n, s
  * pyramid, else the online ring (n_slots, see sbev_msmv_fwd_ring); params [B*Q, G, C*C + Pout*T*P]; y [B*Q, G, Pout, C].
  */
 int sbev_sample_mix_supported(int L, int C, int P, int T, int gdiv, int G);
+/* The fused kernel's taps are 31-bit BUFFER byte offsets (an out-of-map bilinear corner is a hardware-zeroed out-of-range load, never a
+ * read: msmv_sampling_forward.cu:47-66), so every level's (sample-batch) slab -- N views of H_l x W_l pixels -- must stay below 2 GiB;
+ * 1 if so.  hw = {H_0, W_0, H_1, W_1, ...}, strides in elements.  sbev_msmv_fwd itself has a 64-bit path for larger slabs. */
+int sbev_sample_mix_slabs_ok(const int32_t* hw, int L, int feat_dtype, int N, int C, const int64_t* stride_v, int64_t stride_px);
 int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
                         int64_t B, int N, int Q, int T, int G, int P, int C,
                         const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,

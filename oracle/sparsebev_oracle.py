@@ -110,7 +110,10 @@ def msmv_sampling_kernel_semantics(feats_cl, loc, weights):
             hc, wc = h0 + dh, w0 + dw
             inb = ok & (hc >= 0) & (hc <= H - 1) & (wc >= 0) & (wc <= W - 1)
             v = f[b_ix, view_ix, hc.clamp(0, H - 1), wc.clamp(0, W - 1)]          # [B',Q,P,C]
-            val = val + torch.where(inb, cw, torch.zeros_like(cw))[..., None] * v
+            # an out-of-map corner is never READ by the reference (:47-66 leave v1..v4 at 0): its value is 0, not "0 x whatever the
+            # clamped pixel holds" -- the difference shows once a border pixel is Inf / NaN (fp16 backbones, val.py:115)
+            v = torch.where(inb[..., None], v, torch.zeros_like(v))
+            val = val + cw[..., None] * v
         acc = acc + val * weights[..., l][..., None]
     return acc.permute(0, 1, 3, 2).contiguous()
 

@@ -127,7 +127,9 @@ SIGNATURES = {
     'sbev_linear_splitk_plan': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_group_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
     'sbev_copy_widen_f32': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int64, _vp]),
+    'sbev_msmv_buffer_taps': (ctypes.c_int, [ctypes.c_int]),
     'sbev_sample_mix_supported': (ctypes.c_int, [ctypes.c_int] * 6),
+    'sbev_sample_mix_slabs_ok': (ctypes.c_int, [_c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_i64p, ctypes.c_int64]),
     'sbev_sample_mix_f32': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,

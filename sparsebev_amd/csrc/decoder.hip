@@ -136,6 +136,21 @@ struct ProfCallScope {      // see sbev_profile_stride below
 };
 }  // namespace sbev
 
+// the fused gather + mixing kernel covers this config: shape (sbev_sample_mix_supported), the 5-level fp32 switch, and every level's
+// per-(sample, frame) NHWC slab below 2 GiB (the fused kernel's taps are 31-bit buffer offsets: sbev_sample_mix_slabs_ok)
+static bool sample_mix_fusable(const sbev_decoder_config& c) {
+    if (sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) == 0) return false;
+    if (c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0) return false;
+    int32_t hw[2 * SBEV_MAX_LEVELS];
+    int64_t sv[SBEV_MAX_LEVELS];
+    for (int l = 0; l < c.L; ++l) {
+        hw[2 * l] = c.hw[l][0];
+        hw[2 * l + 1] = c.hw[l][1];
+        sv[l] = (int64_t)c.hw[l][0] * c.hw[l][1] * c.D;
+    }
+    return sbev_sample_mix_slabs_ok(hw, c.L, c.feat_dtype, c.N, c.D / c.G, sv, c.D) != 0;
+}
+
 // Kernel launches sbev_decoder_forward enqueues per layer for this config / weight set under the current switches (what
 // bench.py reports; the decision code is the forward's own)
 extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, const sbev_decoder_weights* w) {
@@ -146,7 +161,7 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
     const bool chain = g_row_chain.load(std::memory_order_relaxed) != 0 && w->chain_pack != nullptr && !fork && sbev::row_chain_supported(c) &&
                        sbev::row_chain_pays(BQ);
     const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                       sbev_sample_mix_supported(c.L, c.D / c.G, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
+                       sample_mix_fusable(c);
     const int split = (c.gemm_mode == SBEV_GEMM_BF16X6 || c.gemm_mode == SBEV_GEMM_BF16X3S) ? 1      // x1 -> bf16 image fragments
                       : (c.gemm_mode == SBEV_GEMM_F16X3 || c.gemm_mode == SBEV_GEMM_F16X4) ? (chain ? 0 : 1)      // x1 -> fp16 image fragments (the attention chain writes them)
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
@@ -283,7 +298,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                               sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
+                               sample_mix_fusable(c);
             if (fused) {
                 TRY(mix_fused(stream));
             } else {
@@ -347,7 +362,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         // (round 2 kept two launches for 5 fp32 levels: 168 registers + spills, 272 vs 277 samples/s at config 4; the lean chunk code
         // of round 3 fits without spills -- g_fuse_l5_f32; 4 fp32 levels +1.6 % at config 2, 5 bf16 levels +4.3 % at config 5)
         const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                           sbev_sample_mix_supported(c.L, Cg, c.P, c.T, c.G, c.G) != 0 && !(c.L == 5 && c.feat_dtype == SBEV_F32 && g_fuse_l5_f32.load(std::memory_order_relaxed) == 0);
+                           sample_mix_fusable(c);
         if (!fused) {
             if (c.n_slots > 0)
                 TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,

@@ -230,10 +230,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
                 if (u + 4 < NU) lv_next = fetch_lv(u + 4);
                 unsigned ubo = b * (unsigned)T + (unsigned)t;
                 if (m.ring_T) ubo = b * (unsigned)m.n_slots + (unsigned)m.slots[t];
-                const FT* base[L];
+                long long slab[L];
 #pragma unroll
-                for (int l = 0; l < L; ++l)
-                    base[l] = reinterpret_cast<const FT*>(m.feat[l]) + (long long)ubo * m.stride_bo[l] + (long long)g * m.stride_g + j4;
+                for (int l = 0; l < L; ++l) slab[l] = (long long)ubo * m.stride_bo[l] + (long long)g * m.stride_g;     // wave-uniform
+                constexpr bool BUF = true;                      // buffer-load taps: every slab below 2 GiB (host-checked)
+                TapSrc<L, FT, BUF> src;
+                src.init(m, slab, j4);
                 const int npts = 4;
                 [[maybe_unused]] const bool chan_ok = true;
                 {
@@ -510,6 +512,15 @@ extern "C" int sbev_sample_mix_supported(int L, int C, int P, int T, int gdiv, i
     return (L == 4 || L == 5) && C == 64 && (P == 4 || P == 8) && gdiv == G && T >= 1 && (pin <= 64 || (pin > 112 && pin <= 120));
 }
 
+// the fused kernel gathers through buffer loads only: every level's (sample-batch) slab must stay below 2 GiB (sbev_msmv_fwd has a
+// 64-bit path for larger ones).  hw = {H0, W0, H1, W1, ...}, strides in elements.
+extern "C" int sbev_sample_mix_slabs_ok(const int32_t* hw, int L, int feat_dtype, int N, int Cg, const int64_t* stride_v, int64_t stride_px) {
+    if (!hw || !stride_v || L < 1 || L > SBEV_MAX_LEVELS) return 0;
+    for (int l = 0; l < L; ++l)
+        if (!msmv_slab_fits_buffer(N, hw[2 * l], hw[2 * l + 1], stride_v[l], stride_px, Cg, feat_dtype == SBEV_F32 ? 4 : 2)) return 0;
+    return 1;
+}
+
 static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
                            int64_t B, int N, int Q, int T, int G, int P, int Cg,
                            const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
@@ -530,8 +541,9 @@ static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, i
     for (int l = 0; l < L; ++l) {
         SBEV_REQUIRE(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_sample_mix_f32: level %d", l);
         SBEV_REQUIRE(stride_bo[l] % 4 == 0 && stride_v[l] % 4 == 0 && stride_v[l] >= 0 && stride_px >= 0 &&
-                         (int64_t)(N - 1) * stride_v[l] + ((int64_t)hw[2 * l] * hw[2 * l + 1] - 1) * stride_px + Cg <= 0x7fffffffLL,
-                     "sbev_sample_mix_f32: level %d strides (multiples of 4; one slab must fit the 32-bit in-slab offset)", l);
+                         msmv_slab_fits_buffer(N, hw[2 * l], hw[2 * l + 1], stride_v[l], stride_px, Cg, feat_dtype == SBEV_F32 ? 4 : 2),
+                     "sbev_sample_mix_f32: level %d strides (multiples of 4; one (sample-batch) slab must stay below 2 GiB: the taps are 31-bit "
+                     "buffer offsets -- sbev_sample_mix_slabs_ok; use sbev_msmv_fwd + sbev_adaptive_mixing_f32 otherwise)", l);
         m.feat[l] = feats[l];
         m.H[l] = hw[2 * l]; m.W[l] = hw[2 * l + 1];
         m.stride_bo[l] = stride_bo[l]; m.stride_v[l] = stride_v[l];

@@ -32,6 +32,67 @@ __device__ __forceinline__ float4 widen(const uint2 r) {  // 4 x bf16 -> fp32 (e
                        __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
 }
 
+// ---- where a lane's taps come from ------------------------------------------------------------------------------------------
+// BUF = true (round 4, every realistic map): raw BUFFER loads.  The (sample-batch, group) slab of a level is a wave-uniform buffer
+// resource (base in SGPRs, num_records 2^31 - 1), a tap is a 32-bit BYTE offset in one VGPR, and a corner OUTSIDE its map carries bit
+// 31 in that offset: the hardware's range check answers such a load with zeros and touches no memory -- exactly the reference's
+// semantics (msmv_sampling_forward.cu:47-66 never reads an out-of-map corner, so an Inf / NaN stored in a border pixel does not
+// reach a tap whose footprint only straddles it), at no VALU cost: round 3's lean form multiplied the CLAMPED pixel by a zero
+// coefficient (NaN for a non-finite pixel), the form before it paid 80 v_cndmask per 5-level chunk.  Also per tap: one v_add_u32
+// instead of a sign extension + v_lshl_add_u64, and one address register instead of two.
+// BUF = false: 64-bit global loads + a select on the loaded channels, for slabs of 2 GiB and more (the in-slab element offset is
+// still 32-bit; host-checked).  Same results.
+constexpr unsigned MSMV_OUTSIDE = 0x80000000u;
+constexpr unsigned MSMV_BUF_RECORDS = 0x7fffffffu;
+constexpr int MSMV_RSRC_DW3 = 0x00020000;           // gfx9 raw buffer, 32-bit data format (composable_kernel's constant for gfx9)
+
+// host: the largest in-slab byte offset a tap of this level can carry (last pixel of the last view + the lanes' channel offset + one
+// 16-byte load) stays below the buffer's 2^31 - 1 records
+inline bool msmv_slab_fits_buffer(long long N, long long H, long long W, long long stride_v, long long stride_px, long long C, long long esize) {
+    const long long last = (N - 1) * stride_v + (H * W - 1) * stride_px + (C > 64 ? C : 64) + 4;
+    return last * esize < (long long)MSMV_BUF_RECORDS;
+}
+
+template <int L, typename FT, bool BUF>
+struct TapSrc;
+template <int L, typename FT>
+struct TapSrc<L, FT, true> {
+    __amdgpu_buffer_rsrc_t rs[L];
+    unsigned lane_off;                                // bytes: this lane's channel quad inside a pixel
+    // slab_elems[l]: wave-uniform element offset of the (sample-batch, group) slab; lane_elems: this lane's channel offset
+    __device__ __forceinline__ void init(const MsmvArgs& a, const long long* slab_elems, int lane_elems) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const unsigned long long p = (unsigned long long)(reinterpret_cast<const FT*>(a.feat[l]) + slab_elems[l]);
+            // wave-uniform by construction (blockIdx, readfirstlane'd wave index): say so, or the resource costs a waterfall loop
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+            rs[l] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)MSMV_BUF_RECORDS, MSMV_RSRC_DW3);
+        }
+        lane_off = (unsigned)lane_elems * (unsigned)sizeof(FT);
+    }
+    // setup lane: element offset inside the slab + "inside the map" -> what the gathering lanes are handed
+    __device__ __forceinline__ static int encode(int off_elems, bool inb) {
+        const unsigned b = (unsigned)off_elems * (unsigned)sizeof(FT);          // < 2^31 (host-checked)
+        return (int)(inb ? b : (b | MSMV_OUTSIDE));
+    }
+    __device__ __forceinline__ auto load(int l, int toff) const {
+        const int vo = (int)((unsigned)toff + lane_off);                        // bit 31 survives: lane_off < 2^16
+        if constexpr (sizeof(FT) == 4) return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs[l], vo, 0, 0));
+        else return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs[l], vo, 0, 0));
+    }
+};
+template <int L, typename FT>
+struct TapSrc<L, FT, false> {
+    const FT* base[L];
+    __device__ __forceinline__ void init(const MsmvArgs& a, const long long* slab_elems, int lane_elems) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) base[l] = reinterpret_cast<const FT*>(a.feat[l]) + slab_elems[l] + lane_elems;
+    }
+    __device__ __forceinline__ static int encode(int off_elems, bool inb) { return inb ? off_elems : (int)((unsigned)off_elems | MSMV_OUTSIDE); }
+    __device__ __forceinline__ auto load(int l, int toff) const { return load_raw(base[l] + (toff & 0x7fffffff)); }      // always a valid address
+};
+
 // Reduce-scatter over the 4 corner groups (16-lane rows r = 0..3 of the wave) without LDS:
 // given one value per item i = 0..3 in every lane, returns in row r the sum over all 4 rows of item r.
 // permlane16_swap(x, y) exchanges the odd rows of x with the even rows of y, so x + y afterwards holds

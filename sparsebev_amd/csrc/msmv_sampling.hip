@@ -20,12 +20,14 @@
 // Bound: HBM/L2 gather bandwidth (about 2 flop per loaded float).  Algorithmic bytes per sampled point
 // (SURVEY.md section 8d): L*4*C*sizeof(feat) + 12 + 4L + 4C  (4124 B at L=4, C=64, fp32).
 #include "sbev_common.hpp"
+#include <atomic>
+#include <cstdlib>
 
 namespace {
 
 #include "msmv_common.hpp"
 
-template <int L, typename FT, int OUT, int QPW>
+template <int L, typename FT, int OUT, int QPW, bool BUF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(msmv_min_waves<L, FT>()))) void msmv_fwd_kernel(const MsmvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,10 +64,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(msmv_min_wa
     for (int c0 = 0; c0 < C; c0 += 64) {
         const bool chan_ok = (c0 + j4) < C;
         const int cj = chan_ok ? c0 + j4 : 0;
-        const FT* base[L];
+        long long slab[L];
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-            base[l] = reinterpret_cast<const FT*>(a.feat[l]) + bo * a.stride_bo[l] + gi * a.stride_g + cj;
+        for (int l = 0; l < L; ++l) slab[l] = bo * a.stride_bo[l] + gi * a.stride_g;       // wave-uniform
+        TapSrc<L, FT, BUF> src;
+        src.init(a, slab, cj);
 
         for (int p0 = 0; p0 < P; p0 += 4) {
             // ONE coalesced request for this chunk's 12 coordinates (lanes 0..11) and 4*L level weights (lanes
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(msmv_min_wa
     }   // item loop
 }
 
-template <int L, typename FT>
+template <int L, typename FT, bool BUF>
 int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
     // pipelined items per wave when a query is a single chunk and there are enough items to keep every SIMD fed
     const bool pipe = a.P <= 4 && a.C <= 64 && a.n_waves >= 4LL * 1024 * SBEV_MSMV_QPW;
@@ -140,25 +143,33 @@ int launch_l(const MsmvArgs& a, int out_layout, hipStream_t s) {
     hipEvent_t e0, e1;
     const bool prof = sbev::profile_begin(s, &e0, &e1);
     if (out_layout == SBEV_OUT_REF) {
-        if (pipe) hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF, SBEV_MSMV_QPW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (pipe) hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF, SBEV_MSMV_QPW, BUF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_REF, 1, BUF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else {
-        if (pipe) hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX, SBEV_MSMV_QPW>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (pipe) hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX, SBEV_MSMV_QPW, BUF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((msmv_fwd_kernel<L, FT, SBEV_OUT_MIX, 1, BUF>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     }
     if (prof) sbev::profile_end(s, e0, e1);
     return sbev::check_launch("sbev_msmv_fwd");
 }
 
-template <typename FT>
-int launch_t(const MsmvArgs& a, int L, int out_layout, hipStream_t s) {
+template <typename FT, bool BUF>
+int launch_b(const MsmvArgs& a, int L, int out_layout, hipStream_t s) {
     switch (L) {
-        case 1: return launch_l<1, FT>(a, out_layout, s);
-        case 2: return launch_l<2, FT>(a, out_layout, s);
-        case 3: return launch_l<3, FT>(a, out_layout, s);
-        case 4: return launch_l<4, FT>(a, out_layout, s);
-        default: return launch_l<5, FT>(a, out_layout, s);
+        case 1: return launch_l<1, FT, BUF>(a, out_layout, s);
+        case 2: return launch_l<2, FT, BUF>(a, out_layout, s);
+        case 3: return launch_l<3, FT, BUF>(a, out_layout, s);
+        case 4: return launch_l<4, FT, BUF>(a, out_layout, s);
+        default: return launch_l<5, FT, BUF>(a, out_layout, s);
     }
+}
+// buffer-load taps (hardware zeros for an out-of-map corner) when every slab of every level is below 2 GiB;
+// sbev_msmv_buffer_taps(0) / SBEV_MSMV_NO_BUF=1 force the 64-bit global-load path (tests, A/B; same results)
+std::atomic<int> g_buffer_taps{getenv("SBEV_MSMV_NO_BUF") ? 0 : 1};
+template <typename FT>
+int launch_t(const MsmvArgs& a, int L, int out_layout, bool slabs_fit_buffer, hipStream_t s) {
+    return slabs_fit_buffer && g_buffer_taps.load(std::memory_order_relaxed) != 0 ? launch_b<FT, true>(a, L, out_layout, s)
+                                                                                   : launch_b<FT, false>(a, L, out_layout, s);
 }
 
 }  // namespace
@@ -181,6 +192,8 @@ static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int
     const bool empty = Bp == 0 || Q == 0;          // an empty call still validates its level descriptors
     SBEV_REQUIRE(empty || (loc && weights && out), "sbev_msmv_fwd: null loc/weights/out");
     MsmvArgs a{};
+    bool fit = true;        // every (sample-batch, group) slab + a lane's channel offset addressable by a 31-bit BYTE offset
+    const int64_t esize = feat_dtype == SBEV_F32 ? 4 : 2;
     for (int l = 0; l < L; ++l) {
         SBEV_REQUIRE(empty || feats[l] != nullptr, "sbev_msmv_fwd: feats[%d] is null", l);
         SBEV_REQUIRE(hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_msmv_fwd: level %d has empty map", l);
@@ -191,6 +204,7 @@ static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int
                          (int64_t)(N - 1) * stride_v[l] + ((int64_t)hw[2 * l] * hw[2 * l + 1] - 1) * stride_px + C <= 0x7fffffffLL,
                      "sbev_msmv_fwd: level %d: one (sample-batch) slab spans %lld elements, the in-slab tap offset is 32-bit (limit 2^31 - 1)",
                      l, (long long)((int64_t)(N - 1) * stride_v[l] + ((int64_t)hw[2 * l] * hw[2 * l + 1] - 1) * stride_px + C));
+        fit = fit && msmv_slab_fits_buffer(N, hw[2 * l], hw[2 * l + 1], stride_v[l], stride_px, C, esize);
         a.feat[l] = feats[l];
         a.H[l] = hw[2 * l];
         a.W[l] = hw[2 * l + 1];
@@ -216,8 +230,12 @@ static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int
         }
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return feat_dtype == SBEV_F32 ? launch_t<float>(a, L, out_layout, s)
-                                  : launch_t<unsigned short>(a, L, out_layout, s);
+    return feat_dtype == SBEV_F32 ? launch_t<float>(a, L, out_layout, fit, s)
+                                  : launch_t<unsigned short>(a, L, out_layout, fit, s);
+}
+
+extern "C" int sbev_msmv_buffer_taps(int enable) {
+    return g_buffer_taps.exchange(enable ? 1 : 0, std::memory_order_relaxed);
 }
 
 extern "C" int sbev_msmv_fwd(const void* const* feats, const int32_t* hw, int L, int feat_dtype,

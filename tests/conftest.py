@@ -31,6 +31,20 @@ def feats_of(g):
     return [g['feat%d' % i] for i in range(n)]
 
 
+def assert_same_with_nonfinite(got, ref, tol, what='', kinds=True):
+    """Outputs that legitimately hold Inf / NaN (fixture G12): the SAME elements must be non-finite -- with kinds=True also of the same kind
+    (NaN, +Inf, -Inf) -- and the finite ones agree to `tol`."""
+    got, ref = torch.as_tensor(got).float().cpu(), torch.as_tensor(ref).float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(got), fin), '%s: non-finite positions differ (%d vs %d)' % (what, int((~torch.isfinite(got)).sum()), int((~fin).sum()))
+    if kinds:
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), '%s: NaN positions differ (%d vs %d NaNs)' % (what, int(torch.isnan(got).sum()), int(torch.isnan(ref).sum()))
+        assert torch.equal(torch.isposinf(got), torch.isposinf(ref)) and torch.equal(torch.isneginf(got), torch.isneginf(ref)), what + ': Inf positions differ'
+    assert fin.any() and (~fin).any(), what + ': the fixture must hold both finite and non-finite outputs'
+    assert (got[fin] - ref[fin]).abs().max() < tol, what
+
+
 @pytest.fixture(scope='session')
 def golden():
     return load_golden

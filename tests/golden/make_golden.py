@@ -311,6 +311,57 @@ def main_version():
 
 
 
+def plant_nonfinite_borders(feats_cl, g):
+    """Inf / NaN in border pixels (what an fp16 backbone can leave, val.py:115): per (sample-batch entry, level) the whole outer
+    ring, or single border pixels in some channels, or nothing -- the SAME pixels in all 6 views of the entry, because the native
+    path's grid_sample is trilinear over the view axis and reads the neighbouring view with weight 0 (0 x Inf = NaN) where the CUDA
+    kernel rounds to one view: with identical patterns both read a bad pixel for exactly the same points.  Interior pixels stay
+    finite."""
+    for f in feats_cl:
+        Bp, N, H, W, C = f.shape
+        if min(H, W) < 4:                   # (a 2 x 6 map is border only)
+            continue
+        for b in range(Bp):
+            r = b % 3
+            bad = float('inf') if b % 2 == 0 else float('nan')
+            if r == 0:                      # the whole ring
+                f[b, :, 0], f[b, :, H - 1] = bad, bad
+                f[b, :, :, 0], f[b, :, :, W - 1] = bad, bad
+            elif r == 1:                    # one corner pixel and one edge pixel, some channels only
+                f[b, :, 0, 0, ::2] = bad
+                f[b, :, H - 1, W // 2, 1::3] = bad
+    return feats_cl
+
+
+def main_nonfinite():
+    """G12: the reference's native-PyTorch sampler (csrc/wrapper.py:14-38 -> F.grid_sample, zeros padding) on maps whose BORDER
+    pixels hold Inf / NaN, sample points from far outside to well inside: an out-of-map bilinear corner is never read
+    (msmv_sampling_forward.cu:47-66; grid_sample's within-bounds test), so a point wholly outside a map gets exactly 0 from it
+    and only points whose footprint really covers a bad pixel turn non-finite.  WHICH elements are non-finite is what this fixture
+    pins (the kind may differ: the native path adds 0 x Inf = NaN from the neighbouring view, see plant_nonfinite_borders).  `python tests/golden/make_golden.py nonfinite`."""
+    tr, smp, wrap, utils = import_reference()
+    assert wrap.MSMV_CUDA is False
+    for tag, pyr, C, Bp in (('L4_C64', 'tiny', 64, 3), ('L5_C64', 'tiny5', 64, 2)):
+        g = torch.Generator().manual_seed(1200 + len(S.PYRAMIDS[pyr][2]))
+        sizes = S.PYRAMIDS[pyr][2]
+        Q, P, L = 24, 4, len(sizes)
+        feats_cl = plant_nonfinite_borders([torch.randn(Bp, 6, h, w, C, generator=g) for h, w in sizes], g)
+        # random coordinates only: on an exact pixel / border coordinate (edge_locs' specials) the native path's grid arithmetic and the
+        # CUDA kernel's round differently by an ulp and legitimately pick different corners
+        loc = torch.rand(Bp, Q, P, 3, generator=g)
+        loc[..., 2] = torch.randint(0, 6, (Bp, Q, P), generator=g).float() / 5
+        loc[:, Q // 2:, :, :2] = loc[:, Q // 2:, :, :2] * 1.6 - 0.3          # half the queries: x, y in [-0.3, 1.3]
+        loc[:, :2, :, 0] = -3.0                                              # far outside
+        loc[:, 2:4, :, 1] = 4.0
+        wts = torch.softmax(torch.randn(Bp, Q, P, L, generator=g), -1)
+        out = wrap.msmv_sampling_pytorch(cf_from_cl(feats_cl), loc, wts)
+        nf = ~torch.isfinite(out)
+        print('  G12 %s: %.1f %% of the outputs non-finite' % (tag, 100 * nf.float().mean()))
+        assert 0.02 < nf.float().mean() < 0.9
+        save('g12_msmv_nonfinite_' + tag, loc=loc, weights=wts, out=out, sizes=np.array(sizes),
+             **{'feat%d' % i: f for i, f in enumerate(feats_cl)})
+
+
 sample_indices = S.grad_sample_indices
 
 
@@ -377,8 +428,11 @@ if __name__ == '__main__':
         main_version()
     elif len(sys.argv) > 1 and sys.argv[1] == 'train':
         main_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'nonfinite':
+        main_nonfinite()
     else:
         main()
         main_head()
         main_version()
         main_train()
+        main_nonfinite()

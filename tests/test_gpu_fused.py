@@ -51,6 +51,33 @@ def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtyp
     assert got.abs().max() > 0
 
 
+@pytest.mark.parametrize('pyr,dtype', [('tiny', torch.float32), ('tiny5', torch.bfloat16)])
+def test_fused_launch_with_nonfinite_border_pixels(pyr, dtype):
+    """Inf in every border pixel: the fused kernel's gather (buffer-load taps) must poison exactly the items the two launches
+    poison -- an item whose sampled rows hold an Inf is NaN after its LayerNorm, every other item is bit-identical."""
+    B, Q, T, P = 1, 200, 4, 4
+    ih, iw, sizes = S.PYRAMIDS[pyr]
+    L, G, C = len(sizes), 4, 64
+    g = torch.Generator(device=DEV).manual_seed(77)
+    levels = [torch.randn(B * T * 6, h, w, G * C, generator=g, device=DEV) for h, w in sizes]
+    for f in levels:
+        if min(f.shape[1:3]) >= 4:
+            f[:, 0], f[:, -1], f[:, :, 0], f[:, :, -1] = float('inf'), float('inf'), float('inf'), float('inf')
+    levels = [f.to(dtype) for f in levels]
+    loc = torch.rand(B * T * G, Q, P, 3, generator=g, device=DEV) * 0.5 + 0.25           # interior ...
+    loc[:, ::3] = loc[:, ::3] * 4 - 1.5                                                  # ... every third query: from far outside to the border
+    loc[..., 2] = torch.randint(0, 6, (B * T * G, Q, P), generator=g, device=DEV).float() / 5
+    w = torch.softmax(torch.randn(B * T * G, Q, P, L, generator=g, device=DEV), -1)
+    params = torch.randn(B, Q, G * (C * C + 128 * T * P), generator=g, device=DEV) * 0.3
+    x = ops.msmv_sampling_nhwc(levels, B, T, G, loc, w, out_layout=ops.OUT_MIX)
+    want = mixing(x, params)
+    got = ops.sample_mix(levels, B, T, G, loc, w, params, 128)
+    bad = ~torch.isfinite(want)
+    assert 0.02 < bad.float().mean() < 0.9
+    assert torch.equal(~torch.isfinite(got), bad)
+    assert torch.equal(got[~bad], want[~bad])
+
+
 def test_fused_launch_on_the_frame_ring():
     B, Q, T, n_slots, G, P, C = 2, 50, 4, 6, 4, 4, 64
     ih, iw, sizes = S.PYRAMIDS['tiny']

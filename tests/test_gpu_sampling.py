@@ -166,6 +166,57 @@ def test_full_size_c2_vs_c_oracle_and_properties():
     assert torch.equal(ops.msmv_sampling(feats, loc, wbp), out)
 
 
+@pytest.mark.parametrize('tag', ['L4_C64', 'L5_C64'])
+@pytest.mark.parametrize('buffer_taps', [1, 0])
+def test_g12_nonfinite_border_pixels_match_the_cuda_kernel_semantics(tag, buffer_taps):
+    """Inf / NaN planted in border pixels (fixture G12).  The reference never reads an out-of-map bilinear corner
+    (msmv_sampling_forward.cu:47-66): a point wholly outside a map gets exactly 0 from it, a point whose footprint covers a bad pixel
+    turns non-finite.  The HIP sampler -- buffer-load taps (out-of-map = out-of-range offset, hardware zeros) and the 64-bit
+    global-load path (select) -- must give the non-finite elements of the kernel-semantics oracle EXACTLY (positions and kind),
+    the finite ones to 1e-4, in both output layouts and for bf16 storage; the reference's own output pins the positions."""
+    from conftest import assert_same_with_nonfinite
+    from oracle import sparsebev_oracle as O
+    from sparsebev_amd import _lib
+    g = load_golden('g12_msmv_nonfinite_' + tag)
+    feats_cl = feats_of(g)
+    want = O.msmv_sampling_kernel_semantics(feats_cl, g['loc'], g['weights'])
+    prev = _lib.load().sbev_msmv_buffer_taps(buffer_taps)
+    try:
+        feats = [dev(f) for f in feats_cl]
+        out = ops.msmv_sampling(feats, dev(g['loc']), dev(g['weights']))
+        assert_same_with_nonfinite(out, want, TOL, 'HIP vs kernel semantics')
+        assert_same_with_nonfinite(out, g['out'], TOL, 'HIP vs the reference', kinds=False)
+        mix = ops.msmv_sampling(feats, dev(g['loc']), dev(g['weights']), out_layout=ops.OUT_MIX, T=1, G=1)
+        a, b = mix[:, :, 0].permute(0, 1, 3, 2), out
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+        feats_bf = [f.to(torch.bfloat16) for f in feats_cl]
+        want_bf = O.msmv_sampling_kernel_semantics([f.float() for f in feats_bf], g['loc'], g['weights'])
+        out_bf = ops.msmv_sampling([dev(f) for f in feats_bf], dev(g['loc']), dev(g['weights']))
+        assert_same_with_nonfinite(out_bf, want_bf, TOL, 'HIP bf16 storage vs kernel semantics')
+    finally:
+        _lib.load().sbev_msmv_buffer_taps(prev)
+
+
+def test_points_outside_every_map_ignore_nonfinite_pixels_at_full_size():
+    """Config-2 shape with every border pixel of every map set to Inf: the sample points of the synthetic rig that hit no camera
+    (7.7 %, arbitrary coordinates) and any other point wholly outside a level must come out exactly as with zeroed borders."""
+    feats, pts, l2i, loc, wbp, _, (ih, iw, B, Q, T, G, P, L) = c2_inputs()
+    bad, zero = [f.clone() for f in feats], [f.clone() for f in feats]
+    for fb, fz in zip(bad, zero):
+        for t, v in ((fb, float('inf')), (fz, 0.0)):
+            t[:, :, 0], t[:, :, -1], t[:, :, :, 0], t[:, :, :, -1] = v, v, v, v
+    o_bad, o_zero = ops.msmv_sampling(bad, loc, wbp), ops.msmv_sampling(zero, loc, wbp)
+    fin = torch.isfinite(o_bad)
+    assert 0.5 < fin.float().mean() < 1.0                       # most points are interior; some really cover a border pixel
+    assert torch.equal(o_bad[fin], o_zero[fin])
+    # a point is finite exactly when none of its in-map corners is a border pixel: check the "wholly outside" ones explicitly
+    x, y = loc[..., 0], loc[..., 1]                             # [B', Q, P]
+    H0, W0 = feats[0].shape[2:4]
+    far = (x < -1.0 / (8 - 1)) | (x > 1 + 1.0 / (8 - 1)) | (y < -1.0 / (8 - 1)) | (y > 1 + 1.0 / (8 - 1))   # outside even the coarsest map's one-pixel band
+    assert far.any()
+    assert (o_bad.permute(0, 1, 3, 2)[far] == 0).all()
+
+
 def test_int64_offsets_beyond_2g_elements():
     """The reference's int32 offsets overflow once B'*N*H*W*C >= 2^31.  Sample the
     LAST batch entry of a 2.2e9-element level and check it against a small tensor holding just that entry."""

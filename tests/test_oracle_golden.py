@@ -27,6 +27,24 @@ def test_g1_sampler_both_restatements(tag):
     assert (a1 - g['out']).abs().max() < TOL           # CUDA-kernel semantics vs grid_sample: < 1e-4
 
 
+@pytest.mark.parametrize('tag', ['L4_C64', 'L5_C64'])
+def test_g12_nonfinite_border_pixels_all_three_restatements(tag):
+    """Inf / NaN planted in border pixels, sample points from far outside to well inside (fixture G12 = the reference's own
+    native-PyTorch sampler): an out-of-map bilinear corner is never read (msmv_sampling_forward.cu:47-66), so a point wholly outside
+    a map gets exactly 0 from it.  The reference's output pins WHICH elements are non-finite (and the finite values); the kind
+    (NaN / Inf) is the CUDA kernel's -- one view, no zero-weighted neighbour view -- on which the kernel-semantics restatement and
+    the C oracle must agree exactly."""
+    from conftest import assert_same_with_nonfinite
+    from oracle import c_oracle
+    g = load_golden('g12_msmv_nonfinite_' + tag)
+    feats_cl = feats_of(g)
+    assert_same_with_nonfinite(O.msmv_sampling_gridsample(cl_to_cf(feats_cl), g['loc'], g['weights']), g['out'], 1e-6, 'grid_sample')
+    a1 = O.msmv_sampling_kernel_semantics(feats_cl, g['loc'], g['weights'])
+    assert_same_with_nonfinite(a1, g['out'], TOL, 'kernel semantics vs the reference', kinds=False)
+    ref_c = c_oracle.msmv_fwd([f.numpy() for f in feats_cl], g['loc'].numpy(), g['weights'].numpy())
+    assert_same_with_nonfinite(ref_c, a1, TOL, 'C oracle vs kernel semantics')
+
+
 @pytest.mark.parametrize('T', [1, 8])
 def test_g2_projection_mask_bit_exact_and_quirks(T):
     g = load_golden('g2_sampling4d_T%d' % T)

@@ -422,6 +422,13 @@ int sbev_linear_splitk_bf16s(const float* X, const uint16_t* Wp, const float* bi
 int sbev_pack_f16s_frags(const float* W, int64_t ldw, uint16_t* out, float* scales, int N, int K, int per_tensor, sbev_stream_t stream);
 int sbev_linear_f16s_gen(const uint16_t* Xs, const float* xscale, const uint16_t* Ws, const float* wdown, const float* bias, float* Y,
                          int64_t M, int N, int K, int64_t ldy, int relu, int nprod, sbev_stream_t stream);
+
+/* K = 256 with two images per operand (f16x3 / f16x4 / bf16x3s) runs on the WEIGHT-STATIONARY generator kernel: a wave keeps the
+ * weights of its 32 output columns in registers for the whole launch, only X streams (LDS-DMA ring), persistent workgroups walk
+ * (column tile, row split) tasks -- half the operand bytes per MFMA of the tiled kernel, bit-identical results.  0 restores the tiled
+ * ping-pong kernel everywhere (A/B, tests; env SBEV_NO_GEN_WS=1); returns the previous setting. */
+int sbev_linear_gen_weight_stationary(int enable);
+
 int sbev_linear_splitk_f16s(const float* X, int x_is_pairs, int x_up_log2, const uint16_t* Wp, const float* nscale, const float* bias, const float* residual,
                             const float* ln_w, const float* ln_b, float ln_eps, float* Y,
                             int64_t M, int N, int K, int64_t ldx, int relu, int nprod, float* workspace, sbev_stream_t stream);

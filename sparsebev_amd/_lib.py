@@ -76,6 +76,7 @@ SIGNATURES = {
     'sbev_bf16s_image_elems': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_split_bf16s_rows': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_pack_bf16s_frags': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_linear_gen_weight_stationary': (ctypes.c_int, [ctypes.c_int]),
     'sbev_linear_bf16s_gen_ok': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     'sbev_linear_bf16s_gen': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int, ctypes.c_int, _vp]),

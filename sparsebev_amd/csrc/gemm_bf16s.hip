@@ -25,6 +25,7 @@
 //              caller-supplied power of two);  gemm_bf16s_out4_kernel (fp16 modes, the decoder's path) -- <= 128 rows x 256 columns
 //              x one chunk, X handed over as (fp16 hi, fp16 lo) PAIRS by the mixing kernel's epilogue (sbev_*_pairs_f16), W through
 //              a wave-private LDS-DMA ring, the two K halves folded through an [m][n] image of the tile in LDS.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include "sbev_common.hpp"
@@ -643,6 +644,170 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     }
 }
 
+// ---- generator, WEIGHT-STATIONARY version (round 4; K = 256, two images) ------------------------------------------------------------
+// What bounded the kernel above: a 256 x 256 tile streams 32 KB per 16-k stage through the L2 -> CU path
+// (~21 B/clk/CU by LDS-DMA) for 1632 cycles of MFMAs, alternately -- the FETCH phase of one wave group is as long as the COMPUTE phase
+// of the other, and both operands of every tile come through that path again (X: once per column tile).  With M ~ 10^3 rows and
+// K = 256 the weights of 32 output columns are 16 k-steps x 2 images x 4 registers = 128 VGPRs: a wave can HOLD its B operands for
+// the whole kernel.  So here a workgroup owns 256 output columns (wave w: columns 32 w .. 32 w + 31, its 32 KB of W fragments loaded
+// once into registers) and walks row fragments: the only stream is X -- one 32-row fragment (all K: 32 KB, contiguous in the packed
+// operand) per 48 MFMAs of each of the 8 waves, i.e. 32 KB per 3072 matrix-pipe cycles of a SIMD = 10.7 B/clk/CU, half of what the
+// tiled kernel needs, read by every wave from a 3-slot LDS ring the workgroup fills by LDS-DMA two fragments ahead.  No phases: the
+// two waves of a SIMD run the same MFMA-dominated stream and fill each other's gaps (each wave's 48 MFMAs of a fragment are one
+// dependent chain on one accumulator; the partner's chain interleaves with it); the finished fragment's 16 stores ride between the
+// next fragment's MFMAs, one per k-step (a lane owns one output column: a wave-store is two full 128-byte lines), through a buffer
+// resource of M ldy 4 bytes, so rows >= M of the last fragment are dropped by the range check and need no branch.
+// One barrier per fragment.  LDS-DMA ordering (guide: read a staged buffer one barrier after the wait that retires it): at the END of
+// fragment f every wave waits vmcnt(DMA pieces of fragment f + 2 only) -- its own pieces of f + 1 have landed (loads return in order;
+// stores still in flight only make the wait longer: the counter counts them too) -- then the barrier publishes all waves' pieces;
+// slot (f - 1) % 3 is refilled right after that barrier, when every wave has finished reading it.
+// Same products in the same order as gemm_bf16s_gen3_kernel<MODE, 4>: results are bit-identical to it.
+struct GenWsArgs {
+    const unsigned short* Xs;    // [ceil(M/32)][16][2][64][8]
+    const unsigned short* Ws;    // [N/32][16][2][64][8]
+    const float* bias;           // [N] or null
+    float* Y;                    // [M, ldy]
+    int M, N;
+    long long ldy;
+    int relu;
+    int nrs, base, rem;          // row splits: the first `rem` own base + 1 fragments, the others `base`
+    int ntask;                   // (N / 256) * nrs
+    const float* colscale;       // fp16 modes: [N] 2^-ew; null otherwise
+    const float* xscale;         // fp16 modes: {2^ex, 2^-ex}
+};
+
+constexpr int WS_KS = 16;                        // k-steps of 16: K = 256
+constexpr int WS_FRAG = WS_KS * 2 * 1024;        // bytes of one row fragment of X (all K, both images)
+constexpr int WS_SLOTS = 3;
+
+// workgroup barrier with LDS-DMA in flight: a bare s_barrier behind this wave's LDS traffic -- __syncthreads()' release fence would
+// also wait vmcnt(0) for the compiler-visible Y stores (and with them for the prefetched fragments)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a) {
+    typedef Fmt<MODE> PR;
+    static_assert(PR::NIMG == 2, "two-image modes only: the stationary weights are 128 registers");
+    constexpr bool F16 = PR::F16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // the only LDS object: [WS_SLOTS][WS_FRAG]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned voff = (unsigned)lane * 16u;
+    const int nfrag = (a.M + 31) / 32;
+    // Y through a buffer resource: per-lane byte offset of (row 4 lh, column n) in a 32-bit register, rows >= M fall outside num_records
+    const unsigned long long yb = (unsigned long long)a.Y;
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(yb >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)yb)),
+        0, (int)(unsigned)((long long)a.M * a.ldy * 4), 0x00020000);
+    const unsigned ldyb = (unsigned)(a.ldy * 4);
+
+    for (int task = (int)xcd_contiguous(blockIdx.x, gridDim.x); task < a.ntask; task += (int)gridDim.x) {
+        const int ct = task / a.nrs, rs = task - ct * a.nrs;
+        const int f0 = rs * a.base + (rs < a.rem ? rs : a.rem);
+        const int nf = a.base + (rs < a.rem ? 1 : 0);
+        if (nf <= 0) continue;
+        const int n = ct * G_COLS + wave * 32 + l31;                       // this lane's output column
+        // ---- the wave's weights: 32 columns x K, both images -> 128 registers
+        bf16x8 wf[WS_KS][2];
+        {
+            const unsigned short* wb = a.Ws + ((long long)(ct * 8 + wave) * (WS_KS * 2) * 64 + lane) * 8;
+#pragma unroll
+            for (int ks = 0; ks < WS_KS; ++ks)
+#pragma unroll
+                for (int img = 0; img < 2; ++img) wf[ks][img] = *reinterpret_cast<const bf16x8*>(wb + (ks * 2 + img) * 512);
+        }
+        const float bv = a.bias ? a.bias[n] : 0.f;
+        const float cv = F16 ? a.colscale[n] * a.xscale[1] : 1.f;
+        const unsigned ycol = (unsigned)(4 * lh) * ldyb + (unsigned)n * 4u;
+        // ---- X stream: fragment f0 + i -> slot i % 3; wave w copies pieces 4 w .. 4 w + 3 (4 KB, contiguous on both sides)
+        const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.Xs) + (long long)f0 * WS_FRAG + wave * 4096;
+        auto issue = [&](int i) {                                         // (callers guarantee i < nf)
+            const unsigned long long sb = (unsigned long long)(xg + (long long)i * WS_FRAG);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
+            const void* sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((i % WS_SLOTS) * WS_FRAG + wave * 4096);
+            asm volatile(
+                "s_mov_b32 m0, %0\n\t"
+                "s_nop 4\n\t"
+                "global_load_lds_dwordx4 %1, %2\n\t"
+                "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                :
+                : "s"(dst), "v"(voff), "s"(sbase)
+                : "memory");
+        };
+        issue(0);
+        if (nf > 1) issue(1);
+        wait_vmcnt_imm<0>();                                              // (also this wave's weights)
+        lds_barrier();
+        f32x16 prev;                                                      // the finished fragment, scaled + biased, waiting for its stores
+#pragma unroll
+        for (int e = 0; e < 16; ++e) prev[e] = 0.f;
+        for (int i = 0; i < nf; ++i) {
+            if (i + 2 < nf) issue(i + 2);                                 // slot (i - 1) % 3: every wave is past the barrier that ended fragment i - 1
+            const unsigned char* st = lds + (i % WS_SLOTS) * WS_FRAG + voff;
+            // fragment i - 1; at i = 0 there is none: bit 31 puts the 16 stores outside the buffer (M ldy 4 < 2^31, host-checked) and
+            // the hardware drops them -- no branch in the k loop
+            const unsigned yprev = i > 0 ? ycol + (unsigned)((f0 + i - 1) * 32) * ldyb : (ycol | 0x80000000u);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            // k-step regions pinned by sched_barrier: the fragments of k-step ks + 1 are requested before the MFMAs of ks, and the 16
+            // stores of the previous fragment go out in the FIRST 8 k-steps (two each) -- hipcc otherwise sinks them all behind the last
+            // MFMAs, right in front of the counted wait below, which then sits out their write latency
+            bf16x8 xc[2], xn[2];
+            xc[0] = *reinterpret_cast<const bf16x8*>(st);
+            xc[1] = *reinterpret_cast<const bf16x8*>(st + 1024);
+#pragma unroll
+            for (int ks = 0; ks < WS_KS; ++ks) {
+                if (ks + 1 < WS_KS) {
+                    xn[0] = *reinterpret_cast<const bf16x8*>(st + (ks * 2 + 2) * 1024);
+                    xn[1] = *reinterpret_cast<const bf16x8*>(st + (ks * 2 + 3) * 1024);
+                }
+                if (ks < 8) {
+#pragma unroll
+                    for (int e = 2 * ks; e < 2 * ks + 2; ++e) {
+                        const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb;
+#ifndef SBEV_EXP_NOSTORE
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(yprev + ro), 0, 0);
+#endif
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < PR::N - 1; ++p) acc = SBEV_MFMA(xc[PR::ia(p)], wf[ks][PR::ib(p)], acc);
+                acc = SBEV_MFMA(xc[0], wf[ks][0], acc);
+                __builtin_amdgcn_sched_barrier(0);
+                xc[0] = xn[0];
+                xc[1] = xn[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = F16 ? fmaf(acc[e], cv, bv) : acc[e] + bv;
+                prev[e] = a.relu ? fmaxf(v, 0.f) : v;
+            }
+            // fragment i + 1: this wave's pieces landed (only the 4 pieces of fragment i + 2, if issued, may be outstanding), then published
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < nf) wait_vmcnt_imm<4>();
+            else wait_vmcnt_imm<0>();
+            lds_barrier();
+        }
+        {                                                                 // the last fragment's stores
+            const unsigned ylast = ycol + (unsigned)((f0 + nf - 1) * 32) * ldyb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(ylast + (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb), 0, 0);
+        }
+    }
+}
+
 // ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
 struct OutArgs {
     const float* X;              // [M, ldx] fp32
@@ -1196,6 +1361,11 @@ extern "C" int sbev_f16s_tensor_scale(const float* X, int64_t ldx, int64_t rows,
     return sbev::check_launch("sbev_f16s_tensor_scale");
 }
 
+// the weight-stationary generator kernel where it applies (K = 256, two images); sbev_linear_gen_weight_stationary(0) / SBEV_NO_GEN_WS=1
+// restore the tiled ping-pong kernel everywhere (A/B; results are bit-identical)
+static std::atomic<int> g_gen_ws{getenv("SBEV_NO_GEN_WS") ? 0 : 1};
+extern "C" int sbev_linear_gen_weight_stationary(int enable) { return g_gen_ws.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
+
 static int ntm_of(int64_t M) { return (int)(((M + 31) / 32 + 7) / 8); }      // row tiles of <= 8 fragments
 
 extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {
@@ -1210,6 +1380,43 @@ static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias,
     SBEV_REQUIRE(Xs && Ws && Y && ldy >= N && ldy % 4 == 0, "sbev_linear_bf16s_gen: bad pointers / leading dimension");
     SBEV_REQUIRE((((uintptr_t)Xs | (uintptr_t)Ws | (uintptr_t)Y) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0), "sbev_linear_bf16s_gen: 16-byte alignment");
     const int nfrag = (int)((M + 31) / 32);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    // weight-stationary kernel (round 4): K = 256, two images, Y addressable by a 31-bit byte offset
+    if (g_gen_ws.load(std::memory_order_relaxed) != 0 && K == 16 * WS_KS && nimg != 3 && M * ldy * 4 < 0x7fffffffLL) {
+        // row splits: tasks = column tiles x splits walked by <= one workgroup per CU; a task costs its fragments + ~4 fragments' worth
+        // of weight load (256 KB that nothing overlaps).  c2 (29 fragments, 128 column tiles): 2 splits = 256 tasks of 15 / 14 fragments
+        const int nct = N / G_COLS;
+        int nrs = 1;
+        double best = 1e30;
+        for (int r = 1; r <= 16 && r <= nfrag; ++r) {
+            const long long tasks = (long long)nct * r;
+            const double cost = (double)((tasks + cus - 1) / cus) * ((nfrag + r - 1) / r + 4.0);
+            if (cost < best - 1e-9) { best = cost; nrs = r; }
+        }
+        GenWsArgs w{Xs, Ws, bias, Y, (int)M, N, (long long)ldy, relu, nrs, nfrag / nrs, nfrag % nrs, nct * nrs, colscale, xscale};
+        const unsigned grid = (unsigned)(w.ntask < cus ? w.ntask : cus);
+        const int lds = WS_SLOTS * WS_FRAG;
+        int st;
+        const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
+#define SBEV_LAUNCH_WS(MD)                                                                                  \
+        {                                                                                                   \
+            st = reserve_lds(gemm_f16s_gen_ws_kernel<MD>, lds, "sbev_linear_bf16s_gen");                    \
+            if (st != SBEV_OK) return st;                                                                   \
+            hipLaunchKernelGGL((gemm_f16s_gen_ws_kernel<MD>), dim3(grid), dim3(512), lds, s, w);            \
+        }
+        if (nimg == 2) SBEV_LAUNCH_WS(0)
+        else if (nimg == 4) SBEV_LAUNCH_WS(2)
+        else SBEV_LAUNCH_WS(3)
+#undef SBEV_LAUNCH_WS
+        if (prof) sbev::profile_end(s, e0, e1, 1);
+        return sbev::check_launch("sbev_linear_bf16s_gen");
+    }
     // 256-row tiles (wave = 128 x 64) carry 1.5x the MFMA work per operand byte; 128-row tiles only where they fill the chip
     // better (few rows) -- SBEV_BF16S_GEN_RF=2/4 forces one (A/B runs)
     static const int forced_rf = getenv("SBEV_BF16S_GEN_RF") ? atoi(getenv("SBEV_BF16S_GEN_RF")) : 0;
@@ -1218,13 +1425,6 @@ static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias,
     const int ntm = (nfrag + tf - 1) / tf;
     GenArgs a{Xs, Ws, bias, Y, (int)M, N, K, (long long)ldy, relu, ntm, nfrag / ntm, nfrag % ntm, colscale, xscale};
     const int nim = nimg == 3 ? 3 : 2;          // images per operand
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipEvent_t e0, e1;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        return n;
-    }();
     // one row tile per workgroup for life: grid = a multiple of ntm, at most the CU count, at most the tile count
     long long per = cus / ntm < 1 ? 1 : cus / ntm;
     if (per > N / G_COLS) per = N / G_COLS;

@@ -272,6 +272,34 @@ def test_generator_f16_ragged_rows(M, N, K, relu, use_bias):
     assert (y.double() - ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('mode', ['f16x3', 'f16x4', 'bf16x3s'])
+@pytest.mark.parametrize('M,N,relu,use_bias', [(900, 32768, False, True), (1, 256, True, True), (33, 512, False, False), (449, 1024, True, True),
+                                               (1600, 77824, False, True), (3600, 32768, False, True)])
+def test_weight_stationary_generator_is_bit_identical_to_the_tiled_kernel(M, N, relu, use_bias, mode):
+    """Round 4: K = 256 with two images runs on the weight-stationary kernel (gemm_f16s_gen_ws_kernel: a wave holds its 32 columns'
+    weights in registers, X streams through a 3-slot LDS-DMA ring, row splits x column tiles walked by persistent workgroups).  Same
+    image products in the same order as the tiled ping-pong kernel -> equal bit for bit, every M % 32, every split."""
+    K = 256
+    lib = _lib.load()
+    x, w = _rand((M, K), M + N, wide=True), _rand((N, K), M + K, K ** -0.5, wide=True)
+    b = _rand((N,), 12) if use_bias else None
+
+    def run():
+        if mode == 'bf16x3s':
+            return dense.linear_bf16s_gen(x, dense.pack_bf16s_frags(w, 2), b, nimg=2, relu=relu)
+        wf, wsc = dense.pack_f16s_frags(w)
+        return dense.linear_f16s_gen(x, wf, wsc, b, nprod=3 if mode == 'f16x3' else 4, relu=relu)
+    prev = lib.sbev_linear_gen_weight_stationary(1)
+    try:
+        y_ws = run()
+        lib.sbev_linear_gen_weight_stationary(0)
+        y_tiled = run()
+    finally:
+        lib.sbev_linear_gen_weight_stationary(prev)
+    assert torch.equal(y_ws, y_tiled)
+    assert torch.isfinite(y_ws).all() and y_ws.abs().max() > 0
+
+
 @pytest.mark.parametrize('pairs', [False, True])
 @pytest.mark.parametrize('M,K', [(1, 256), (33, 512), (64, 1024), (65, 2048), (97, 4096), (100, 32768), (129, 2048), (3200, 4096), (7, 32768 + 32)])
 def test_out_projection_f16_ragged(M, K, pairs):

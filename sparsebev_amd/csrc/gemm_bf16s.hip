@@ -676,9 +676,12 @@ struct GenWsArgs {
     const float* xscale;         // fp16 modes: {2^ex, 2^-ex}
 };
 
+#ifndef SBEV_WS_NCH
+#define SBEV_WS_NCH 2
+#endif
 constexpr int WS_KS = 16;                        // k-steps of 16: K = 256
 constexpr int WS_FRAG = WS_KS * 2 * 1024;        // bytes of one row fragment of X (all K, both images)
-constexpr int WS_SLOTS = 3;
+constexpr int WS_SLOTS = 4;
 
 // workgroup barrier with LDS-DMA in flight: a bare s_barrier behind this wave's LDS traffic -- __syncthreads()' release fence would
 // also wait vmcnt(0) for the compiler-visible Y stores (and with them for the prefetched fragments)
@@ -688,7 +691,7 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MODE>
+template <int MODE, bool RELU>
 __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a) {
     typedef Fmt<MODE> PR;
     static_assert(PR::NIMG == 2, "two-image modes only: the stationary weights are 128 registers");
@@ -698,7 +701,6 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const unsigned voff = (unsigned)lane * 16u;
-    const int nfrag = (a.M + 31) / 32;
     // Y through a buffer resource: per-lane byte offset of (row 4 lh, column n) in a 32-bit register, rows >= M fall outside num_records
     const unsigned long long yb = (unsigned long long)a.Y;
     __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -706,106 +708,200 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)yb)),
         0, (int)(unsigned)((long long)a.M * a.ldy * 4), 0x00020000);
     const unsigned ldyb = (unsigned)(a.ldy * 4);
+    [[maybe_unused]] const int tid = (int)threadIdx.x;
+    SBEV_WGTIME(0)
 
-    for (int task = (int)xcd_contiguous(blockIdx.x, gridDim.x); task < a.ntask; task += (int)gridDim.x) {
-        const int ct = task / a.nrs, rs = task - ct * a.nrs;
-        const int f0 = rs * a.base + (rs < a.rem ? rs : a.rem);
-        const int nf = a.base + (rs < a.rem ? 1 : 0);
-        if (nf <= 0) continue;
-        const int n = ct * G_COLS + wave * 32 + l31;                       // this lane's output column
-        // ---- the wave's weights: 32 columns x K, both images -> 128 registers
-        bf16x8 wf[WS_KS][2];
-        {
-            const unsigned short* wb = a.Ws + ((long long)(ct * 8 + wave) * (WS_KS * 2) * 64 + lane) * 8;
-#pragma unroll
-            for (int ks = 0; ks < WS_KS; ++ks)
-#pragma unroll
-                for (int img = 0; img < 2; ++img) wf[ks][img] = *reinterpret_cast<const bf16x8*>(wb + (ks * 2 + img) * 512);
-        }
-        const float bv = a.bias ? a.bias[n] : 0.f;
-        const float cv = F16 ? a.colscale[n] * a.xscale[1] : 1.f;
-        const unsigned ycol = (unsigned)(4 * lh) * ldyb + (unsigned)n * 4u;
-        // ---- X stream: fragment f0 + i -> slot i % 3; wave w copies pieces 4 w .. 4 w + 3 (4 KB, contiguous on both sides)
-        const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.Xs) + (long long)f0 * WS_FRAG + wave * 4096;
-        auto issue = [&](int i) {                                         // (callers guarantee i < nf)
-            const unsigned long long sb = (unsigned long long)(xg + (long long)i * WS_FRAG);
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
-            const void* sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
-            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((i % WS_SLOTS) * WS_FRAG + wave * 4096);
-            asm volatile(
-                "s_mov_b32 m0, %0\n\t"
-                "s_nop 4\n\t"
-                "global_load_lds_dwordx4 %1, %2\n\t"
-                "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                :
-                : "s"(dst), "v"(voff), "s"(sbase)
-                : "memory");
-        };
-        issue(0);
-        if (nf > 1) issue(1);
-        wait_vmcnt_imm<0>();                                              // (also this wave's weights)
-        lds_barrier();
-        f32x16 prev;                                                      // the finished fragment, scaled + biased, waiting for its stores
-#pragma unroll
-        for (int e = 0; e < 16; ++e) prev[e] = 0.f;
-        for (int i = 0; i < nf; ++i) {
-            if (i + 2 < nf) issue(i + 2);                                 // slot (i - 1) % 3: every wave is past the barrier that ended fragment i - 1
-            const unsigned char* st = lds + (i % WS_SLOTS) * WS_FRAG + voff;
-            // fragment i - 1; at i = 0 there is none: bit 31 puts the 16 stores outside the buffer (M ldy 4 < 2^31, host-checked) and
-            // the hardware drops them -- no branch in the k loop
-            const unsigned yprev = i > 0 ? ycol + (unsigned)((f0 + i - 1) * 32) * ldyb : (ycol | 0x80000000u);
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            // k-step regions pinned by sched_barrier: the fragments of k-step ks + 1 are requested before the MFMAs of ks, and the 16
-            // stores of the previous fragment go out in the FIRST 8 k-steps (two each) -- hipcc otherwise sinks them all behind the last
-            // MFMAs, right in front of the counted wait below, which then sits out their write latency
-            bf16x8 xc[2], xn[2];
-            xc[0] = *reinterpret_cast<const bf16x8*>(st);
-            xc[1] = *reinterpret_cast<const bf16x8*>(st + 1024);
-#pragma unroll
-            for (int ks = 0; ks < WS_KS; ++ks) {
-                if (ks + 1 < WS_KS) {
-                    xn[0] = *reinterpret_cast<const bf16x8*>(st + (ks * 2 + 2) * 1024);
-                    xn[1] = *reinterpret_cast<const bf16x8*>(st + (ks * 2 + 3) * 1024);
-                }
-                if (ks < 8) {
-#pragma unroll
-                    for (int e = 2 * ks; e < 2 * ks + 2; ++e) {
-                        const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb;
-#ifndef SBEV_EXP_NOSTORE
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(yprev + ro), 0, 0);
+    // GB: the wave belongs to the second group (waves 4 .. 7; wave w + 4 shares its SIMD with wave w), which runs HALF A FRAGMENT behind
+    // the first: everything a wave does besides MFMAs sits at its fragment boundary (the finished fragment's scale / bias, the counted
+    // wait, the barrier, 4 LDS-DMA issues of ~100 cycles each: ~1400 cycles per 3072 of matrix work), and with both waves of a SIMD at
+    // their boundary together the matrix pipe idled through it -- the MFMA phase ran at 61 % with the LDS reads, the stores, the DMA or
+    // the accumulator dependency removed in turn (tools/exp/r4_run2.sh, r4_run3.sh).  The workgroup still meets at ONE barrier per
+    // fragment; group A reaches it at its fragment boundary, group B in the MIDDLE of its fragment (after k-step 7), so one wave's
+    // boundary lies beside its partner's MFMA stream.  What the barrier b_i (A has finished fragment i, B its first half) orders:
+    //   before it every wave waits for its own pieces of fragment i + 1 (loads return in order: at most the 4 pieces of fragment
+    //     i + 2 may be outstanding; stores still in flight only make the wait longer) -- A reads i + 1 right after it, B half a period later;
+    //   after it every wave refills slot (i + 3) % 4 = (i - 1) % 4: A left fragment i - 1 a period ago, B at ITS boundary before b_i.
+    // A's stores of fragment i - 1 ride in the first half of fragment i, B's in the second: always behind the barrier, never in front
+    // of the counted wait (hipcc otherwise sinks them there and the wait sits out their write latency).
+    auto run = [&](auto gb) {
+        constexpr bool GB = decltype(gb)::value;
+        for (int task = (int)xcd_contiguous(blockIdx.x, gridDim.x); task < a.ntask; task += (int)gridDim.x) {
+            const int ct = task / a.nrs, rs = task - ct * a.nrs;
+            const int f0 = rs * a.base + (rs < a.rem ? rs : a.rem);
+            const int nf = a.base + (rs < a.rem ? 1 : 0);
+            if (nf <= 0) continue;
+            const int n = ct * G_COLS + wave * 32 + l31;                   // this lane's output column
+            const float bv = a.bias ? a.bias[n] : 0.f;
+            const float cv = F16 ? a.colscale[n] * a.xscale[1] : 1.f;
+            const unsigned ycol = (unsigned)(4 * lh) * ldyb + (unsigned)n * 4u;
+            // ---- X stream: fragment f0 + i -> slot i % 4.  Staggered groups: only the waves of group A copy (wave w: pieces 8 w .. 8 w + 7,
+            // 8 KB contiguous on both sides) -- they have ~1600 cycles of slack at every barrier, group B is the critical path and its ~540
+            // cycles of DMA issue per fragment lengthened every period (cycle trace, tools/exp/r4_trace_ws.py).  Lock-step build: every
+            // wave copies 4 pieces.
+#ifdef SBEV_WS_LOCKSTEP
+            constexpr bool COPIES = true;
+            constexpr int NPC = 4;
+#else
+            constexpr bool COPIES = !GB;
+            constexpr int NPC = 8;
 #endif
+            const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.Xs) + (long long)f0 * WS_FRAG + (wave & (32 / NPC - 1)) * (NPC * 1024);
+            auto issue = [&](int i) {                                     // (callers guarantee i < nf)
+                if constexpr (COPIES) {
+                    const unsigned long long sb = (unsigned long long)(xg + (long long)i * WS_FRAG);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
+                    const void* sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((i % WS_SLOTS) * WS_FRAG + (wave & (32 / NPC - 1)) * (NPC * 1024));
+#ifndef SBEV_EXP_NOGLDS
+                    asm volatile(
+                        "s_mov_b32 m0, %0\n\t"
+                        "s_nop 4\n\t"
+                        "global_load_lds_dwordx4 %1, %2\n\t"
+                        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                        :
+                        : "s"(dst), "v"(voff), "s"(sbase)
+                        : "memory");
+                    if constexpr (NPC == 8)
+                        asm volatile(
+                            "s_mov_b32 m0, %0\n\t"
+                            "s_nop 4\n\t"
+                            "global_load_lds_dwordx4 %1, %2\n\t"
+                            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                            "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                            :
+                            : "s"(dst + 4096u), "v"(voff + 4096u), "s"(sbase)
+                            : "memory");
+#endif
+                }
+            };
+            issue(0);
+            if (nf > 1) issue(1);
+            if (nf > 2) issue(2);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the wave's weights: 32 columns x K, both images -> 128 registers.  Requested BEHIND the first fragments' DMA: loads
+            // return in order, so "at most these 32 outstanding" = the fragments have landed, and the first MFMAs start as soon as
+            // k-step 0's weights arrive (the compiler's own counted waits)
+            bf16x8 wf[WS_KS][2];
+            {
+                const unsigned short* wb = a.Ws + ((long long)(ct * 8 + wave) * (WS_KS * 2) * 64 + lane) * 8;
+#pragma unroll
+                for (int ks = 0; ks < WS_KS; ++ks)
+#pragma unroll
+                    for (int img = 0; img < 2; ++img) wf[ks][img] = *reinterpret_cast<const bf16x8*>(wb + (ks * 2 + img) * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (COPIES) wait_vmcnt_imm<32>();
+            lds_barrier();
+            f32x16 prev;                                                  // the finished fragment, scaled + biased, waiting for its stores
+#pragma unroll
+            for (int e = 0; e < 16; ++e) prev[e] = 0.f;
+            for (int i = 0; i < nf; ++i) {
+                SBEV_TRACE(i, 0)
+                const unsigned char* st = lds + (i % WS_SLOTS) * WS_FRAG + voff;
+                // fragment i - 1; at i = 0 there is none: bit 31 puts the 16 stores outside the buffer (M ldy 4 < 2^31, host-checked) and
+                // the hardware drops them -- no branch in the k loop
+                const unsigned yprev = i > 0 ? ycol + (unsigned)((f0 + i - 1) * 32) * ldyb : (ycol | 0x80000000u);
+                // NCH accumulator chains (k-step ks -> chain ks % NCH, summed at the end).  A dependent v_mfma_f32_32x32x16 (same accumulator)
+                // issues only every ~100 cycles against 32 for independent ones: with ONE chain per wave the two waves of a SIMD kept the
+                // matrix pipe ~60 % busy whatever else was taken out of the kernel (r4_run2 / r4_run3: LDS reads, stores, DMA, stagger).
+                // The partial sums also round less than one long chain (max error vs fp64 at c2: 1.6e-6 against 2.8e-6).
+                constexpr int NCH = SBEV_WS_NCH;
+                f32x16 accs[NCH];                                         // (bf16 modes: chain 0 starts from the bias, like the tiled kernel's accumulators)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) accs[c][e] = (F16 || c > 0) ? 0.f : bv;
+                // blocks of NCH k-steps: the block's MFMAs go round the NCH chains product by product, so consecutive MFMAs of a wave never
+                // share an accumulator; the NEXT block's fragments are requested before them (double-buffered registers)
+                constexpr int NBLK = WS_KS / NCH;
+                static_assert(WS_KS % NCH == 0 && NBLK % 2 == 0 && 16 % (NBLK / 2) == 0, "NCH divides the k-steps into an even number of blocks");
+                constexpr int SPB = 16 / (NBLK / 2);                      // stores per block of the half that carries them
+                bf16x8 xr[2][NCH][2];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    xr[0][c][0] = *reinterpret_cast<const bf16x8*>(st + (c * 2) * 1024);
+                    xr[0][c][1] = *reinterpret_cast<const bf16x8*>(st + (c * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+#ifndef SBEV_EXP_NOREAD
+                    if (blk + 1 < NBLK) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            xr[(blk + 1) & 1][c][0] = *reinterpret_cast<const bf16x8*>(st + (((blk + 1) * NCH + c) * 2) * 1024);
+                            xr[(blk + 1) & 1][c][1] = *reinterpret_cast<const bf16x8*>(st + (((blk + 1) * NCH + c) * 2 + 1) * 1024);
+                        }
+                    }
+#endif
+                    if ((blk >= NBLK / 2) == GB) {                        // SPB stores of the previous fragment per block of "its" half
+#pragma unroll
+                        for (int e = SPB * (blk % (NBLK / 2)); e < SPB * (blk % (NBLK / 2)) + SPB; ++e) {
+                            const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb;
+#ifndef SBEV_EXP_NOSTORE
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(yprev + ro), 0, 0);
+#endif
+                        }
+                    }
+#ifdef SBEV_EXP_NOREAD
+                    const auto& xc = xr[0];
+#else
+                    const auto& xc = xr[blk & 1];
+#endif
+#pragma unroll
+                    for (int p = 0; p < PR::N; ++p)
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            const int ks = blk * NCH + c;
+                            if (p < PR::N - 1) accs[c] = SBEV_MFMA(xc[c][PR::ia(p)], wf[ks][PR::ib(p)], accs[c]);
+                            else accs[c] = SBEV_MFMA(xc[c][0], wf[ks][0], accs[c]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((GB && blk == NBLK / 2 - 1) || (!GB && blk == NBLK - 1)) {
+                        // b_i: this wave's pieces of fragment i + 1 have landed (only fragment i + 2's may be outstanding), then published;
+                        // slot (i + 3) % 4 is free behind it
+                        SBEV_TRACE(i, 1)
+                        if constexpr (COPIES) {                           // (a wave that copies nothing has nothing to wait for: its stores are its own)
+                            if (i + 2 < nf) wait_vmcnt_imm<NPC>();
+                            else wait_vmcnt_imm<0>();
+                        }
+                        SBEV_TRACE(i, 2)
+                        lds_barrier();
+                        SBEV_TRACE(i, 3)
+                        if (i + 3 < nf) issue(i + 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        SBEV_TRACE(i, 4)
                     }
                 }
+                f32x16 acc = accs[0];
 #pragma unroll
-                for (int p = 0; p < PR::N - 1; ++p) acc = SBEV_MFMA(xc[PR::ia(p)], wf[ks][PR::ib(p)], acc);
-                acc = SBEV_MFMA(xc[0], wf[ks][0], acc);
-                __builtin_amdgcn_sched_barrier(0);
-                xc[0] = xn[0];
-                xc[1] = xn[1];
-            }
+                for (int c = 1; c < NCH; ++c) acc += accs[c];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = F16 ? fmaf(acc[e], cv, bv) : acc[e] + bv;
-                prev[e] = a.relu ? fmaxf(v, 0.f) : v;
+                for (int e = 0; e < 16; ++e) {
+                    const float v = F16 ? fmaf(acc[e], cv, bv) : acc[e];
+                    prev[e] = RELU ? fmaxf(v, 0.f) : v;
+                }
             }
-            // fragment i + 1: this wave's pieces landed (only the 4 pieces of fragment i + 2, if issued, may be outstanding), then published
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 2 < nf) wait_vmcnt_imm<4>();
-            else wait_vmcnt_imm<0>();
+            {                                                             // the last fragment's stores
+                const unsigned ylast = ycol + (unsigned)((f0 + nf - 1) * 32) * ldyb;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(ylast + (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb), 0, 0);
+            }
+            // the ring is reused by the next task: every wave must be done reading (group B is half a fragment behind the last barrier)
             lds_barrier();
         }
-        {                                                                 // the last fragment's stores
-            const unsigned ylast = ycol + (unsigned)((f0 + nf - 1) * 32) * ldyb;
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(ylast + (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb), 0, 0);
-        }
-    }
+    };
+#ifdef SBEV_WS_LOCKSTEP
+    run(std::false_type{});
+#else
+    if (wave < 4) run(std::false_type{});
+    else run(std::true_type{});
+#endif
+    SBEV_WGTIME(1)
 }
 
 // ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
@@ -1406,9 +1502,10 @@ static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias,
         const bool prof = sbev::profile_begin(s, &e0, &e1, 1);
 #define SBEV_LAUNCH_WS(MD)                                                                                  \
         {                                                                                                   \
-            st = reserve_lds(gemm_f16s_gen_ws_kernel<MD>, lds, "sbev_linear_bf16s_gen");                    \
+            auto kern = relu ? gemm_f16s_gen_ws_kernel<MD, true> : gemm_f16s_gen_ws_kernel<MD, false>;       \
+            st = reserve_lds(kern, lds, "sbev_linear_bf16s_gen");                                           \
             if (st != SBEV_OK) return st;                                                                   \
-            hipLaunchKernelGGL((gemm_f16s_gen_ws_kernel<MD>), dim3(grid), dim3(512), lds, s, w);            \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, w);                                     \
         }
         if (nimg == 2) SBEV_LAUNCH_WS(0)
         else if (nimg == 4) SBEV_LAUNCH_WS(2)

@@ -275,10 +275,11 @@ def test_generator_f16_ragged_rows(M, N, K, relu, use_bias):
 @pytest.mark.parametrize('mode', ['f16x3', 'f16x4', 'bf16x3s'])
 @pytest.mark.parametrize('M,N,relu,use_bias', [(900, 32768, False, True), (1, 256, True, True), (33, 512, False, False), (449, 1024, True, True),
                                                (1600, 77824, False, True), (3600, 32768, False, True)])
-def test_weight_stationary_generator_is_bit_identical_to_the_tiled_kernel(M, N, relu, use_bias, mode):
+def test_weight_stationary_generator_equals_the_tiled_kernel(M, N, relu, use_bias, mode):
     """Round 4: K = 256 with two images runs on the weight-stationary kernel (gemm_f16s_gen_ws_kernel: a wave holds its 32 columns'
     weights in registers, X streams through a 3-slot LDS-DMA ring, row splits x column tiles walked by persistent workgroups).  Same
-    image products in the same order as the tiled ping-pong kernel -> equal bit for bit, every M % 32, every split."""
+    image products as the tiled ping-pong kernel, summed in two interleaved accumulator chains instead of one: equal to fp32
+    accumulation round-off (2^-18 of the output scale on 12-binade operands), every M % 32, every split; and not further from fp64 than the tiled kernel."""
     K = 256
     lib = _lib.load()
     x, w = _rand((M, K), M + N, wide=True), _rand((N, K), M + K, K ** -0.5, wide=True)
@@ -296,8 +297,15 @@ def test_weight_stationary_generator_is_bit_identical_to_the_tiled_kernel(M, N, 
         y_tiled = run()
     finally:
         lib.sbev_linear_gen_weight_stationary(prev)
-    assert torch.equal(y_ws, y_tiled)
     assert torch.isfinite(y_ws).all() and y_ws.abs().max() > 0
+    scale = y_tiled.abs().max().item()
+    assert (y_ws - y_tiled).abs().max().item() <= 2.0 ** -18 * scale          # two fp32 summation orders over 768 products of 12-binade operands
+    if M * N <= 900 * 32768:
+        ref = x.double() @ w.double().t() + (b.double() if use_bias else 0.0)
+        if relu:
+            ref = ref.clamp_min(0)
+        e_ws, e_t = (y_ws.double() - ref).abs().max().item(), (y_tiled.double() - ref).abs().max().item()
+        assert e_ws <= 1.25 * e_t + 1e-7 * scale, (e_ws, e_t)
 
 
 @pytest.mark.parametrize('pairs', [False, True])

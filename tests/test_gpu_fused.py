@@ -53,18 +53,17 @@ def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtyp
 
 @pytest.mark.parametrize('pyr,dtype', [('tiny', torch.float32), ('tiny5', torch.bfloat16)])
 def test_fused_launch_with_nonfinite_border_pixels(pyr, dtype):
-    """Inf in every border pixel: the fused kernel's gather (buffer-load taps) must poison exactly the items the two launches
-    poison -- an item whose sampled rows hold an Inf is NaN after its LayerNorm, every other item is bit-identical."""
+    """Inf in every border pixel of the finest level: the fused kernel's gather (buffer-load taps) must poison exactly the items the
+    two launches poison, every other item is bit-identical."""
     B, Q, T, P = 1, 200, 4, 4
     ih, iw, sizes = S.PYRAMIDS[pyr]
     L, G, C = len(sizes), 4, 64
     g = torch.Generator(device=DEV).manual_seed(77)
     levels = [torch.randn(B * T * 6, h, w, G * C, generator=g, device=DEV) for h, w in sizes]
-    for f in levels:
-        if min(f.shape[1:3]) >= 4:
-            f[:, 0], f[:, -1], f[:, :, 0], f[:, :, -1] = float('inf'), float('inf'), float('inf'), float('inf')
+    f = levels[0]                                                                        # the finest level: its interior is not border
+    f[:, 0], f[:, -1], f[:, :, 0], f[:, :, -1] = float('inf'), float('inf'), float('inf'), float('inf')
     levels = [f.to(dtype) for f in levels]
-    loc = torch.rand(B * T * G, Q, P, 3, generator=g, device=DEV) * 0.5 + 0.25           # interior ...
+    loc = torch.rand(B * T * G, Q, P, 3, generator=g, device=DEV) * 0.4 + 0.3            # interior ...
     loc[:, ::3] = loc[:, ::3] * 4 - 1.5                                                  # ... every third query: from far outside to the border
     loc[..., 2] = torch.randint(0, 6, (B * T * G, Q, P), generator=g, device=DEV).float() / 5
     w = torch.softmax(torch.randn(B * T * G, Q, P, L, generator=g, device=DEV), -1)
@@ -72,11 +71,15 @@ def test_fused_launch_with_nonfinite_border_pixels(pyr, dtype):
     x = ops.msmv_sampling_nhwc(levels, B, T, G, loc, w, out_layout=ops.OUT_MIX)
     want = mixing(x, params)
     got = ops.sample_mix(levels, B, T, G, loc, w, params, 128)
-    bad = ~torch.isfinite(want)
-    assert 0.02 < bad.float().mean() < 0.9
-    assert torch.equal(~torch.isfinite(got), bad)
-    assert torch.equal(got[~bad], want[~bad])
-
+    # an item whose sampled rows hold an Inf is NaN after its first LayerNorm and exactly 0 after the ReLU behind it (v_max_f32 returns
+    # the non-NaN operand; torch.relu would keep the NaN -- the reference nan_to_num's the decoder output in the end): the poisoned
+    # items are the all-zero ones, and they must be the same items in both paths
+    dead = (want.reshape(B, Q, G, -1) == 0).all(-1)
+    assert 0.01 < dead.float().mean() < 0.9, dead.float().mean()
+    assert torch.equal((got.reshape(B, Q, G, -1) == 0).all(-1), dead)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    # the interior queries (never near a border) are untouched by the planted pixels
+    assert not dead[:, 1::3].any() and not dead[:, 2::3].any()
 
 def test_fused_launch_on_the_frame_ring():
     B, Q, T, n_slots, G, P, C = 2, 50, 4, 6, 4, 4, 64

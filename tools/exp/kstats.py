@@ -6,5 +6,5 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 for r in rows[:n]:
     name = r['Name']
-    name = name.split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+    name = name.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
     print('%-72s calls %6s  avg %9.2f us  %5.1f %%' % (name[:72], r['Calls'], float(r['AverageNs']) / 1e3, float(r['Percentage'])))

@@ -337,6 +337,18 @@ int sbev_nms_free_decode(const float* cls_scores, const float* bbox_preds, int B
  */
 int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int channels, int hw, sbev_stream_t stream);
 
+/* Staging launches of a REPLAYABLE step (sparsebev_amd/runtime.py StepGraphs): the source pointer is table[index], read on the
+ * device when the kernel starts.  `table` is a device array of 64-bit pointers that the host refreshes before every launch of the
+ * captured graph, so a caller that passes newly allocated tensors of the same shape every step -- how the reference's loops feed
+ * model(...) (timing.py:77-96, val.py) -- replays ONE graph.  Sources must be 16-byte aligned.
+ * sbev_nchw_to_nhwc_f32_indirect = sbev_nchw_to_nhwc_f32 with in = table[index]; sbev_copy_indirect: nseg <= 4 contiguous copies in one
+ * launch, segment k = nbytes[k] bytes from table[index[k]] to dst[k] (index, dst, nbytes: host arrays). */
+int sbev_nchw_to_nhwc_f32_indirect(const void* const* table, int index, float* out, int64_t n_images, int channels, int hw,
+                                   sbev_stream_t stream);
+int sbev_copy_indirect(const void* const* table, int nseg, const int32_t* index, void* const* dst, const int64_t* nbytes,
+                       sbev_stream_t stream);
+
+
 /*
  * y = relu(LayerNorm(x[:, 0:3] @ w^T + b)): the first half of the position encoder
  * (nn.Linear(3, D), nn.LayerNorm(D), nn.ReLU: models/sparsebev_transformer.py:116-119).  x [M, ldx], w [N,3].

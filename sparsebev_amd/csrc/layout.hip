@@ -17,6 +17,10 @@ struct TrArgs {
     const float* in;   // [N, R, S]   (R = channels, S = H*W pixels)
     float* out;        // [N, S, R]
     int R, S;
+    // indirect source (sbev_nchw_to_nhwc_f32_indirect): `in` is read from table[index] when the kernel starts -- a captured graph
+    // then follows a caller that passes newly allocated feature tensors every step by refreshing one device word, not a node
+    const void* const* table;
+    int index;
 };
 
 constexpr int TS = 64, TLD = 65;
@@ -27,7 +31,7 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const TrArgs a) {
     const int tid = threadIdx.x;
     const int s0 = blockIdx.x * TS, r0 = blockIdx.y * TS;
     const long long img = blockIdx.z;
-    const float* in = a.in + img * a.R * a.S;
+    const float* in = (a.table ? static_cast<const float*>(a.table[a.index]) : a.in) + img * a.R * a.S;
     float* out = a.out + img * a.R * a.S;
     if (VEC) {   // S % 4 == 0 and R % 4 == 0
         // read: thread -> (channel = tid/16 + 16*i, 4 pixels at (tid%16)*4)
@@ -96,7 +100,77 @@ __global__ __launch_bounds__(256) void copy_widen_kernel(const ST* __restrict__ 
     }
 }
 
+// contiguous byte copies (up to 4 segments in ONE launch) whose source pointers are read from table[index[k]]; 16-byte aligned
+// sources and destinations
+struct CopySegs {
+    const void* const* table;
+    int nseg;
+    int index[4];
+    unsigned char* dst[4];
+    long long nbytes[4];
+    unsigned first_block[5];     // segment k owns blocks [first_block[k], first_block[k + 1])
+};
+__global__ __launch_bounds__(256) void copy_indirect_kernel(const CopySegs a) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (j < a.nseg && blockIdx.x >= a.first_block[j]) k = j;
+    const unsigned char* __restrict__ src = static_cast<const unsigned char*>(a.table[a.index[k]]);
+    unsigned char* __restrict__ dst = a.dst[k];
+    const long long nbytes = a.nbytes[k];
+    const long long i = ((long long)(blockIdx.x - a.first_block[k]) * 256 + threadIdx.x) * 16;
+    if (i + 16 <= nbytes) {
+        *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+    } else {
+        for (long long j = i; j < nbytes; ++j) dst[j] = src[j];
+    }
+}
+
 }  // namespace
+
+// The two staging launches of a replayable step (runtime.StepGraphs): their SOURCE pointer is table[index], read on the device when
+// the kernel starts -- table is a device array the host refreshes before every graph launch, so a caller may hand in newly allocated
+// tensors of the same shape each step (the reference's timing.py / val.py loops do) and still replay ONE captured graph.
+// Sources must be 16-byte aligned (the caller checks the tensors it writes into the table).
+extern "C" int sbev_nchw_to_nhwc_f32_indirect(const void* const* table, int index, float* out, int64_t n_images, int channels, int hw,
+                                              sbev_stream_t stream) {
+    SBEV_REQUIRE(n_images >= 0 && channels >= 1 && hw >= 1 && index >= 0, "sbev_nchw_to_nhwc_f32_indirect: bad sizes");
+    if (n_images == 0) return SBEV_OK;
+    SBEV_REQUIRE(table && out && (((uintptr_t)table) & 7) == 0, "sbev_nchw_to_nhwc_f32_indirect: null / unaligned pointer");
+    SBEV_REQUIRE(n_images <= 65535, "sbev_nchw_to_nhwc_f32_indirect: at most 65535 images per call");
+    TrArgs a{nullptr, out, channels, hw, table, index};
+    dim3 grid((hw + TS - 1) / TS, (channels + TS - 1) / TS, (unsigned)n_images);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = (hw % 4 == 0) && (channels % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(transpose_tiles_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(transpose_tiles_kernel<false>, grid, dim3(256), 0, s, a);
+    return sbev::check_launch("sbev_nchw_to_nhwc_f32_indirect");
+}
+
+extern "C" int sbev_copy_indirect(const void* const* table, int nseg, const int32_t* index, void* const* dst, const int64_t* nbytes,
+                                  sbev_stream_t stream) {
+    SBEV_REQUIRE(nseg >= 0 && nseg <= 4, "sbev_copy_indirect: 0 .. 4 segments");
+    if (nseg == 0) return SBEV_OK;
+    SBEV_REQUIRE(table && index && dst && nbytes && (((uintptr_t)table) & 7) == 0, "sbev_copy_indirect: null / unaligned pointer");
+    CopySegs a{};
+    a.table = table;
+    a.nseg = nseg;
+    long long blocks = 0;
+    for (int k = 0; k < nseg; ++k) {
+        SBEV_REQUIRE(index[k] >= 0 && nbytes[k] > 0 && dst[k] && (((uintptr_t)dst[k]) & 15) == 0, "sbev_copy_indirect: segment %d (index >= 0, nbytes > 0, 16-byte aligned dst)", k);
+        a.index[k] = index[k];
+        a.dst[k] = static_cast<unsigned char*>(dst[k]);
+        a.nbytes[k] = nbytes[k];
+        a.first_block[k] = (unsigned)blocks;
+        blocks += (nbytes[k] + 4095) / 4096;
+        SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_copy_indirect: too many bytes for one launch");
+    }
+    a.first_block[nseg] = (unsigned)blocks;
+    hipLaunchKernelGGL(copy_indirect_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_copy_indirect");
+}
 
 extern "C" int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int channels, int hw,
                                      sbev_stream_t stream) {
@@ -104,7 +178,7 @@ extern "C" int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_imag
     if (n_images == 0) return SBEV_OK;
     SBEV_REQUIRE(in && out && in != out, "sbev_nchw_to_nhwc_f32: null or aliased pointers");
     SBEV_REQUIRE(n_images <= 65535, "sbev_nchw_to_nhwc_f32: at most 65535 images per call");
-    TrArgs a{in, out, channels, hw};
+    TrArgs a{in, out, channels, hw, nullptr, 0};
     dim3 grid((hw + TS - 1) / TS, (channels + TS - 1) / TS, (unsigned)n_images);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool vec = (hw % 4 == 0) && (channels % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);

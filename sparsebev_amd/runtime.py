@@ -55,18 +55,27 @@ class DecoderRuntime:
         self._weights = None
         self._ws = None
         self._ws_key = None
-        self._params = None        # cached parameter list (re-collected every 64 signature checks)
+        self._params = None        # cached parameter SLOTS (module._parameters dict, name); re-collected every 64 signature checks
+        self._graph_ws = {}        # workspace of the captured step graphs, shared by all graphs of one size (they replay on one stream)
         self._sig_calls = 0
         self.step_graphs = StepGraphs(self)
 
     # -- weights -----------------------------------------------------------------------------------------
     def _signature(self):
-        # walking the module tree costs ~0.15 ms; the Parameter OBJECTS of a module only change when somebody assigns new ones
-        # (load_state_dict / .to() / optimizers update them in place), so the list is cached and re-collected every 64th call
+        """((data_ptr, _version) of every parameter).  Walking the module tree costs ~0.15 ms per call, so the (module._parameters
+        dict, name) SLOTS are cached and each call only looks the current Parameter object of every slot up -- a replaced
+        Parameter (``load_state_dict(assign=True)``, ``lin.weight = nn.Parameter(...)``, pruning / parametrize) is a different
+        object with its own (data_ptr, _version) and re-binds at once; the slot list itself (modules added or removed) is
+        re-collected every 64th call."""
         self._sig_calls += 1
         if self._params is None or (self._sig_calls & 63) == 0:
-            self._params = list(self.decoder.parameters())
-        return tuple((p.data_ptr(), p._version) for p in self._params)
+            self._params = [(m._parameters, n) for m in self.decoder.modules() for n, p in m._parameters.items() if p is not None]
+        try:
+            ps = [d[n] for d, n in self._params]
+            return tuple((p.data_ptr(), p._version) for p in ps)
+        except (KeyError, AttributeError):          # a slot vanished or became None: re-collect now
+            self._params = [(m._parameters, n) for m in self.decoder.modules() for n, p in m._parameters.items() if p is not None]
+            return tuple((d[n].data_ptr(), d[n]._version) for d, n in self._params)
 
     def _ensure_bound(self):
         """(Re-)bind when a parameter was replaced or modified in place; returns the current signature."""
@@ -201,8 +210,10 @@ class DecoderRuntime:
         if need < 0:
             raise _lib.SbevError('sbev_decoder_workspace_bytes: ' + lib.sbev_last_error().decode())
         key = (str(dev), need)
-        if own_workspace:                   # a captured graph keeps its workspace for life (eager calls share the runtime's)
-            ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+        if own_workspace:                   # captured graphs keep a workspace of their own (eager calls use the runtime's), ONE per
+            ws = self._graph_ws.get(key)    # size: graphs of a runtime replay on the caller's stream, one after the other
+            if ws is None:
+                ws = self._graph_ws[key] = torch.empty(need + 256, device=dev, dtype=torch.uint8)
         else:
             if self._ws is None or self._ws_key != key:
                 self._ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
@@ -258,35 +269,71 @@ class DecoderRuntime:
 
 
 class StepGraphs:
-    """hipGraph replay of the whole per-call step for callers that pass the SAME tensors again -- a serving loop that refreshes
-    queries / feature maps in place (bench.py, the reference's timing.py): from the second pointer-identical call on, the
-    feature relayout (NCHW inputs) and all decoder launches are ONE captured graph; per call the host packs the per-sample
-    constants (time_diff, lidar2img), refreshes the graph's device copy of them through the pinned upload ring and launches.
-    Results are bit-identical to the eager path (same kernels, same order).  A new tensor (other address / shape / dtype), a
-    weight update, another attention mask object or a changed ring slot table misses the cache and runs eagerly; the second
-    such call captures its own graph (at most ``MAX`` are kept, least recently used first out).
+    """hipGraph replay of the whole per-call step: staging of the inputs, feature relayout and all decoder launches are ONE captured
+    graph from the second call of a kind on; per call the host packs the per-sample constants (time_diff, lidar2img) and the
+    input POINTERS into one small array, refreshes the graph's device copy of it through the pinned upload ring and launches.
+    Results are bit-identical to the eager path (same kernels, same order).
+
+    What a graph is keyed on -- round 4: shapes, not addresses.  The reference's loops hand ``model(...)`` freshly allocated
+    tensors every step (timing.py:77-96, val.py; mmdet's eval loop: new backbone outputs, new query tensors out of
+    ``SparseBEVHead.forward``), so:
+      * queries and the attention mask are always STAGED: one in-graph copy launch reads their addresses from the refreshed
+        table (sbev_copy_indirect) into buffers the graph owns;
+      * fp32 NCHW feature lists (the reference's layout) go through the in-graph relayout, whose source address also comes from
+        the table (sbev_nchw_to_nhwc_f32_indirect) -- any tensors of the same shapes replay the same graph, and the graph pins
+        none of the caller's tensors;
+      * inputs that are read IN PLACE by the decoder kernels -- channels-last lists, FeaturePyramid / the online ring's buffers --
+        keep their addresses in the key.  A tensor list is only captured when the SAME tensor objects come back (weak
+        references from the first sighting: a recycled address of a dead tensor is not "the same input"), and while
+        ``MAX_WASTED`` address-keyed graphs stand captured but never replayed no further one is captured (the ring's own
+        buffers are persistent by construction and exempt).
+    A weight update, other switches, another layer count or box convention miss the cache.  At most ``MAX`` graphs are kept (least
+    recently used first out); all graphs of one workspace size share one workspace (DecoderRuntime._graph_ws).
     Replaces per-call Python + launch overhead of the reference's eager module chain (models/sparsebev_transformer.py:86-97)."""
 
     MAX = 8
+    MAX_WASTED = 3
 
     def __init__(self, runtime):
         self.rt = runtime
-        self.entries = {}          # key -> dict(graph, ctx_buf, layout, keep, cls, box) or None (seen once, not captured yet)
+        self.entries = {}          # key -> dict(graph, ctx_buf, ...) or a _FirstSighting (seen once, not captured yet)
         self.replays = 0
         self.captures = 0
+        self.wasted = 0            # address-keyed graphs evicted or cleared without a single replay
+        self._warned = False
 
     def clear(self):
         for e in self.entries.values():
-            if e:
+            if isinstance(e, dict):
                 e['graph'].destroy()
         self.entries.clear()
 
+    def _drop(self, key):
+        e = self.entries.pop(key)
+        if isinstance(e, dict):
+            if e['pinned'] and e['replays'] == 0:
+                self.wasted += 1
+            e['graph'].destroy()
+
+    def _unproven(self):
+        """address-keyed graphs (alive or already evicted) that were captured and never replayed afterwards"""
+        return self.wasted + sum(1 for e in self.entries.values() if isinstance(e, dict) and e['pinned'] and e['replays'] == 0)
+
     @staticmethod
-    def _feat_key(feats):
-        if hasattr(feats, 'levels'):        # FeaturePyramid / RingPyramid: resident channels-last buffers (+ the ring's slot table)
+    def _relayout_ok(f):
+        return f.dim() == 5 and f.dtype == torch.float32 and f.is_contiguous() and f.data_ptr() % 16 == 0 and \
+            not f.permute(0, 1, 3, 4, 2).is_contiguous()
+
+    def _feat_key(self, feats):
+        """(key part, the tensors whose identity an address-keyed entry depends on, staged?)"""
+        if hasattr(feats, 'levels'):        # FeaturePyramid / RingPyramid: resident channels-last buffers (+ the ring's slot table);
+            # their level tensors are views made per call, so there is no object identity to remember: MAX_WASTED bounds a caller
+            # that builds a new pyramid over new buffers every step
             return ('pyr', tuple((f.data_ptr(), tuple(f.shape), f.dtype) for f in feats.levels),
-                    tuple(getattr(feats, 'frame_slots', ())), getattr(feats, 'n_slots', 0))
-        return ('list', tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats))
+                    tuple(getattr(feats, 'frame_slots', ())), getattr(feats, 'n_slots', 0)), [], False
+        if all(self._relayout_ok(f) for f in feats):
+            return ('nchw', tuple(tuple(f.shape) for f in feats)), [], True
+        return ('list', tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats)), list(feats), False
 
     def run(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
         """(cls, box) of the graph's own output buffers (the caller clones or post-processes out of place), or None when this
@@ -294,47 +341,72 @@ class StepGraphs:
         rt = self.rt
         if _STATE['profile'] or not (query_bbox.is_cuda and query_bbox.is_contiguous() and query_feat.is_contiguous()):
             return None                      # (bracketing launches with HIP events needs the eager enqueue)
-        if attn_mask is not None and not (attn_mask.is_cuda and attn_mask.dtype == torch.uint8 and attn_mask.is_contiguous()):
-            return None                      # the runtime would convert it into a temporary: no stable pointer to capture
+        if query_bbox.data_ptr() % 16 or query_feat.data_ptr() % 16:
+            return None
+        if attn_mask is not None and not (attn_mask.is_cuda and attn_mask.dtype == torch.uint8 and attn_mask.is_contiguous() and attn_mask.data_ptr() % 16 == 0):
+            return None                      # the runtime would convert it into a temporary: nothing stable to stage from
         if not hasattr(mlvl_feats, 'levels') and not all(torch.is_tensor(f) and f.is_cuda for f in mlvl_feats):
             return None
         from . import transformer as TR
         sig = rt._ensure_bound()
-        key = (query_bbox.data_ptr(), query_feat.data_ptr(), tuple(query_feat.shape), self._feat_key(mlvl_feats),
-               None if attn_mask is None else (attn_mask.data_ptr(), tuple(attn_mask.shape)), sig,
+        fkey, ident, staged = self._feat_key(mlvl_feats)
+        key = (tuple(query_bbox.shape), tuple(query_feat.shape), fkey, None if attn_mask is None else tuple(attn_mask.shape), sig,
                torch.cuda.current_device(), _STATE['row_chain'], _STATE['fuse'], _lib.load().sbev_get_box_convention(),
                rt.decoder.num_layers, tuple(rt.decoder.pc_range))
         e = self.entries.get(key, False)
-        if e is False:                       # first sighting: eager this time, capture if it comes again
-            if len(self.entries) >= self.MAX:
-                old = next(iter(self.entries))
-                if self.entries[old]:
-                    self.entries[old]['graph'].destroy()
-                del self.entries[old]
-            self.entries[key] = None
+        if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
+            # first sighting (or an address whose tensor died and was recycled): eager this time, capture if it comes again
+            if not staged and not hasattr(mlvl_feats, 'frame_slots') and self._unproven() >= self.MAX_WASTED:
+                if not self._warned:
+                    import warnings
+                    warnings.warn('sparsebev_amd: %d step graphs keyed on input addresses were captured and never replayed (the caller '
+                                  'passes new channels-last / pyramid buffers every call): no further address-keyed graphs; pass fp32 '
+                                  'NCHW feature lists or reuse the buffers' % self._unproven())
+                    self._warned = True
+                return None
+            if e is False and len(self.entries) >= self.MAX:
+                self._drop(next(iter(self.entries)))
+            self.entries[key] = _FirstSighting(ident)
             return None
         B = query_bbox.shape[0]
-        if e is None:
-            e = self._capture(key, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, B)
+        packed, layout, ih, iw = TR.DecoderContext.pack(img_metas, B)
+        if isinstance(e, _FirstSighting):
+            e = self._capture(key, query_bbox, query_feat, mlvl_feats, attn_mask, B, packed, layout, ih, iw, staged)
             if e is None:
                 return None
         else:
-            packed, layout, ih, iw = TR.DecoderContext.pack(img_metas, B)
             if layout != e['layout'] or (ih, iw) != e['image']:
                 return None                  # other camera count / image size: not this graph's step
-            TR._upload(packed, query_bbox.device, out=e['ctx_buf'])
+            TR._upload(self._with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask), query_bbox.device, out=e['ctx_buf'])
         self.entries[key] = self.entries.pop(key)            # most recently used last
         e['graph'].replay()
+        e['replays'] += 1
         self.replays += 1
         return e['graph'].cls, e['graph'].box
 
-    def _capture(self, key, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, B):
+    @staticmethod
+    def _with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask):
+        """packed per-sample constants + the pointer table of this call (int64 words viewed as fp32 pairs) in ONE upload."""
+        import numpy as np
+        ptrs = [query_bbox.data_ptr(), query_feat.data_ptr(), attn_mask.data_ptr() if attn_mask is not None else 0]
+        if e['staged']:
+            ptrs += [f.data_ptr() for f in mlvl_feats]
+        full = np.empty(e['n_packed'] + 2 * len(ptrs), dtype=np.float32)
+        full[:packed.size] = packed
+        full[packed.size:e['n_packed']] = 0.0
+        full[e['n_packed']:].view(np.int64)[:] = ptrs
+        return full
+
+    def _capture(self, key, query_bbox, query_feat, mlvl_feats, attn_mask, B, packed, layout, ih, iw, staged):
+        import numpy as np
         from . import transformer as TR
         rt, lib = self.rt, _lib.load()
         dev = query_bbox.device
-        ctx = TR.DecoderContext(img_metas, B, dev)
-        ctx_buf = ctx.buffer                                  # the graph reads the constants from this tensor on every replay
-        relayout = []                                         # (source NCHW tensor, resident NHWC buffer)
+        # graph-owned staging buffers of the queries / mask (the decoder kernels read these)
+        qb = torch.empty_like(query_bbox)
+        qf = torch.empty_like(query_feat)
+        mask = torch.empty_like(attn_mask) if attn_mask is not None else None
+        relayout = []                                         # (table index, resident NHWC buffer, n_images, channels, hw)
         if hasattr(mlvl_feats, 'levels'):
             pyramid = mlvl_feats
         else:
@@ -343,27 +415,38 @@ class StepGraphs:
             pyramid.B, TN, pyramid.GC = f0.shape[0], f0.shape[1], f0.shape[2]
             pyramid.T = TN // TR.N_VIEWS
             pyramid.levels, pyramid.copied = [], 0
-            for f in mlvl_feats:
+            for l, f in enumerate(mlvl_feats):
                 nhwc = f.permute(0, 1, 3, 4, 2)
-                if not nhwc.is_contiguous():
-                    if f.dtype != torch.float32 or not f.is_contiguous():
-                        return None          # a layout the in-graph relayout kernel does not take: eager path
+                if staged:
                     buf = torch.empty(f.shape[0], TN, f.shape[3], f.shape[4], pyramid.GC, device=dev, dtype=torch.float32)
-                    relayout.append((f, buf))
+                    relayout.append((3 + l, buf, f.shape[0] * TN, pyramid.GC, f.shape[3] * f.shape[4]))
                     nhwc = buf
                     pyramid.copied += 1
+                elif not nhwc.is_contiguous():
+                    return None              # a layout neither read in place nor taken by the in-graph relayout kernel: eager path
                 pyramid.levels.append(nhwc.reshape(pyramid.B * TN, f.shape[3], f.shape[4], pyramid.GC))
-        args, keep, cls, box = rt._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask, own_workspace=True)
+        n_packed = (packed.size + 3) // 4 * 4                 # the table behind the constants, 16-byte aligned
+        # 'replays' counts launches AFTER the capturing call's own; 'pinned': keyed on addresses of buffers a caller may not bring back
+        # (the online ring's buffers are persistent by construction)
+        e = {'staged': staged, 'n_packed': n_packed, 'layout': layout, 'image': (ih, iw), 'replays': -1,
+             'pinned': not staged and not hasattr(mlvl_feats, 'frame_slots')}
+        full = self._with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask)
+        ctx = TR.DecoderContext.from_packed(full, layout, ih, iw, dev)     # the graph reads constants AND table from this tensor on every replay
+        table = ctypes.c_void_p(ctx.buffer.data_ptr() + 4 * n_packed)
+        args, keep, cls, box = rt._prepare(qb, qf, pyramid, ctx, mask, own_workspace=True)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         sp = ctypes.c_void_p(side.cuda_stream)
+        segs = [(0, qb), (1, qf)] + ([(2, mask)] if mask is not None else [])
+        c_idx = (ctypes.c_int32 * len(segs))(*[i for i, _ in segs])
+        c_dst = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for _, t in segs])
+        c_nb = (ctypes.c_int64 * len(segs))(*[t.numel() * t.element_size() for _, t in segs])
         _lib.check(lib.sbev_capture_begin(sp), 'sbev_capture_begin')
         ok = True
         try:
-            for f, buf in relayout:
-                TN, GC, H, W = f.shape[1], f.shape[2], f.shape[3], f.shape[4]
-                st = lib.sbev_nchw_to_nhwc_f32(_ptr(f), _ptr(buf), f.shape[0] * TN, GC, H * W, sp)
-                ok = ok and st == 0
+            ok = lib.sbev_copy_indirect(table, len(segs), c_idx, c_dst, c_nb, sp) == 0
+            for idx, buf, n_img, ch, hw in relayout:
+                ok = ok and lib.sbev_nchw_to_nhwc_f32_indirect(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
             ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
         finally:
             handle = ctypes.c_void_p()
@@ -372,11 +455,25 @@ class StepGraphs:
             raise _lib.SbevError('graph capture of the decoder step failed: ' + lib.sbev_last_error().decode())
         _lib.check(st, 'sbev_capture_end')
         torch.cuda.current_stream().wait_stream(side)
-        graph = DecoderGraph(handle, (keep, relayout, mlvl_feats, pyramid, ctx, query_bbox, query_feat, attn_mask), cls, box)
-        e = {'graph': graph, 'ctx_buf': ctx_buf, 'layout': ctx.layout, 'image': (ctx.image_h, ctx.image_w)}
+        # what the graph's launches read or write: its own buffers, and -- address-keyed entries only -- the caller's feature buffers
+        pinned = None if staged else (mlvl_feats, pyramid)
+        graph = DecoderGraph(handle, (keep, [r[1] for r in relayout], qb, qf, mask, ctx, pinned), cls, box)
+        e.update(graph=graph, ctx_buf=ctx.buffer)
         self.entries[key] = e
         self.captures += 1
         return e
+
+
+class _FirstSighting:
+    """An input combination seen once.  Address-keyed entries remember the tensor OBJECTS (weakly): the second sighting only counts
+    when the same live objects come back -- a recycled address of a freed tensor is a different input."""
+
+    def __init__(self, tensors):
+        import weakref
+        self.refs = [weakref.ref(t) for t in tensors]
+
+    def same(self, tensors):
+        return len(tensors) == len(self.refs) and all(r() is t for r, t in zip(self.refs, tensors))
 
 
 class DecoderGraph:

@@ -412,6 +412,18 @@ class DecoderContext:
     def __init__(self, img_metas, B, device, out=None):
         """``out``: a device buffer of a previous context with the same layout to refresh in place (graph replay)."""
         packed, layout, self.image_h, self.image_w = self.pack(img_metas, B)
+        self._bind(packed, layout, device, out)
+
+    @classmethod
+    def from_packed(cls, packed, layout, image_h, image_w, device):
+        """From an already packed array that may carry extra words behind the constants (runtime.StepGraphs: the pointer table of a
+        replayable step travels in the same upload)."""
+        self = cls.__new__(cls)
+        self.image_h, self.image_w = image_h, image_w
+        self._bind(packed, layout, device, None)
+        return self
+
+    def _bind(self, packed, layout, device, out):
         self.layout = layout
         self.buffer = dev = _upload(packed, device, out=out)
         offs, td_shape, l2i_shape, d_shape = layout

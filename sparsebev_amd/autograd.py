@@ -102,13 +102,27 @@ class Tap:
         self.ids = {id(p) for p in params if p.requires_grad}
         self.bufs = {}
         self.deferred = {}          # id(weight) -> [(grad_y [M, N], x [M, K]), ...]: small weight gradients, reduced in one launch at the end
-        self.deferred_bias = {}     # id(bias) -> id(weight): bias gradient = column sums of that weight's recorded grad_y matrices
+        self.deferred_bias = {}     # id(bias) -> [grad_y [M, N], ...]: the bias's OWN recorded matrices (their column sums, at the end) -- not
+                                    # the weight's list: a node that adds its bias gradient directly still records for the weight
         self.deferred_ln = {}       # (id(gamma), id(beta)) -> [gamma, beta, relu, [(grad_y, x, row statistics), ...]]
         self.token = ParamTap.apply(self, *params) if self.ids else None
         self._empty = None
+        self._task = None           # the backward pass (autograd graph task) the recorded segments belong to
+
+    def fresh_pass(self):
+        """Called by every recording node: segments left behind by a backward pass that raised before ParamTap ran must not leak into
+        a retry of the same graph (retain_graph)."""
+        task = torch._C._current_graph_task_id() if hasattr(torch._C, '_current_graph_task_id') else None
+        if task != self._task:
+            if self._task is not None:      # the previous pass never reached ParamTap (which resets _task): drop its partial sums
+                self.deferred, self.deferred_bias, self.deferred_ln, self.bufs = {}, {}, {}, {}
+            self._task = task
 
     def has(self, pid):
-        return self.token is not None and pid in self.ids
+        if self.token is None:
+            return False
+        self.fresh_pass()                   # (every tapped backward node asks this first)
+        return pid in self.ids
 
     def token_grad(self):
         if self._empty is None:
@@ -125,13 +139,15 @@ class ParamTap(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtoken):
         tap = ctx.tap
-        _group_bias_grads(tap)
-        _group_ln_grads(tap)
-        for pid, segs in tap.deferred.items():
-            _multi_wgrad(tap, pid, segs)
-        tap.deferred, tap.deferred_bias, tap.deferred_ln = {}, {}, {}
-        bufs = tap.bufs
-        return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
+        try:
+            _group_bias_grads(tap)
+            _group_ln_grads(tap)
+            for pid, segs in tap.deferred.items():
+                _multi_wgrad(tap, pid, segs)
+            bufs = tap.bufs
+            return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
+        finally:                        # whatever happened: the next backward pass starts from empty lists
+            tap.deferred, tap.deferred_bias, tap.deferred_ln, tap._task = {}, {}, {}, None
 
 
 def _group_bias_grads(tap):
@@ -140,10 +156,9 @@ def _group_bias_grads(tap):
         return
     lib = _lib.load()
     by_rows = {}
-    for b_id, w_id in tap.deferred_bias.items():
-        segs = tap.deferred.get(w_id)
-        if segs:
-            by_rows.setdefault(segs[0][0].shape[0], []).append((b_id, [g for g, _ in segs]))
+    for b_id, gs in tap.deferred_bias.items():
+        if gs:
+            by_rows.setdefault(gs[0].shape[0], []).append((b_id, gs))
     for M, items in by_rows.items():
         rounds = {}                     # chunk index -> [(bias id, <= 8 matrices, accumulate)]: the second chunk of a bias (more than 8
         for b_id, gs in items:          # layers) adds to what the first one wrote, so it goes into a LATER launch
@@ -232,6 +247,7 @@ def _tap_gemm(tap, pid, *gemm_args):
     """grad_W (+)= into the tapped parameter's buffer; gemm_args as for gemm() without out / ldc / accumulate.  Small gradients
     (grad_y^T . x with both operands k-major) are only recorded here: ParamTap reduces all layers' pairs in one launch."""
     A, a_km, lda, B, b_km, ldb, M, N, K = gemm_args
+    tap.fresh_pass()
     if _defers(tap, pid, A, a_km, lda, b_km, ldb, M, N, K):
         tap.deferred.setdefault(pid, []).append((A, B))
         return
@@ -360,12 +376,16 @@ class Linear(torch.autograd.Function):
         x2 = _c(x).reshape(-1, K)
         w_tapped = ctx.needs_input_grad[1] and tap is not None and tap.has(ctx.w_id)
         want_db = ctx.has_b and ctx.needs_input_grad[2]
-        if (w_tapped and want_db and tap.has(ctx.b_id) and ctx.b_id not in tap.bufs
-                and _defers(tap, ctx.w_id, gy2, True, N, True, K, N, K, gy2.shape[0])):
-            tap.deferred_bias[ctx.b_id] = ctx.w_id          # column sums of the grad_y matrices recorded for the weight, at the end
-            # (a ReLU Linear: only the mask now -- a fully parallel elementwise launch; the one-launch mask + column sum has N / 64
-            # workgroups, 4 for a 256-wide layer, and took 10 us on the layer's critical path)
+        if tap is not None:
+            tap.fresh_pass()
+        recorded = tap.deferred_bias.get(ctx.b_id) if tap is not None else None
+        if (w_tapped and want_db and tap.has(ctx.b_id) and gy2.shape[0] * N <= _DEFER_MAX and gy2.is_contiguous()
+                and (not recorded or recorded[0].shape == gy2.shape)):
+            # the bias gradient = column sums of this node's (masked) grad_y, recorded in the bias's own list and summed over all layers
+            # at the end (a ReLU Linear: only the mask now -- a fully parallel elementwise launch; the one-launch mask + column sum has
+            # N / 64 workgroups, 4 for a 256-wide layer, and took 10 us on the layer's critical path)
             gz, db = (_bias_relu_bwd(gy2, y.reshape(-1, N), False)[0] if ctx.relu else gy2), None
+            tap.deferred_bias.setdefault(ctx.b_id, []).append(gz)
         else:
             gz, db = _bias_relu_bwd(gy2, y.reshape(-1, N) if ctx.relu else None, want_db, tap, ctx.b_id)
         gx, gw = _linear_grads(gz, x2, _c(w), ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not w_tapped)
@@ -402,7 +422,11 @@ class LayerNorm(torch.autograd.Function):
         gx = torch.empty_like(x2)
         tap = ctx.tap
         tapped = tap is not None and tap.has(ctx.g_id) and tap.has(ctx.b_id)
-        if tapped and _LN_GROUP and ctx.g_id not in tap.bufs and g.is_contiguous() and b.is_contiguous():
+        if tapped:
+            tap.fresh_pass()
+        rec = tap.deferred_ln.get((ctx.g_id, ctx.b_id)) if tapped else None
+        if (tapped and _LN_GROUP and ctx.g_id not in tap.bufs and g.is_contiguous() and b.is_contiguous()
+                and (rec is None or not rec[3] or rec[3][0][0].shape == gy2.shape)):
             # shared LayerNorm: dX and the row statistics now, dgamma / dbeta of all layers in one grouped launch at the end of the call
             stats = torch.empty(2 * M, device=x.device, dtype=torch.float32)
             st = _lib.load().sbev_layer_norm_bwd_rows(_p(gy2), _p(x2), _p(g), _p(b), _EPS, int(ctx.relu), _p(gx), _p(stats), M, N, _stream())

@@ -217,9 +217,13 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* w, long lon
 }
 // one power of two for a whole matrix: up to 64 blocks each reduce a slice to a partial maximum, the block that draws the last
 // ticket reduces the partials (a maximum: order-free) and writes {2^e, 2^-e}.  (One 1024-thread block for 900 x 256 values: 26 us.)
-__device__ float g_scale_part[64];
-__device__ unsigned g_scale_ticket;
-__global__ __launch_bounds__(256) void tensor_scale_kernel(const float* x, long long ldx, long long rows, int K, float* updown) {
+// The partials and the ticket of a launch live in one of SCALE_SLOTS device slots, handed out round-robin by the host: launches in
+// flight on different streams (training beside inference, a multi-threaded host) no longer share them -- a shared ticket mixed
+// their partial maxima into a wrong 2^e; a single-block launch needs no slot at all.
+constexpr int SCALE_SLOTS = 64;
+__device__ float g_scale_part[SCALE_SLOTS][64];
+__device__ unsigned g_scale_ticket[SCALE_SLOTS];
+__global__ __launch_bounds__(256) void tensor_scale_kernel(const float* x, long long ldx, long long rows, int K, float* updown, int slot) {
     __shared__ float red[4];
     __shared__ int is_last;
     float mx = 0.f;
@@ -234,20 +238,28 @@ __global__ __launch_bounds__(256) void tensor_scale_kernel(const float* x, long 
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
+    if (gridDim.x == 1) {                      // one block: its maximum is the tensor's
+        if (threadIdx.x == 0) scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), updown, updown + 1);
+        return;
+    }
     if (threadIdx.x == 0) {
-        g_scale_part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        g_scale_part[slot][blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         __threadfence();
-        const unsigned t = atomicAdd(&g_scale_ticket, 1u);
+        const unsigned t = atomicAdd(&g_scale_ticket[slot], 1u);
         is_last = t == gridDim.x - 1;
-        if (is_last) g_scale_ticket = 0u;
+        if (is_last) g_scale_ticket[slot] = 0u;
     }
     __syncthreads();
     if (!is_last || threadIdx.x >= 64) return;
     __threadfence();
-    float m = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&g_scale_part[threadIdx.x]) : 0.f;
+    float m = threadIdx.x < gridDim.x ? __builtin_nontemporal_load(&g_scale_part[slot][threadIdx.x]) : 0.f;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (threadIdx.x == 0) scale_of(m, updown, updown + 1);
+}
+inline int next_scale_slot() {
+    static std::atomic<unsigned> n{0};
+    return (int)(n.fetch_add(1u, std::memory_order_relaxed) % SCALE_SLOTS);
 }
 
 // ---- LDS-DMA: 1 KiB per wave-instruction, LDS destination = M0 + 16 lane (lane-linear), source = sbase + voff per lane ----------
@@ -1439,7 +1451,7 @@ extern "C" int sbev_pack_f16s_frags(const float* W, int64_t ldw, uint16_t* out, 
     if (per_tensor == 1) {
         const long long n4 = (long long)N * (K / 4);
         const unsigned nb = (unsigned)(n4 / 1024 < 1 ? 1 : n4 / 1024 > 64 ? 64 : n4 / 1024);
-        hipLaunchKernelGGL(tensor_scale_kernel, dim3(nb), dim3(256), 0, s, W, (long long)ldw, (long long)N, K, scales);
+        hipLaunchKernelGGL(tensor_scale_kernel, dim3(nb), dim3(256), 0, s, W, (long long)ldw, (long long)N, K, scales, next_scale_slot());
     }
     else if (per_tensor == 0) hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, (long long)ldw, N, K, scales, scales + N);
     const long long n = (long long)((N + 31) / 32) * (K / 16) * 64;
@@ -1453,7 +1465,7 @@ extern "C" int sbev_f16s_tensor_scale(const float* X, int64_t ldx, int64_t rows,
                  "sbev_f16s_tensor_scale: rows=%lld, K=%d (multiple of 4), ldx=%lld (multiple of 4), X 16-byte aligned", (long long)rows, K, (long long)ldx);
     const long long n4 = (long long)rows * (K / 4);
     const unsigned nb = (unsigned)(n4 / 1024 < 1 ? 1 : n4 / 1024 > 64 ? 64 : n4 / 1024);
-    hipLaunchKernelGGL(tensor_scale_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, (long long)ldx, (long long)rows, K, updown);
+    hipLaunchKernelGGL(tensor_scale_kernel, dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, (long long)ldx, (long long)rows, K, updown, next_scale_slot());
     return sbev::check_launch("sbev_f16s_tensor_scale");
 }
 

@@ -8,6 +8,9 @@ from . import _lib
 
 MAX_LEVELS = 5
 GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_BF16X3S, GEMM_F16X3, GEMM_F16X4 = 0, 1, 2, 3, 4, 5      # sbev_gemm_mode
+# fp16 modes: how many binades a typical (4 sigma, median |gamma|) generator input may sit below the a-priori scale bound before the
+# runtime refuses the split (lo stays a normal fp16 number down to 2^-17 of the bound; 2^-12 leaves 5 binades for the values' own spread)
+F16_MAX_HEADROOM_LOG2 = 12
 GEMM_MODES = {'f32': GEMM_F32, 'bf16x3': GEMM_BF16X3, 'bf16x6': GEMM_BF16X6, 'bf16x3s': GEMM_BF16X3S, 'f16x3': GEMM_F16X3, 'f16x4': GEMM_F16X4}
 _f = ctypes.c_void_p
 
@@ -58,6 +61,8 @@ class DecoderRuntime:
         self._params = None        # cached parameter SLOTS (module._parameters dict, name); re-collected every 64 signature checks
         self._graph_ws = {}        # workspace of the captured step graphs, shared by all graphs of one size (they replay on one stream)
         self._sig_calls = 0
+        self.mode_eff = gemm_mode
+        self.f16_headroom_log2 = 0.0
         self.step_graphs = StepGraphs(self)
 
     # -- weights -----------------------------------------------------------------------------------------
@@ -119,6 +124,28 @@ class DecoderRuntime:
             reg0_w=rb[0].weight, reg0_b=rb[0].bias, reg2_w=rb[2].weight, reg2_b=rb[2].bias,
             reg4_w=rb[4].weight, reg4_b=rb[4].bias)
         keep = {k: v.detach().contiguous() for k, v in t.items()}
+        self.mode_eff = self.gemm_mode      # what the launches run in: an fp16 mode falls back to the exact kernels when norm1 is unfit (below)
+        if self.gemm_mode in (GEMM_F16X3, GEMM_F16X4):
+            import math
+            # The generator's input is norm1's output; its fp16 scale is fixed per bind from |LayerNorm(x) g + b| <= sqrt(D - 1) max|g| +
+            # max|b| (no pass over the activations).  ONE power of two serves the whole tensor, so a channel whose |g| sits far below the
+            # largest one lives that many binades under the fp16 range's top: hi stays normal down to 2^-29 of the bound, lo down to 2^-17.
+            # A checkpoint with an outlier in norm1 (max|g| or max|b| thousands of times the typical |g|) would push the bulk of the
+            # channels below that and quietly lose their lo image: refuse the split then and run the exact f32 kernels.
+            g_abs = keep['norm1_g'].abs().float()
+            gmax, gmed, bmax = float(g_abs.max()), float(g_abs.median()), float(keep['norm1_b'].abs().max())
+            bound = math.sqrt(D - 1) * gmax + bmax
+            typical = 4.0 * gmed             # a 4-sigma element of a typical channel
+            self.f16_headroom_log2 = math.log2(bound / typical) if (typical > 0 and math.isfinite(bound) and bound > 0) else float('inf')
+            if not (self.f16_headroom_log2 <= F16_MAX_HEADROOM_LOG2):
+                self.mode_eff = GEMM_F32
+                if not getattr(DecoderRuntime, '_warned_f16_bound', False):
+                    import warnings
+                    warnings.warn('sparsebev_amd: norm1 puts typical generator inputs %.1f binades below the a-priori fp16 scale bound '
+                                  '(max|gamma| %.3g, median|gamma| %.3g, max|beta| %.3g; limit %d): the two mixing GEMMs run on the exact f32 '
+                                  'kernels instead of %s' % (self.f16_headroom_log2, gmax, gmed, bmax, F16_MAX_HEADROOM_LOG2,
+                                                              'f16x3' if self.gemm_mode == GEMM_F16X3 else 'f16x4'))
+                    DecoderRuntime._warned_f16_bound = True
         if self.gemm_mode == GEMM_BF16X3:      # one-off (hi, lo) bf16 images of the two big weight matrices
             lib = _lib.load()
             for name in ('pg_w', 'op_w'):
@@ -133,7 +160,7 @@ class DecoderRuntime:
             nimg = 3 if self.gemm_mode == GEMM_BF16X6 else 2
             keep['pg_ws'] = dense.pack_bf16s_frags(keep['pg_w'], nimg)
             keep['op_wp'] = dense.pack_bf16s_frags(keep['op_w'], nimg)
-        if self.gemm_mode in (GEMM_F16X3, GEMM_F16X4):         # scaled fp16 hi + lo images (csrc/gemm_bf16s.hip), one power of two per weight row
+        if self.mode_eff in (GEMM_F16X3, GEMM_F16X4):          # scaled fp16 hi + lo images (csrc/gemm_bf16s.hip), one power of two per weight row
             from . import dense
             lib = _lib.load()
             keep['pg_ws'], pg_sc = dense.pack_f16s_frags(keep['pg_w'])
@@ -141,9 +168,7 @@ class DecoderRuntime:
             keep['pg_wdown'] = pg_sc[1].contiguous()
             c0 = DecoderConfig()
             c0.G, c0.D, c0.out_points = smp.num_groups, D, mix.out_points
-            # the generator's input is norm1's output: |LayerNorm(x) g + b| <= sqrt(D - 1) max|g| + max|b| -> its power of two, fixed per bind
-            import math
-            bound = math.sqrt(D - 1) * float(keep['norm1_g'].abs().max()) + float(keep['norm1_b'].abs().max())
+            # the generator's input scale: the power of two of the bound computed above, fixed per bind
             e = 0 if not (bound > 0 and math.isfinite(bound)) else max(-100, min(100, math.floor(math.log2(65504.0 / bound) - 1e-9)))
             keep['pg_xscale'] = torch.tensor([2.0 ** e, 2.0 ** -e], device=pg_sc.device, dtype=torch.float32)
             keep['op_nscale'] = torch.empty(D, device=pg_sc.device, dtype=torch.float32)
@@ -190,7 +215,7 @@ class DecoderRuntime:
         cfg.num_classes, cfg.code_size, cfg.num_layers = layer.num_classes, layer.code_size, dec.num_layers
         cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
         cfg.feat_dtype = 1 if pyramid.levels[0].dtype == torch.bfloat16 else 0
-        cfg.gemm_mode = self.gemm_mode
+        cfg.gemm_mode = self.mode_eff
         slots = getattr(pyramid, 'frame_slots', None)
         if slots is not None:
             cfg.n_slots = pyramid.n_slots
@@ -241,7 +266,7 @@ class DecoderRuntime:
         cfg.D, cfg.H, cfg.ffn = layer.embed_dims, layer.self_attn.num_heads, layer.ffn.layers[0][0].weight.shape[0]
         cfg.num_classes, cfg.code_size, cfg.num_layers = layer.num_classes, layer.code_size, dec.num_layers
         cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
-        cfg.gemm_mode, cfg.overlap = self.gemm_mode, int(self.overlap)
+        cfg.gemm_mode, cfg.overlap = self.mode_eff, int(self.overlap)
         return int(_lib.load().sbev_decoder_launches_per_layer(ctypes.byref(cfg), ctypes.byref(self._weights)))
 
     def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):

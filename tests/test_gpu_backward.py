@@ -517,6 +517,59 @@ def test_shared_parameter_gradients_collected_per_call_equal_autograd_accumulati
 
 
 @torch.enable_grad()
+def test_tap_with_one_linear_at_two_row_counts_and_an_aborted_pass():
+    """a shared Linear called with DIFFERENT row counts inside one tapped call -- the bias gradient's recorded segments are
+    its own (a node that adds its bias directly still records its grad_y for the weight: borrowing the weight's list counted that
+    bias twice) -- and a backward pass that raises before ParamTap runs must not leak its partial sums into the retry."""
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(256, 256, generator=g) / 16).to(DEV).requires_grad_(True)
+    b = torch.randn(256, generator=g).to(DEV).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True)
+    bet = (0.1 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True)
+    xs = [torch.randn(m, 256, generator=g).to(DEV) for m in (36, 20, 36, 36, 20)]
+
+    def loss_of(lin, ln):
+        ys = [ln(lin(x, w, b), gam, bet) for x in xs]
+        return sum((y * (i + 1)).pow(2).sum() for i, y in enumerate(ys))
+
+    ref = loss_of(lambda x, w_, b_: F.relu(F.linear(x, w_, b_)), lambda y, g_, b_: F.layer_norm(y, (256,), g_, b_, 1e-5))
+    want = torch.autograd.grad(ref, [w, b, gam, bet])
+    tap = AG.Tap([w, b, gam, bet])
+    out = loss_of(lambda x, w_, b_: AG.linear(x, w_, b_, relu=True, tap=tap), lambda y, g_, b_: AG.layer_norm(y, g_, b_, tap=tap))
+    assert abs(out.item() - ref.item()) <= 1e-4 * abs(ref.item())
+
+    w.grad = b.grad = gam.grad = bet.grad = None
+    out.backward(retain_graph=True)
+    for p, r, name in zip((w, b, gam, bet), want, ('weight', 'bias', 'gamma', 'beta')):
+        assert (p.grad - r).abs().max() <= 2e-5 * r.abs().max().item(), name
+
+    class Boom(torch.autograd.Function):                      # sits UPSTREAM of the first Linear: its backward runs after every tapped
+        armed = True                                          # node has recorded / accumulated, before ParamTap
+
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            if Boom.armed:
+                raise RuntimeError('boom')
+            return gr
+    leaf = xs[0].clone().requires_grad_(True)
+    xs[0] = Boom.apply(leaf)
+    tap = AG.Tap([w, b, gam, bet])
+    out = loss_of(lambda x, w_, b_: AG.linear(x, w_, b_, relu=True, tap=tap), lambda y, g_, b_: AG.layer_norm(y, g_, b_, tap=tap))
+    w.grad = b.grad = gam.grad = bet.grad = None
+    with pytest.raises(RuntimeError, match='boom'):
+        out.backward(retain_graph=True)
+    Boom.armed = False
+    w.grad = b.grad = gam.grad = bet.grad = None
+    out.backward()
+    for p, r, name in zip((w, b, gam, bet), want, ('weight', 'bias', 'gamma', 'beta')):
+        assert (p.grad - r).abs().max() <= 2e-5 * r.abs().max().item(), name
+
+
+@torch.enable_grad()
 def test_eval_mode_with_grad_is_differentiable_and_matches_the_inference_runtime():
     """Grad enabled + something requires grad -> the module is differentiable like the reference's (no silent detached
     outputs); its forward values equal the fused inference runtime's to rounding; under no_grad the runtime runs."""

@@ -259,6 +259,95 @@ def test_out_projection_f16_not_narrower_than_f32_mfma(nprod, pairs):
     assert (yl.double() - ref).abs().max().item() < 5e-3         # (12-binade inputs: outputs of O(100))
 
 
+def _qual_inputs(kind, M, N, K, seed):
+    """Operands for the round-4 qualification of f16x3:
+    'binades24' -- every row of X and of W spans 24+ binades;  'outlier' -- one element per row 2^20 times the rest;
+    'norm1' -- X = LayerNorm(z) gamma + beta with a trained-like gamma in [0.01, 30] (log-uniform), beta ~ N(0, 1): the generator's
+    real input, scaled by the runtime's A-PRIORI bound sqrt(K - 1) max|gamma| + max|beta| instead of its measured maximum."""
+    g = torch.Generator().manual_seed(seed)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    x_bound = None
+    if kind == 'binades24':
+        x = x * torch.exp2(torch.randint(-12, 13, (M, K), generator=g).float())
+        w = w * torch.exp2(torch.randint(-12, 13, (N, K), generator=g).float())
+    elif kind == 'outlier':
+        x[torch.arange(M), torch.randint(0, K, (M,), generator=g)] *= 2.0 ** 20
+        w[torch.arange(N), torch.randint(0, K, (N,), generator=g)] *= 2.0 ** 20
+    elif kind == 'norm1':
+        import math
+        gam = torch.exp(torch.rand(K, generator=g) * (math.log(30.0) - math.log(0.01)) + math.log(0.01))
+        bet = torch.randn(K, generator=g)
+        x = torch.nn.functional.layer_norm(x * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).float()), (K,), gam, bet, 1e-5)
+        x_bound = math.sqrt(K - 1) * float(gam.max()) + float(bet.abs().max())
+    return x.to(DEV), w.to(DEV), torch.randn(N, generator=g).to(DEV), x_bound
+
+
+def _check_f16_vs_exact(name, y, yf, x, w, b, ref, norms=True, x_max=None):
+    """norms: not further from fp64 than the exact f32-MFMA kernel in max and rms (the decoder's operand classes).
+    Always: element by element inside an EXPLICIT bound,
+        |y - ref| <= 2^-19 (|x| |w|^T + |b|)  +  2^-38 (xmax ||w_n||_1 + wmax_n ||x_r||_1)
+    -- the first term is fp32-class and componentwise (a K-long fp32 fma chain guarantees K 2^-24; the exact kernel's own ratio is printed: 37 .. 66 x 2^-24 on the outlier operands);
+    the second is what one power of two per tensor (X) / per row (W) costs: an element more than 2^-17 below its scale's maximum has a
+    subnormal lo image (absolute error 2^-25 in scaled units = 2^-39 of that maximum), invisible next to the first term unless an
+    outlier 2^20 above the rest stretches the scale (measured: a 6.6e-5 element under a 3.3e6 tensor maximum keeps 3 bits).
+    norms=False: such outlier operands -- there hi + lo is NOT "not worse than exact" (dropped lo x lo: up to 2^-22 of a single
+    dominant product; crushed small elements), only inside the bound.  The decoder's operands cannot do that: LayerNorm outputs are
+    bounded by sqrt(n - 1) sigma, and a norm1 with an outlier gamma makes the runtime fall back to the exact kernels."""
+    e, r = _errs(y, ref)
+    ef, rf = _errs(yf, ref)
+    xa, wa = x.double().abs(), w.double().abs()
+    mag = xa @ wa.t() + b.double().abs()
+    xm = float(xa.max()) if x_max is None else float(x_max)
+    floor = 2.0 ** -38 * (xm * wa.sum(1)[None, :] + wa.max(1).values[None, :] * xa.sum(1)[:, None])
+    err, errf = (y.double() - ref).abs(), (yf.double() - ref).abs()
+    ratio = (err / (mag * 2.0 ** -19 + floor)).max().item()
+    ratio_f = (errf / mag).max().item() * 2.0 ** 24
+    print('%s  max/rms err vs fp64: f16x3 %.3e %.3e   f32-mfma %.3e %.3e   f16x3 / explicit bound %.3f   exact componentwise %.2f x 2^-24' % (name, e, r, ef, rf, ratio, ratio_f))
+    if norms:
+        assert e <= ef and r <= rf, (name, 'fp16 hi + lo is further from fp64 than the f32 MFMA kernel', e, r, ef, rf)
+    assert ratio <= 1.0, (name, 'error above the explicit element-wise bound', ratio)
+
+
+@pytest.mark.parametrize('kind', ['binades24', 'outlier', 'norm1'])
+def test_generator_f16x3_wide_rows_outliers_and_trained_norm1(kind):
+    M, N, K = 900, 32768, 256
+    x, w, b, x_bound = _qual_inputs(kind, M, N, K, 31)
+    wf, wsc = dense.pack_f16s_frags(w)
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if x_bound is None:
+        y = dense.linear_f16s_gen(x, wf, wsc, b, nprod=3)
+    else:                      # the decoder's way: X's power of two from the bound, not from the data (runtime._bind)
+        import math
+        e = math.floor(math.log2(65504.0 / x_bound) - 1e-9)
+        assert float(x.abs().max()) * 2.0 ** e < 65504.0
+        xsc = torch.tensor([2.0 ** e, 2.0 ** -e], device=DEV)
+        xs = torch.empty((M + 31) // 32, K // 16, 2, 64, 8, device=DEV, dtype=torch.int16)
+        assert lib.sbev_pack_f16s_frags(p(x), K, p(xs), p(xsc), M, K, 2, st) == 0, lib.sbev_last_error()
+        y = torch.empty(M, N, device=DEV)
+        assert lib.sbev_linear_f16s_gen(p(xs), p(xsc), p(wf), p(wsc[1]), p(b), p(y), M, N, K, N, 0, 3, st) == 0, lib.sbev_last_error()
+    yf = dense.linear(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    _check_f16_vs_exact('generator ' + kind, y, yf, x, w, b, ref, norms=kind != 'outlier', x_max=x_bound)
+
+
+@pytest.mark.parametrize('kind', ['binades24', 'outlier'])
+@pytest.mark.parametrize('pairs', [False, True])
+def test_out_projection_f16x3_wide_rows_and_outliers(kind, pairs):
+    import math
+    M, N, K = 900, 256, 32768
+    x, w, b, _ = _qual_inputs(kind, M, N, K, 32)
+    x = x.abs()                                               # (the out-projection's input is a ReLU output)
+    up = 15 - math.frexp(float(x.max()))[1]
+    wf, wsc = dense.pack_f16s_frags(w)
+    xin = dense.f16s_pairs(x, up) if pairs else x
+    y = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=3, x_up_log2=up, x_is_pairs=pairs)
+    yf = dense.linear(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    _check_f16_vs_exact('out-projection %s pairs=%s' % (kind, pairs), y, yf, x, w, b, ref, norms=kind != 'outlier')
+
+
 @pytest.mark.parametrize('M', [1, 31, 33, 97, 129, 900, 1600, 3600])
 @pytest.mark.parametrize('N,K,relu,use_bias', [(512, 256, False, True), (256, 32, True, True), (1024, 96, False, False), (77824, 256, False, True)])
 def test_generator_f16_ragged_rows(M, N, K, relu, use_bias):

@@ -226,6 +226,55 @@ def test_dn_attention_mask_through_runtime():
     assert (cls_n - cls).abs().max() > 1e-3
 
 
+def test_trained_like_norm1_keeps_f16x3_and_an_outlier_gamma_falls_back_to_the_exact_kernels():
+    """the generator input's fp16 scale is an a-priori bound from norm1 (no pass over the activations).  A
+    trained-like norm1 (gamma log-uniform in [0.01, 30]) stays within the bound's budget and keeps f16x3 -- and stays within 1e-4 of
+    the oracle; a checkpoint with an outlier (one gamma 10^5 times the others) would leave the bulk of the channels without their lo
+    image: the runtime refuses the split, warns once and runs the exact f32 kernels -- bit-identical to gemm_mode='f32'."""
+    import math
+    import warnings
+    from oracle import sparsebev_oracle as O
+    from sparsebev_amd import runtime as RT
+    B, Q, T, L = 1, 64, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    bbox, feat = S.make_queries(B, Q, seed=72)
+    feats = S.make_features(B, T, sizes, seed=73)
+    metas = S.make_img_metas(B, T, ih, iw)
+    g = torch.Generator().manual_seed(74)
+    params = S.make_params(71, embed_dims=256, num_frames=T, num_points=4, num_levels=L)
+    params['norm1.weight'] = torch.exp(torch.rand(256, generator=g) * (math.log(30.0) - math.log(0.01)) + math.log(0.01))
+    params['norm1.bias'] = torch.randn(256, generator=g)
+    # (the wide gamma makes the generator's input 30x larger: keep the dynamic mixing weights at the scale the synthetic model has)
+    params['mixing.parameter_generator.weight'] = params['mixing.parameter_generator.weight'] / 10.0
+
+    def model_of(p, mode):
+        m = SparseBEVTransformer(256, num_frames=T, num_points=4, num_layers=1, num_levels=L, num_classes=10, code_size=10, pc_range=S.PC_RANGE)
+        m.load_state_dict({PREFIX + k: v for k, v in p.items()}, strict=True)
+        m = m.to(DEV).eval()
+        m.decoder.gemm_mode = mode
+        return m
+    args = lambda: (bbox.to(DEV), feat.to(DEV), [f.to(DEV) for f in feats], None, copy.deepcopy(metas))
+    m16 = model_of(params, 'f16x3')
+    cls, box = m16(*args())
+    rt = m16.decoder._runtime
+    assert rt.mode_eff == RT.GEMM_F16X3 and 6.0 < rt.f16_headroom_log2 <= RT.F16_MAX_HEADROOM_LOG2
+    cls_r, box_r, _ = O.decoder(params, bbox, feat, feats, metas, S.PC_RANGE, num_layers=1, sampler=O.msmv_sampling_kernel_semantics)
+    assert (cls[0].cpu() - cls_r[0]).abs().max() < TOL and (box[0].cpu() - box_r[0]).abs().max() < TOL
+    # the outlier checkpoint
+    bad = dict(params)
+    bad['norm1.weight'] = params['norm1.weight'].clone()
+    bad['norm1.weight'][17] = 3.0e6
+    RT.DecoderRuntime._warned_f16_bound = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        mb = model_of(bad, 'f16x3')
+        cls_b, box_b = mb(*args())
+    assert mb.decoder._runtime.mode_eff == RT.GEMM_F32 and mb.decoder._runtime.f16_headroom_log2 > RT.F16_MAX_HEADROOM_LOG2
+    assert any('exact f32' in str(x.message) for x in w)
+    cls_f, box_f = model_of(bad, 'f32')(*args())
+    assert torch.equal(cls_b, cls_f) and torch.equal(box_b, box_f)
+
+
 @pytest.mark.parametrize('P,T,L,pyr', [(8, 2, 5, 'tiny5'), (2, 4, 4, 'tiny'), (8, 15, 4, 'tiny')])
 def test_other_point_and_frame_counts_vs_oracle(P, T, L, pyr):
     """num_points / num_frames other than the r50 defaults: the reference's eva02 config uses P = 8, T = 15

@@ -467,12 +467,34 @@ def main():
                 g_ms = [runtime.read_kernel_ms(k) for k in (1, 2)]
                 runtime.profile_sampler(False)
                 alt[mode] = {'gemm': what, 'value': round(args.steps * B / dt3, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt3 / args.steps, 4),
-                             'generator_us': round(1e3 * sum(g_ms[0]) / max(len(g_ms[0]), 1), 2), 'out_proj_us': round(1e3 * sum(g_ms[1]) / max(len(g_ms[1]), 1), 2),
+                             'generator_us': round(1e3 * sum(g_ms[0]) / len(g_ms[0]), 2) if g_ms[0] else None,      # (None: this mode's kernel is not bracketed)
+                             'out_proj_us': round(1e3 * sum(g_ms[1]) / len(g_ms[1]), 2) if g_ms[1] else None,
                              'max_abs_dev_vs_default_layer0': round(float(max((cls3[0] - cls[0]).abs().max(), (box3[0] - box[0]).abs().max())), 8)}
             except Exception as e:      # noqa: BLE001  (a secondary figure must never take the metric line down)
                 alt[mode] = {'error': repr(e)[:300]}
             finally:
                 model.decoder.gemm_mode = args.gemm
+
+    # ... and the same step EAGER (no graph replay) on the exact kernels: the figure that stays comparable with rounds 1-2 and with an
+    # eager reference loop
+    eager_f32 = None
+    if world == 1 and args.gemm == DEFAULT_GEMM and not args.no_alt:
+        sg, model.decoder.static_graph, model.decoder.gemm_mode = model.decoder.static_graph, False, 'f32'
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            eager_f32 = {'value': round(args.steps * B / dt, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt / args.steps, 4),
+                         'what': 'the same steps enqueued eagerly (no hipGraph replay), exact f32-input MFMA kernels for the two mixing GEMMs'}
+        except Exception as e:      # noqa: BLE001
+            eager_f32 = {'error': repr(e)[:300]}
+        finally:
+            model.decoder.static_graph, model.decoder.gemm_mode = sg, args.gemm
 
     detector = None
     if world == 1 and (args.detector or (args.config == 'c2' and not args.no_detector and not args.online)):
@@ -511,6 +533,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed_max / args.steps, 4),
             'host_issue_ms_per_step': round(1e3 * host_issue, 4),
+            # the two comparison figures up front (short fields: they survive a truncated record): the graph-replayed step on the exact
+            # f32-input MFMA kernels, and that step enqueued eagerly
+            'exact_f32': ({'value': alt['f32']['value'], 'ms_per_step': alt['f32']['ms_per_step']} if (alt and 'value' in alt.get('f32', {})) else None),
+            'eager_f32': ({'value': eager_f32['value'], 'ms_per_step': eager_f32['ms_per_step']} if (eager_f32 and 'value' in eager_f32) else None),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + ('' if args.gemm == 'f32' else ' (the two mixing GEMMs: %s = %s)' % (args.gemm, GEMM_WHAT[args.gemm])),
             'data': 'synthetic',
@@ -565,6 +591,12 @@ def main():
                                      'event_sampling': 'HIP events around the fused launches of every %dth of the eager steps run right after the timed region (which replays a captured graph)' % PROFILE_EVERY}
             if kt and 'adaptive_mixing_kernel' in kt:
                 out['roofline_fused']['avg_us_rocprof'] = kt['adaptive_mixing_kernel']
+            # the kernel the timed steps spend the most time in (the stand-alone sampler above is BASELINE.json's metric kernel; inside
+            # the step its gather runs fused): first-class, same numbers as roofline_fused
+            rf = out['roofline_fused']
+            out['roofline']['dominant_kernel'] = {'kernel': 'adaptive_mixing_kernel (gather + adaptive mixing, one launch)', 'bound': 'hbm',
+                                                  'avg_us': rf['avg_us'], 'achieved': rf['achieved'], 'frac': rf['frac'], 'traffic': rf['traffic'],
+                                                  'share_of_step': round(6 * rf['avg_us'] * 1e-3 / (1e3 * elapsed_max / args.steps), 3)}
         # the kernels that dominate the step by TIME are the two mixing GEMMs (MFMA-bound, exact fp32): same live HIP-event
         # measurement, priced against the f32-input MFMA peak; PMC MFMA-pipe utilisation from profiles/ when present
         if args.gemm != 'f32' and all(gemm_ms):
@@ -578,16 +610,17 @@ def main():
                 {'kernel': name, 'bound': 'mfma', 'achieved': round(npr * fl / (us * 1e-6) / 1e12, 1), 'peak': MFMA_16BIT_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                  'frac': round(npr * fl / (us * 1e-6) / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4), 'image_products': npr,
                  'fp32_equiv_tflops': round(fl / (us * 1e-6) / 1e12, 1), 'launches': len(ms), 'avg_us': round(us, 2), 'algorithmic_flop_per_launch': fl}
-                for name, fl, us, ms in (('gemm_bf16s_gen3_kernel (mixing parameter generator, %s)' % args.gemm, fl_g, g_us, gemm_ms[0]),
+                for name, fl, us, ms in (('%s (mixing parameter generator, %s)' % ('gemm_f16s_gen_ws_kernel' if GEMM_PRODUCTS[args.gemm] in (3, 4) and args.gemm != 'bf16x3' else 'gemm_bf16s_gen3_kernel', args.gemm), fl_g, g_us, gemm_ms[0]),
                                          ('gemm_bf16s_out%s_kernel (mixing out-projection, split-K, %s)' % ('4' if args.gemm.startswith('f16') else '3', args.gemm), fl_o, o_us, gemm_ms[1]))]
             # the fp32-class emulation may be the default once generator + out-projection <= 2 x 60 us at config 2
             out['gemm_gate'] = {'generator_us': round(g_us, 2), 'out_proj_us': round(o_us, 2), 'sum_us': round(g_us + o_us, 2),
                                 'measured': 'HIP events around the two launches of 10 eager steps right after the timed region (an upper bound: the records '
                                             'include the launch gap)', 'config': args.config}
-            if kt and 'gemm_bf16s_gen3_kernel' in kt:
+            gk = (kt or {}).get('gemm_f16s_gen_ws_kernel', (kt or {}).get('gemm_bf16s_gen3_kernel'))
+            if gk:
                 ok = kt.get('gemm_bf16s_out4_kernel', kt.get('gemm_bf16s_out3_kernel'))
-                out['gemm_gate'].update({'generator_us_rocprof': kt['gemm_bf16s_gen3_kernel'], 'out_proj_us_rocprof': ok,
-                                         'sum_us_rocprof': round(kt['gemm_bf16s_gen3_kernel'] + ok, 2) if ok else None,
+                out['gemm_gate'].update({'generator_us_rocprof': gk, 'out_proj_us_rocprof': ok,
+                                         'sum_us_rocprof': round(gk + ok, 2) if ok else None,
                                          'rocprof': 'rocprofv3 --kernel-trace --stats of 23 steps of this command re-run now on this box: AverageNs of the two kernels'})
         if args.gemm == 'f32' and all(gemm_ms):
             D_, Pin_, Pout_ = 256, T * P_, 128
@@ -603,6 +636,8 @@ def main():
                                           ('gemm_nt_f32_regtile_kernel (mixing out-projection, split-K)', 'gemm_nt_f32_regtile_kernel', flops2, gemm_ms[1]))]
         if alt is not None:
             out['alt_gemm'] = alt
+        if eager_f32 is not None:
+            out['eager_f32_detail'] = eager_f32
         if detector is not None:
             out['detector_standin'] = detector
         if world == 1 and not args.no_cpu_baseline:

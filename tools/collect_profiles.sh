@@ -3,7 +3,7 @@
 # gpurun) into profiles/ under the round's prefix.  usage: tools/collect_profiles.sh r3
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-ROUND=${1:-r3}
+ROUND=${1:-r4}
 S=$R/gpurun_out/prof_$ROUND
 D=$R/profiles
 mkdir -p $D

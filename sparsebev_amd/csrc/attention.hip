@@ -33,6 +33,13 @@ constexpr int LDK = HD + 4;   // K tile row stride (B operand of QK^T is read al
 constexpr int LDV = KT + 4;    // V tile is staged TRANSPOSED, [dim][key]: the B operand of PV is then one 16-byte read along the keys
 constexpr int LDP = KT + 4;   // P patch row stride
 
+#ifdef SBEV_SASA_TRACE           // phase stamps of wave 0 of workgroup 0 (tools/exp/r4_sasa_trace.py; never in the product build)
+__device__ long long g_sasa_trace[64];
+#define SASA_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_sasa_trace[i] = (long long)__builtin_readcyclecounter();
+#else
+#define SASA_STAMP(i)
+#endif
+
 struct AttnArgs {
     const float* qkvt;          // [B, Q, ld]: q | k | v | tau
     const float* bbox;          // [B, Q, 10]: columns 0, 1 = normalised centre -> metres via lo/span (decode_bbox)
@@ -74,6 +81,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SASA_STAMP(0)
     const int qg = wave % NQ, ks = wave / NQ;
     const int fi = lane & 15, fk = lane >> 4;
     const int qtiles = (a.Q + 16 * NQ - 1) / (16 * NQ);
@@ -156,12 +164,15 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
     fetch(0);
     stash();
     __syncthreads();
+    SASA_STAMP(1)
+    [[maybe_unused]] int it_ = 0;
 
-    for (int k0 = 0; k0 < a.Q; k0 += KS * KT) {
+    for (int k0 = 0; k0 < a.Q; k0 += KS * KT, ++it_) {
         const bool more = k0 + KS * KT < a.Q;
         // in flight during this iteration's compute.  Unconditional (the last iteration re-fetches tile 0 and drops
         // it): under `if (more)` hipcc copies the loaded registers at the join and waits for them right here.
         fetch(more ? k0 + KS * KT : 0);
+        SASA_STAMP(2 + 8 * it_)
         const int kbase = k0 + ks * KT;                        // this wave's key tile
         if (kbase < a.Q) {
             // S = (Q/sqrt(d)) K^T : 4 key sub-tiles of 16
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
                     for (int j = 0; j < 4; ++j) s_acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[blk][j], kb[j], s_acc[c], 0, 0, 0);
                 }
             }
+            SASA_STAMP(3 + 8 * it_)
             // + distance bias, masks; tile row max.  C layout: column (key) = fi, row (query) = fk*4 + e
             float tmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -217,6 +229,7 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o_acc[t][e] *= alpha[e];
+            SASA_STAMP(4 + 8 * it_)
             // P: C layout -> LDS -> A layout (row = fi, k = key)
 #pragma unroll
             for (int c = 0; c < KT / 16; ++c)
@@ -238,11 +251,15 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
                 }
             }
         }
+        SASA_STAMP(5 + 8 * it_)
         __syncthreads();                                       // every wave is done with these K/V/centre tiles
+        SASA_STAMP(6 + 8 * it_)
         if (more) {
             stash();
+            SASA_STAMP(7 + 8 * it_)
             __syncthreads();
         }
+        SASA_STAMP(8 + 8 * it_)
     }
     // merge the KS key-split partials of each row group (flash-decoding combine) through LDS, then normalise.
     // Ks is free now: slot layout [ks][qg][12 values][64 lanes]
@@ -288,7 +305,14 @@ __global__ __launch_bounds__(64 * NWAVES) void sasa_kernel(const AttnArgs a) {
             }
         }
     }
+    SASA_STAMP(63)
 }
+
+#ifdef SBEV_SASA_TRACE
+}  // namespace
+extern "C" int sbev_debug_sasa_trace_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sasa_trace), sizeof(g_sasa_trace)); }
+namespace {
+#endif
 
 __global__ __launch_bounds__(256) void refine_kernel(const MiscArgs a) { refine_rows(a, blockIdx.x); }
 

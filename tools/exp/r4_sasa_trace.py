@@ -27,9 +27,8 @@ for it in range(4):
     b = 2 + 8 * it
     if t[b] == 0:
         break
-    print('  iteration %d: fetch issue %d | S = QK^T %d | bias + softmax %d | P patch + PV %d | barrier %d | stash %d | barrier %d   total %d' % (
-        it, t[b] - prev, t[b + 1] - t[b], t[b + 2] - t[b + 1], t[b + 3] - t[b + 2], t[b + 4] - t[b + 3], (t[b + 5] - t[b + 4]) if t[b + 5] else 0,
-        (t[b + 6] - (t[b + 5] if t[b + 5] else t[b + 4])), t[b + 6] - prev))
+    print('  iteration %d: early tile I/O %d | S^T = K Q^T %d | bias + softmax %d | PV %d | late tile I/O %d | barrier %d   total %d' % (
+        it, t[b] - prev, t[b + 1] - t[b], t[b + 2] - t[b + 1], t[b + 3] - t[b + 2], t[b + 4] - t[b + 3], t[b + 5] - t[b + 4], t[b + 6] - prev))
     prev = t[b + 6]
 print('merge + store: %d cycles; kernel (this wave): %d cycles' % (t[63] - prev, t[63] - t[0]))
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]

@@ -236,6 +236,7 @@ def _multi_wgrad(tap, pid, segs):
 
 
 _DEFER_MAX = 1 << 18      # weight gradients up to 512 x 512 wait for the end of the call (their operands are < 2 MB per layer)
+_BIAS_DEFER_MAX = 1 << 21 # recorded (masked) grad_y matrices of a bias: rows x columns per layer (8 MB at most)
 
 
 def _defers(tap, pid, A, a_km, lda, b_km, ldb, M, N, K):
@@ -379,7 +380,7 @@ class Linear(torch.autograd.Function):
         if tap is not None:
             tap.fresh_pass()
         recorded = tap.deferred_bias.get(ctx.b_id) if tap is not None else None
-        if (w_tapped and want_db and tap.has(ctx.b_id) and gy2.shape[0] * N <= _DEFER_MAX and gy2.is_contiguous()
+        if (w_tapped and want_db and tap.has(ctx.b_id) and gy2.shape[0] * N <= _BIAS_DEFER_MAX and gy2.is_contiguous()
                 and (not recorded or recorded[0].shape == gy2.shape)):
             # the bias gradient = column sums of this node's (masked) grad_y, recorded in the bias's own list and summed over all layers
             # at the end (a ReLU Linear: only the mask now -- a fully parallel elementwise launch; the one-launch mask + column sum has

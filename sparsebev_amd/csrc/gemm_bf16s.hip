@@ -664,16 +664,13 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
 // the whole kernel.  So here a workgroup owns 256 output columns (wave w: columns 32 w .. 32 w + 31, its 32 KB of W fragments loaded
 // once into registers) and walks row fragments: the only stream is X -- one 32-row fragment (all K: 32 KB, contiguous in the packed
 // operand) per 48 MFMAs of each of the 8 waves, i.e. 32 KB per 3072 matrix-pipe cycles of a SIMD = 10.7 B/clk/CU, half of what the
-// tiled kernel needs, read by every wave from a 3-slot LDS ring the workgroup fills by LDS-DMA two fragments ahead.  No phases: the
-// two waves of a SIMD run the same MFMA-dominated stream and fill each other's gaps (each wave's 48 MFMAs of a fragment are one
-// dependent chain on one accumulator; the partner's chain interleaves with it); the finished fragment's 16 stores ride between the
-// next fragment's MFMAs, one per k-step (a lane owns one output column: a wave-store is two full 128-byte lines), through a buffer
-// resource of M ldy 4 bytes, so rows >= M of the last fragment are dropped by the range check and need no branch.
-// One barrier per fragment.  LDS-DMA ordering (guide: read a staged buffer one barrier after the wait that retires it): at the END of
-// fragment f every wave waits vmcnt(DMA pieces of fragment f + 2 only) -- its own pieces of f + 1 have landed (loads return in order;
-// stores still in flight only make the wait longer: the counter counts them too) -- then the barrier publishes all waves' pieces;
-// slot (f - 1) % 3 is refilled right after that barrier, when every wave has finished reading it.
-// Same products in the same order as gemm_bf16s_gen3_kernel<MODE, 4>: results are bit-identical to it.
+// tiled kernel needs, read by every wave from a 4-slot LDS ring the workgroup fills by LDS-DMA up to three fragments ahead.  The
+// finished fragment's 16 stores ride between the next fragment's MFMAs (a lane owns one output column: a wave-store is two full
+// 128-byte lines), through a buffer resource of M ldy 4 bytes, so rows >= M of the last fragment are dropped by the range check and
+// need no branch.  Each wave sums a fragment's products in TWO interleaved accumulator chains (a dependent v_mfma_f32_32x32x16 issues
+// every ~73 cycles against 32 for independent ones): same image products as gemm_bf16s_gen3_kernel<MODE, 4>, other summation order --
+// equal to it to fp32 round-off, closer to fp64 (tests/test_gpu_bf16s.py).
+// LDS-DMA ordering (guide: read a staged buffer one barrier after the wait that retires it): see the comment in the kernel.
 struct GenWsArgs {
     const unsigned short* Xs;    // [ceil(M/32)][16][2][64][8]
     const unsigned short* Ws;    // [N/32][16][2][64][8]
@@ -723,20 +720,15 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
     [[maybe_unused]] const int tid = (int)threadIdx.x;
     SBEV_WGTIME(0)
 
-    // GB: the wave belongs to the second group (waves 4 .. 7; wave w + 4 shares its SIMD with wave w), which runs HALF A FRAGMENT behind
-    // the first: everything a wave does besides MFMAs sits at its fragment boundary (the finished fragment's scale / bias, the counted
-    // wait, the barrier, 4 LDS-DMA issues of ~100 cycles each: ~1400 cycles per 3072 of matrix work), and with both waves of a SIMD at
-    // their boundary together the matrix pipe idled through it -- the MFMA phase ran at 61 % with the LDS reads, the stores, the DMA or
-    // the accumulator dependency removed in turn (tools/exp/r4_run2.sh, r4_run3.sh).  The workgroup still meets at ONE barrier per
-    // fragment; group A reaches it at its fragment boundary, group B in the MIDDLE of its fragment (after k-step 7), so one wave's
-    // boundary lies beside its partner's MFMA stream.  What the barrier b_i (A has finished fragment i, B its first half) orders:
-    //   before it every wave waits for its own pieces of fragment i + 1 (loads return in order: at most the 4 pieces of fragment
-    //     i + 2 may be outstanding; stores still in flight only make the wait longer) -- A reads i + 1 right after it, B half a period later;
-    //   after it every wave refills slot (i + 3) % 4 = (i - 1) % 4: A left fragment i - 1 a period ago, B at ITS boundary before b_i.
-    // A's stores of fragment i - 1 ride in the first half of fragment i, B's in the second: always behind the barrier, never in front
-    // of the counted wait (hipcc otherwise sinks them there and the wait sits out their write latency).
-    auto run = [&](auto gb) {
-        constexpr bool GB = decltype(gb)::value;
+    // One barrier per fragment, all eight waves in the same phase.  (Tried, measured, not kept: the two waves of a SIMD half a fragment
+    // apart -- the second group meeting the barrier in the MIDDLE of its fragment, so that one wave's boundary work lies beside its partner's
+    // MFMA stream -- and the LDS-DMA issued by one group only: 49.0 vs 49.3 us at c2, 189 vs 190 at c3.  The kernel is power-capped, not
+    // schedule-bound: DESIGN.md section 10.2.)  What the barrier b_i at the end of fragment i orders: before it every wave waits for its own
+    // pieces of fragment i + 1 (loads return in order: at most the 4 pieces of fragment i + 2 may be outstanding; stores still in flight only
+    // make the wait longer); after it every wave refills slot (i + 3) % 4 = (i - 1) % 4, which everybody has finished reading.  The stores of
+    // fragment i - 1 ride in the first half of fragment i: behind the barrier, never in front of the counted wait (hipcc otherwise sinks them
+    // there and the wait sits out their write latency).
+    {
         for (int task = (int)xcd_contiguous(blockIdx.x, gridDim.x); task < a.ntask; task += (int)gridDim.x) {
             const int ct = task / a.nrs, rs = task - ct * a.nrs;
             const int f0 = rs * a.base + (rs < a.rem ? rs : a.rem);
@@ -746,25 +738,15 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
             const float bv = a.bias ? a.bias[n] : 0.f;
             const float cv = F16 ? a.colscale[n] * a.xscale[1] : 1.f;
             const unsigned ycol = (unsigned)(4 * lh) * ldyb + (unsigned)n * 4u;
-            // ---- X stream: fragment f0 + i -> slot i % 4.  Staggered groups: only the waves of group A copy (wave w: pieces 8 w .. 8 w + 7,
-            // 8 KB contiguous on both sides) -- they have ~1600 cycles of slack at every barrier, group B is the critical path and its ~540
-            // cycles of DMA issue per fragment lengthened every period (cycle trace, tools/exp/r4_trace_ws.py).  Lock-step build: every
-            // wave copies 4 pieces.
-#ifdef SBEV_WS_LOCKSTEP
-            constexpr bool COPIES = true;
-            constexpr int NPC = 4;
-#else
-            constexpr bool COPIES = !GB;
-            constexpr int NPC = 8;
-#endif
-            const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.Xs) + (long long)f0 * WS_FRAG + (wave & (32 / NPC - 1)) * (NPC * 1024);
+            // ---- X stream: fragment f0 + i -> slot i % 4; wave w copies pieces 4 w .. 4 w + 3 (4 KB, contiguous on both sides)
+            const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.Xs) + (long long)f0 * WS_FRAG + wave * 4096;
             auto issue = [&](int i) {                                     // (callers guarantee i < nf)
-                if constexpr (COPIES) {
+                {
                     const unsigned long long sb = (unsigned long long)(xg + (long long)i * WS_FRAG);
                     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb);
                     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sb >> 32));
                     const void* sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
-                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((i % WS_SLOTS) * WS_FRAG + (wave & (32 / NPC - 1)) * (NPC * 1024));
+                    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((i % WS_SLOTS) * WS_FRAG + wave * 4096);
 #ifndef SBEV_EXP_NOGLDS
                     asm volatile(
                         "s_mov_b32 m0, %0\n\t"
@@ -776,17 +758,6 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
                         :
                         : "s"(dst), "v"(voff), "s"(sbase)
                         : "memory");
-                    if constexpr (NPC == 8)
-                        asm volatile(
-                            "s_mov_b32 m0, %0\n\t"
-                            "s_nop 4\n\t"
-                            "global_load_lds_dwordx4 %1, %2\n\t"
-                            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                            "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                            :
-                            : "s"(dst + 4096u), "v"(voff + 4096u), "s"(sbase)
-                            : "memory");
 #endif
                 }
             };
@@ -806,7 +777,7 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
                     for (int img = 0; img < 2; ++img) wf[ks][img] = *reinterpret_cast<const bf16x8*>(wb + (ks * 2 + img) * 512);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (COPIES) wait_vmcnt_imm<32>();
+            wait_vmcnt_imm<32>();
             lds_barrier();
             f32x16 prev;                                                  // the finished fragment, scaled + biased, waiting for its stores
 #pragma unroll
@@ -849,7 +820,7 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
                         }
                     }
 #endif
-                    if ((blk >= NBLK / 2) == GB) {                        // SPB stores of the previous fragment per block of "its" half
+                    if (blk < NBLK / 2) {                                 // SPB stores of the previous fragment per block of the first half
 #pragma unroll
                         for (int e = SPB * (blk % (NBLK / 2)); e < SPB * (blk % (NBLK / 2)) + SPB; ++e) {
                             const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb;
@@ -872,14 +843,12 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
                             else accs[c] = SBEV_MFMA(xc[c][0], wf[ks][0], accs[c]);
                         }
                     __builtin_amdgcn_sched_barrier(0);
-                    if ((GB && blk == NBLK / 2 - 1) || (!GB && blk == NBLK - 1)) {
+                    if (blk == NBLK - 1) {
                         // b_i: this wave's pieces of fragment i + 1 have landed (only fragment i + 2's may be outstanding), then published;
                         // slot (i + 3) % 4 is free behind it
                         SBEV_TRACE(i, 1)
-                        if constexpr (COPIES) {                           // (a wave that copies nothing has nothing to wait for: its stores are its own)
-                            if (i + 2 < nf) wait_vmcnt_imm<NPC>();
-                            else wait_vmcnt_imm<0>();
-                        }
+                        if (i + 2 < nf) wait_vmcnt_imm<4>();
+                        else wait_vmcnt_imm<0>();
                         SBEV_TRACE(i, 2)
                         lds_barrier();
                         SBEV_TRACE(i, 3)
@@ -903,16 +872,8 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
                 for (int e = 0; e < 16; ++e)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[e]), yrs, (int)(ylast + (unsigned)((e & 3) + 8 * (e >> 2)) * ldyb), 0, 0);
             }
-            // the ring is reused by the next task: every wave must be done reading (group B is half a fragment behind the last barrier)
-            lds_barrier();
         }
-    };
-#ifdef SBEV_WS_LOCKSTEP
-    run(std::false_type{});
-#else
-    if (wave < 4) run(std::false_type{});
-    else run(std::true_type{});
-#endif
+    }
     SBEV_WGTIME(1)
 }
 

@@ -671,6 +671,19 @@ int64_t sbev_decoder_chain_pack_floats(const sbev_decoder_config* cfg);
 int sbev_decoder_chain_pack(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights, float* out, sbev_stream_t stream);
 int sbev_decoder_row_chain(int enable);
 
+/* Pair mode of the tail chain (round 4).  A chain workgroup streams every weight of its chain through its CU's ~60 GB/s L2 path, so
+ * where two workgroups per row block fit the device in ONE round (<= ~1000 rows at 8 rows per pair, <= ~2000 at 16, on 256 CUs) the
+ * tail runs on PAIRS: the members split ffn.layers.0 by columns and ffn.layers.1 by k (partial sums exchanged), take one branch each
+ * (classification | regression + refine_bbox + the next position encoder) and split the attention in-projection by columns -- half
+ * the weight stream per CU, two hand-offs through write-through stores and one arrival counter per pair in the decoder workspace
+ * (zeroed by the layer's attention chain; bounded polls).  Results equal the single-workgroup chain to fp32 round-off.
+ * sbev_decoder_chain_pair(0 / 1) switches it (returns the previous setting; default 1, SBEV_NO_CHAIN_PAIR=1 in the environment
+ * starts with 0).  sbev_decoder_chain_pair_timeouts: hand-offs whose partner did not arrive within the poll bound (~1 s) since the
+ * library was loaded -- 0 unless something kept half of a pair off the GPU; the results of such a launch are undefined; synchronises
+ * the device; -1 on a HIP error. */
+int sbev_decoder_chain_pair(int enable);
+int64_t sbev_decoder_chain_pair_timeouts(void);
+
 /* Kernel launches per layer sbev_decoder_forward enqueues for this config and weight set under the current process-wide switches
  * (row chains, gather + mixing fusion), -1 on an invalid config: 6 with the row chains, 17 op by op, + 1 for the two-launch gather
  * + mixing, + 1 for the activation split of the split-bf16 GEMM modes. */

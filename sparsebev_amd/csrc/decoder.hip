@@ -29,7 +29,8 @@ struct Carver {
 
 struct Buffers {
     float *t0, *t1, *x, *x1, *x2, *x3, *qkvt, *att, *so, *wbp, *loc, *sampled, *params, *mixed, *slabs,
-        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc;
+        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc, *pair_x;
+    uint32_t* pair_sync;
     size_t bytes;
 };
 
@@ -65,6 +66,8 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.x1s = k.take(2 * BQ * D + 64 * (size_t)D);   // x1 as bf16 image fragments (<= 3 images of 2 bytes, rows padded to 32): the
                                                    // generator's operand in the split-bf16 / fp16 modes
     b.xsc = k.take(64);                            // fp16 modes: {2^e, 2^-e} of x1 (written by the pack launch of every layer)
+    b.pair_x = k.take((size_t)sbev::chain_pair_floats((long long)BQ));                   // tail chain in pair mode (row_chain.hip): exchange rows
+    b.pair_sync = reinterpret_cast<uint32_t*>(k.take((size_t)sbev::chain_pair_sync_words((long long)BQ)));      // ... and arrival counters
     b.bytes = k.off;
     return b;
 }
@@ -290,7 +293,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
-                                        nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr));
+                                        nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr, b.pair_sync));
             if (nimg)
                 TRY(generator_bf16s(stream, true));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)
@@ -318,7 +321,7 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             else
                 TRY(sbev::launch_splitk_slabs(b.mixed, w->op_w, BQ, D, mixN, mixN, mixN, splits, b.slabs, &used, s_main));
             TRY(sbev::launch_chain_tail(c, *w, b.slabs, used, b.x1, bbox, c.T > 1 ? vel_div : nullptr, b.x3, cls_l, box_l,
-                                        layer + 1 < c.num_layers, b.x, b.qkvt, eps, s_main));
+                                        layer + 1 < c.num_layers, b.x, b.qkvt, eps, s_main, b.pair_x, b.pair_sync));
             bbox = box_l;
             continue;
         }

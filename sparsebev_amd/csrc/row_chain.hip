@@ -53,7 +53,9 @@ struct Lin {
     int in_off, ld;      // LDS rows it reads
     int KH;              // k-pieces per column group (RG = 1: K / 128)
     int items;           // 64-column groups x KH
-    int chunks;          // 16-k chunks per item = K / (16 KH); a multiple of 4
+    int chunks;          // 16-k chunks per item = K / (16 KHT); a multiple of 4
+    int kh0, KHT;        // this Linear covers the k-pieces [kh0, kh0 + KH) of the KHT pieces of a full row (KHT == KH, kh0 == 0 but for
+                         // the k-half a pair member takes of ffn.layers.1)
 };
 struct Unit {
     Lin a, b;            // b.items == 0: one Linear
@@ -62,7 +64,7 @@ struct Unit {
 };
 
 #ifdef SBEV_CHAIN_TRACE
-#define SBEV_TRACE(i) if (blockIdx.x == 7 && lane == 0) a.trace[wave * 64 + (i)] = (long long)__builtin_readcyclecounter();
+#define SBEV_TRACE(i) if ((blockIdx.x == 7 || blockIdx.x == 15) && lane == 0) a.trace[(blockIdx.x == 15 ? 64 * 512 : 0) + wave * 64 + (i)] = (long long)__builtin_amdgcn_s_memrealtime();   // 100 MHz
 #else
 #define SBEV_TRACE(i)
 #endif
@@ -72,7 +74,12 @@ struct ChainArgs {
     long long* trace;
 #endif
     Unit units[8];
+    Unit units_b[8];             // pair mode: the second member's units (same count, same epilogues)
     int n_units, pre, front;     // front: EPI_OUT continues with the next layer's position encoder
+    int n_pairs;                 // pair mode: pairs of workgroups (= row blocks)
+    float* pair_x;               // pair mode: exchange rows [n_pairs][3][R][256] (ffn.1 partial sums of member 0 / 1, x rows)
+    unsigned* pair_sync;         // pair mode: one arrival counter per pair; the ATTENTION chain of the same layer zeroes them:
+    unsigned* zero_words; int n_zero;
     const float* warm;           // the launch's packed weights: one contiguous span of the chain_pack image ...
     int warm_lines;              // ... of this many 128-byte lines (L2 warm-up, see warm_l2)
     const float* vec;            // the launch's small vectors in the image -> LDS parameter block [vec_off, vec_off + vec_n)
@@ -172,11 +179,11 @@ struct Walk {            // position of a wave in its item stream
     int u, it, step;
 };
 
-__device__ __forceinline__ int unit_items(const ChainArgs& a, int u) { return a.units[u].a.items + a.units[u].b.items; }
+__device__ __forceinline__ int unit_items(const Unit* U, int u) { return U[u].a.items + U[u].b.items; }
 
 // first item of this wave at or after (u, it)
-__device__ __forceinline__ void walk_settle(const ChainArgs& a, Walk& w, int wave) {
-    while (w.u < a.n_units && w.it >= unit_items(a, w.u)) {
+__device__ __forceinline__ void walk_settle(const ChainArgs& a, const Unit* U, Walk& w, int wave) {
+    while (w.u < a.n_units && w.it >= unit_items(U, w.u)) {
         ++w.u;
         w.it = wave;
     }
@@ -185,7 +192,9 @@ __device__ __forceinline__ void walk_settle(const ChainArgs& a, Walk& w, int wav
 __device__ __forceinline__ const float* item_weights(const Unit& un, int it) {
     const bool second = it >= un.a.items;
     const Lin& l = second ? un.b : un.a;
-    return l.wp + (long long)(it - (second ? un.a.items : 0)) * (l.chunks * CHUNK_FLOATS);
+    const int j = it - (second ? un.a.items : 0);
+    const int piece = l.KHT == l.KH ? j : (j / l.KH) * l.KHT + l.kh0 + j % l.KH;
+    return l.wp + (long long)piece * (l.chunks * CHUNK_FLOATS);
 }
 
 // (M0 carries the LDS destination of an LDS-DMA load and is written inside the asm block; hipcc does not use M0 anywhere else
@@ -204,6 +213,7 @@ __device__ __forceinline__ void issue_chunk(const float* g, unsigned lds_byte, u
 }
 
 struct Stream {
+    const Unit* U;       // the workgroup's unit table (kernel arguments)
     Walk iw;             // item of the next chunk to issue
     const float* g;      // its weights (next chunk)
     int nchunk;          // chunks of that item
@@ -214,10 +224,10 @@ struct Stream {
 };
 
 __device__ __forceinline__ void stream_seek(const ChainArgs& a, Stream& st, int wave) {
-    walk_settle(a, st.iw, wave);
+    walk_settle(a, st.U, st.iw, wave);
     st.iw.step = 0;
     if (st.iw.u < a.n_units) {
-        const Unit& un = a.units[st.iw.u];
+        const Unit& un = st.U[st.iw.u];
         st.g = item_weights(un, st.iw.it);
         st.nchunk = st.iw.it >= un.a.items ? un.b.chunks : un.a.chunks;
     }
@@ -297,7 +307,7 @@ __device__ __forceinline__ void mma_item_wide(const ChainArgs& a, Stream& st, RC
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[rg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kh = j % l.KH;
+    const int kh = l.kh0 + j % l.KH;
     const float* arow = smem + l.in_off + kh * (l.chunks * 16) + (lane & 3) * l.ld + (lane >> 2);
     float avn[RG];                                 // the A registers (16 k x 4 rows per row group) of the NEXT chunk: read one chunk ahead
 #pragma unroll
@@ -379,6 +389,64 @@ __device__ __forceinline__ void gather4(float (&v)[4], const float* P, int base,
     else gather4_t<4, R>(v, P, base, cg0, row, lane, bias, bias0);
 }
 
+// the k-pieces of the 4 column groups of a Linear added in order, no bias (pair mode: a member's partial sums)
+template <int R>
+__device__ __forceinline__ void gather4_raw(float (&v)[4], const float* P, int KH, int row, int lane) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = 0.f;
+        for (int kh = 0; kh < KH; ++kh) s += P[(c * KH + kh) * (R * 64) + row * 64 + lane];
+        v[c] = s;
+    }
+}
+
+// ---- pair mode: two workgroups share a row block (PAIR instantiations of the tail) --------------------------------------------------
+// Every workgroup of a chain streams every weight, and a CU takes ~60 GB/s from the L2 whatever the row count (DESIGN.md section
+// 10.3): the only way to stream less per CU is to split a row block's Linears between CUs.  A PAIR of workgroups owns R rows;
+// both reduce the out-projection slabs and run norm2 (bit-identical x2 rows), then
+//   ffn.layers.0    member s computes the hidden columns [256 s, 256 s + 256)            (its half of the weight's ROWS)
+//   ffn.layers.1    member s sums over k in [256 s, 256 s + 256) -- the hidden columns it has -- for all 256 outputs; the partial
+//                   sums are EXCHANGED, added member 0 + member 1 in both, + bias + residual -> norm3: x3 in both
+//   branches        member 0 runs the classification branch, member 1 the regression branch, refine_bbox and (front) the position
+//                   encoder; its x rows (feat + pos) are HANDED to member 0
+//   in-projection   member 0 computes column groups 0 .. 7, member 1 the rest
+// so a member streams ~1.65 of the 3.25 MB and the pair meets twice.  Hand-off (MI355X guide, inter-workgroup visibility): payload
+// with 16-byte sc0 sc1 (write-through) stores, EVERY wave drains them, workgroup barrier, one lane adds to the pair's counter with a
+// relaxed agent-scope atomic; the reader polls that word from one lane (s_sleep between polls; BOUNDED: a lost partner raises
+// g_chain_pair_timeouts instead of hanging the GPU), workgroup barrier, sc0 sc1 loads.  Valid for any workgroup -> XCD placement; the
+// block -> pair map puts both members on one XCD under round-robin dispatch (speed only).  The counters are zeroed by the attention
+// chain of the same layer, which always runs between two tails on the stream (no memset node).
+__device__ unsigned g_chain_pair_timeouts;
+constexpr unsigned PAIR_POLL_LIMIT = 1u << 22;       // x (s_sleep 2 + one L2 round trip): a second or so
+
+__device__ __forceinline__ void pair_store4(float* p, const float (&v)[4]) {
+    const f32x4 q = {v[0], v[1], v[2], v[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void pair_load4(const float* p, float (&v)[4]) {
+    f32x4 q;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(p) : "memory");
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void pair_arrive(unsigned* word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its payload stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pair_wait(unsigned* word, unsigned arrivals) {
+    if (threadIdx.x == 0) {
+        unsigned n = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++n > PAIR_POLL_LIMIT) {
+                __hip_atomic_fetch_add(&g_chain_pair_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void store_rows(float* smem, int off, int ld, int row, int lane, const float (&v)[4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) smem[off + row * ld + lane + 64 * c] = v[c];
@@ -402,21 +470,36 @@ __device__ __forceinline__ void pe0_row(const ChainArgs& a, float* smem, int row
 }
 
 // PRE: how the input rows are produced (compile-time: the three chains are three instantiations)
-template <int PRE, int RG>
+template <int PRE, int RG, bool PAIR = false>
 __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a) {
     using L = Lay<RG>;
+    static_assert(!PAIR || (PRE == PRE_SLABS && RG > 1), "pair mode: the tail, wide row blocks");
     constexpr int R = L::R, RPW = L::RPW, OFF_X2 = L::OFF_X2, OFF_X3 = L::OFF_X3, OFF_H = L::OFF_H, OFF_C = L::OFF_C, OFF_R = L::OFF_R,
                   OFF_P = L::OFF_P, OFF_PARAM = L::OFF_PARAM;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // L::LDS_TOTAL_FLOATS (dynamic: > 64 KB)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long row0 = (long long)blockIdx.x * R;
+    // pair mode: block b -> XCD b % 8 under round-robin dispatch, so the members of pair p are blocks b and b + 8
+    int pair = (int)blockIdx.x, member = 0;
+    if constexpr (PAIR) {
+        const int li = (int)blockIdx.x >> 3;
+        pair = (li >> 1) * 8 + ((int)blockIdx.x & 7);
+        member = li & 1;
+        if (pair >= a.n_pairs) return;
+    }
+    const Unit* const U = (PAIR && member) ? a.units_b : a.units;
+    unsigned* const pword = PAIR ? a.pair_sync + pair : nullptr;
+    float* const px = PAIR ? a.pair_x + (long long)pair * (3 * R * DM) : nullptr;       // [3][R][256]
+    const long long row0 = (long long)pair * R;
     float* P = smem + OFF_P;
+    if (PRE == PRE_ATT && a.zero_words && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.n_zero; i += 64 * NWAVE) a.zero_words[i] = 0u;
 
     // the weight stream starts before anything else: three chunks in flight
     SBEV_TRACE(0)
     warm_l2<RG>(a, wave, lane);
     Stream st;
+    st.U = U;
     st.iw = Walk{0, wave, 0};
     st.issued = st.used = st.islot = st.uslot = 0;
     st.ring_byte = (unsigned)(L::OFF_RING + wave * (RING_SLOTS * CHUNK_FLOATS)) * 4u;
@@ -535,7 +618,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
 
     SBEV_TRACE(1)
     for (int u = 0; u < a.n_units; ++u) {
-        const Unit& un = a.units[u];
+        const Unit& un = U[u];
         const int items = un.a.items + un.b.items;
         for (int it = wave; it < items; it += NWAVE) {
             const bool second = it >= un.a.items;
@@ -545,15 +628,30 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         SBEV_TRACE(2 + 4 * u)
         __syncthreads();
         SBEV_TRACE(3 + 4 * u)
+        if constexpr (PAIR) {
+            if (un.epi == EPI_FFN1) {
+                // this member's partial sums of ffn.layers.1 (its k-half) -> exchange rows; lane = columns lane + 64 c, stored as one float4
+                for (int row = wave; row < R; row += NWAVE) {
+                    float v[4];
+                    gather4_raw<R>(v, P, un.a.KH, row, lane);
+                    pair_store4(px + (member * R + row) * DM + lane * 4, v);
+                }
+                pair_arrive(pword);
+                pair_wait(pword, 2u);
+            } else if (un.epi == EPI_PE3 && member == 0) {
+                pair_wait(pword, 3u);      // member 1's x rows
+            }
+        }
         // ---- epilogue: task = (row, side); wave-local row ops ----------------------------------------------------------
         for (int task = wave; task < 2 * R; task += NWAVE) {
             const int row = task % R, side = task / R;
             const long long g = row0 + row;
             const bool live = g < a.M;
             float v[4];
+            if (PAIR && side != member && (un.epi == EPI_FFN0 || un.epi == EPI_BR1 || un.epi == EPI_BR2 || un.epi == EPI_OUT)) continue;
             switch (un.epi) {
             case EPI_FFN0: {     // relu(x2 W0^T + b0): side = column half
-                gather4<R>(v, P, 0, un.a.KH, side * 4, row, lane, pv + PV_FFN0_B, side * 256);
+                gather4<R>(v, P, 0, un.a.KH, PAIR ? 0 : side * 4, row, lane, pv + PV_FFN0_B, side * 256);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) smem[OFF_H + row * LDH + side * 256 + lane + 64 * c] = fmaxf(v[c], 0.f);
             } break;
@@ -563,12 +661,20 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
                 float res[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) res[c] = smem[OFF_X2 + row * LDX + lane + 64 * c];
-                gather4<R>(v, P, 0, un.a.KH, 0, row, lane, pv + PV_FFN1_B, 0);
+                if constexpr (PAIR) {       // member 0's + member 1's partial sums, in that order in both members
+                    float own[4], oth[4];
+                    gather4_raw<R>(own, P, un.a.KH, row, lane);
+                    pair_load4(px + ((1 - member) * R + row) * DM + lane * 4, oth);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = ((member ? oth[c] : own[c]) + (member ? own[c] : oth[c])) + pv[PV_FFN1_B + lane + 64 * c];
+                } else {
+                    gather4<R>(v, P, 0, un.a.KH, 0, row, lane, pv + PV_FFN1_B, 0);
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] += res[c];
                 ln4(v, lw, a.eps, false);
                 store_rows(smem, OFF_X3, LDX, row, lane, v);
-                if (live) {
+                if (live && member == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a.x3[g * DM + lane + 64 * c] = v[c];
                 }
@@ -624,6 +730,11 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             } break;
             case EPI_PE3: {      // position_encoder[3..5] + query_feat -> x (:166-167)
                 if (side) break;
+                if (PAIR && member == 0) {       // the x rows come from member 1
+                    pair_load4(px + (2 * R + row) * DM + lane * 4, v);
+                    store_rows(smem, OFF_X2, LDX, row, lane, v);
+                    break;
+                }
                 const LnW lw(pv + PV_PE4G, pv + PV_PE4B, lane);
                 float res[4];
 #pragma unroll
@@ -633,6 +744,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] += res[c];
                 store_rows(smem, OFF_X2, LDX, row, lane, v);
+                if (PAIR) pair_store4(px + (2 * R + row) * DM + lane * 4, v);
                 if (live) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a.x[g * DM + lane + 64 * c] = v[c];
@@ -707,6 +819,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
             }
         }
         SBEV_TRACE(4 + 4 * u)
+        if (PAIR && un.epi == EPI_PE3 && member == 1) pair_arrive(pword);
         __syncthreads();
         SBEV_TRACE(5 + 4 * u)
     }
@@ -777,9 +890,13 @@ Lin lin(const float* wp, int in_off, int ld, int N, int K, int kh = 0, int cg0 =
     const int KH = kh > 0 ? kh : K / 128;
     const int all = (N + 63) / 64;
     if (ncg < 0) ncg = all - cg0;
-    return Lin{wp + (long long)cg0 * K * 64, in_off, ld, KH, ncg * KH, K / (16 * KH)};
+    return Lin{wp + (long long)cg0 * K * 64, in_off, ld, KH, ncg * KH, K / (16 * KH), 0, KH};
 }
-const Lin kNone{nullptr, 0, LDX, 1, 0, 8};
+// k-half `half` of a packed [N, K] weight (pair mode): kh pieces of the half, i.e. pieces [half kh, half kh + kh) of 2 kh per row
+Lin lin_khalf(const float* wp, int in_off, int ld, int N, int K, int kh, int half) {
+    return Lin{wp, in_off, ld, kh, ((N + 63) / 64) * kh, K / (32 * kh), half * kh, 2 * kh};
+}
+const Lin kNone{nullptr, 0, LDX, 1, 0, 8, 0, 1};
 
 // k-pieces per column group of a unit with `cgs` column groups in all: RG = 1 keeps 128-k items; RG > 1 aims at 8 items per
 // unit (one per wave; each piece at least 64 k = RDEPTH chunks)
@@ -806,9 +923,43 @@ int row_groups(long long rows) {
 }
 Offs offs(int rg) { return rg == 1 ? offs_of<1>() : rg == 2 ? offs_of<2>() : offs_of<4>(); }
 
+// Pair mode of the tail (see "pair mode" above): row groups per PAIR of workgroups, 0 = not applicable.  Both members of every
+// pair must be resident at once -- one workgroup per CU (88 KB of LDS and more) -- so the launch, 16 blocks per 8 pairs, has to
+// fit the device's CUs in one round: 8 rows per pair, <= 1024 rows on 256 CUs.  (16 rows per pair would reach 2048 rows, but
+// four row groups per weight chunk are MFMA-bound, not stream-bound: 88 vs 66 us for the single-workgroup tail at 1600 rows;
+// SBEV_CHAIN_PAIR16=1 enables it for A/B runs.)
+std::atomic<int> g_chain_pair{getenv("SBEV_NO_CHAIN_PAIR") ? 0 : 1};
+int pair_blocks(long long rows, int rg) {
+    const long long pairs = (rows + 4 * rg - 1) / (4 * rg);
+    return (int)(16 * ((pairs + 7) / 8));
+}
+int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int v = cus[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+int pair_row_groups(long long rows) {
+    if (g_chain_pair.load(std::memory_order_relaxed) == 0 || rows > 256 * 16) return 0;
+    const int cus = device_cus();
+    static const int max_rg = getenv("SBEV_CHAIN_PAIR16") ? 4 : 2;
+    for (int rg = 2; rg <= max_rg; rg *= 2)
+        if (pair_blocks(rows, rg) <= cus) return rg;
+    return 0;
+}
+
 }  // namespace
 
 namespace sbev {
+
+// pair mode workspace: exchange rows (floats) and arrival counters (words) for `rows` rows, whatever the row block it picks
+long long chain_pair_floats(long long rows) { return 3 * (rows + 15) * DM; }
+long long chain_pair_sync_words(long long rows) { return (rows + 7) / 8; }
 
 bool row_chain_supported(const sbev_decoder_config& c) {
     return c.D == DM && c.ffn == FF && c.code_size == 10 && c.num_classes >= 1 && c.num_classes <= 64 &&
@@ -846,23 +997,23 @@ static int add_front(ChainArgs& a, int n, const sbev_decoder_config& c, const fl
 
 // the kernels use 159 KB of dynamic LDS: raised once per instantiation (also from sbev_decoder_chain_pack, so that the first
 // launch may already be inside a stream capture)
-template <int PRE, int RG>
+template <int PRE, int RG, bool PAIR = false>
 static hipError_t lds_attr() {
     static std::atomic<unsigned long long> done{0};      // bit d: raised on device d (a process may drive several devices)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE, RG>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel<PRE, RG, PAIR>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, Lay<RG>::LDS_TOTAL_FLOATS * 4);
     if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
     return e;
 }
 
-template <int PRE, int RG>
+template <int PRE, int RG, bool PAIR = false>
 static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
     constexpr int R = Lay<RG>::R, LDS_TOTAL_FLOATS = Lay<RG>::LDS_TOTAL_FLOATS;
-    const hipError_t attr = lds_attr<PRE, RG>();
+    const hipError_t attr = lds_attr<PRE, RG, PAIR>();
     if (attr != hipSuccess) {
         set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, LDS_TOTAL_FLOATS * 4, hipGetErrorString(attr));
         return SBEV_ELAUNCH;
@@ -873,22 +1024,25 @@ static int launch_t(const ChainArgs& a, hipStream_t s, const char* what) {
 #ifdef SBEV_CHAIN_TRACE
     static long long* tr = nullptr;
     static int calls = 0;
-    if (!tr) { (void)hipMalloc(&tr, 64 * 8 * 8 * 64); (void)hipMemset(tr, 0, 64 * 8 * 8 * 64); }
+    if (!tr) { (void)hipMalloc(&tr, 2 * 64 * 8 * 8 * 64); (void)hipMemset(tr, 0, 2 * 64 * 8 * 8 * 64); }
     b.trace = tr + (calls % 64) * 512;
 #endif
-    hipLaunchKernelGGL((row_chain_kernel<PRE, RG>), dim3((unsigned)((a.M + R - 1) / R)), dim3(64 * NWAVE), LDS_TOTAL_FLOATS * 4, s, b);
+    const unsigned grid = PAIR ? (unsigned)pair_blocks(a.M, RG) : (unsigned)((a.M + R - 1) / R);
+    hipLaunchKernelGGL((row_chain_kernel<PRE, RG, PAIR>), dim3(grid), dim3(64 * NWAVE), LDS_TOTAL_FLOATS * 4, s, b);
 #ifdef SBEV_CHAIN_TRACE
     if (++calls == 13) {        // the first step's 13 launches
         (void)hipDeviceSynchronize();
-        static long long h[64 * 512];
+        static long long h[2 * 64 * 512];
         (void)hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost);
         for (int c = 0; c < 13; ++c) {
             const long long* t = h + c * 512;
-            printf("launch %d:", c);
-            for (int w = 0; w < 8; w += 7) {
-                printf(" [w%d]", w);
-                for (int i = 1; i < 2 + 4 * 8 && t[w * 64 + i]; ++i) printf(" %lld", t[w * 64 + i] - t[w * 64]);
-            }
+            printf("launch %d (PRE %d RG %d PAIR %d; 10 ns ticks):", c, PRE, RG, (int)PAIR);
+            for (int blk = 0; blk < 2; ++blk)
+                for (int w = 0; w < 8; w += 7) {
+                    const long long* tb = t + blk * 64 * 512;
+                    printf(" [b%d w%d]", blk ? 15 : 7, w);
+                    for (int i = 0; i < 2 + 4 * 8 && tb[w * 64 + i]; ++i) printf(" %lld", tb[w * 64 + i] - t[0]);
+                }
             printf("\n");
         }
     }
@@ -900,7 +1054,10 @@ template <int RG>
 static bool lds_ready_rg() {
     return lds_attr<PRE_SLABS, RG>() == hipSuccess && lds_attr<PRE_FRONT, RG>() == hipSuccess && lds_attr<PRE_ATT, RG>() == hipSuccess;
 }
-bool chain_lds_ready() { return lds_ready_rg<1>() && lds_ready_rg<2>() && lds_ready_rg<4>(); }
+bool chain_lds_ready() {
+    return lds_ready_rg<1>() && lds_ready_rg<2>() && lds_ready_rg<4>() && lds_attr<PRE_SLABS, 2, true>() == hipSuccess &&
+           lds_attr<PRE_SLABS, 4, true>() == hipSuccess;
+}
 
 template <int RG>
 static int launch_rg(const ChainArgs& a, hipStream_t s, const char* what) {
@@ -930,11 +1087,13 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
 // attention out-projection + residual + norm1 -> x1, sampling Linear -> sample points -> projection (loc, level weights)
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
                       const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
-                      hipStream_t s, uint16_t* x1_frag, const float* x1_scale) {
+                      hipStream_t s, uint16_t* x1_frag, const float* x1_scale, uint32_t* pair_sync) {
     const PackMap m = pack_map(c);
     ChainArgs a{};
     fill_common(a, c, eps);
     a.pre = PRE_ATT;
+    a.zero_words = pair_sync;            // the arrival counters of this layer's tail (pair mode), zeroed here: chain_pair_sync_words()
+    a.n_zero = pair_sync ? (int)chain_pair_sync_words(a.M) : 0;
     a.att = att; a.x = const_cast<float*>(x); a.x1_out = x1; a.so = nullptr;
     a.x1_frag = x1_frag; a.x1_scale = x1_scale;
     a.proj = sbev_ops::sample_point_args(bbox, time_diff, lidar2img, c.pc_range, c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w,
@@ -953,7 +1112,7 @@ int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& 
 // out_proj slabs -> norm2 -> ffn -> norm3 -> branches -> refine_bbox [-> the next layer's position encoder + in-projection]
 int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* slabs, int splits, const float* x1,
                       const float* bbox, const float* vel_div, float* x3, float* cls_out, float* box_out, int with_front, float* x,
-                      float* qkvt, float eps, hipStream_t s) {
+                      float* qkvt, float eps, hipStream_t s, float* pair_x, uint32_t* pair_sync) {
     const PackMap m = pack_map(c);
     const float* pk = w.chain_pack;
     ChainArgs a{};
@@ -961,10 +1120,45 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
     a.pre = PRE_SLABS;
     a.slabs = slabs; a.splits = splits; a.x1 = x1; a.bbox = bbox; a.vel_div = vel_div;
     a.x3 = x3; a.cls_out = cls_out; a.box_out = box_out; a.front = with_front; a.x = x; a.qkvt = qkvt;
+    a.warm = pk + m.ffn0;
+    a.warm_lines = (int)(((with_front ? m.attn_out : m.pe3) - m.ffn0) / 32);
+    a.vec = pk + m.vec; a.vec_off = 0; a.vec_n = with_front ? PV_FRONT_END : PV_TAIL_END;
+    const int dcg = c.D / 64;
+    const int prg = pair_x && pair_sync ? pair_row_groups(a.M) : 0;
+    if (prg) {
+        // pair mode: two workgroups per row block, each with its own unit table (see "pair mode" above the kernel)
+        const int rg = prg;
+        const Offs o = offs(rg);
+        const int half_cg = c.ffn / 128;                                   // column groups of half the hidden layer
+        const int kh1 = pieces(rg, dcg, c.ffn / 2);                        // k-pieces of a member's half of ffn.layers.1
+        const int qcg = (c.attn_in_rows + 63) / 64, q0 = qcg < 8 ? qcg : 8;   // in-projection: member 0 takes <= 8 column groups
+        int n = 0;
+        for (int mem = 0; mem < 2; ++mem) {
+            Unit* u = mem ? a.units_b : a.units;
+            n = 0;
+            u[n++] = Unit{lin(pk + m.ffn0, o.x2, LDX, c.ffn, c.D, pieces(rg, half_cg, c.D), mem * half_cg, half_cg), kNone, EPI_FFN0, 0};
+            u[n++] = Unit{lin_khalf(pk + m.ffn1, o.h, LDH, c.D, c.ffn, kh1, mem), kNone, EPI_FFN1, 0};
+            const Lin br1 = lin(pk + (mem ? m.reg0 : m.cls0), o.x3, LDX, c.D, c.D, pieces(rg, dcg, c.D));
+            const Lin br2 = lin(pk + (mem ? m.reg2 : m.cls3), mem ? o.r : o.c, LDX, c.D, c.D, pieces(rg, dcg, c.D));
+            const Lin out = mem ? lin(pk + m.reg4, o.r, LDX, c.code_size, c.D, pieces(rg, 1, c.D)) : lin(pk + m.cls6, o.c, LDX, c.num_classes, c.D, pieces(rg, 1, c.D));
+            u[n++] = mem ? Unit{kNone, br1, EPI_BR1, 0} : Unit{br1, kNone, EPI_BR1, 0};
+            u[n++] = mem ? Unit{kNone, br2, EPI_BR2, 0} : Unit{br2, kNone, EPI_BR2, 0};
+            u[n++] = mem ? Unit{kNone, out, EPI_OUT, 0} : Unit{out, kNone, EPI_OUT, 0};
+            if (with_front) {
+                u[n++] = Unit{mem ? lin(pk + m.pe3, o.c, LDX, c.D, c.D, pieces(rg, dcg, c.D)) : kNone, kNone, EPI_PE3, 0};
+                const int cg0 = mem ? q0 : 0, ncg = mem ? qcg - q0 : q0;
+                u[n++] = Unit{ncg > 0 ? lin(pk + m.attn_in, o.x2, LDX, c.attn_in_rows, c.D, pieces(rg, ncg, c.D), cg0, ncg) : kNone, kNone, EPI_QKV, cg0 * 64};
+            }
+        }
+        a.n_units = n;
+        a.n_pairs = (int)((a.M + 4 * rg - 1) / (4 * rg));
+        a.pair_x = pair_x;
+        a.pair_sync = pair_sync;
+        return rg == 2 ? launch_t<PRE_SLABS, 2, true>(a, s, "row chain (tail, pairs)") : launch_t<PRE_SLABS, 4, true>(a, s, "row chain (tail, pairs)");
+    }
     int n = 0;
     const int rg = row_groups(a.M);
     const Offs o = offs(rg);
-    const int dcg = c.D / 64;
     a.units[n++] = Unit{lin(pk + m.ffn0, o.x2, LDX, c.ffn, c.D, pieces(rg, c.ffn / 64, c.D)), kNone, EPI_FFN0, 0};
     a.units[n++] = Unit{lin(pk + m.ffn1, o.h, LDH, c.D, c.ffn, pieces(rg, dcg, c.ffn)), kNone, EPI_FFN1, 0};
     a.units[n++] = Unit{lin(pk + m.cls0, o.x3, LDX, c.D, c.D, pieces(rg, 2 * dcg, c.D)), lin(pk + m.reg0, o.x3, LDX, c.D, c.D, pieces(rg, 2 * dcg, c.D)),
@@ -975,13 +1169,21 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
                         EPI_OUT, 0};
     if (with_front) n = add_front(a, n, c, pk, m, rg);
     a.n_units = n;
-    a.warm = pk + m.ffn0;
-    a.warm_lines = (int)(((with_front ? m.attn_out : m.pe3) - m.ffn0) / 32);
-    a.vec = pk + m.vec; a.vec_off = 0; a.vec_n = with_front ? PV_FRONT_END : PV_TAIL_END;
     return launch(a, rg, s, "row chain (tail)");
 }
 
 }  // namespace sbev
+
+// pair mode of the tail: on (default) / off; returns the previous setting (A/B measurements, tests)
+extern "C" int sbev_decoder_chain_pair(int enable) { return g_chain_pair.exchange(enable != 0 ? 1 : 0); }
+
+// partners that did not show up within the poll bound since the library was loaded (0 unless the GPU was shared with something
+// that kept half of a pair from being scheduled for about a second); synchronises the device
+extern "C" int64_t sbev_decoder_chain_pair_timeouts(void) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_chain_pair_timeouts), sizeof(v)) != hipSuccess) return -1;
+    return (int64_t)v;
+}
 
 extern "C" int64_t sbev_decoder_chain_pack_floats(const sbev_decoder_config* cfg) {
     if (!cfg || !sbev::row_chain_supported(*cfg)) return 0;

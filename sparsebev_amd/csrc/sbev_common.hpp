@@ -56,10 +56,12 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
                        float* qkvt, float eps, hipStream_t s);
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
                       const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
-                      hipStream_t s, uint16_t* x1_frag = nullptr, const float* x1_scale = nullptr);
+                      hipStream_t s, uint16_t* x1_frag = nullptr, const float* x1_scale = nullptr, uint32_t* pair_sync = nullptr);
 int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* slabs, int splits, const float* x1,
                       const float* bbox, const float* vel_div, float* x3, float* cls_out, float* box_out, int with_front, float* x,
-                      float* qkvt, float eps, hipStream_t s);
+                      float* qkvt, float eps, hipStream_t s, float* pair_x = nullptr, uint32_t* pair_sync = nullptr);
+long long chain_pair_floats(long long rows);         // pair mode of the tail: exchange rows / arrival counters for `rows` rows
+long long chain_pair_sync_words(long long rows);
 
 // gemm.hip: pairs of independent small ops of a decoder layer's tail in ONE launch (see pair_kernel)
 bool small_linear_shape(int64_t M, int N, int K);

@@ -376,7 +376,7 @@ class StepGraphs:
         sig = rt._ensure_bound()
         fkey, ident, staged = self._feat_key(mlvl_feats)
         key = (tuple(query_bbox.shape), tuple(query_feat.shape), fkey, None if attn_mask is None else tuple(attn_mask.shape), sig,
-               torch.cuda.current_device(), _STATE['row_chain'], _STATE['fuse'], _lib.load().sbev_get_box_convention(),
+               torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _lib.load().sbev_get_box_convention(),
                rt.decoder.num_layers, tuple(rt.decoder.pc_range))
         e = self.entries.get(key, False)
         if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
@@ -528,7 +528,8 @@ class DecoderGraph:
 
 
 # process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
-_STATE = {'row_chain': True, 'fuse': True, 'profile': 0}
+import os as _os
+_STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0}
 
 
 def fuse_sample_mix(enable):
@@ -544,6 +545,25 @@ def row_chain(enable):
     agree to fp32 round-off, not bit for bit).  ``SBEV_NO_ROW_CHAIN=1`` in the environment switches it off for A/B runs."""
     _lib.check(_lib.load().sbev_decoder_row_chain(int(bool(enable))), 'sbev_decoder_row_chain')
     _STATE['row_chain'] = bool(enable)
+
+
+def chain_pair(enable):
+    """The tail chain on PAIRS of workgroups per row block (half the weight stream per CU, two in-launch hand-offs; default on
+    where both members of every pair fit the device in one round: <= ~2000 rows on 256 CUs; results agree with the
+    single-workgroup tail to fp32 round-off).  ``SBEV_NO_CHAIN_PAIR=1`` in the environment starts with it off.  Returns the
+    previous setting."""
+    prev = _lib.load().sbev_decoder_chain_pair(int(bool(enable)))
+    _STATE['chain_pair'] = bool(enable)
+    return bool(prev)
+
+
+def chain_pair_timeouts():
+    """Pair hand-offs whose partner did not arrive within the poll bound since the library was loaded (0 on a GPU of our own;
+    synchronises the device)."""
+    n = _lib.load().sbev_decoder_chain_pair_timeouts()
+    if n < 0:
+        raise RuntimeError('sbev_decoder_chain_pair_timeouts: HIP error')
+    return int(n)
 
 
 def profile_sampler(enable):

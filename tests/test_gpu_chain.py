@@ -101,6 +101,60 @@ def test_row_chains_equal_op_by_op_to_roundoff(B, Q, T, pyr, layers):
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
 
 
+@pytest.mark.parametrize('B,Q,T,pyr,layers', [(1, 1, 2, 'tiny', 2), (1, 4, 2, 'tiny', 1), (1, 9, 2, 'tiny', 3), (1, 900, 8, 'tiny', 6),
+                                              (2, 441, 2, 'tiny', 2), (1, 961, 2, 'tiny5', 3), (1, 1024, 2, 'tiny', 2), (1, 1089, 2, 'tiny', 2)])
+def test_tail_on_pairs_of_workgroups_equals_the_single_workgroup_tail(B, Q, T, pyr, layers):
+    """Round 4: two workgroups per row block in the tail (ffn split by columns / k with an exchange of partial sums, one branch
+    each, the x rows handed over).  1 .. 9 rows (one pair, partial), 900 (config 2), 961 with 5 levels, 1024 (256 blocks of
+    8-row pairs: the whole device), 1089 (too many pairs for one round of 256 CUs: the single-workgroup tail, bit-identical
+    either way).  Same growth law as above against the single-workgroup chains, no poll ran out, bit-stable run to run."""
+    feats, bbox, feat, metas, L = inputs(B, Q, T, pyr, 71)
+    model, _ = build(T, L, 72, layers)
+    t0 = runtime.chain_pair_timeouts()
+    a = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    prev_setting = runtime.chain_pair(False)
+    try:
+        b = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    finally:
+        runtime.chain_pair(prev_setting)
+    assert prev_setting is True
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    if B * Q > 1024:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    prev = 0.0
+    for l in range(layers):
+        dev = max((a[0][l] - b[0][l]).abs().max().item(), (a[1][l] - b[1][l]).abs().max().item())
+        tol = 2e-5 if l == 0 else 3e-4 if l == 1 else 10.0 * max(prev, 3e-5)
+        assert dev < tol, (l, dev, prev)
+        prev = dev
+    for _ in range(3):
+        a2 = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+        assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+    assert runtime.chain_pair_timeouts() == t0
+
+
+def test_tail_pairs_under_uneven_load_and_graph_replay():
+    """The hand-offs under load: 200 replays of the captured 6-layer step at config 2's row count while a second stream keeps part
+    of the device busy with long-running copies, every output word compared with the first replay (a stale exchange row, a lost
+    arrival or a counter that was not re-zeroed shows as a difference or a timeout)."""
+    B, Q, T = 1, 900, 8
+    feats, bbox, feat, metas, L = inputs(B, Q, T, 'tiny', 81)
+    model, _ = build(T, L, 82, 6)
+    t0 = runtime.chain_pair_timeouts()
+    ref = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device=DEV)
+    for i in range(200):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                junk2 = junk * 1.0001 + 1.0           # ~0.5 GB of traffic beside the step
+        out = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), i
+    torch.cuda.synchronize()
+    del junk2
+    assert runtime.chain_pair_timeouts() == t0
+
+
 def test_row_chains_every_layer_from_the_same_inputs():
     """Layer by layer at the config-2 query count: every layer's chain launches from the op-by-op path's own inputs, so
     each comparison is one layer deep (2e-5), including the tail + next-front launch whose output (x, qkvt) only the NEXT

@@ -1131,7 +1131,11 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
         const Offs o = offs(rg);
         const int half_cg = c.ffn / 128;                                   // column groups of half the hidden layer
         const int kh1 = pieces(rg, dcg, c.ffn / 2);                        // k-pieces of a member's half of ffn.layers.1
-        const int qcg = (c.attn_in_rows + 63) / 64, q0 = qcg < 8 ? qcg : 8;   // in-projection: member 0 takes <= 8 column groups
+        // in-projection: member 1 has the x rows in its LDS, member 0 gets them a hand-off (~1.5 us) later -- so member 1 takes up to
+        // 8 column groups (one round of 16-chunk items) and member 0 the rest (5 of config 2's 13: 10 items of 8 chunks)
+        static const int q0_forced = getenv("SBEV_CHAIN_PAIR_Q0") ? atoi(getenv("SBEV_CHAIN_PAIR_Q0")) : -1;      // A/B
+        const int qcg = (c.attn_in_rows + 63) / 64;
+        const int q0 = q0_forced >= 0 && q0_forced <= qcg ? q0_forced : (qcg > 8 ? qcg - 8 : qcg / 2);
         int n = 0;
         for (int mem = 0; mem < 2; ++mem) {
             Unit* u = mem ? a.units_b : a.units;

@@ -7,15 +7,13 @@ mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_chain.py -x -q  2>&1 | tail -3
 
 Q="--no-cpu-baseline --no-alt --no-detector --no-live-pmc --steps 30"
-for c in c2 c5 c6; do
+for c in c2 c5 c6 c3; do
 python bench.py --config $c $Q 2>/dev/null | python tools/exp/bline.py "$c pairs   "
 SBEV_NO_CHAIN_PAIR=1 python bench.py --config $c $Q 2>/dev/null | python tools/exp/bline.py "$c no pairs"
 done
 cd /tmp && export TMPDIR=/tmp
-for c in c2 c6; do
+for c in c2 c3; do
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$c -o bench -- python $R/bench.py --config $c $Q --steps 20 > $O/kt_$c.log 2>&1
 python $R/tools/exp/kstats.py $(find $O/kt_$c -name "*kernel_stats.csv" | head -1) 12 | grep "row_chain\|sasa"
 done
-SBEV_NO_CHAIN_PAIR=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c6np -o bench -- python $R/bench.py --config c6 $Q --steps 20 > $O/kt_c6np.log 2>&1
-python $R/tools/exp/kstats.py $(find $O/kt_c6np -name "*kernel_stats.csv" | head -1) 12 | grep "row_chain"
 rm -f $(find $O -name "*kernel_trace.csv") $(find $O -name "*agent_info.csv")

@@ -683,6 +683,10 @@ int sbev_decoder_row_chain(int enable);
  * the device; -1 on a HIP error. */
 int sbev_decoder_chain_pair(int enable);
 int64_t sbev_decoder_chain_pair_timeouts(void);
+/* Test hook for the poll bound: with 1, one member of the first pair of every pair-mode tail exits at once; its partner must time out
+ * (sbev_decoder_chain_pair_timeouts grows, the launch ends after about a second per hand-off, only that pair's 8 rows are wrong).
+ * Returns the previous setting.  Never set in production. */
+int sbev_debug_chain_pair_drop(int enable);
 
 /* Kernel launches per layer sbev_decoder_forward enqueues for this config and weight set under the current process-wide switches
  * (row chains, gather + mixing fusion), -1 on an invalid config: 6 with the row chains, 17 op by op, + 1 for the two-launch gather

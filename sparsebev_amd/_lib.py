@@ -147,6 +147,7 @@ SIGNATURES = {
     'sbev_decoder_row_chain': (ctypes.c_int, [ctypes.c_int]),
     'sbev_decoder_chain_pair': (ctypes.c_int, [ctypes.c_int]),
     'sbev_decoder_chain_pair_timeouts': (ctypes.c_int64, []),
+    'sbev_debug_chain_pair_drop': (ctypes.c_int, [ctypes.c_int]),
     'sbev_gemm_f32_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
     'sbev_gemm_f32': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, _vp, _vp]),

@@ -80,6 +80,7 @@ struct ChainArgs {
     float* pair_x;               // pair mode: exchange rows [n_pairs][3][R][256] (ffn.1 partial sums of member 0 / 1, x rows)
     unsigned* pair_sync;         // pair mode: one arrival counter per pair; the ATTENTION chain of the same layer zeroes them:
     unsigned* zero_words; int n_zero;
+    int debug_drop;              // test hook (sbev_debug_chain_pair_drop): member 1 of pair 0 leaves at once -- its partner must time out, not hang
     const float* warm;           // the launch's packed weights: one contiguous span of the chain_pack image ...
     int warm_lines;              // ... of this many 128-byte lines (L2 warm-up, see warm_l2)
     const float* vec;            // the launch's small vectors in the image -> LDS parameter block [vec_off, vec_off + vec_n)
@@ -417,7 +418,7 @@ __device__ __forceinline__ void gather4_raw(float (&v)[4], const float* P, int K
 // block -> pair map puts both members on one XCD under round-robin dispatch (speed only).  The counters are zeroed by the attention
 // chain of the same layer, which always runs between two tails on the stream (no memset node).
 __device__ unsigned g_chain_pair_timeouts;
-constexpr unsigned PAIR_POLL_LIMIT = 1u << 22;       // x (s_sleep 2 + one L2 round trip): a second or so
+constexpr unsigned PAIR_POLL_LIMIT = 1u << 20;       // x (s_sleep 2 + one memory round trip, ~1 us): about a second
 
 __device__ __forceinline__ void pair_store4(float* p, const float (&v)[4]) {
     const f32x4 q = {v[0], v[1], v[2], v[3]};
@@ -486,6 +487,7 @@ __global__ __launch_bounds__(64 * NWAVE) void row_chain_kernel(const ChainArgs a
         pair = (li >> 1) * 8 + ((int)blockIdx.x & 7);
         member = li & 1;
         if (pair >= a.n_pairs) return;
+        if (a.debug_drop && pair == 0 && member == 1) return;
     }
     const Unit* const U = (PAIR && member) ? a.units_b : a.units;
     unsigned* const pword = PAIR ? a.pair_sync + pair : nullptr;
@@ -929,6 +931,7 @@ Offs offs(int rg) { return rg == 1 ? offs_of<1>() : rg == 2 ? offs_of<2>() : off
 // four row groups per weight chunk are MFMA-bound, not stream-bound: 88 vs 66 us for the single-workgroup tail at 1600 rows;
 // SBEV_CHAIN_PAIR16=1 enables it for A/B runs.)
 std::atomic<int> g_chain_pair{getenv("SBEV_NO_CHAIN_PAIR") ? 0 : 1};
+std::atomic<int> g_chain_pair_drop{0};
 int pair_blocks(long long rows, int rg) {
     const long long pairs = (rows + 4 * rg - 1) / (4 * rg);
     return (int)(16 * ((pairs + 7) / 8));
@@ -1158,6 +1161,7 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
         a.n_pairs = (int)((a.M + 4 * rg - 1) / (4 * rg));
         a.pair_x = pair_x;
         a.pair_sync = pair_sync;
+        a.debug_drop = g_chain_pair_drop.load(std::memory_order_relaxed);
         return rg == 2 ? launch_t<PRE_SLABS, 2, true>(a, s, "row chain (tail, pairs)") : launch_t<PRE_SLABS, 4, true>(a, s, "row chain (tail, pairs)");
     }
     int n = 0;
@@ -1180,6 +1184,10 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
 
 // pair mode of the tail: on (default) / off; returns the previous setting (A/B measurements, tests)
 extern "C" int sbev_decoder_chain_pair(int enable) { return g_chain_pair.exchange(enable != 0 ? 1 : 0); }
+
+// TEST HOOK: with 1, member 1 of pair 0 of every pair-mode tail exits at once, so that its partner runs into the poll bound (the rows
+// of that pair are garbage, every other row is unaffected, the launch ends); returns the previous setting
+extern "C" int sbev_debug_chain_pair_drop(int enable) { return g_chain_pair_drop.exchange(enable != 0 ? 1 : 0); }
 
 // partners that did not show up within the poll bound since the library was loaded (0 unless the GPU was shared with something
 // that kept half of a pair from being scheduled for about a second); synchronises the device

@@ -155,6 +155,33 @@ def test_tail_pairs_under_uneven_load_and_graph_replay():
     assert runtime.chain_pair_timeouts() == t0
 
 
+def test_a_lost_pair_member_times_out_instead_of_hanging():
+    """The poll bound: with the test hook one member of pair 0 leaves at once; its partner must give up after the bound (~1 s per
+    hand-off), count a timeout and finish -- rows 8 .. of a ONE-layer run are untouched (rows are independent within the tail; the
+    next layer's attention would mix the broken rows in), and the next launch without the hook is exact again."""
+    import time
+    from sparsebev_amd import _lib
+    feats, bbox, feat, metas, L = inputs(1, 100, 2, 'tiny', 91)
+    model, _ = build(2, L, 92, 1)
+    model.decoder.static_graph = False          # (a captured step would keep the hook's setting of the call it was recorded in)
+    ref = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
+    t0 = runtime.chain_pair_timeouts()
+    lib = _lib.load()
+    assert lib.sbev_debug_chain_pair_drop(1) == 0
+    try:
+        tic = time.time()
+        out = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+        torch.cuda.synchronize()
+        took = time.time() - tic
+    finally:
+        assert lib.sbev_debug_chain_pair_drop(0) == 1
+    assert took < 60.0
+    assert runtime.chain_pair_timeouts() > t0
+    assert torch.equal(out[0][:, :, 8:], ref[0][:, :, 8:]) and torch.equal(out[1][:, :, 8:], ref[1][:, :, 8:])
+    again = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+
+
 def test_row_chains_every_layer_from_the_same_inputs():
     """Layer by layer at the config-2 query count: every layer's chain launches from the op-by-op path's own inputs, so
     each comparison is one layer deep (2e-5), including the tail + next-front launch whose output (x, qkvt) only the NEXT

@@ -517,6 +517,77 @@ def test_shared_parameter_gradients_collected_per_call_equal_autograd_accumulati
 
 
 @torch.enable_grad()
+@pytest.mark.parametrize('feat_grad', [False, True])
+def test_captured_training_step_replays_with_new_data_and_equals_the_eager_step(feat_grad):
+    """sparsebev_amd.train_graph.CapturedTrainStep: forward + backward of a 3-layer decoder captured as ONE hipGraph on batch A, then
+    replayed on batch B (new features / queries copied into the static tensors, new camera matrices and time stamps through
+    ``replay(img_metas)``): loss, outputs and every gradient equal an eager step on batch B (1e-5 relative: the feature-gradient
+    scatter and the split-K reductions add in another order from run to run), and a second replay of B reproduces the first."""
+    from sparsebev_amd.train_graph import CapturedTrainStep
+    B, Q, T, layers = 1, 100, 2, 3
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, len(sizes), 77, layers).train()
+    model.decoder.decoder_layer.self_attn.attn_drop = 0.0
+    model.decoder.decoder_layer.ffn_drop = 0.0
+    cot = [torch.randn(layers, B, Q, 10, generator=torch.Generator().manual_seed(5 + i)).to(DEV) for i in range(2)]
+    loss_fn = lambda cls, box: (cls * cot[0]).sum() + (box * cot[1]).sum()
+
+    def batch(seed):
+        feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=seed)]
+        bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=seed + 1)]
+        metas = S.make_img_metas(B, T, ih, iw)
+        for m in metas:
+            m['img_timestamp'] = [t_ - 0.013 * seed * (i // 6) for i, t_ in enumerate(m['img_timestamp'])]
+            m['lidar2img'] = [np.asarray(a, np.float32) * (1.0 + 1e-3 * seed) for a in m['lidar2img']]
+        return feats, bbox, feat, metas
+
+    fa, ba, qa, ma = batch(1)
+    sf = [f.clone().requires_grad_(feat_grad) for f in fa]
+    sb, sq = ba.clone(), qa.clone().requires_grad_(True)
+    step = CapturedTrainStep(model, sb, sq, sf, ma, loss_fn)
+    assert len(step.grads) == 48
+    fb, bb, qb, mb = batch(2)
+    with torch.no_grad():
+        for d, s_ in zip(sf, fb):
+            d.copy_(s_)
+        sb.copy_(bb)
+        sq.copy_(qb)
+    loss, cls, box = [t.clone() for t in step.replay(mb)]
+    g1 = {n: t.clone() for n, t in step.grads.items()}
+    gq = step.input_grads['query_feat'].clone()
+    gf = [t.clone() for t in step.input_grads['mlvl_feats']] if feat_grad else []
+    loss2 = step.replay()[0].clone()
+    assert rel(loss2, loss) < 1e-6 and all(rel(step.grads[n], g1[n]) < 1e-5 for n in g1)
+    del step
+    # eager on batch B, fresh leaves
+    for p in model.parameters():
+        p.grad = None
+    ef = [f.clone().requires_grad_(feat_grad) for f in fb]
+    eq = qb.clone().requires_grad_(True)
+    ecls, ebox = model(bb, eq, list(ef), None, copy.deepcopy(mb))
+    eloss = loss_fn(ecls, ebox)
+    eloss.backward()
+    assert rel(cls, ecls) < 1e-6 and rel(box, ebox) < 1e-6 and rel(loss, eloss) < 1e-6
+    assert rel(gq, eq.grad) < 1e-5
+    for n, p in model.decoder.named_parameters():
+        assert rel(g1[n], p.grad) < 1e-5, n
+    for a_, b_ in zip(gf, ef):
+        assert rel(a_, b_.grad) < 1e-5
+    # and the two batches really differ
+    assert g1['decoder_layer.ffn.layers.1.weight'].abs().max() > 0 and rel(qa, qb) > 0.1
+
+
+def test_captured_training_step_refuses_dropout():
+    from sparsebev_amd.train_graph import CapturedTrainStep
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(2, len(sizes), 78, 1).train()          # mmcv's dropouts (0.1) are on in train() mode
+    feats = [f.to(DEV) for f in S.make_features(1, 2, sizes, seed=3)]
+    bbox, feat = [t.to(DEV) for t in S.make_queries(1, 49, seed=4)]
+    with torch.enable_grad(), pytest.raises(ValueError, match='dropout'):
+        CapturedTrainStep(model, bbox, feat.requires_grad_(True), feats, S.make_img_metas(1, 2, ih, iw), lambda c, b: c.sum())
+
+
+@torch.enable_grad()
 def test_tap_with_one_linear_at_two_row_counts_and_an_aborted_pass():
     """a shared Linear called with DIFFERENT row counts inside one tapped call -- the bias gradient's recorded segments are
     its own (a node that adds its bias directly still records its grad_y for the weight: borrowing the weight's list counted that

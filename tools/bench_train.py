@@ -14,6 +14,7 @@ ap.add_argument('--pyr', default='r50_704x256')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--feat-grad', action='store_true')
 ap.add_argument('--dropout', action='store_true')
+ap.add_argument('--graph', action='store_true', help='also time the step captured as ONE hipGraph (sparsebev_amd.train_graph.CapturedTrainStep; needs dropout off)')
 ap.add_argument('--recompute', action='store_true', help='re-run generator GEMM + mixing in backward (the reference\'s checkpoint policy) instead of keeping 236 MB per layer')
 a = ap.parse_args()
 dev = 'cuda:0'
@@ -36,6 +37,21 @@ def step():
     cls, box = m(bbox, feat, list(feats), None, copy.deepcopy(metas))
     (cls.sum() + box.sum()).backward()
 
+dg = None
+if a.graph:
+    # first thing in the process: the captured step wants the parameters' AccumulateGrad nodes on ITS stream (train_graph.py)
+    from sparsebev_amd.train_graph import CapturedTrainStep
+    cap = CapturedTrainStep(m, bbox, feat, feats, metas, lambda cls, box: cls.sum() + box.sum())
+    for _ in range(3):
+        cap.replay(metas)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cap.replay(metas)
+    torch.cuda.synchronize()
+    dg = (time.perf_counter() - t0) / a.steps
+    del cap
+
 for _ in range(3):
     step()
 torch.cuda.synchronize()
@@ -54,5 +70,7 @@ with torch.no_grad():
         m(bbox, feat, list(feats), None, copy.deepcopy(metas))
     torch.cuda.synchronize()
     di = (time.perf_counter() - t0) / a.steps
-print('train step (fwd+bwd, 6 layers, Q=%d T=%d B=%d, feat_grad=%s, dropout=%s, recompute=%s): %.2f ms   inference step: %.2f ms   peak mem %.2f GB'
-      % (a.q, a.t, a.b, a.feat_grad, a.dropout, a.recompute, dt * 1e3, di * 1e3, torch.cuda.max_memory_allocated() / 1e9))
+print('train step (fwd+bwd, 6 layers, Q=%d T=%d B=%d, feat_grad=%s, dropout=%s, recompute=%s): %.2f ms%s   inference step: %.2f ms   peak mem %.2f GB'
+      % (a.q, a.t, a.b, a.feat_grad, a.dropout, a.recompute, dt * 1e3,
+         '' if dg is None else '   captured as one hipGraph (CapturedTrainStep, camera constants refreshed every step): %.2f ms' % (dg * 1e3),
+         di * 1e3, torch.cuda.max_memory_allocated() / 1e9))

@@ -16,8 +16,11 @@ bbox, feat = [t.to(dev) for t in S.make_queries(1, 900, seed=0)]
 feat.requires_grad_(True)
 metas = S.make_img_metas(1, 8, ih, iw)
 params = [p for p in m.parameters()]
+from sparsebev_amd.transformer import FeaturePyramid, DecoderContext
+ctx = DecoderContext(metas, 1, torch.device(dev))      # host -> device copies of the camera matrices / time stamps: outside the capture
 def step():
-    cls, box = m(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    pyr = FeaturePyramid(list(feats))                  # the NCHW -> NHWC relayout stays inside (device work only)
+    cls, box = m.decoder.forward_differentiable(bbox, feat, list(feats), pyr, None, ctx)
     (cls.sum() + box.sum()).backward()
 def timeit(fn, n=10):
     for _ in range(3): fn()
@@ -28,11 +31,12 @@ def eager():
     for p in params: p.grad = None
     feat.grad = None
     step()
-print('eager train step %.2f ms' % timeit(eager))
-# capture
+# everything on ONE side stream from the first step on: the parameters' AccumulateGrad nodes remember the stream they were created
+# on, and a backward under capture that has to hop to another (non-capturing) stream ends the capture with a crash inside HIP
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
+    print('eager train step %.2f ms' % timeit(eager), flush=True)
     for _ in range(3):
         for p in params: p.grad = None
         feat.grad = None
@@ -42,13 +46,21 @@ g = torch.cuda.CUDAGraph()
 for p in params: p.grad = None
 feat.grad = None
 try:
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=s):
         step()
-    ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
-    print('graph replay train step %.2f ms' % timeit(g.replay))
+    gbuf = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}      # the graph's own gradient buffers (static memory)
+    gfeat = feat.grad
+    print('graph replay train step %.2f ms' % timeit(g.replay), flush=True)
     g.replay(); torch.cuda.synchronize()
+    got = {n: t.clone() for n, t in gbuf.items()}
+    got_feat = gfeat.clone()
     eager(); torch.cuda.synchronize()
-    worst = max((p.grad - ref[n]).abs().max().item() for n, p in m.named_parameters() if p.grad is not None and n in ref)
-    print('max |grad(graph) - grad(eager)| = %.3e over %d parameters' % (worst, len(ref)))
+    worst, scale = 0.0, 0.0
+    for n, p in m.named_parameters():
+        if p.grad is not None and n in got:
+            worst = max(worst, (p.grad - got[n]).abs().max().item())
+            scale = max(scale, p.grad.abs().max().item())
+    print('max |grad(graph) - grad(eager)| = %.3e (largest gradient entry %.3e) over %d parameters; query_feat grad diff %.3e'
+          % (worst, scale, len(got), (feat.grad - got_feat).abs().max().item()))
 except Exception as e:
     print('capture failed:', repr(e)[:500])

@@ -610,6 +610,19 @@ int sbev_refine_bbox_bwd(const float* grad_out, const float* out, const float* q
 /* y = x * keep / (1 - p), keep_i = hash(seed, i) >= p: the mmcv FFN dropouts; the backward is the same call on grad_y. */
 int sbev_dropout_f32(const float* x, float* y, int64_t n, uint64_t seed, float p, sbev_stream_t stream);
 
+/* The three dropout launches with a part of the seed in DEVICE memory (round 4): the keep decisions hash `seed + *seed_dev` (seed_dev
+ * null: `seed` alone, i.e. the calls above).  A training step captured as a hipGraph freezes every by-value argument, so the host
+ * seeds of its dropout sites stay what they were at capture; the word behind `seed_dev` is what the caller changes between replays
+ * (sparsebev_amd/train_graph.py refreshes it with one small launch before each replay).  Forward and backward of a site must see the
+ * same word: change it only between steps. */
+int sbev_sasa_train_fwd_f32_ds(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range, const uint8_t* mask,
+                               float* out, int B, int Q, int H, int head_dim, float attn_drop, uint64_t seed, const uint64_t* seed_dev,
+                               sbev_stream_t stream);
+int sbev_sasa_bwd_f32_ds(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range, const uint8_t* mask,
+                         const float* out, const float* grad_out, float* grad_qkvt, float* workspace, int B, int Q, int H, int head_dim,
+                         float attn_drop, uint64_t seed, const uint64_t* seed_dev, sbev_stream_t stream);
+int sbev_dropout_f32_ds(const float* x, float* y, int64_t n, uint64_t seed, const uint64_t* seed_dev, float p, sbev_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Whole-decoder runtime: ONE call enqueues every kernel of every layer (18 launches per layer) on `stream`.
  * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward

@@ -184,6 +184,11 @@ SIGNATURES = {
                                                _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp]),
     'sbev_refine_bbox_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_dropout_f32': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, _vp]),
+    'sbev_sasa_train_fwd_f32_ds': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double), _vp, _vp,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, _vp, _vp]),
+    'sbev_sasa_bwd_f32_ds': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp, _vp, _vp,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, _vp, _vp]),
+    'sbev_dropout_f32_ds': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_uint64, _vp, ctypes.c_float, _vp]),
 }
 
 _lib = None

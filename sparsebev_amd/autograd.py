@@ -504,6 +504,29 @@ class Linear3LnRelu(torch.autograd.Function):
         return gb, gw, db, dg, dbeta, None, tap.token_grad() if (tap is not None and tap.token is not None) else None
 
 
+# Dropout under graph capture: a captured training step freezes the host seeds of its dropout sites; with a device seed installed
+# (train_graph.CapturedTrainStep does it around its warm-up and capture) every dropout launch also adds the int64 word behind this
+# tensor, which the owner changes between replays.  None: the host seed alone (eager training, the reference-parity tests).
+_DEVICE_SEED = [None]
+
+
+class device_seed:
+    """``with device_seed(t):`` -- dropout launches issued inside hash ``seed + t[0]`` (t: one int64 element on the device, kept alive
+    by the autograd nodes that use it)."""
+
+    def __init__(self, t):
+        assert t is None or (t.is_cuda and t.dtype == torch.int64 and t.numel() == 1)
+        self.t = t
+
+    def __enter__(self):
+        self.prev, _DEVICE_SEED[0] = _DEVICE_SEED[0], self.t
+        return self.t
+
+    def __exit__(self, *exc):
+        _DEVICE_SEED[0] = self.prev
+        return False
+
+
 class SasaCore(torch.autograd.Function):
     """softmax(q k^T / sqrt(d) - dist * tau (+ DN mask)) v on the packed q | k | v | tau rows (attention.hip /
     attention_bwd.hip).  query_bbox only feeds the no-grad distance term (calc_bbox_dists is @torch.no_grad)."""
@@ -518,25 +541,27 @@ class SasaCore(torch.autograd.Function):
         att = torch.empty(B, Q, Dm, device=qkvt.device, dtype=torch.float32)
         pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
         lib = _lib.load()
+        ds = _DEVICE_SEED[0] if attn_drop > 0.0 else None
         if attn_drop > 0.0:
-            st = lib.sbev_sasa_train_fwd_f32(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), B, Q, num_heads, hd, float(attn_drop), int(seed), _stream())
+            st = lib.sbev_sasa_train_fwd_f32_ds(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), B, Q, num_heads, hd, float(attn_drop), int(seed),
+                                                _p(ds), _stream())
             _lib.check(st, 'sbev_sasa_train_fwd_f32')
         else:
             _lib.check(lib.sbev_sasa_f32(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), B, Q, num_heads, hd, _stream()), 'sbev_sasa_f32')
         ctx.save_for_backward(qkvt, bbox, mask, att)
-        ctx.cfg = (pc_range, num_heads, float(attn_drop), int(seed))
+        ctx.cfg = (pc_range, num_heads, float(attn_drop), int(seed), ds)
         return att
 
     @staticmethod
     def backward(ctx, gatt):
         qkvt, bbox, mask, att = ctx.saved_tensors
-        pc_range, H, p, seed = ctx.cfg
+        pc_range, H, p, seed, ds = ctx.cfg
         B, Q, ld = qkvt.shape
         gq = torch.empty_like(qkvt)
         ws = torch.empty(2 * B * H * Q, device=qkvt.device, dtype=torch.float32)
         pc = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
-        st = _lib.load().sbev_sasa_bwd_f32(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), _p(_c(gatt)), _p(gq), _p(ws), B, Q, H, 32,
-                                           p, seed, _stream())
+        st = _lib.load().sbev_sasa_bwd_f32_ds(_p(qkvt), ld, _p(bbox), pc, _p(mask), _p(att), _p(_c(gatt)), _p(gq), _p(ws), B, Q, H, 32,
+                                              p, seed, _p(ds), _stream())
         _lib.check(st, 'sbev_sasa_bwd_f32')
         return gq, None, None, None, None, None, None
 
@@ -764,16 +789,17 @@ class Dropout(torch.autograd.Function):
     def forward(ctx, x, p, seed):
         x = _c(x)
         y = torch.empty_like(x)
-        _lib.check(_lib.load().sbev_dropout_f32(_p(x), _p(y), x.numel(), int(seed), float(p), _stream()), 'sbev_dropout_f32')
-        ctx.cfg = (float(p), int(seed))
+        ds = _DEVICE_SEED[0]
+        _lib.check(_lib.load().sbev_dropout_f32_ds(_p(x), _p(y), x.numel(), int(seed), _p(ds), float(p), _stream()), 'sbev_dropout_f32')
+        ctx.cfg = (float(p), int(seed), ds)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        p, seed = ctx.cfg
+        p, seed, ds = ctx.cfg
         gy = _c(gy)
         gx = torch.empty_like(gy)
-        _lib.check(_lib.load().sbev_dropout_f32(_p(gy), _p(gx), gy.numel(), seed, p, _stream()), 'sbev_dropout_f32')
+        _lib.check(_lib.load().sbev_dropout_f32_ds(_p(gy), _p(gx), gy.numel(), seed, _p(ds), p, _stream()), 'sbev_dropout_f32')
         return gx, None, None
 
 

@@ -30,6 +30,7 @@ struct SasaBwdArgs {
     float scale;
     float p_drop, inv_keep;
     unsigned long long seed;
+    const unsigned long long* seed_dev;     // null, or a word of device memory ADDED to `seed` when the kernel runs (captured training steps)
 };
 
 __device__ __forceinline__ unsigned mix32(unsigned long long z) {
@@ -40,7 +41,7 @@ __device__ __forceinline__ unsigned mix32(unsigned long long z) {
 }
 __device__ __forceinline__ bool keep_of(const SasaBwdArgs& a, unsigned thr, int b, int h, int i, int j) {
     const unsigned long long idx = (((unsigned long long)b * a.H + h) * a.Q + i) * a.Q + j;
-    return mix32(a.seed * 0x100000001b3ull + idx) >= thr;
+    return mix32((a.seed + (a.seed_dev ? *a.seed_dev : 0ull)) * 0x100000001b3ull + idx) >= thr;
 }
 
 constexpr int NW = 4;              // waves per workgroup: wave w walks the key tiles w, w + 4, ...
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(64 * NW) void sasa_dropout_fwd_kernel(const SasaBwd
 }
 
 int fill(SasaBwdArgs& a, const float* qkvt, int64_t ld, const float* bbox, const double* pc_range, const uint8_t* mask,
-         int B, int Q, int H, int head_dim, float p_drop, uint64_t seed, const char* who) {
+         int B, int Q, int H, int head_dim, float p_drop, uint64_t seed, const uint64_t* seed_dev, const char* who) {
     SBEV_REQUIRE(B >= 0 && Q >= 0 && H >= 1, "%s: bad sizes", who);
     SBEV_REQUIRE(head_dim == HD, "%s: built for head_dim 32 (got %d)", who, head_dim);
     SBEV_REQUIRE(ld >= 3 * H * HD + H && ld % 4 == 0 && (((uintptr_t)qkvt) & 15) == 0, "%s: row stride %lld must be >= 3*H*32 + H and a multiple of 4, qkvt 16-byte aligned", who, (long long)ld);
@@ -160,6 +161,7 @@ int fill(SasaBwdArgs& a, const float* qkvt, int64_t ld, const float* bbox, const
     a.qkvt = qkvt; a.bbox = bbox; a.mask = mask;
     a.B = B; a.Q = Q; a.H = H; a.ld = (int)ld; a.scale = 1.0f / sqrtf((float)HD);
     a.p_drop = p_drop; a.inv_keep = 1.f / (1.f - p_drop); a.seed = seed;
+    a.seed_dev = reinterpret_cast<const unsigned long long*>(seed_dev);
     for (int i = 0; i < 2; ++i) {
         a.lo[i] = (float)pc_range[i];
         a.span[i] = (float)(pc_range[3 + i] - pc_range[i]);
@@ -172,8 +174,14 @@ int fill(SasaBwdArgs& a, const float* qkvt, int64_t ld, const float* bbox, const
 extern "C" int sbev_sasa_train_fwd_f32(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
                                        const uint8_t* mask, float* out, int B, int Q, int H, int head_dim,
                                        float attn_drop, uint64_t seed, sbev_stream_t stream) {
+    return sbev_sasa_train_fwd_f32_ds(qkvt, ld, query_bbox, pc_range, mask, out, B, Q, H, head_dim, attn_drop, seed, nullptr, stream);
+}
+
+extern "C" int sbev_sasa_train_fwd_f32_ds(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                                          const uint8_t* mask, float* out, int B, int Q, int H, int head_dim,
+                                          float attn_drop, uint64_t seed, const uint64_t* seed_dev, sbev_stream_t stream) {
     SasaBwdArgs a{};
-    int st = fill(a, qkvt, ld, query_bbox, pc_range, mask, B, Q, H, head_dim, attn_drop, seed, "sbev_sasa_train_fwd_f32");
+    int st = fill(a, qkvt, ld, query_bbox, pc_range, mask, B, Q, H, head_dim, attn_drop, seed, seed_dev, "sbev_sasa_train_fwd_f32");
     if (st != SBEV_OK) return st;
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(qkvt && query_bbox && pc_range && out, "sbev_sasa_train_fwd_f32: null pointer");
@@ -187,13 +195,21 @@ extern "C" int sbev_sasa_bwd_f32(const float* qkvt, int64_t ld, const float* que
                                  const uint8_t* mask, const float* out, const float* grad_out, float* grad_qkvt,
                                  float* workspace, int B, int Q, int H, int head_dim, float attn_drop, uint64_t seed,
                                  sbev_stream_t stream) {
+    return sbev_sasa_bwd_f32_ds(qkvt, ld, query_bbox, pc_range, mask, out, grad_out, grad_qkvt, workspace, B, Q, H, head_dim, attn_drop, seed,
+                                nullptr, stream);
+}
+
+extern "C" int sbev_sasa_bwd_f32_ds(const float* qkvt, int64_t ld, const float* query_bbox, const double* pc_range,
+                                    const uint8_t* mask, const float* out, const float* grad_out, float* grad_qkvt,
+                                    float* workspace, int B, int Q, int H, int head_dim, float attn_drop, uint64_t seed,
+                                    const uint64_t* seed_dev, sbev_stream_t stream) {
     SasaBwdArgs a{};
-    int st = fill(a, qkvt, ld, query_bbox, pc_range, mask, B, Q, H, head_dim, attn_drop, seed, "sbev_sasa_bwd_f32");
+    int st = fill(a, qkvt, ld, query_bbox, pc_range, mask, B, Q, H, head_dim, attn_drop, seed, seed_dev, "sbev_sasa_bwd_f32");
     if (st != SBEV_OK) return st;
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(qkvt && query_bbox && pc_range && out && grad_out && grad_qkvt && workspace, "sbev_sasa_bwd_f32: null pointer");
     float* lse = workspace;                              // [B, H, Q]
     float* dvec = workspace + (long long)B * H * Q;      // [B, H, Q]
     return sbev::launch_sasa_bwd_mfma(qkvt, ld, query_bbox, a.lo, a.span, mask, out, grad_out, grad_qkvt, lse, dvec, B, Q, H,
-                                      a.scale, attn_drop, seed, reinterpret_cast<hipStream_t>(stream));
+                                      a.scale, attn_drop, seed, seed_dev, reinterpret_cast<hipStream_t>(stream));
 }

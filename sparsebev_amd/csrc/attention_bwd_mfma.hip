@@ -33,6 +33,7 @@ struct Args {
     int B, Q, H, ld;
     float scale, p_drop, inv_keep;
     unsigned long long seed;
+    const unsigned long long* seed_dev;     // null, or a device word added to `seed` at run time (attention_bwd.hip)
 };
 
 #define SBEV_DPP(v, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), ctrl, 0xf, 0xf, true))
@@ -61,7 +62,7 @@ __device__ __forceinline__ unsigned mix32(unsigned long long z) {
 }
 __device__ __forceinline__ bool keep_of(const Args& a, unsigned thr, int b, int h, int i, int j) {
     const unsigned long long idx = (((unsigned long long)b * a.H + h) * a.Q + i) * a.Q + j;
-    return mix32(a.seed * 0x100000001b3ull + idx) >= thr;
+    return mix32((a.seed + (a.seed_dev ? *a.seed_dev : 0ull)) * 0x100000001b3ull + idx) >= thr;
 }
 
 // stage 64 rows x 32 floats of `src` (row r at src + rows[r] * ld) into tile[64][LDT], scaled; 64 lanes, one row each
@@ -452,10 +453,11 @@ namespace sbev {
 // called by sbev_sasa_bwd_f32 (attention_bwd.hip) after argument validation
 int launch_sasa_bwd_mfma(const float* qkvt, int64_t ld, const float* bbox, const float* lo, const float* span, const uint8_t* mask,
                          const float* out, const float* grad_out, float* grad_qkvt, float* lse, float* dvec,
-                         int B, int Q, int H, float scale, float p_drop, uint64_t seed, hipStream_t s) {
+                         int B, int Q, int H, float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, hipStream_t s) {
     sbev_attn_bwd::Args a{};
     a.qkvt = qkvt; a.bbox = bbox; a.mask = mask; a.O = out; a.dO = grad_out; a.dqkvt = grad_qkvt; a.lse = lse; a.dvec = dvec;
     a.B = B; a.Q = Q; a.H = H; a.ld = (int)ld; a.scale = scale; a.p_drop = p_drop; a.inv_keep = 1.f / (1.f - p_drop); a.seed = seed;
+    a.seed_dev = reinterpret_cast<const unsigned long long*>(seed_dev);
     for (int i = 0; i < 2; ++i) { a.lo[i] = lo[i]; a.span[i] = span[i]; }
     const bool drop = p_drop > 0.f;
     if (mask) return drop ? sbev_attn_bwd::launch_both<true, true>(a, s) : sbev_attn_bwd::launch_both<true, false>(a, s);

@@ -574,10 +574,11 @@ __device__ __forceinline__ unsigned mix32(unsigned long long z) {       // split
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
-                                                      unsigned long long seed, float p, float scale) {
+                                                      unsigned long long seed, const unsigned long long* seed_dev, float p, float scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned thr = (unsigned)((double)p * 4294967296.0);
+    if (seed_dev) seed += *seed_dev;        // captured training steps: the part of the seed that changes from replay to replay
     y[i] = mix32(seed * 0x100000001b3ull + (unsigned long long)i) >= thr ? x[i] * scale : 0.f;
 }
 
@@ -772,10 +773,14 @@ extern "C" int sbev_sampling_front_bwd(const float* query_bbox, const float* off
 }
 
 extern "C" int sbev_dropout_f32(const float* x, float* y, int64_t n, uint64_t seed, float p, sbev_stream_t stream) {
+    return sbev_dropout_f32_ds(x, y, n, seed, nullptr, p, stream);
+}
+
+extern "C" int sbev_dropout_f32_ds(const float* x, float* y, int64_t n, uint64_t seed, const uint64_t* seed_dev, float p, sbev_stream_t stream) {
     SBEV_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, "sbev_dropout_f32: need 0 <= p < 1");
     if (n == 0) return SBEV_OK;
     SBEV_REQUIRE(x && y, "sbev_dropout_f32: null pointer");
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y,
-                       (long long)n, (unsigned long long)seed, p, 1.f / (1.f - p));
+                       (long long)n, (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(seed_dev), p, 1.f / (1.f - p));
     return sbev::check_launch("sbev_dropout_f32");
 }

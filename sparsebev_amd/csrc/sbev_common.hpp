@@ -89,7 +89,7 @@ bool ln_linear_fusable(int64_t M, int N, int K);
 // attention_bwd_mfma.hip: the MFMA flash backward behind sbev_sasa_bwd_f32 (lse / dvec: [B, H, Q] scratch each)
 int launch_sasa_bwd_mfma(const float* qkvt, int64_t ld, const float* bbox, const float* lo, const float* span, const uint8_t* mask,
                          const float* out, const float* grad_out, float* grad_qkvt, float* lse, float* dvec,
-                         int B, int Q, int H, float scale, float p_drop, uint64_t seed, hipStream_t s);
+                         int B, int Q, int H, float scale, float p_drop, uint64_t seed, const uint64_t* seed_dev, hipStream_t s);
 
 // optional HIP-event bracket around sampler launches (decoder.hip; switched by sbev_profile_sampler)
 bool profile_begin(hipStream_t s, hipEvent_t* e0, hipEvent_t* e1, int kind = 0);

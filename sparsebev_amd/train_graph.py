@@ -10,8 +10,10 @@ step's.  This is torch.cuda.graphs' whole-network recipe; what this module adds 
   * everything -- warm-up, capture, replay -- runs on ONE side stream: the parameters' AccumulateGrad nodes remember the stream they
     were created on, and a backward under capture that has to hop to another, non-capturing stream does not end with an error but
     with a crash inside hipStreamEndCapture; the warm-up watches for torch's stream-mismatch warning and refuses to capture instead;
-  * dropout must be off: the differentiable path draws its dropout seed on the host per call, a captured step would replay ONE mask
-    for ever (eval() mode with grad enabled -- fine-tuning -- runs without dropout, or set ``attn_drop`` / ``ffn_drop`` to 0).
+  * dropout: the differentiable path draws one host seed per layer call, which a capture freezes -- so with dropout on, the step is
+    captured with a DEVICE seed installed (autograd.device_seed): every dropout launch hashes host seed + one int64 word in device
+    memory, and ``replay`` draws a new word (one small torch launch, torch's CUDA generator) before it replays the graph.  Forward and
+    backward of a step see the same word.
 
 Inputs are STATIC tensors: write the next batch into them with ``copy_()`` (the features, the queries), pass the next ``img_metas`` to
 ``replay``.  Gradients land in the same ``.grad`` tensors every replay and OVERWRITE them (they were ``None`` at capture): run the
@@ -24,9 +26,9 @@ import warnings
 
 import torch
 
+from . import autograd as AG
 from .transformer import DecoderContext, FeaturePyramid, _upload
 from .utils import VERSION
-
 
 class CapturedTrainStep:
     """``step = CapturedTrainStep(model, query_bbox, query_feat, mlvl_feats, img_metas, loss_fn)`` captures
@@ -41,9 +43,7 @@ class CapturedTrainStep:
         self.model = model
         self.decoder = dec = model.decoder if hasattr(model, 'decoder') else model
         layer = dec.decoder_layer
-        if dec.training and (layer.self_attn.attn_drop > 0 or layer.ffn_drop > 0):
-            raise ValueError('CapturedTrainStep: dropout is on -- its seed is drawn on the host per call, a captured step would replay one '
-                             'mask; use eval() (grad stays enabled) or set decoder_layer.self_attn.attn_drop = decoder_layer.ffn_drop = 0')
+        self.dropout = bool(dec.training and (layer.self_attn.attn_drop > 0 or layer.ffn_drop > 0))
         if not (query_bbox.is_cuda and query_bbox.dtype == torch.float32 and query_bbox.is_contiguous()
                 and query_feat.dtype == torch.float32 and query_feat.is_contiguous()):
             raise ValueError('CapturedTrainStep: query_bbox / query_feat must be contiguous fp32 CUDA tensors (they are read in place)')
@@ -53,6 +53,8 @@ class CapturedTrainStep:
         self.B = query_bbox.shape[0]
         self.device = query_bbox.device
         self.ctx = DecoderContext(img_metas, self.B, self.device)          # host -> device: outside the graph
+        # the part of the dropout seeds that changes from replay to replay (see the module text); None without dropout
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device).random_() if self.dropout else None
         self._leaves = [p for p in dec.parameters() if p.requires_grad]
         self._leaves += [t for t in [query_feat, query_bbox] + self.mlvl_feats if t.requires_grad]
         self.stream = torch.cuda.Stream(device=self.device)
@@ -82,6 +84,10 @@ class CapturedTrainStep:
             t.grad = None
 
     def _step(self):
+        with AG.device_seed(self.seed_dev):
+            return self._run()
+
+    def _run(self):
         dec = self.decoder
         pyr = FeaturePyramid(list(self.mlvl_feats))          # the NCHW -> NHWC relayout: device work, part of the step
         cls, box = dec.forward_differentiable(self.query_bbox, self.query_feat, list(self.mlvl_feats), pyr, self.attn_mask, self.ctx)
@@ -91,14 +97,17 @@ class CapturedTrainStep:
         loss.backward()
         return loss.detach(), cls.detach(), box.detach()
 
-    def replay(self, img_metas=None):
+    def replay(self, img_metas=None, new_masks=True):
         """Run the captured step on the current contents of the static inputs; ``img_metas`` (same batch size, frame and camera
-        counts) refreshes the camera matrices / time stamps first.  Returns the graph's own (loss, cls_scores, bbox_preds) tensors --
-        clone what has to survive the next replay."""
+        counts) refreshes the camera matrices / time stamps first; with dropout on, new masks are drawn unless ``new_masks=False``
+        (``seed_dev`` may also be set by hand).  Returns the graph's own (loss, cls_scores, bbox_preds) tensors -- clone what has to
+        survive the next replay."""
         if img_metas is not None:
             packed, layout, image_h, image_w = DecoderContext.pack(img_metas, self.B)
             if layout != self.ctx.layout or (image_h, image_w) != (self.ctx.image_h, self.ctx.image_w):
                 raise ValueError('CapturedTrainStep.replay: img_metas with another shape than the captured step (frames, cameras, image size)')
             _upload(packed, self.device, out=self.ctx.buffer)          # in place: the graph reads this buffer
+        if self.seed_dev is not None and new_masks:
+            self.seed_dev.random_()
         self.graph.replay()
         return self.loss, self.cls_scores, self.bbox_preds

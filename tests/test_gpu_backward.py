@@ -577,14 +577,47 @@ def test_captured_training_step_replays_with_new_data_and_equals_the_eager_step(
     assert g1['decoder_layer.ffn.layers.1.weight'].abs().max() > 0 and rel(qa, qb) > 0.1
 
 
-def test_captured_training_step_refuses_dropout():
+@torch.enable_grad()
+def test_captured_training_step_with_dropout_draws_new_masks_per_replay_and_equals_eager_for_the_same_seeds():
+    """train() mode, mmcv's dropouts (0.1) on: the captured step hashes host seed (frozen at capture) + a device word that ``replay``
+    re-draws -- two replays differ, a replay with the same word repeats bit for bit, and an eager step with the same host seeds (same
+    CPU generator state) and the same device word gives the same loss and gradients."""
     from sparsebev_amd.train_graph import CapturedTrainStep
+    B, Q, T, layers = 1, 100, 2, 2
     ih, iw, sizes = S.PYRAMIDS['tiny']
-    model = build(2, len(sizes), 78, 1).train()          # mmcv's dropouts (0.1) are on in train() mode
-    feats = [f.to(DEV) for f in S.make_features(1, 2, sizes, seed=3)]
-    bbox, feat = [t.to(DEV) for t in S.make_queries(1, 49, seed=4)]
-    with torch.enable_grad(), pytest.raises(ValueError, match='dropout'):
-        CapturedTrainStep(model, bbox, feat.requires_grad_(True), feats, S.make_img_metas(1, 2, ih, iw), lambda c, b: c.sum())
+    model = build(T, len(sizes), 79, layers).train()
+    assert model.decoder.decoder_layer.self_attn.attn_drop > 0 and model.decoder.decoder_layer.ffn_drop > 0
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=3)]
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=4)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    loss_fn = lambda cls, box: cls.sum() + box.sum()
+    torch.manual_seed(7)
+    sq = feat.clone().requires_grad_(True)
+    step = CapturedTrainStep(model, bbox, sq, feats, metas, loss_fn, warmup=1)
+    assert step.dropout and step.seed_dev is not None
+    l1 = step.replay()[0].clone()
+    w1 = step.seed_dev.clone()
+    l2 = step.replay()[0].clone()
+    assert not torch.equal(step.seed_dev, w1) and abs(l1.item() - l2.item()) > 1e-6 * abs(l1.item())
+    step.seed_dev.copy_(w1)
+    l1b = step.replay(new_masks=False)[0].clone()
+    assert torch.equal(l1, l1b)
+    g1 = {n: t.clone() for n, t in step.grads.items()}
+    del step
+    # eager: the capture was the second step after manual_seed(7) (one warm-up step = `layers` draws of a host seed before it)
+    torch.manual_seed(7)
+    for _ in range(layers):
+        torch.randint(0, 2 ** 62, (1,))
+    for p in model.parameters():
+        p.grad = None
+    eq = feat.clone().requires_grad_(True)
+    with AG.device_seed(w1):
+        ecls, ebox = model(bbox, eq, list(feats), None, copy.deepcopy(metas))
+        eloss = loss_fn(ecls, ebox)
+        eloss.backward()
+    assert rel(l1, eloss) < 1e-6
+    for n, p in model.decoder.named_parameters():
+        assert rel(g1[n], p.grad) < 1e-5, n
 
 
 @torch.enable_grad()

@@ -29,7 +29,7 @@ python $R/bench.py --nhwc $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_nhwc.
 python $R/bench.py --online $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_online.json; cut -c1-200 $OUT/bench_online.json
 SBEV_NO_SAMPLE_MIX=1 python $R/bench.py $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_unfused.json; cut -c1-200 $OUT/bench_unfused.json
 for i in 1 2 3; do python $R/tools/bench_train.py --graph 2>&1 | tail -1 >> $OUT/train.log; done; tail -3 $OUT/train.log
-python $R/tools/bench_train.py --feat-grad --dropout >> $OUT/train.log 2>&1; tail -1 $OUT/train.log
+python $R/tools/bench_train.py --graph --feat-grad --dropout >> $OUT/train.log 2>&1; tail -1 $OUT/train.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -o train -- python $R/tools/bench_train.py --steps 5 > $OUT/kt_train.log 2>&1
 find $OUT -name "*kernel_stats.csv"
 rm -f $(find $OUT -name "*kernel_trace.csv") $(find $OUT -name "*agent_info.csv")

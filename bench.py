@@ -339,6 +339,9 @@ def main():
     ap.add_argument('--no-detector', action='store_true', help='skip the labelled detector-level stand-in figure (default N=1 c2 run reports it)')
     ap.add_argument('--detector', action='store_true', help='force the detector figure for other configs too: also report a LABELLED detector-level samples/s: stock-PyTorch ResNet-50 + FPN stand-in (tools/backbone_standin.py, fp16) on the 6 new images -> frame ring -> SparseBEVHead -> NMS-free decode (online mode, like the reference FPS)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
+    ap.add_argument('--query-order', type=int, default=None, choices=(0, 1),
+                    help='fused gather + mixing items in the order of sbev_query_order (1) or in launch order (0); default: the library setting (SBEV_QUERY_ORDER). Results are bit-identical')
+    ap.add_argument('--shuffle-queries', action='store_true', help='permute the query rows (a trained head does not keep the BEV raster order of its initialisation): robustness A/B for --query-order')
     ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
     ap.add_argument('--gemm', default=DEFAULT_GEMM, choices=sorted(runtime.GEMM_MODES),
                     help='the two big mixing GEMMs: f16x3 = fp32-class scaled fp16 hi + lo split, 3 products (default); f32 = exact f32-input MFMA; '
@@ -365,8 +368,13 @@ def main():
         args.nhwc = True
         feats = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
     bbox, qfeat = S.make_queries(B, Q, seed=rank)
+    if args.shuffle_queries:
+        perm = torch.randperm(Q, generator=torch.Generator().manual_seed(1234))
+        bbox, qfeat = bbox[:, perm].contiguous(), qfeat[:, perm].contiguous()
     bbox, qfeat = bbox.to(device), qfeat.to(device)
     metas = S.make_img_metas(B, T, ih, iw)
+    if args.query_order is not None:
+        runtime.query_order(bool(args.query_order))
 
     if args.online:
         from sparsebev_amd.cache import FrameFeatureCache
@@ -544,6 +552,7 @@ def main():
                                    '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
                        'launches_per_layer': launches_per_layer, 'step_graph': graph_info,
+                       'query_order': bool(runtime._STATE['order']), 'shuffled_queries': bool(args.shuffle_queries),
                        'checksum': checksum_sum},
             # per-rank spread (weak scaling: every rank runs the same per-GPU batch): slowest / fastest rank's own rate
             'per_rank_samples_per_s': {'min': round(args.steps * B / elapsed_max, 3), 'max': round(args.steps * B / elapsed_min, 3)},

@@ -492,6 +492,35 @@ int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, int L, int 
 /* sbev_decoder_forward uses the fused launch where supported (default 1); 0 restores sampler + mixing as two launches. */
 int sbev_decoder_fuse_sample_mix(int enable);
 
+/*
+ * Launch order of the fused gather + mixing items (round 4).  The gather's fabric traffic is set by WHICH items share an XCD's
+ * private L2 and WHEN they run: in launch order (block b = item (row b / G, group b % G) on XCD b % 8) every group is split
+ * over two XCDs by row parity and both fetch the whole group's coarse levels, and rows far apart on the BEV grid evict each
+ * other's lines (tools/sampler_footprint.py: 172 MB of fabric reads per launch at config 2 against 124 MB of distinct tap
+ * segments; 800 against 503 MB at the 1600-query config).  sbev_query_order sorts each sample's rows by the direction of the
+ * box centre around the ego origin -- order [B*Q] int32, sample b's rows b*Q + q in slots [b*Q, (b+1)*Q), one workgroup per
+ * sample, Q <= sbev_query_order_max() -- and sbev_sample_mix_*_ordered walk the GROUP-major list (g, position) in eight
+ * contiguous pieces, one per XCD: one group and one arc of the camera ring per L2.  A placement hint only: results are
+ * bit-identical for ANY permutation (order = NULL: launch order).  query_bbox rows: ld floats apart, columns 0, 1 = normalised
+ * centre (decode_bbox, models/bbox/utils.py:69-70; the reference has no counterpart: its CUDA op takes the launch order).
+ * sbev_decoder_forward sorts every layer's input boxes on its side stream beside the self attention when
+ * sbev_decoder_query_order(1) (env SBEV_QUERY_ORDER; returns the previous setting) and the fused launch is in use.
+ */
+int sbev_query_order_max(void);
+int sbev_query_order(const float* query_bbox, int64_t ld, const double* pc_range, int B, int Q, int32_t* order, sbev_stream_t stream);
+int sbev_sample_mix_f32_ordered(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                int64_t B, int N, int Q, int T, int G, int P, int C,
+                                const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                const float* params, float* y, int Pout, float eps, const int32_t* order, sbev_stream_t stream);
+int sbev_sample_mix_pairs_f16_ordered(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                      int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                                      const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                      const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                      const float* params, void* y, int Pout, float eps, int up_log2, const int32_t* order,
+                                      sbev_stream_t stream);
+int sbev_decoder_query_order(int enable);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Training: backward passes of the decoder layer.
  * Replaces: torch autograd through SparseBEVTransformerDecoderLayer.forward and the activation-checkpointed

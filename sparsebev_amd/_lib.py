@@ -142,6 +142,17 @@ SIGNATURES = {
                                                  _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,
                                                  _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     'sbev_decoder_fuse_sample_mix': (ctypes.c_int, [ctypes.c_int]),
+    'sbev_query_order_max': (ctypes.c_int, []),
+    'sbev_query_order': (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'sbev_sample_mix_f32_ordered': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,
+                                                   _vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp]),
+    'sbev_sample_mix_pairs_f16_ordered': (ctypes.c_int, [ctypes.POINTER(_vp), _c_i32p, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         _c_i64p, ctypes.c_int64, _c_i64p, ctypes.c_int64, _vp, _vp, _c_i32p, ctypes.c_int,
+                                                         _vp, _vp, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp, _vp]),
+    'sbev_decoder_query_order': (ctypes.c_int, [ctypes.c_int]),
     'sbev_decoder_chain_pack_floats': (ctypes.c_int64, [_vp]),
     'sbev_decoder_chain_pack': (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     'sbev_decoder_row_chain': (ctypes.c_int, [ctypes.c_int]),

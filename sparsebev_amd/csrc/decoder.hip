@@ -31,6 +31,7 @@ struct Buffers {
     float *t0, *t1, *x, *x1, *x2, *x3, *qkvt, *att, *so, *wbp, *loc, *sampled, *params, *mixed, *slabs,
         *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc, *pair_x;
     uint32_t* pair_sync;
+    int32_t* order;
     size_t bytes;
 };
 
@@ -68,6 +69,7 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.xsc = k.take(64);                            // fp16 modes: {2^e, 2^-e} of x1 (written by the pack launch of every layer)
     b.pair_x = k.take((size_t)sbev::chain_pair_floats((long long)BQ));                   // tail chain in pair mode (row_chain.hip): exchange rows
     b.pair_sync = reinterpret_cast<uint32_t*>(k.take((size_t)sbev::chain_pair_sync_words((long long)BQ)));      // ... and arrival counters
+    b.order = reinterpret_cast<int32_t*>(k.take(BQ));                                    // launch order of the gather items (sbev_query_order)
     b.bytes = k.off;
     return b;
 }
@@ -79,6 +81,11 @@ std::atomic<int> g_fuse_sample_mix{1};
 // kept the two launches; with the lean chunk code (msmv_chunk.inc, round 3) it fits 168 without a spill.  SBEV_NO_FUSE_L5F32=1
 // restores the two launches (A/B).
 std::atomic<int> g_fuse_l5_f32{getenv("SBEV_NO_FUSE_L5F32") ? 0 : 1};
+
+// the fused gather + mixing launch walks its items in the order of sbev_query_order (one group and one arc of the camera ring per XCD:
+// 16-27 % fewer fabric reads for the gather -- tools/sampler_footprint.py); the sort of a layer's boxes runs on
+// the side stream beside the self attention.  sbev_decoder_query_order(0) / SBEV_QUERY_ORDER=0 restores the launch order (bit-identical).
+std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? atoi(getenv("SBEV_QUERY_ORDER")) : 0};
 
 // the row-local op chains of a layer as three launches (row_chain.hip) when the caller supplied packed weights
 // (sbev_decoder_weights.chain_pack); sbev_decoder_row_chain(0) restores the op-by-op launches (A/B measurements)
@@ -170,7 +177,8 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
     // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
     // op by op: 17 with the fused gather + mixing
-    return (chain ? 6 : 17) + (fused ? 0 : 1) + split;
+    const bool ordered = chain && fused && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
+    return (chain ? 6 : 17) + (fused ? 0 : 1) + split + (ordered ? 1 : 0);
 }
 
 // fp16 modes: the out-projection's input -- relu(LayerNorm without affine over n = out_points * C / G elements), so |x| <= sqrt(n - 1)
@@ -266,12 +274,13 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
 
     // the mixing launches: in the fp16 GEMM modes their epilogue leaves `mixed` as (fp16 hi, fp16 lo) pairs of mixed 2^mixed_up -- the
     // out-projection's operand, split once per element where the VALU is idle instead of inside the GEMM
-    auto mix_fused = [&](sbev_stream_t st) -> int {
+    auto mix_fused = [&](sbev_stream_t st, const int32_t* order = nullptr) -> int {
         if (nimg >= 4)
-            return sbev_sample_mix_pairs_f16(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
-                                             c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, mixed_up, st);
-        return sbev_sample_mix_f32(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
-                                   c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, st);
+            return sbev_sample_mix_pairs_f16_ordered(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
+                                                     c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, mixed_up,
+                                                     order, st);
+        return sbev_sample_mix_f32_ordered(feats_nhwc, hw, c.L, c.feat_dtype, c.B, c.N, c.Q, c.T, c.G, c.P, Cg, sbo, Cg, sv, D, b.loc, b.wbp,
+                                           c.n_slots > 0 ? c.frame_slots : nullptr, c.n_slots, b.params, b.mixed, c.out_points, eps, order, st);
     };
     auto mix_plain = [&](sbev_stream_t st) -> int {
         if (nimg >= 4) return sbev_adaptive_mixing_pairs_f16(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, mixed_up, st);
@@ -290,6 +299,20 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         float* cls_l = cls_out + (int64_t)layer * BQ * c.num_classes;
         float* box_l = bbox_out + (int64_t)layer * BQ * c.code_size;
         if (chain) {
+            const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
+                               sample_mix_fusable(c);
+            // launch order of this layer's gather items: sorted from the layer's input boxes on the side stream, beside the self attention
+            // (one workgroup per sample; the fused launch below joins it)
+            const bool ordered = fused && ax.ok && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
+            hipEvent_t ev_ord = nullptr;
+            if (ordered) {
+                hipEvent_t e = next_ev();
+                TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
+                TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
+                TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, reinterpret_cast<sbev_stream_t>(ax.stream)));
+                ev_ord = next_ev();
+                TRY(hip_ok(hipEventRecord(ev_ord, ax.stream), "hipEventRecord"));
+            }
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
@@ -300,10 +323,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                 TRY(generator_bf16x3(stream));
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
-            const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
-                               sample_mix_fusable(c);
             if (fused) {
-                TRY(mix_fused(stream));
+                if (ordered) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_ord, 0), "hipStreamWaitEvent"));
+                TRY(mix_fused(stream, ordered ? b.order : nullptr));
             } else {
                 if (c.n_slots > 0)
                     TRY(sbev_msmv_fwd_ring(feats_nhwc, hw, c.L, c.feat_dtype, (int64_t)c.B * c.T * c.G, c.N, Cg, c.Q, c.P,
@@ -514,6 +536,11 @@ extern "C" int sbev_decoder_row_chain(int enable) {
 extern "C" int sbev_decoder_fuse_sample_mix(int enable) {
     g_fuse_sample_mix.store(enable ? 1 : 0, std::memory_order_relaxed);
     return SBEV_OK;
+}
+
+// returns the previous setting
+extern "C" int sbev_decoder_query_order(int enable) {
+    return g_query_order.exchange(enable ? 1 : 0, std::memory_order_relaxed);
 }
 
 extern "C" int sbev_profile_sampler(int enable) {

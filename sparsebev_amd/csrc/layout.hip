@@ -126,6 +126,51 @@ __global__ __launch_bounds__(256) void copy_indirect_kernel(const CopySegs a) {
     }
 }
 
+
+// ---- launch order of the gather items (sbev_query_order) -------------------------------------------------------------------------
+// One workgroup per sample sorts its Q rows by the direction of the box centre around the ego origin (a bitonic network over
+// (key << 32 | row) words in LDS: a total order, hence always a permutation, NaN centres included).  The key is the "diamond angle" of
+// (x, y) -- monotone in atan2(y, x), no transcendental: queries that are neighbours in the order look into the same camera at nearby
+// columns, which is what the gather's L2 footprint follows (tools/sampler_footprint.py).
+constexpr int ORDER_MAX_Q = 4096, ORDER_THREADS = 1024;
+struct OrderArgs {
+    const float* bbox;     // [B, Q, ld]: columns 0, 1 = normalised centre
+    int* order;            // [B * Q]: sample b's rows b*Q + q in its slots [b*Q, (b+1)*Q)
+    int Q, ld, n2;         // n2 = power of two >= Q
+    float ox, oy, sx, sy;  // metres = c * s + o  (decode_bbox, models/bbox/utils.py:69-70)
+};
+__global__ __launch_bounds__(ORDER_THREADS) void query_order_kernel(const OrderArgs a) {
+    __shared__ unsigned long long keys[ORDER_MAX_Q];
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.x;
+    for (int i = tid; i < a.n2; i += ORDER_THREADS) {
+        unsigned long long k = ~0ull;                   // padding sorts last
+        if (i < a.Q) {
+            const float* r = a.bbox + (b * a.Q + i) * a.ld;
+            const float x = r[0] * a.sx + a.ox, y = r[1] * a.sy + a.oy;
+            const float n = fabsf(x) + fabsf(y);
+            const float d = n > 0.f ? x / n : 1.f;       // cos-like, in [-1, 1]
+            const float ang = y >= 0.f ? 1.f - d : 3.f + d;      // [0, 4): 0 = +x, 1 = +y, 2 = -x, 3 = -y
+            k = ((unsigned long long)__float_as_uint(ang) << 32) | (unsigned)i;     // ang >= 0: its bit pattern orders like the value
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= a.n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < a.n2; i += ORDER_THREADS) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long u = keys[i], v = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((u > v) == up) { keys[i] = v; keys[p] = u; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < a.Q; i += ORDER_THREADS) a.order[b * a.Q + i] = (int)(b * a.Q) + (int)(unsigned)(keys[i] & 0xffffffffull);
+}
+
 }  // namespace
 
 // The two staging launches of a replayable step (runtime.StepGraphs): their SOURCE pointer is table[index], read on the device when
@@ -225,4 +270,25 @@ extern "C" int sbev_copy_widen_f32(const void* src, int src_dtype, float* dst, i
     else if (src_dtype == 1) hipLaunchKernelGGL(copy_widen_kernel<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const unsigned short*>(src), dst, (long long)n);
     else hipLaunchKernelGGL(copy_widen_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const _Float16*>(src), dst, (long long)n);
     return sbev::check_launch("sbev_copy_widen_f32");
+}
+
+// order[b*Q + i] = the row (b*Q + q) that comes i-th when sample b's queries are sorted by the direction of their box centre around the
+// ego origin: the launch order sbev_sample_mix_*_ordered walks (one contiguous arc of the camera ring per XCD).  Purely a placement
+// hint -- any permutation gives bit-identical results.  Q <= sbev_query_order_max() (one workgroup sorts a sample in LDS).
+extern "C" int sbev_query_order_max(void) { return ORDER_MAX_Q; }
+
+extern "C" int sbev_query_order(const float* query_bbox, int64_t ld, const double* pc_range, int B, int Q, int32_t* order, sbev_stream_t stream) {
+    SBEV_REQUIRE(B >= 0 && Q >= 0 && ld >= 2, "sbev_query_order: bad sizes");
+    SBEV_REQUIRE(Q <= ORDER_MAX_Q, "sbev_query_order: at most %d queries per sample (got %d)", ORDER_MAX_Q, Q);
+    if (B == 0 || Q == 0) return SBEV_OK;
+    SBEV_REQUIRE(query_bbox && pc_range && order, "sbev_query_order: null pointer");
+    SBEV_REQUIRE((long long)B * Q <= 0x7fffffffLL, "sbev_query_order: too many rows");
+    OrderArgs a{};
+    a.bbox = query_bbox; a.order = order; a.Q = Q; a.ld = (int)ld;
+    a.n2 = 1;
+    while (a.n2 < Q) a.n2 <<= 1;
+    a.ox = (float)pc_range[0]; a.oy = (float)pc_range[1];
+    a.sx = (float)(pc_range[3] - pc_range[0]); a.sy = (float)(pc_range[4] - pc_range[1]);
+    hipLaunchKernelGGL(query_order_kernel, dim3((unsigned)B), dim3(ORDER_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_query_order");
 }

@@ -58,6 +58,10 @@ struct SampleMixArgs {
     int Pin;
     float eps;
     float out_up;
+    // launch order (sbev_query_order; null = block b is item b): XCD x = b % 8 walks entries [x * order_per, (x + 1) * order_per) of the
+    // GROUP-major list (g, position) and takes row order[position] -- one group and one contiguous arc of the camera ring per L2
+    const int* order;
+    int order_per;
     MsmvArgs s;           // sampler descriptors: s.loc [B*T*G, Q, P, 3], s.w [B*G*T, Q, P, L]; s.Q, s.T, s.G, s.P (== 4), s.N
 };
 template <int SL>
@@ -140,7 +144,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long item = blockIdx.x;
+    long long item = blockIdx.x;
+    if constexpr (L > 0) {
+        if (a.order) {
+            const unsigned m = (blockIdx.x & 7u) * (unsigned)a.order_per + (blockIdx.x >> 3);
+            if (m >= (unsigned)a.n_items) return;               // (the grid is 8 * order_per blocks; whole workgroups leave, before any barrier)
+            const unsigned rows = (unsigned)a.n_items / (unsigned)a.s.G;
+            const unsigned g = m / rows;
+            item = (long long)a.order[m - g * rows] * a.s.G + g;
+        }
+    }
     const float* xg = a.x + item * Pin * C;
     const float* pg = a.params + item * (C * C + POUT * Pin);
     const float* sg = pg + C * C;
@@ -451,7 +464,7 @@ int launch_sample_mix(const SampleMixArgs& a, hipStream_t s) {
     }
     hipEvent_t e0, e1;
     const bool prof = sbev::profile_begin(s, &e0, &e1, 3);
-    hipLaunchKernelGGL(k, dim3((unsigned)a.n_items), dim3(256), bytes, s, a);
+    hipLaunchKernelGGL(k, dim3(a.order ? 8u * (unsigned)a.order_per : (unsigned)a.n_items), dim3(256), bytes, s, a);
     if (prof) sbev::profile_end(s, e0, e1, 3);
     return sbev::check_launch("sbev_sample_mix_f32");
 }
@@ -525,7 +538,7 @@ static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, i
                            int64_t B, int N, int Q, int T, int G, int P, int Cg,
                            const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
                            const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
-                           const float* params, float* y, int Pout, float eps, float out_up, sbev_stream_t stream) {
+                           const float* params, float* y, int Pout, float eps, float out_up, const int32_t* order, sbev_stream_t stream) {
     SBEV_REQUIRE(feats && hw && stride_bo && stride_v, "sbev_sample_mix_f32: null descriptor array");
     SBEV_REQUIRE(sbev_sample_mix_supported(L, Cg, P, T, G, G), "sbev_sample_mix_f32: needs L in {4,5}, C = 64, P in {4,8}, T*P in 4..64 or 116..120 (got L=%d C=%d P=%d T=%d)", L, Cg, P, T);
     SBEV_REQUIRE(Pout == POUT, "sbev_sample_mix_f32: built for 128 out points");
@@ -537,6 +550,9 @@ static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, i
     SBEV_REQUIRE(B * Q * G <= 0x7fffffffLL && B * (int64_t)T * G * Q <= 0x7fffffffLL, "sbev_sample_mix_f32: too many items");
     SampleMixArgs a{};
     a.params = params; a.y = y; a.n_items = B * Q * G; a.Pin = T * P; a.eps = eps; a.out_up = out_up;
+    a.order = order;
+    a.order_per = (int)((a.n_items + 7) / 8);
+    SBEV_REQUIRE(!order || (((uintptr_t)order) & 3) == 0, "sbev_sample_mix_f32: order must be 4-byte aligned");
     MsmvArgs& m = a.s;
     for (int l = 0; l < L; ++l) {
         SBEV_REQUIRE(feats[l] != nullptr && hw[2 * l] >= 1 && hw[2 * l + 1] >= 1, "sbev_sample_mix_f32: level %d", l);
@@ -571,7 +587,18 @@ extern "C" int sbev_sample_mix_f32(const void* const* feats, const int32_t* hw, 
                                    const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
                                    const float* params, float* y, int Pout, float eps, sbev_stream_t stream) {
     return sample_mix_impl(feats, hw, L, feat_dtype, B, N, Q, T, G, P, Cg, stride_bo, stride_g, stride_v, stride_px, loc, weights, frame_slots, n_slots,
-                           params, y, Pout, eps, 0.f, stream);
+                           params, y, Pout, eps, 0.f, nullptr, stream);
+}
+
+// the same launch with its workgroups in the order of sbev_query_order (order [B*Q]: a permutation of the rows b*Q + q, each sample's
+// rows contiguous): results are bit-identical, only WHERE and WHEN an item runs changes (see SampleMixArgs::order); null = launch order
+extern "C" int sbev_sample_mix_f32_ordered(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                           int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                                           const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                           const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                           const float* params, float* y, int Pout, float eps, const int32_t* order, sbev_stream_t stream) {
+    return sample_mix_impl(feats, hw, L, feat_dtype, B, N, Q, T, G, P, Cg, stride_bo, stride_g, stride_v, stride_px, loc, weights, frame_slots, n_slots,
+                           params, y, Pout, eps, 0.f, order, stream);
 }
 
 // the same, y as (fp16 hi, fp16 lo) pairs of y 2^up_log2 (see sbev_adaptive_mixing_pairs_f16)
@@ -582,5 +609,16 @@ extern "C" int sbev_sample_mix_pairs_f16(const void* const* feats, const int32_t
                                          const float* params, void* y, int Pout, float eps, int up_log2, sbev_stream_t stream) {
     SBEV_REQUIRE(up_log2 >= -100 && up_log2 <= 100, "sbev_sample_mix_pairs_f16: up_log2=%d", up_log2);
     return sample_mix_impl(feats, hw, L, feat_dtype, B, N, Q, T, G, P, Cg, stride_bo, stride_g, stride_v, stride_px, loc, weights, frame_slots, n_slots,
-                           params, static_cast<float*>(y), Pout, eps, ldexpf(1.f, up_log2), stream);
+                           params, static_cast<float*>(y), Pout, eps, ldexpf(1.f, up_log2), nullptr, stream);
+}
+
+extern "C" int sbev_sample_mix_pairs_f16_ordered(const void* const* feats, const int32_t* hw, int L, int feat_dtype,
+                                                 int64_t B, int N, int Q, int T, int G, int P, int Cg,
+                                                 const int64_t* stride_bo, int64_t stride_g, const int64_t* stride_v, int64_t stride_px,
+                                                 const float* loc, const float* weights, const int32_t* frame_slots, int n_slots,
+                                                 const float* params, void* y, int Pout, float eps, int up_log2, const int32_t* order,
+                                                 sbev_stream_t stream) {
+    SBEV_REQUIRE(up_log2 >= -100 && up_log2 <= 100, "sbev_sample_mix_pairs_f16: up_log2=%d", up_log2);
+    return sample_mix_impl(feats, hw, L, feat_dtype, B, N, Q, T, G, P, Cg, stride_bo, stride_g, stride_v, stride_px, loc, weights, frame_slots, n_slots,
+                           params, static_cast<float*>(y), Pout, eps, ldexpf(1.f, up_log2), order, stream);
 }

@@ -259,10 +259,25 @@ def sample_mix_supported(L, C, P, T, G):
     return bool(_lib.load().sbev_sample_mix_supported(L, C, P, T, G, G))
 
 
-def sample_mix(levels, B, T, G, sampling_locations, scale_weights, params, out_points, frame_slots=None, n_slots=0):
+def query_order(query_bbox, pc_range):
+    """Launch order of the fused gather + mixing items (sbev_query_order): int32 [B*Q], sample b's rows b*Q + q sorted by the
+    direction of the box centre around the ego origin.  query_bbox [B, Q, >= 2] fp32 (columns 0, 1 = normalised centre)."""
+    _need_device(query_bbox)
+    if query_bbox.dim() != 3 or query_bbox.dtype != torch.float32 or query_bbox.shape[-1] < 2:
+        raise RuntimeError('query_order: query_bbox must be fp32 [B, Q, >= 2]')
+    qb = query_bbox.contiguous()
+    B, Q = qb.shape[:2]
+    order = torch.empty(B * Q, device=qb.device, dtype=torch.int32)
+    pcr = (ctypes.c_double * 6)(*[float(v) for v in pc_range])
+    _lib.check(_lib.load().sbev_query_order(_ptr(qb), qb.shape[-1], pcr, B, Q, _ptr(order), _stream()), 'sbev_query_order')
+    return order
+
+
+def sample_mix(levels, B, T, G, sampling_locations, scale_weights, params, out_points, frame_slots=None, n_slots=0, order=None):
     """Gather + adaptive mixing in one launch (sbev_sample_mix_f32): levels as for msmv_sampling_nhwc (or the ring's
     buffers with frame_slots / n_slots), params [B,Q,G*(C*C + out_points*T*P)] -> mixed [B,Q,G*out_points*C].
-    Bit-identical to msmv_sampling_nhwc(..., OUT_MIX) followed by the mixing kernel."""
+    Bit-identical to msmv_sampling_nhwc(..., OUT_MIX) followed by the mixing kernel.  order (query_order(); any permutation of
+    the B*Q rows as int32): the workgroups' launch order -- a placement hint, the result does not depend on it."""
     feats = list(levels)
     _need_device(sampling_locations, scale_weights, params, *feats)
     _no_grad_only(sampling_locations, scale_weights, params, *feats)
@@ -283,9 +298,13 @@ def sample_mix(levels, B, T, G, sampling_locations, scale_weights, params, out_p
     c_sbo = (ctypes.c_int64 * L)(*[N * h * w * GC for h, w in hw])
     c_sv = (ctypes.c_int64 * L)(*[h * w * GC for h, w in hw])
     c_slots = (ctypes.c_int32 * T)(*[int(v) for v in frame_slots]) if frame_slots is not None else None
-    st = _lib.load().sbev_sample_mix_f32(c_feats, c_hw, L, _feat_dtype(feats), B, N, Q, T, G, P, C, c_sbo, C, c_sv, GC,
-                                         _ptr(sampling_locations.contiguous()), _ptr(scale_weights.contiguous()), c_slots, n_slots,
-                                         _ptr(params), _ptr(y), out_points, 1e-5, _stream())
+    if order is not None:
+        _need_device(order)
+        if order.dtype != torch.int32 or order.numel() != B * Q or not order.is_contiguous():
+            raise RuntimeError('sample_mix: order must be a contiguous int32 permutation of the B*Q rows')
+    st = _lib.load().sbev_sample_mix_f32_ordered(c_feats, c_hw, L, _feat_dtype(feats), B, N, Q, T, G, P, C, c_sbo, C, c_sv, GC,
+                                                 _ptr(sampling_locations.contiguous()), _ptr(scale_weights.contiguous()), c_slots, n_slots,
+                                                 _ptr(params), _ptr(y), out_points, 1e-5, _ptr(order) if order is not None else None, _stream())
     _lib.check(st, 'sbev_sample_mix_f32')
     return y
 

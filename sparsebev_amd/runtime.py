@@ -376,7 +376,7 @@ class StepGraphs:
         sig = rt._ensure_bound()
         fkey, ident, staged = self._feat_key(mlvl_feats)
         key = (tuple(query_bbox.shape), tuple(query_feat.shape), fkey, None if attn_mask is None else tuple(attn_mask.shape), sig,
-               torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _lib.load().sbev_get_box_convention(),
+               torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _STATE['order'], _lib.load().sbev_get_box_convention(),
                rt.decoder.num_layers, tuple(rt.decoder.pc_range))
         e = self.entries.get(key, False)
         if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
@@ -529,7 +529,16 @@ class DecoderGraph:
 
 # process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
 import os as _os
-_STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0}
+_STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0,
+          'order': int(_os.environ.get('SBEV_QUERY_ORDER', '0') or 0) != 0}
+
+
+def query_order(enable):
+    """The fused gather + mixing launch walks its items in sbev_query_order's order (one group and one arc of the camera ring per
+    XCD); False restores the launch order.  Bit-identical results either way.  Returns the previous setting."""
+    prev = bool(_lib.load().sbev_decoder_query_order(int(bool(enable))))
+    _STATE['order'] = bool(enable)
+    return prev
 
 
 def fuse_sample_mix(enable):

@@ -159,6 +159,20 @@ def test_round2_entry_points_validate_without_gpu(lib):
     assert lib.sbev_copy_widen_f32(one, 3, one, 4, None) == -1
 
 
+def test_query_order_entry_points_validate_without_gpu(lib):
+    """round 4: the launch-order sort and switch (sbev_query_order, sbev_decoder_query_order) check their arguments before any HIP call"""
+    one = ctypes.c_void_p(16)
+    pc = (ctypes.c_double * 6)(-51.2, -51.2, -5, 51.2, 51.2, 3)
+    assert lib.sbev_query_order_max() == 4096
+    assert lib.sbev_query_order(None, 10, pc, 0, 900, None, None) == 0 and lib.sbev_query_order(None, 10, pc, 2, 0, None, None) == 0      # empty
+    assert lib.sbev_query_order(one, 10, pc, 1, 4097, one, None) == -1 and b'at most 4096' in lib.sbev_last_error()
+    assert lib.sbev_query_order(one, 1, pc, 1, 8, one, None) == -1          # a row holds at least the two centre columns
+    assert lib.sbev_query_order(None, 10, pc, 1, 8, one, None) == -1 and lib.sbev_query_order(one, 10, None, 1, 8, one, None) == -1
+    prev = lib.sbev_decoder_query_order(1)
+    assert lib.sbev_decoder_query_order(prev) == 1                           # returns the previous setting
+    assert lib.sbev_decoder_query_order(prev) == prev
+
+
 def test_round3_training_entry_points_validate_without_gpu(lib):
     """The grouped parameter-gradient launches and the fp16 hi + lo training GEMMs refuse what they do not cover before any HIP call."""
     one = ctypes.c_void_p(16)

@@ -82,10 +82,12 @@ std::atomic<int> g_fuse_sample_mix{1};
 // restores the two launches (A/B).
 std::atomic<int> g_fuse_l5_f32{getenv("SBEV_NO_FUSE_L5F32") ? 0 : 1};
 
-// the fused gather + mixing launch walks its items in the order of sbev_query_order (one group and one arc of the camera ring per XCD:
-// 16-27 % fewer fabric reads for the gather -- tools/sampler_footprint.py); the sort of a layer's boxes runs on
-// the side stream beside the self attention.  sbev_decoder_query_order(0) / SBEV_QUERY_ORDER=0 restores the launch order (bit-identical).
-std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? atoi(getenv("SBEV_QUERY_ORDER")) : 0};
+// the fused gather + mixing launch walks its items in the order of sbev_query_order (one group and one arc of the camera ring per XCD):
+// 20 % fewer fabric reads for the launch at config 2 (PMC: 290 -> 232 MB, L2 hit 0.39 -> 0.47; tools/sampler_footprint.py predicts
+// it) and NOT faster -- the launch is bound by a workgroup's chain of memory latencies at 4 workgroups per CU, not by fabric bytes
+//  -- and the sort is one more launch per layer: OFF by default, kept for A/B and for a chip whose HBM is
+// shared.  sbev_decoder_query_order(1) / SBEV_QUERY_ORDER=1 switches it on (bit-identical results).
+std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? (atoi(getenv("SBEV_QUERY_ORDER")) != 0) : 0};
 
 // the row-local op chains of a layer as three launches (row_chain.hip) when the caller supplied packed weights
 // (sbev_decoder_weights.chain_pack); sbev_decoder_row_chain(0) restores the op-by-op launches (A/B measurements)
@@ -301,18 +303,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
         if (chain) {
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
                                sample_mix_fusable(c);
-            // launch order of this layer's gather items: sorted from the layer's input boxes on the side stream, beside the self attention
-            // (one workgroup per sample; the fused launch below joins it)
-            const bool ordered = fused && ax.ok && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
-            hipEvent_t ev_ord = nullptr;
-            if (ordered) {
-                hipEvent_t e = next_ev();
-                TRY(hip_ok(hipEventRecord(e, s_main), "hipEventRecord"));
-                TRY(hip_ok(hipStreamWaitEvent(ax.stream, e, 0), "hipStreamWaitEvent"));
-                TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, reinterpret_cast<sbev_stream_t>(ax.stream)));
-                ev_ord = next_ev();
-                TRY(hip_ok(hipEventRecord(ev_ord, ax.stream), "hipEventRecord"));
-            }
+            // launch order of this layer's gather items: sorted from the layer's input boxes (one workgroup per sample)
+            const bool ordered = fused && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
+            if (ordered) TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, stream));
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
@@ -324,7 +317,6 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             else
                 TRY(sbev_linear_f32(b.x1, w->pg_w, w->pg_b, nullptr, b.params, BQ, pgN, D, D, D, pgN, 0, stream));
             if (fused) {
-                if (ordered) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_ord, 0), "hipStreamWaitEvent"));
                 TRY(mix_fused(stream, ordered ? b.order : nullptr));
             } else {
                 if (c.n_slots > 0)

@@ -71,6 +71,20 @@ struct MixArgsOf<4> { typedef SampleMixArgs type; };
 template <>
 struct MixArgsOf<5> { typedef SampleMixArgs type; };
 
+#ifdef SBEV_MIX_TRACE          // wall-clock phase stamps (s_memrealtime, 10 ns ticks) of thread 0 of every workgroup of the fused launch
+                               // (tools/exp/r4_mix_trace.py; never in the product build)
+constexpr int MIX_TRACE_SLOTS = 16, MIX_TRACE_WGS = 8192;
+__device__ long long g_mix_trace[MIX_TRACE_WGS * MIX_TRACE_SLOTS];
+#define MIX_STAMP(i)                                                                                               \
+    if (L > 0 && threadIdx.x == 0 && blockIdx.x < MIX_TRACE_WGS) {                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        g_mix_trace[blockIdx.x * MIX_TRACE_SLOTS + (i)] = (long long)__builtin_amdgcn_s_memrealtime();            \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+#else
+#define MIX_STAMP(i)
+#endif
+
 constexpr int C = 64, POUT = 128;
 constexpr int LDA = C + 4;    // A-operand rows (x): 16-B aligned rows, <= 2-way bank conflict on fragment reads
 constexpr int LDB = C + 16;   // B-operand rows (M, y1): row stride = 16 banks -> conflict-free fragment reads
@@ -145,6 +159,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     long long item = blockIdx.x;
+    MIX_STAMP(0)
+#ifdef SBEV_MIX_TRACE
+    if (L > 0 && threadIdx.x == 0 && blockIdx.x < MIX_TRACE_WGS) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_mix_trace[blockIdx.x * MIX_TRACE_SLOTS + 15] = ((long long)xcc << 32) | hwid;
+    }
+#endif
     if constexpr (L > 0) {
         if (a.order) {
             const unsigned m = (blockIdx.x & 7u) * (unsigned)a.order_per + (blockIdx.x >> 3);
@@ -263,12 +286,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
                 }
             }
         }
+        MIX_STAMP(1)                                            // this wave's gather is done (its rows are in LDS)
         if (!SBEV_SAMPLE_MIX_PREFETCH) {                        // M / S requested only now: the gather phase keeps its 3 waves per SIMD
             __builtin_amdgcn_sched_barrier(0);
             SBEV_LOAD_MF()
             SBEV_LOAD_S()
         }
         __syncthreads();
+        MIX_STAMP(2)                                            // every wave's gather is done
         Xrows = Xg;
         if constexpr (!XLDS) {
 #pragma unroll
@@ -286,6 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 #undef SBEV_LOAD_S
 
     const int cw = wave * 16;                                   // this wave's channel slab
+    MIX_STAMP(3)                                                // x fragments in registers
 
     // ---- matmul 1: y1[Pin, 64] = x[Pin, 64] @ M[64, 64]; wave w -> columns [16w, 16w+16) ----------------
     f32x4 acc1[RT];
@@ -315,6 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r][j], bq[j], acc1[r], 0, 0, 0);
     }
+    MIX_STAMP(4)                                                // matmul 1 issued (its M fragments have arrived)
     if constexpr (XLDS) __syncthreads();                        // every wave is done with the gathered rows: S may land on them
     // C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg
     // ---- LayerNorm over all Pin*64 elements (no affine, biased variance), ReLU --------------------------
@@ -342,8 +369,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             if (!PAD || i4 < POUT * Pin) *reinterpret_cast<f32x4*>(&Ss[(i4 / Pin) * lds_s + i4 % Pin]) = sreg[k];
         }
     }
+    MIX_STAMP(5)                                                // S parked in LDS (its loads have arrived)
     float mean1, rstd1;
     block_mean_rstd(s, qv, nw1, a.eps, red, wave, lane, mean1, rstd1);
+    MIX_STAMP(6)
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -387,6 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             }
         }
     }
+    MIX_STAMP(7)                                                // matmul 2 issued
     // ---- LayerNorm over 128*64 elements, ReLU ------------------------------------------------------------
     const float nw2 = (float)(POUT * 16);
     s = 0.f;
@@ -415,6 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
         for (int e = 0; e < 4; ++e)
             Yo[(r * 16 + fk * 4 + e) * LDY + cw + fi] = fmaxf((acc2[r][e] - mean2) * rstd2, 0.f);
     __syncthreads();
+    MIX_STAMP(8)                                                // LayerNorm 2 + the transposed tile in LDS
     float* yg = a.y + item * POUT * C;
     const float up = a.out_up;
 #pragma unroll
@@ -424,6 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
         if (up != 0.f) { v.x = f16_pair(v.x * up); v.y = f16_pair(v.y * up); v.z = f16_pair(v.z * up); v.w = f16_pair(v.w * up); }
         *reinterpret_cast<float4*>(yg + r * C + c4) = v;
     }
+    MIX_STAMP(9)                                                // stores issued
 }
 
 template <int RT, bool WIDE>
@@ -481,6 +513,12 @@ int launch_sample_mix_rt(const SampleMixArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef SBEV_MIX_TRACE
+extern "C" int sbev_debug_mix_trace_read(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mix_trace), sizeof(long long) * (size_t)n);
+}
+#endif
 
 static int adaptive_mixing_impl(const float* x, const float* params, float* y, int64_t BQ, int G, int Pin, int Cg, int Pout, float eps,
                                 float out_up, sbev_stream_t stream) {

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../sparsebev_amd/csrc"
 tag=$1; unit=$2; shift 2
 python -m sparsebev_amd.csrc.build >/dev/null 2>&1 || (cd ../.. && python -m sparsebev_amd.csrc.build >/dev/null)
 extra=""
-case $unit in msmv_sampling_bwd.hip) extra="-munsafe-fp-atomics";; head.hip|project.hip) extra="-ffp-contract=off";; esac
+case $unit in msmv_sampling_bwd.hip) extra="-munsafe-fp-atomics";; head.hip|project.hip|mixing.hip|backward_ops.hip) extra="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c $unit -o build/${unit%.hip}_$tag.o
 objs=""
 for o in build/*.o; do

@@ -137,7 +137,7 @@ __device__ __forceinline__ float f16_pair(float x) {
                                          // spills, 318 -> 326 samples/s at config 2 (unfused 320; requesting M / S before the gather: 313..319)
 #endif
 template <int L, int RT>
-constexpr int mix_min_waves() { return L > 0 && RT <= 4 ? SBEV_SAMPLE_MIX_WAVES : L > 0 ? 2 : 1; }   // RT = 8: 128 registers of x fragments
+constexpr int mix_min_waves() { return L > 0 ? SBEV_SAMPLE_MIX_WAVES : 1; }   // (plain RT = 8: 128 registers of x fragments)
 
 // PAD: Pin % 16 != 0 on the WIDE path (round 3; the last row tile of x and the last k block of S are partly padding) and, fused,
 // 4 or 8 points per frame -- a template parameter so that the Pin % 16 == 0, P = 4 instantiations stay exactly the tuned code of rounds 1-2
@@ -145,7 +145,11 @@ template <int RT, bool WIDE, int L = 0, typename FT = float, bool PAD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_waves<L, RT>()))) void adaptive_mixing_kernel(const typename MixArgsOf<L>::type a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Pin = a.Pin;
-    const int lds_s = Pin + 4;                                  // S row stride
+    // fused, more than 4 row tiles (Pin > 64): S goes through LDS in TWO k halves ([128][64 + 4] floats each, round 4) -- the whole
+    // [128][Pin + 4] block was 63.5 KB at Pin = 120 and held a CU to 2 workgroups; with 34.8 KB the registers decide (3 per CU)
+    constexpr bool KSPLIT = L > 0 && RT > 4;
+    constexpr int KH = 64;                                      // columns of the first half
+    const int lds_s = KSPLIT ? KH + 4 : Pin + 4;                // S row stride
     // WIDE (Pin % 16 == 0, the decoder's case): the x fragments come straight from HBM into registers and y1 never leaves
     // them (the B fragment of matmul 2 is exactly what the lane's own matmul-1 accumulators hold), so LDS only carries
     // S (and the output staging): 34.8 KiB -> 4 workgroups per CU instead of 3, and nothing waits for a staging barrier.
@@ -219,9 +223,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
     // S is not needed before matmul 2: WIDE requests it now but parks it in registers (2 RT float4 per thread) and writes
     // it to LDS behind matmul 1, in front of the LayerNorm-1 exchange whose barriers publish it -- its HBM latency hides
     // behind matmul 1 and the staging barrier only waits for M
-    f32x4 sreg[WIDE ? 2 * RT : 1];
+    f32x4 sreg[WIDE ? (KSPLIT ? RT : 2 * RT) : 1];
+    // KSPLIT: the same 8 registers carry columns [0, 64) first (thread -> row e / 16, 16-byte column e % 16 of element e = tid + 256 k)
+    // and, requested once those are in LDS, columns [64, Pin) (row e / nb, column 64 + 4 (e % nb), nb = (Pin - 64) / 4 sixteen-byte
+    // pieces per row; e past the end: clamped, dropped)
+    const int nb2 = KSPLIT ? (Pin - KH) >> 2 : 1;
 #define SBEV_LOAD_S() \
-    _Pragma("unroll") for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (PAD ? min((tid + 256 * k) * 4, POUT * Pin - 4) : (tid + 256 * k) * 4));
+    if constexpr (KSPLIT) {                                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < RT; ++k) {                                                                           \
+            const int e = tid + 256 * k;                                                                                           \
+            sreg[k] = *reinterpret_cast<const f32x4*>(sg + (e >> 4) * Pin + (e & 15) * 4);                                         \
+        }                                                                                                                          \
+    } else {                                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 2 * RT; ++k) sreg[k] = *reinterpret_cast<const f32x4*>(sg + (PAD ? min((tid + 256 * k) * 4, POUT * Pin - 4) : (tid + 256 * k) * 4)); \
+    }
     if (WIDE && (L == 0 || SBEV_SAMPLE_MIX_PREFETCH)) { SBEV_LOAD_S() }
     for (int i = tid; i < (WIDE ? 0 : POUT * Pin / 4); i += 256) {
         const int r = (i * 4) / Pin, c4 = (i * 4) % Pin;
@@ -362,7 +377,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             qv += (r * 16 + fk * 4 + e) < Pin ? d * d : 0.f;
         }
     qv = wave_sum(qv);
-    if (WIDE) {
+    if constexpr (KSPLIT) {                                     // the first k half
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            const int e = tid + 256 * k;
+            *reinterpret_cast<f32x4*>(&Ss[(e >> 4) * lds_s + (e & 15) * 4]) = sreg[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {                          // ... and the request for the second half (lands under LayerNorm 1 and the first four k blocks)
+            const int e = min(tid + 256 * k, POUT * nb2 - 1);
+            const int r = e / nb2;
+            sreg[k] = *reinterpret_cast<const f32x4*>(sg + r * Pin + KH + (e - r * nb2) * 4);
+        }
+    } else if (WIDE) {
 #pragma unroll
         for (int k = 0; k < 2 * RT; ++k) {
             const int i4 = (tid + 256 * k) * 4;
@@ -389,13 +417,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
     if (WIDE) {
 #pragma unroll
         for (int blk = 0; blk < RT; ++blk) {                    // Pin / 16 == RT
+            if constexpr (KSPLIT) {
+                if (blk == KH / 16) {                           // the second k half replaces the first (same accumulation order as one block)
+                    __syncthreads();                            // every wave has read its fragments of the first half
+#pragma unroll
+                    for (int k = 0; k < RT; ++k) {
+                        const int e = tid + 256 * k;
+                        const int r = e / nb2;
+                        if (e < POUT * nb2) *reinterpret_cast<f32x4*>(&Ss[r * lds_s + (e - r * nb2) * 4]) = sreg[k];
+                    }
+                    __syncthreads();
+                }
+            }
             float bq[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bq[j] = acc1[blk][j];   // y1[16 blk + 4 fk + j][cw + fi]: this lane's own accumulators
             f32x4 a4[POUT / 16];
             // k >= Pin (last block, Pin % 16 != 0): the A value is zeroed -- y1's padding rows are finite but not 0 after LayerNorm
             const bool kpad = PAD && blk == RT - 1 && 16 * blk + 4 * fk >= Pin;
-            const int kc = kpad ? 0 : 16 * blk + 4 * fk;
+            const int kc = kpad ? 0 : 16 * blk + 4 * fk - (KSPLIT && blk >= KH / 16 ? KH : 0);
 #pragma unroll
             for (int r = 0; r < POUT / 16; ++r) {
                 a4[r] = *reinterpret_cast<const f32x4*>(&Ss[(r * 16 + fi) * lds_s + kc]);
@@ -486,7 +526,8 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
 template <int RT, int L, typename FT>
 int launch_sample_mix(const SampleMixArgs& a, hipStream_t s) {
     const int Pin = a.Pin;
-    size_t floats = (size_t)POUT * (Pin + 4) + (Pin > 64 ? 0 : (size_t)Pin * LDA);        // S, then the gathered x behind it (Pin > 64: on it)
+    // S, then the gathered x behind it; Pin > 64: S in two k halves of 64 + 4 columns, the gathered x ON that buffer (Pin <= 128 rows fit)
+    size_t floats = Pin > 64 ? (size_t)POUT * (64 + 4) : (size_t)POUT * (Pin + 4) + (size_t)Pin * LDA;
     const size_t out_floats = (size_t)POUT * LDY;
     if (floats < out_floats) floats = out_floats;
     const size_t bytes = (floats + 8) * sizeof(float);

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
             float lv_next = wave < NU ? fetch_lv(wave) : 0.f;
 #pragma unroll 1
             for (int u = wave; u < NU; u += 4) {
+                if (u == 4) { MIX_STAMP(10) }                  // wave 0's second unit starts (its loc / weights were requested a unit ago)
                 const int t = u >> pcs;
                 const float lv = lv_next;
                 if (u + 4 < NU) lv_next = fetch_lv(u + 4);
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(mix_min_wav
                 {
                     const MsmvArgs& a = m;                      // the included chunk code names its argument block `a`
 #include "msmv_chunk.inc"
+                    if (u == 4) { MIX_STAMP(12) }              // ... its taps are consumed
                     float4 sv;
                     sv.x = corner_reduce_scatter(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
                     sv.y = corner_reduce_scatter(acc[0].y, acc[1].y, acc[2].y, acc[3].y);

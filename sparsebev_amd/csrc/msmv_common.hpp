@@ -21,6 +21,31 @@ struct MsmvArgs {
     int slots[SBEV_MAX_FRAMES];
 };
 
+// lane i of every 16-lane row <- lane n of that row (v_mov_b32_dpp row_newbcast:n, gfx90a+; n is a constant after unrolling: the
+// switch folds).  All 64 lanes must be active.
+template <int N>
+__device__ __forceinline__ int msmv_row_bcast_c(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false); }
+__device__ __forceinline__ int msmv_row_bcast(int n, int v) {
+    switch (n) {
+        case 0: return msmv_row_bcast_c<0>(v);
+        case 1: return msmv_row_bcast_c<1>(v);
+        case 2: return msmv_row_bcast_c<2>(v);
+        case 3: return msmv_row_bcast_c<3>(v);
+        case 4: return msmv_row_bcast_c<4>(v);
+        case 5: return msmv_row_bcast_c<5>(v);
+        case 6: return msmv_row_bcast_c<6>(v);
+        case 7: return msmv_row_bcast_c<7>(v);
+        case 8: return msmv_row_bcast_c<8>(v);
+        case 9: return msmv_row_bcast_c<9>(v);
+        case 10: return msmv_row_bcast_c<10>(v);
+        case 11: return msmv_row_bcast_c<11>(v);
+        case 12: return msmv_row_bcast_c<12>(v);
+        case 13: return msmv_row_bcast_c<13>(v);
+        case 14: return msmv_row_bcast_c<14>(v);
+        default: return msmv_row_bcast_c<15>(v);
+    }
+}
+
 // A tap is kept in its storage form until it is consumed: 4 bf16 channels stay two registers while the 4 * L loads of a
 // chunk are in flight (converted tap by tap in phase 3), which is what decides the waves per SIMD of this latency-bound
 // kernel (c5, L = 5: 71.5 -> 59 us; L = 4 bf16: 39.9 -> 34.5 us).

@@ -38,6 +38,12 @@ print('%s: %d workgroups; kernel span (first start -> last end) %.1f us; workgro
     cfgname, n, (t[:, 9].max() - t0) * 0.01, life.mean(), np.median(life), np.percentile(life, 10), np.percentile(life, 90)))
 for i, nm in enumerate(names):
     print('  %-36s mean %6.2f  median %6.2f  p90 %6.2f us' % (nm, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
+if t[:, 10].min() > 0:
+    g = (t[:, 11] - t[:, 10]) * 0.01; w = (t[:, 12] - t[:, 11]) * 0.01; r = (t[:, 1] - t[:, 12]) * 0.01; f = (t[:, 10] - t[:, 0]) * 0.01
+    print('  wave 0: first unit incl. its loc / weight fetch %.2f us; second unit: geometry + 16 tap requests %.2f, wait + consume %.2f, reduce + LDS (to the end of the gather) %.2f us' % (f.mean(), g.mean(), w.mean(), r.mean()))
+if t[:, 13].min() > 0:
+    print('    second unit in detail: slab bases + phase 1 (4 shuffles + geometry) %.2f us, phase 2 (32 ds_bpermute) %.2f us, 16 tap requests issued %.2f us' % (
+        ((t[:, 13] - t[:, 10]) * 0.01).mean(), ((t[:, 14] - t[:, 13]) * 0.01).mean(), ((t[:, 11] - t[:, 14]) * 0.01).mean()))
 xcc = (t[:, 15] >> 32) & 0xf
 blk = np.arange(n)
 print('block %% 8 == XCC_ID for %.1f %% of the blocks; (XCC_ID - block) %% 8 histogram: %s' % (100.0 * (xcc == blk % 8).mean(), np.bincount((xcc - blk) % 8, minlength=8).tolist()))

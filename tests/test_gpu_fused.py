@@ -33,7 +33,9 @@ def mixing(x, params, out_points=128):
                                                (2, 20, 3, 'tiny', torch.float32, 4), (1, 30, 5, 'tiny5', torch.float32, 4),
                                                (1, 33, 15, 'tiny', torch.bfloat16, 4), (1, 30, 8, 'tiny', torch.float32, 8),
                                                (1, 50, 15, 'tiny5', torch.bfloat16, 8), (2, 21, 15, 'tiny', torch.float32, 8),
-                                               (1, 40, 15, 'tiny5', torch.float32, 8)])
+                                               (1, 40, 15, 'tiny5', torch.float32, 8),
+                                               # round 4: S through LDS in two k halves (more than 64 in-points); 116 in-points = a second half of 13 pieces per row
+                                               (1, 20, 29, 'tiny', torch.float32, 4), (2, 9, 29, 'tiny5', torch.bfloat16, 4)])
 def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtype, P):
     ih, iw, sizes = S.PYRAMIDS[pyr]
     L, G, C = len(sizes), 4, 64

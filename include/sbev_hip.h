@@ -39,7 +39,8 @@ enum sbev_status {
     SBEV_ENODEV = -3   /* no gfx950 device visible */
 };
 
-enum sbev_dtype { SBEV_F32 = 0, SBEV_BF16 = 1 };
+enum sbev_dtype { SBEV_F32 = 0, SBEV_BF16 = 1, SBEV_F16 = 2 };   /* feature STORAGE types of the sampler (fp32 math throughout): bf16 and fp16 taps are widened exactly.
+                                                                   * fp16 is what the reference's eval mode produces before its out_fp32 cast (val.py:115, models/sparsebev.py:46) */
 enum sbev_gemm_mode {
     SBEV_GEMM_F32 = 0,      /* exact: f32-input MFMA */
     SBEV_GEMM_BF16X3 = 1,   /* opt-in 3 x bf16 split (rounds 1-2 kernels, gemm_bf16x3.hip) */

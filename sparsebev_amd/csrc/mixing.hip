@@ -624,7 +624,7 @@ static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, i
     SBEV_REQUIRE(sbev_sample_mix_supported(L, Cg, P, T, G, G), "sbev_sample_mix_f32: needs L in {4,5}, C = 64, P in {4,8}, T*P in 4..64 or 116..120 (got L=%d C=%d P=%d T=%d)", L, Cg, P, T);
     SBEV_REQUIRE(Pout == POUT, "sbev_sample_mix_f32: built for 128 out points");
     SBEV_REQUIRE(B >= 0 && Q >= 0 && N >= 1 && G >= 1, "sbev_sample_mix_f32: bad sizes");
-    SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16, "sbev_sample_mix_f32: feat_dtype %d", feat_dtype);
+    SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16 || feat_dtype == SBEV_F16, "sbev_sample_mix_f32: feat_dtype %d", feat_dtype);
     SBEV_REQUIRE(stride_px % 4 == 0 && stride_g % 4 == 0, "sbev_sample_mix_f32: pixel/group strides must be multiples of 4 elements");
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(loc && weights && params && y, "sbev_sample_mix_f32: null pointer");
@@ -659,6 +659,7 @@ static int sample_mix_impl(const void* const* feats, const int32_t* hw, int L, i
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (feat_dtype == SBEV_F32) return L == 4 ? launch_sample_mix_rt<4, float>(a, s) : launch_sample_mix_rt<5, float>(a, s);
+    if (feat_dtype == SBEV_F16) return L == 4 ? launch_sample_mix_rt<4, _Float16>(a, s) : launch_sample_mix_rt<5, _Float16>(a, s);
     return L == 4 ? launch_sample_mix_rt<4, unsigned short>(a, s) : launch_sample_mix_rt<5, unsigned short>(a, s);
 }
 

@@ -56,6 +56,19 @@ __device__ __forceinline__ float4 widen(const uint2 r) {  // 4 x bf16 -> fp32 (e
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
                        __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
 }
+// fp16 storage (FT = _Float16, round 4): the same two registers per tap, widened with v_cvt_f32_f16 (exact) -- the features an fp16
+// backbone emits (the reference casts them to fp32 first: @auto_fp16(out_fp32=True), models/sparsebev.py:46) sampled in place
+struct MsmvH4 { uint2 v; };
+typedef _Float16 msmv_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ MsmvH4 load_raw(const _Float16* p) { return MsmvH4{*reinterpret_cast<const uint2*>(p)}; }
+__device__ __forceinline__ float4 widen(const MsmvH4 r) {
+    const msmv_h2 a = __builtin_bit_cast(msmv_h2, r.v.x), b = __builtin_bit_cast(msmv_h2, r.v.y);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+template <typename FT>
+struct MsmvIsF16 { static constexpr bool value = false; };
+template <>
+struct MsmvIsF16<_Float16> { static constexpr bool value = true; };
 
 // ---- where a lane's taps come from ------------------------------------------------------------------------------------------
 // BUF = true (round 4, every realistic map): raw BUFFER loads.  The (sample-batch, group) slab of a level is a wave-uniform buffer
@@ -104,6 +117,7 @@ struct TapSrc<L, FT, true> {
     __device__ __forceinline__ auto load(int l, int toff) const {
         const int vo = (int)((unsigned)toff + lane_off);                        // bit 31 survives: lane_off < 2^16
         if constexpr (sizeof(FT) == 4) return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs[l], vo, 0, 0));
+        else if constexpr (MsmvIsF16<FT>::value) return MsmvH4{__builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs[l], vo, 0, 0))};
         else return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs[l], vo, 0, 0));
     }
 };

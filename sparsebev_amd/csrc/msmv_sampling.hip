@@ -184,7 +184,7 @@ static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int
     SBEV_REQUIRE(P >= 1 && P <= SBEV_MAX_POINTS, "sbev_msmv_fwd: num_point exceed limits (P=%d > %d)", P, SBEV_MAX_POINTS);
     SBEV_REQUIRE(C >= 4 && C % 4 == 0, "sbev_msmv_fwd: C=%d must be a positive multiple of 4", C);
     SBEV_REQUIRE(N >= 1 && Q >= 0 && Bp >= 0 && gdiv >= 1, "sbev_msmv_fwd: bad sizes");
-    SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16, "sbev_msmv_fwd: feat_dtype %d", feat_dtype);
+    SBEV_REQUIRE(feat_dtype == SBEV_F32 || feat_dtype == SBEV_BF16 || feat_dtype == SBEV_F16, "sbev_msmv_fwd: feat_dtype %d", feat_dtype);
     SBEV_REQUIRE(out_layout == SBEV_OUT_REF || out_layout == SBEV_OUT_MIX, "sbev_msmv_fwd: out_layout %d", out_layout);
     SBEV_REQUIRE(stride_px % 4 == 0 && stride_g % 4 == 0, "sbev_msmv_fwd: pixel/group strides must be multiples of 4 elements");
     if (out_layout == SBEV_OUT_MIX)
@@ -231,7 +231,8 @@ static int msmv_fwd_impl(const void* const* feats, const int32_t* hw, int L, int
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return feat_dtype == SBEV_F32 ? launch_t<float>(a, L, out_layout, fit, s)
-                                  : launch_t<unsigned short>(a, L, out_layout, fit, s);
+           : feat_dtype == SBEV_F16 ? launch_t<_Float16>(a, L, out_layout, fit, s)
+                                    : launch_t<unsigned short>(a, L, out_layout, fit, s);
 }
 
 extern "C" int sbev_msmv_buffer_taps(int enable) {

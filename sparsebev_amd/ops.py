@@ -12,7 +12,7 @@ from . import _lib
 
 N_VIEWS = 6           # models/sparsebev_sampling.py:45
 OUT_REF, OUT_MIX = 0, 1
-_F32, _BF16 = 0, 1
+_F32, _BF16, _F16 = 0, 1, 2
 
 
 def _stream():
@@ -73,7 +73,9 @@ def _feat_dtype(feats):
         return _F32
     if dt == torch.bfloat16:
         return _BF16
-    raise RuntimeError('feature dtype must be float32 or bfloat16, got %s' % dt)
+    if dt == torch.float16:
+        return _F16
+    raise RuntimeError('feature dtype must be float32, bfloat16 or float16, got %s' % dt)
 
 
 def _msmv_forward(feats, sampling_locations, scale_weights, out_layout, T, G):

@@ -214,7 +214,7 @@ class DecoderRuntime:
         cfg.D, cfg.H, cfg.ffn = D, layer.self_attn.num_heads, layer.ffn.layers[0][0].weight.shape[0]
         cfg.num_classes, cfg.code_size, cfg.num_layers = layer.num_classes, layer.code_size, dec.num_layers
         cfg.out_points, cfg.attn_in_rows = layer.mixing.out_points, self._attn_in_rows
-        cfg.feat_dtype = 1 if pyramid.levels[0].dtype == torch.bfloat16 else 0
+        cfg.feat_dtype = {torch.bfloat16: 1, torch.float16: 2}.get(pyramid.levels[0].dtype, 0)
         cfg.gemm_mode = self.mode_eff
         slots = getattr(pyramid, 'frame_slots', None)
         if slots is not None:

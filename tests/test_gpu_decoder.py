@@ -327,9 +327,10 @@ def test_captured_graph_replays_bit_identically_and_follows_in_place_updates():
         graph.replay()
 
 
-def test_bf16_feature_storage_through_the_runtime():
-    """bf16 feature maps (storage only: exact widening, fp32 math) handed over channels-last, as configs[4] (ViT neck,
-    bf16) would: the decoder must equal the oracle run on the widened features."""
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_bf16_feature_storage_through_the_runtime(dtype):
+    """bf16 / fp16 feature maps (storage only: exact widening, fp32 math) handed over channels-last, as configs[4] (ViT neck,
+    bf16) or the reference's fp16 eval mode (val.py:115) would: the decoder must equal the oracle run on the widened features."""
     from oracle import sparsebev_oracle as O
     B, Q, T, L = 1, 36, 2, 5
     ih, iw, sizes = S.PYRAMIDS['tiny5']
@@ -337,7 +338,7 @@ def test_bf16_feature_storage_through_the_runtime():
     model = build(T, L, 51)
     bbox, feat = S.make_queries(B, Q, seed=52)
     metas = S.make_img_metas(B, T, ih, iw)
-    feats16 = [f.to(torch.bfloat16) for f in S.make_features(B, T, sizes, seed=53)]
+    feats16 = [f.to(dtype) for f in S.make_features(B, T, sizes, seed=53)]
     dev_feats = [f.to(DEV).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats16]     # NHWC memory
     cls, box = model(bbox.to(DEV), feat.to(DEV), dev_feats, None, copy.deepcopy(metas))
     ref_cls, ref_box, _ = O.decoder(params, bbox, feat, [f.float() for f in feats16], metas, S.PC_RANGE, num_layers=1)

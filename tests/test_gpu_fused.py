@@ -35,7 +35,10 @@ def mixing(x, params, out_points=128):
                                                (1, 50, 15, 'tiny5', torch.bfloat16, 8), (2, 21, 15, 'tiny', torch.float32, 8),
                                                (1, 40, 15, 'tiny5', torch.float32, 8),
                                                # round 4: S through LDS in two k halves (more than 64 in-points); 116 in-points = a second half of 13 pieces per row
-                                               (1, 20, 29, 'tiny', torch.float32, 4), (2, 9, 29, 'tiny5', torch.bfloat16, 4)])
+                                               (1, 20, 29, 'tiny', torch.float32, 4), (2, 9, 29, 'tiny5', torch.bfloat16, 4),
+                                               # round 4: fp16 feature storage
+                                               (1, 100, 8, 'tiny', torch.float16, 4), (2, 37, 4, 'tiny5', torch.float16, 4),
+                                               (1, 50, 15, 'tiny5', torch.float16, 8), (1, 64, 8, 'r50_704x256', torch.float16, 4)])
 def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtype, P):
     ih, iw, sizes = S.PYRAMIDS[pyr]
     L, G, C = len(sizes), 4, 64
@@ -53,7 +56,7 @@ def test_fused_launch_is_bit_identical_to_sampler_then_mixing(B, Q, T, pyr, dtyp
     assert got.abs().max() > 0
 
 
-@pytest.mark.parametrize('pyr,dtype', [('tiny', torch.float32), ('tiny5', torch.bfloat16)])
+@pytest.mark.parametrize('pyr,dtype', [('tiny', torch.float32), ('tiny5', torch.bfloat16), ('tiny', torch.float16)])
 def test_fused_launch_with_nonfinite_border_pixels(pyr, dtype):
     """Inf in every border pixel of the finest level: the fused kernel's gather (buffer-load taps) must poison exactly the items the
     two launches poison, every other item is bit-identical."""

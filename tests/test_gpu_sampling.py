@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden, feats_of
-from sparsebev_amd import ops, synthetic as S
+from sparsebev_amd import _lib, ops, synthetic as S
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -38,6 +38,27 @@ def test_msmv_bf16_features_fp32_accumulate():
     ref = O.msmv_sampling_kernel_semantics([f.float() for f in feats_bf], g['loc'], g['weights'])
     out = ops.msmv_sampling([dev(f) for f in feats_bf], dev(g['loc']), dev(g['weights']))
     assert (out.cpu() - ref).abs().max() < TOL       # bf16 is storage only: exact widening, fp32 math
+
+
+@pytest.mark.parametrize('tag', ['L4_C64', 'L5_C64', 'L4_C16_P7'])
+def test_msmv_fp16_features_fp32_accumulate(tag):
+    """fp16 STORAGE (round 4; what the reference's fp16 eval mode has before its out_fp32 cast, models/sparsebev.py:46): the taps are
+    widened exactly, so the result equals the fp32 kernel's on the widened features BIT for bit, both tap paths, both output layouts"""
+    from oracle import sparsebev_oracle as O
+    g = load_golden('g1_msmv_' + tag)
+    feats_h = [f.to(torch.float16) for f in feats_of(g)]
+    ref = O.msmv_sampling_kernel_semantics([f.float() for f in feats_h], g['loc'], g['weights'])
+    prev = _lib.load().sbev_msmv_buffer_taps(1)
+    try:
+        for buf in (1, 0):
+            _lib.load().sbev_msmv_buffer_taps(buf)
+            out = ops.msmv_sampling([dev(f) for f in feats_h], dev(g['loc']), dev(g['weights']))
+            assert (out.cpu() - ref).abs().max() < TOL
+            assert torch.equal(out, ops.msmv_sampling([dev(f.float()) for f in feats_h], dev(g['loc']), dev(g['weights'])))
+            mix = ops.msmv_sampling([dev(f) for f in feats_h], dev(g['loc']), dev(g['weights']), out_layout=ops.OUT_MIX, T=1, G=1)
+            assert torch.equal(mix[:, :, 0].permute(0, 1, 3, 2), out)
+    finally:
+        _lib.load().sbev_msmv_buffer_taps(prev)
 
 
 @pytest.mark.parametrize('T', [1, 8])
@@ -307,7 +328,7 @@ def test_msmv_backward_point_tails_and_both_kernels_vs_oracle(P, L, C):
         assert (a_.grad.cpu() - r).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_pipelined_items_equal_single_items(dtype):
     """Above 8192 (b', q) items the kernel walks two items per wave with the second one's coordinates prefetched; below
     it handles one per wave.  Same inputs through both code paths (one big call vs the same queries in slices small

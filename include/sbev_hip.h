@@ -346,6 +346,13 @@ int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int cha
  * launch, segment k = nbytes[k] bytes from table[index[k]] to dst[k] (index, dst, nbytes: host arrays). */
 int sbev_nchw_to_nhwc_f32_indirect(const void* const* table, int index, float* out, int64_t n_images, int channels, int hw,
                                    sbev_stream_t stream);
+/* The same relayouts for 2-byte channels -- bf16 or fp16 feature STORAGE (enum sbev_dtype; bytes are moved, never interpreted): what
+ * an fp16 backbone (the reference's eval mode, val.py:115, before the out_fp32 cast of models/sparsebev.py:46) or a bf16 neck emits
+ * goes to the sampler's layout at half the traffic of the fp32 relayout.  128-channel x 64-pixel tiles; any sizes (channels % 8,
+ * hw % 4 and 8- / 16-byte alignment select the vector path). */
+int sbev_nchw_to_nhwc_b16(const void* in, void* out, int64_t n_images, int channels, int hw, sbev_stream_t stream);
+int sbev_nchw_to_nhwc_b16_indirect(const void* const* table, int index, void* out, int64_t n_images, int channels, int hw,
+                                   sbev_stream_t stream);
 int sbev_copy_indirect(const void* const* table, int nseg, const int32_t* index, void* const* dst, const int64_t* nbytes,
                        sbev_stream_t stream);
 

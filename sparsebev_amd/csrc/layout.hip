@@ -72,6 +72,70 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const TrArgs a) {
     }
 }
 
+// ---- the same relayout for 2-byte elements (bf16 / fp16 STORAGE: pure byte movement) ------------------------------------------------
+// An fp16 backbone (the reference's eval mode, val.py:115) or a bf16 neck emits [N, R, S] maps of 2-byte channels.  A workgroup moves
+// 128 channels x 64 pixels: a thread reads 4 consecutive pixels (8 bytes) of TWO neighbouring channels, interleaves them into four
+// (channel pair) words -- in NHWC the pair is adjacent, so the transposition itself is a plain 32-bit one through LDS -- and writes 16
+// bytes = 8 channels of one pixel: 128-byte runs on the read side, 256-byte runs on the write side.
+struct Tr16Args {
+    const unsigned short* in;   // [N, R, S]
+    unsigned short* out;        // [N, S, R]
+    int R, S;
+    const void* const* table;   // indirect source (see TrArgs)
+    int index;
+};
+constexpr int T16_CP = 64, T16_PX = 64, T16_LD = T16_CP + 1;      // channel PAIRS x pixels per tile
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void transpose_tiles16_kernel(const Tr16Args a) {
+    __shared__ unsigned tile[T16_PX * T16_LD];                      // tile[pixel][channel pair]
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * T16_PX, r0 = blockIdx.y * (2 * T16_CP);
+    const long long img = blockIdx.z;
+    const unsigned short* in = (a.table ? static_cast<const unsigned short*>(a.table[a.index]) : a.in) + img * a.R * a.S;
+    unsigned short* out = a.out + img * a.R * a.S;
+    if (VEC) {   // S % 4 == 0, R % 8 == 0, 8-byte aligned planes, 16-byte aligned output
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cp = (tid >> 4) + 16 * i, q = tid & 15;       // channel pair of the tile, pixel quad
+            const int r = r0 + 2 * cp, s = s0 + 4 * q;
+            uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+            if (r < a.R && s < a.S) {                               // (R is even: r + 1 < R too)
+                lo = *reinterpret_cast<const uint2*>(in + (long long)r * a.S + s);
+                hi = *reinterpret_cast<const uint2*>(in + (long long)(r + 1) * a.S + s);
+            }
+            // lo = channel r at pixels s .. s+3 (two per word), hi = channel r + 1: word (pixel) = lo16 | hi16 << 16
+            tile[(4 * q + 0) * T16_LD + cp] = __builtin_amdgcn_perm(hi.x, lo.x, 0x05040100u);
+            tile[(4 * q + 1) * T16_LD + cp] = __builtin_amdgcn_perm(hi.x, lo.x, 0x07060302u);
+            tile[(4 * q + 2) * T16_LD + cp] = __builtin_amdgcn_perm(hi.y, lo.y, 0x05040100u);
+            tile[(4 * q + 3) * T16_LD + cp] = __builtin_amdgcn_perm(hi.y, lo.y, 0x07060302u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = (tid >> 4) + 16 * i, k = tid & 15;       // pixel of the tile, 16-byte piece (4 pairs = 8 channels)
+            const int s = s0 + px, r = r0 + 8 * k;
+            if (s < a.S && r < a.R) {
+                const unsigned* t = &tile[px * T16_LD + 4 * k];
+                *reinterpret_cast<uint4*>(out + (long long)s * a.R + r) = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    } else {
+        unsigned short* t16 = reinterpret_cast<unsigned short*>(tile);      // [pixel][2 * T16_LD] halves
+        for (int i = tid; i < 2 * T16_CP * T16_PX; i += 256) {
+            const int lr = i / T16_PX, ls = i % T16_PX;
+            const int r = r0 + lr, s = s0 + ls;
+            t16[ls * (2 * T16_LD) + lr] = (r < a.R && s < a.S) ? in[(long long)r * a.S + s] : (unsigned short)0;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * T16_CP * T16_PX; i += 256) {
+            const int ls = i / (2 * T16_CP), lr = i % (2 * T16_CP);
+            const int r = r0 + lr, s = s0 + ls;
+            if (r < a.R && s < a.S) out[(long long)s * a.R + r] = t16[ls * (2 * T16_LD) + lr];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void linear3_ln_relu_kernel(const PosArgs a) { lin3_rows(a, blockIdx.x); }
 
 // contiguous copy with widening to fp32 (channels-last frames handed to the online ring: fp32 / fp16 / bf16 storage), 4 elements per thread
@@ -291,4 +355,36 @@ extern "C" int sbev_query_order(const float* query_bbox, int64_t ld, const doubl
     a.sx = (float)(pc_range[3] - pc_range[0]); a.sy = (float)(pc_range[4] - pc_range[1]);
     hipLaunchKernelGGL(query_order_kernel, dim3((unsigned)B), dim3(ORDER_THREADS), 0, reinterpret_cast<hipStream_t>(stream), a);
     return sbev::check_launch("sbev_query_order");
+}
+
+// NCHW -> NHWC for 2-byte channels (bf16 or fp16 storage: bytes are moved, never interpreted).  `in` NULL: the source address is
+// table[index], read on the device (the staged form of a replayable step, like sbev_nchw_to_nhwc_f32_indirect).
+static int nchw_to_nhwc_b16(const void* in, const void* const* table, int index, void* out, int64_t n_images, int channels, int hw,
+                            sbev_stream_t stream, const char* who) {
+    SBEV_REQUIRE(n_images >= 0 && channels >= 1 && hw >= 1 && index >= 0, "%s: bad sizes", who);
+    if (n_images == 0) return SBEV_OK;
+    SBEV_REQUIRE((in || table) && out && in != out, "%s: null or aliased pointers", who);
+    SBEV_REQUIRE(!table || (((uintptr_t)table) & 7) == 0, "%s: unaligned pointer table", who);
+    SBEV_REQUIRE(n_images <= 65535, "%s: at most 65535 images per call", who);
+    Tr16Args a{static_cast<const unsigned short*>(in), static_cast<unsigned short*>(out), channels, hw, in ? nullptr : table, index};
+    dim3 grid((hw + T16_PX - 1) / T16_PX, (channels + 2 * T16_CP - 1) / (2 * T16_CP), (unsigned)n_images);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // (an indirect source is required to be 16-byte aligned by its caller, like the fp32 form)
+    const bool vec = (hw % 4 == 0) && (channels % 8 == 0) && ((((uintptr_t)out) & 15) == 0) && (!in || (((uintptr_t)in) & 7) == 0);
+    if (vec)
+        hipLaunchKernelGGL(transpose_tiles16_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(transpose_tiles16_kernel<false>, grid, dim3(256), 0, s, a);
+    return sbev::check_launch(who);
+}
+
+extern "C" int sbev_nchw_to_nhwc_b16(const void* in, void* out, int64_t n_images, int channels, int hw, sbev_stream_t stream) {
+    SBEV_REQUIRE(n_images == 0 || in, "sbev_nchw_to_nhwc_b16: null input");
+    return nchw_to_nhwc_b16(in, nullptr, 0, out, n_images, channels, hw, stream, "sbev_nchw_to_nhwc_b16");
+}
+
+extern "C" int sbev_nchw_to_nhwc_b16_indirect(const void* const* table, int index, void* out, int64_t n_images, int channels, int hw,
+                                              sbev_stream_t stream) {
+    SBEV_REQUIRE(n_images == 0 || table, "sbev_nchw_to_nhwc_b16_indirect: null table");
+    return nchw_to_nhwc_b16(nullptr, table, index, out, n_images, channels, hw, stream, "sbev_nchw_to_nhwc_b16_indirect");
 }

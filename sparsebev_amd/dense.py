@@ -413,11 +413,15 @@ def refine_bbox(query_bbox, reg, vel_div):
 def to_channels_last(f):
     """[B,TN,GC,H,W] -> contiguous [B,TN,H,W,GC] (one tiled-transpose launch per level)."""
     _dev(f)
-    if f.dtype != torch.float32:
-        return f.permute(0, 1, 3, 4, 2).contiguous()        # bf16 pyramids: expected to arrive channels-last already
+    if f.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return f.permute(0, 1, 3, 4, 2).contiguous()
     B, TN, GC, H, W = f.shape
     f = f.contiguous()
     out = torch.empty(B, TN, H, W, GC, device=f.device, dtype=f.dtype)
-    st = _lib.load().sbev_nchw_to_nhwc_f32(_p(f), _p(out), B * TN, GC, H * W, _stream())
-    _lib.check(st, 'sbev_nchw_to_nhwc_f32')
+    if f.dtype == torch.float32:
+        st = _lib.load().sbev_nchw_to_nhwc_f32(_p(f), _p(out), B * TN, GC, H * W, _stream())
+        _lib.check(st, 'sbev_nchw_to_nhwc_f32')
+    else:                                                    # bf16 / fp16 storage: the 2-byte relayout (bytes are moved, not interpreted)
+        st = _lib.load().sbev_nchw_to_nhwc_b16(_p(f), _p(out), B * TN, GC, H * W, _stream())
+        _lib.check(st, 'sbev_nchw_to_nhwc_b16')
     return out

@@ -346,7 +346,7 @@ class StepGraphs:
 
     @staticmethod
     def _relayout_ok(f):
-        return f.dim() == 5 and f.dtype == torch.float32 and f.is_contiguous() and f.data_ptr() % 16 == 0 and \
+        return f.dim() == 5 and f.dtype in (torch.float32, torch.bfloat16, torch.float16) and f.is_contiguous() and f.data_ptr() % 16 == 0 and \
             not f.permute(0, 1, 3, 4, 2).is_contiguous()
 
     def _feat_key(self, feats):
@@ -357,7 +357,7 @@ class StepGraphs:
             return ('pyr', tuple((f.data_ptr(), tuple(f.shape), f.dtype) for f in feats.levels),
                     tuple(getattr(feats, 'frame_slots', ())), getattr(feats, 'n_slots', 0)), [], False
         if all(self._relayout_ok(f) for f in feats):
-            return ('nchw', tuple(tuple(f.shape) for f in feats)), [], True
+            return ('nchw', tuple((tuple(f.shape), f.dtype) for f in feats)), [], True
         return ('list', tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats)), list(feats), False
 
     def run(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
@@ -443,7 +443,7 @@ class StepGraphs:
             for l, f in enumerate(mlvl_feats):
                 nhwc = f.permute(0, 1, 3, 4, 2)
                 if staged:
-                    buf = torch.empty(f.shape[0], TN, f.shape[3], f.shape[4], pyramid.GC, device=dev, dtype=torch.float32)
+                    buf = torch.empty(f.shape[0], TN, f.shape[3], f.shape[4], pyramid.GC, device=dev, dtype=f.dtype)
                     relayout.append((3 + l, buf, f.shape[0] * TN, pyramid.GC, f.shape[3] * f.shape[4]))
                     nhwc = buf
                     pyramid.copied += 1
@@ -471,7 +471,8 @@ class StepGraphs:
         try:
             ok = lib.sbev_copy_indirect(table, len(segs), c_idx, c_dst, c_nb, sp) == 0
             for idx, buf, n_img, ch, hw in relayout:
-                ok = ok and lib.sbev_nchw_to_nhwc_f32_indirect(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
+                fn = lib.sbev_nchw_to_nhwc_f32_indirect if buf.dtype == torch.float32 else lib.sbev_nchw_to_nhwc_b16_indirect
+                ok = ok and fn(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
             ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
         finally:
             handle = ctypes.c_void_p()

@@ -114,6 +114,20 @@ def test_nchw_to_nhwc(shape):
     assert torch.equal(y, x.permute(0, 1, 3, 4, 2).contiguous())
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 256, 8, 22), (2, 256, 10, 25), (5, 64, 64, 176), (1, 100, 7, 9), (2, 256, 64, 176), (1, 136, 4, 8), (2, 8, 1, 4)])
+def test_nchw_to_nhwc_two_byte_channels(shape, dtype):
+    """bf16 / fp16 STORAGE through the 2-byte relayout (sbev_nchw_to_nhwc_b16: channel pairs interleaved in registers, a 32-bit transpose
+    through LDS): pure byte movement -- every bit pattern must arrive, NaN payloads and negative zeros included; vector path
+    (channels % 8 == 0, hw % 4 == 0) and the scalar one"""
+    n, c, h, w = shape
+    bits = torch.randint(-32768, 32767, (1, n, c, h, w), device=DEV, dtype=torch.int16)
+    x = bits.view(dtype)
+    y = dense.to_channels_last(x)
+    assert y.shape == (1, n, h, w, c) and y.dtype == dtype and y.is_contiguous()
+    assert torch.equal(y.view(torch.int16), bits.permute(0, 1, 3, 4, 2).contiguous())
+
+
 def test_position_encoder_first_layer():
     g = torch.Generator().manual_seed(3)
     bbox = torch.rand(2, 450, 10, generator=g)

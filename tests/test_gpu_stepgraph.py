@@ -208,6 +208,32 @@ def test_fresh_tensors_every_step_replay_one_graph():
     assert best <= 0.2e-3, 'host issue %.3f ms per replayed step' % (best * 1e3)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_two_byte_nchw_features_are_staged_like_fp32_ones(dtype):
+    """fp16 (the reference's eval mode before its out_fp32 cast, val.py:115) or bf16 NCHW feature lists: the in-graph 2-byte relayout
+    (sbev_nchw_to_nhwc_b16_indirect) stages them, fresh tensors every step replay ONE graph, and the result equals the decoder on the
+    same features handed over channels-last (read in place) bit for bit -- and the fp32 decoder on the widened features."""
+    B, Q, T = 2, 100, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny5']
+    g, e = build(T, len(sizes), 21, num_layers=3), build(T, len(sizes), 21, num_layers=3, graph=False)
+    metas = S.make_img_metas(B, T, ih, iw)
+    base = [f.to(DEV).to(dtype) for f in S.make_features(B, T, sizes, seed=43)]
+    bbox0, feat0 = [t.to(DEV) for t in S.make_queries(B, Q, seed=44)]
+    hold = []
+    for step in range(5):
+        feats = [(f.float() * (1.0 + 0.01 * step)).to(dtype) for f in base]       # newly allocated NCHW tensors
+        bbox, feat = bbox0.clone(), feat0 * (1.0 + 0.02 * step)
+        hold.append((feats, bbox, feat))
+        got = [t.clone() for t in g(bbox, feat, feats, None, metas)]
+        nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+        want = e(bbox, feat, nhwc, None, metas)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), step
+        wide = e(bbox, feat, [f.float() for f in feats], None, metas)
+        assert torch.equal(got[0], wide[0]) and torch.equal(got[1], wide[1]), step
+    sg = g.decoder._runtime.step_graphs
+    assert sg.captures == 1 and sg.replays == 4 and len(sg.entries) == 1
+
+
 def test_in_place_inputs_with_new_buffers_every_step_do_not_thrash():
     """Channels-last feature lists are read IN PLACE by the decoder kernels, so their graphs are keyed on addresses.  A caller that
     brings new channels-last buffers every step can never replay: while MAX_WASTED captured graphs stand un-replayed the runtime

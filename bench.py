@@ -22,6 +22,7 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+CHILD_ARGS = []        # workload flags the profiled re-runs of this command (live_kernel_stats / live_pmc) have to repeat
 PROFILE_EVERY = 5      # sampler launches are bracketed with HIP events in every 5th step of the timed region (see main)
 sys.path.insert(0, ROOT)
 
@@ -85,7 +86,7 @@ def live_kernel_stats(config, gemm, timeout=120):
     try:
         cmd = ['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '-o', 'b', '--',
                sys.executable, os.path.join(ROOT, 'bench.py'), '--config', config, '--gemm', gemm, '--steps', '20', '--warmup', '3',
-               '--no-cpu-baseline', '--no-alt', '--no-detector', '--no-live-pmc']
+               '--no-cpu-baseline', '--no-alt', '--no-detector', '--no-live-pmc'] + CHILD_ARGS
         r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
         csvs = [os.path.join(d, f) for d, _, fs in os.walk(tmp) for f in fs if f.endswith('kernel_stats.csv')]
         if r.returncode != 0 or not csvs:
@@ -126,7 +127,7 @@ def live_pmc(config, timeout=90):
             out = os.path.join(tmp, counter)
             cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '-o', 'b', '--',
                    sys.executable, os.path.join(ROOT, 'bench.py'), '--config', config, '--steps', '3', '--warmup', '2',
-                   '--no-cpu-baseline', '--no-alt', '--no-detector', '--no-live-pmc']
+                   '--no-cpu-baseline', '--no-alt', '--no-detector', '--no-live-pmc'] + CHILD_ARGS
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
             csvs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('counter_collection.csv')]
             if r.returncode != 0 or not csvs:
@@ -339,6 +340,9 @@ def main():
     ap.add_argument('--no-detector', action='store_true', help='skip the labelled detector-level stand-in figure (default N=1 c2 run reports it)')
     ap.add_argument('--detector', action='store_true', help='force the detector figure for other configs too: also report a LABELLED detector-level samples/s: stock-PyTorch ResNet-50 + FPN stand-in (tools/backbone_standin.py, fp16) on the 6 new images -> frame ring -> SparseBEVHead -> NMS-free decode (online mode, like the reference FPS)')
     ap.add_argument('--no-alt', action='store_true', help='skip the secondary bf16x3 measurement')
+    ap.add_argument('--feat-dtype', default=None, choices=('fp32', 'fp16', 'bf16'),
+                    help='feature STORAGE type (fp32 math throughout; default: the config\'s own -- fp32, bf16 for c5 / c6).  fp16 = what the reference\'s eval mode holds '
+                         'before its out_fp32 cast (val.py:115): NCHW lists of it go through the 2-byte relayout inside the step unless --nhwc')
     ap.add_argument('--query-order', type=int, default=None, choices=(0, 1),
                     help='fused gather + mixing items in the order of sbev_query_order (1) or in launch order (0); default: the library setting (SBEV_QUERY_ORDER). Results are bit-identical')
     ap.add_argument('--shuffle-queries', action='store_true', help='permute the query rows (a trained head does not keep the BEV raster order of its initialisation): robustness A/B for --query-order')
@@ -348,6 +352,12 @@ def main():
                          'bf16x6 = hi + mid + lo bf16 images, 6 products; f16x4 = 4 fp16 products; bf16x3s / bf16x3 = 3 bf16 products (2^-16 class)')
     args = ap.parse_args()
 
+    for flag, val in (('--feat-dtype', args.feat_dtype), ('--query-order', args.query_order)):
+        if val is not None:
+            CHILD_ARGS.extend([flag, str(val)])
+    for flag, on in (('--nhwc', args.nhwc), ('--online', args.online), ('--shuffle-queries', args.shuffle_queries)):
+        if on:
+            CHILD_ARGS.append(flag)
     torch.set_grad_enabled(False)     # inference benchmark, like the reference's timing.py / val.py (with grad enabled the
                                       # module takes its differentiable path, as the reference's nn.Module would)
     rank, world, device = init_distributed(args.gpus)
@@ -355,6 +365,9 @@ def main():
         torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))      # N host processes share the box: no 256-thread pools each
     cfg = CONFIGS[args.config]
     pyr, Q, T, B, fdtype, P_cfg = cfg_fields(cfg)
+    cfg_nhwc = fdtype != torch.float32          # c5 / c6: bf16 maps channels-last, as a bf16 neck would emit them
+    if args.feat_dtype is not None:
+        fdtype = {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.feat_dtype]
     ih, iw, sizes = S.PYRAMIDS[pyr]
     L = len(sizes)
 
@@ -364,7 +377,7 @@ def main():
     shard = SampleShard(rank, world)
     # per-rank synthetic inputs (seed = rank), generated on the device and left resident
     feats = S.make_features(B, T, sizes, seed=rank, device=device, dtype=fdtype)
-    if args.nhwc or fdtype != torch.float32:
+    if args.nhwc or cfg_nhwc:
         args.nhwc = True
         feats = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
     bbox, qfeat = S.make_queries(B, Q, seed=rank)
@@ -519,7 +532,7 @@ def main():
         smp = model.decoder.decoder_layer.sampling
         G_, P_, Cg_ = smp.num_groups, smp.num_points, 256 // smp.num_groups
         npts = B * T * G_ * Q * P_                                 # B' * Q * P sampled points per launch
-        sf = 2 if fdtype == torch.bfloat16 else 4
+        sf = 4 if fdtype == torch.float32 else 2
         bytes_per_pt = L * 4 * Cg_ * sf + 12 + 4 * L + Cg_ * 4     # SURVEY.md section 8d byte model
         alg_bytes = npts * bytes_per_pt
         alg_gbps = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -527,7 +540,9 @@ def main():
         # committed profile of THIS config over the live HIP-event time -- a fraction of the 8 TB/s peak by construction.
         # The section-8d algorithmic rate prices every tap as a miss and therefore exceeds the pin rate whenever taps hit in
         # L2: it is reported beside it with the implied hit fraction, never as `frac`.
-        pmc, pmc_file = pmc_profile(args.config)
+        # (the committed profiles are of the config's own storage type: with --feat-dtype only counters measured now apply)
+        own_dtype = args.feat_dtype is None or {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.feat_dtype] == cfg_fields(cfg)[4]
+        pmc, pmc_file = pmc_profile(args.config) if own_dtype else (None, None)
         live = live_pmc(args.config) if (world == 1 and not args.no_live_pmc) else None
         live_src = 'measured in this run: bench.py re-ran 5 steps of this config under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes; x2 gfx950 correction), bytes per launch'
         if live and 'msmv_fwd_kernel' in live:
@@ -546,10 +561,11 @@ def main():
             'exact_f32': ({'value': alt['f32']['value'], 'ms_per_step': alt['f32']['ms_per_step']} if (alt and 'value' in alt.get('f32', {})) else None),
             'eager_f32': ({'value': eager_f32['value'], 'ms_per_step': eager_f32['ms_per_step']} if (eager_f32 and 'value' in eager_f32) else None),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32' if fdtype == torch.float32 else 'bf16-storage/f32-math') + ('' if args.gemm == 'f32' else ' (the two mixing GEMMs: %s = %s)' % (args.gemm, GEMM_WHAT[args.gemm])),
+            'dtype': ('f32' if fdtype == torch.float32 else ('bf16' if fdtype == torch.bfloat16 else 'fp16') + '-storage/f32-math') + ('' if args.gemm == 'f32' else ' (the two mixing GEMMs: %s = %s)' % (args.gemm, GEMM_WHAT[args.gemm])),
             'data': 'synthetic',
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
-                                   '%s feature input' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)')),
+                                   '%s feature input%s' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)'),
+                                                           '' if own_dtype else ', %s feature storage' % args.feat_dtype),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
                        'launches_per_layer': launches_per_layer, 'step_graph': graph_info,
                        'query_order': bool(runtime._STATE['order']), 'shuffled_queries': bool(args.shuffle_queries),
@@ -587,7 +603,7 @@ def main():
             f_avg = sum(fused_ms) / len(fused_ms)
             items = B * Q * G_
             f_alg = npts * (L * 4 * Cg_ * sf + 12 + 4 * L) + items * ((Cg_ * Cg_ + 128 * T * P_) * 4 + 128 * Cg_ * 4)
-            fp, fp_file = pmc_profile(args.config, 'adaptive_mixing_kernel')
+            fp, fp_file = pmc_profile(args.config, 'adaptive_mixing_kernel') if own_dtype else (None, None)
             if live and 'adaptive_mixing_kernel' in live:
                 fp, fp_file = live['adaptive_mixing_kernel'], None
             f_traffic = fp['hbm_bytes_per_launch'] if fp else None

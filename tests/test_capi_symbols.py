@@ -173,6 +173,18 @@ def test_query_order_entry_points_validate_without_gpu(lib):
     assert lib.sbev_decoder_query_order(prev) == prev
 
 
+def test_two_byte_relayout_validates_without_gpu(lib):
+    """round 4: sbev_nchw_to_nhwc_b16 / _indirect (bf16 / fp16 storage) check their arguments before any HIP call"""
+    one, two = ctypes.c_void_p(16), ctypes.c_void_p(4096)
+    assert lib.sbev_nchw_to_nhwc_b16(None, None, 0, 256, 64, None) == 0                       # empty
+    assert lib.sbev_nchw_to_nhwc_b16(None, two, 1, 256, 64, None) == -1 and lib.sbev_nchw_to_nhwc_b16(one, None, 1, 256, 64, None) == -1
+    assert lib.sbev_nchw_to_nhwc_b16(one, one, 1, 256, 64, None) == -1                        # aliased
+    assert lib.sbev_nchw_to_nhwc_b16(one, two, 1, 0, 64, None) == -1 and lib.sbev_nchw_to_nhwc_b16(one, two, 70000, 8, 4, None) == -1
+    assert lib.sbev_nchw_to_nhwc_b16_indirect(None, 0, two, 1, 256, 64, None) == -1
+    assert lib.sbev_nchw_to_nhwc_b16_indirect(ctypes.c_void_p(12), 0, two, 1, 256, 64, None) == -1      # table not 8-byte aligned
+    assert lib.sbev_nchw_to_nhwc_b16_indirect(one, -1, two, 1, 256, 64, None) == -1
+
+
 def test_round3_training_entry_points_validate_without_gpu(lib):
     """The grouped parameter-gradient launches and the fp16 hi + lo training GEMMs refuse what they do not cover before any HIP call."""
     one = ctypes.c_void_p(16)

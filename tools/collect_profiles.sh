@@ -14,7 +14,7 @@ cp $S/kt/bench_kernel_stats.csv $D/${ROUND}_bench_kernel_stats.csv
 [ -f $S/kt_train/train_kernel_stats.csv ] && cp $S/kt_train/train_kernel_stats.csv $D/${ROUND}_train_step_kernel_stats.csv
 cp $S/train.log $D/${ROUND}_train_step.log
 tail -1 $S/bench_line.json > $D/${ROUND}_bench_line.json
-for c in c1 c3 c4 c5 c6 c3_f32 c4_f32 c6_f32 nhwc online unfused; do [ -s $S/bench_$c.json ] && cp $S/bench_$c.json $D/${ROUND}_bench_line_$c.json; done
+for c in c1 c3 c4 c5 c6 c3_f32 c4_f32 c6_f32 nhwc online unfused fp16 fp16_nhwc c3_fp16 c4_fp16; do [ -s $S/bench_$c.json ] && cp $S/bench_$c.json $D/${ROUND}_bench_line_$c.json; done
 cp $S/${ROUND}_mfma_summary.json $D/ 2>/dev/null
 cp $S/${ROUND}_mfma_summary_bf16x6.json $D/ 2>/dev/null
 cp $S/${ROUND}_mfma_summary_f32.json $D/ 2>/dev/null

@@ -28,6 +28,10 @@ for c in c3 c4 c6; do python $R/bench.py --config $c $Q --steps 30 --gemm f32 2>
 python $R/bench.py --nhwc $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_nhwc.json; cut -c1-200 $OUT/bench_nhwc.json
 python $R/bench.py --online $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_online.json; cut -c1-200 $OUT/bench_online.json
 SBEV_NO_SAMPLE_MIX=1 python $R/bench.py $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_unfused.json; cut -c1-200 $OUT/bench_unfused.json
+# fp16 feature storage (the reference's eval mode before its out_fp32 cast): NCHW lists through the 2-byte relayout; c2 with live PMC
+python $R/bench.py --feat-dtype fp16 --no-cpu-baseline --no-alt --no-detector --steps 50 2>/dev/null | tail -1 > $OUT/bench_fp16.json; cut -c1-200 $OUT/bench_fp16.json
+python $R/bench.py --feat-dtype fp16 --nhwc $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_fp16_nhwc.json; cut -c1-200 $OUT/bench_fp16_nhwc.json
+for c in c3 c4; do python $R/bench.py --config $c --feat-dtype fp16 $Q --steps 30 2>/dev/null | tail -1 > $OUT/bench_${c}_fp16.json; cut -c1-200 $OUT/bench_${c}_fp16.json; done
 for i in 1 2 3; do python $R/tools/bench_train.py --graph 2>&1 | tail -1 >> $OUT/train.log; done; tail -3 $OUT/train.log
 python $R/tools/bench_train.py --graph --feat-grad --dropout >> $OUT/train.log 2>&1; tail -1 $OUT/train.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train -o train -- python $R/tools/bench_train.py --steps 5 > $OUT/kt_train.log 2>&1

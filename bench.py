@@ -391,7 +391,7 @@ def main():
 
     if args.online:
         from sparsebev_amd.cache import FrameFeatureCache
-        ring = FrameFeatureCache(T, n_slots=T)
+        ring = FrameFeatureCache(T, n_slots=T, dtype=fdtype)      # (fp16 / bf16 storage: the frames stay in their type)
         per_frame = [[f[:, t * 6:(t + 1) * 6].contiguous() for f in feats] for t in range(T)]
         for fr in reversed(per_frame):
             ring.push(fr)

@@ -17,7 +17,14 @@ N_VIEWS = 6
 
 
 class FrameFeatureCache:
-    def __init__(self, num_frames, n_slots=None):
+    """``dtype``: the ring's STORAGE type.  fp32 (default) takes fp32 NCHW frames and channels-last fp32 / fp16 / bf16 frames (widened);
+    ``torch.float16`` / ``torch.bfloat16`` keep an fp16 backbone's / a bf16 neck's frames as they are (half the memory and the relayout
+    traffic; the sampler widens a tap exactly) and take frames of that type only, NCHW (2-byte relayout) or channels-last (copied)."""
+
+    def __init__(self, num_frames, n_slots=None, dtype=torch.float32):
+        if dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            raise ValueError('ring storage must be fp32, fp16 or bf16')
+        self.dtype = dtype
         self.T = num_frames
         self.n_slots = n_slots or num_frames
         if not self.T <= self.n_slots <= 16:
@@ -29,7 +36,7 @@ class FrameFeatureCache:
     def _alloc(self, frame_feats):
         f0 = frame_feats[0]
         self.B = f0.shape[0]
-        self.buffers = [torch.empty(self.B, self.n_slots, N_VIEWS, f.shape[3], f.shape[4], f.shape[2], device=f.device, dtype=torch.float32)
+        self.buffers = [torch.empty(self.B, self.n_slots, N_VIEWS, f.shape[3], f.shape[4], f.shape[2], device=f.device, dtype=self.dtype)
                         for f in frame_feats]
 
     def push(self, frame_feats):
@@ -44,6 +51,20 @@ class FrameFeatureCache:
         for f, buf in zip(frame_feats, self.buffers):
             if not f.is_cuda or f.shape[0] != self.B or f.shape[1] != N_VIEWS:
                 raise RuntimeError('frame features must be device tensors [B, 6, C, H, W]')
+            if self.dtype != torch.float32:                     # 2-byte ring: frames of the ring's own type only, moved as bytes
+                if f.dtype != self.dtype:
+                    raise RuntimeError('a %s ring takes %s frames only (got %s)' % (self.dtype, self.dtype, f.dtype))
+                if f.stride(2) == 1 and f[0].is_contiguous(memory_format=torch.channels_last):
+                    for b in range(self.B):
+                        buf[b, slot].copy_(f[b].permute(0, 2, 3, 1))      # both sides contiguous [6, H, W, C]: a device memcpy
+                else:
+                    f = f.contiguous()
+                    C, H, W = f.shape[2:]
+                    for b in range(self.B):
+                        st = lib.sbev_nchw_to_nhwc_b16(ctypes.c_void_p(f[b].data_ptr()), ctypes.c_void_p(buf[b, slot].data_ptr()),
+                                                       N_VIEWS, C, H * W, stream)
+                        _lib.check(st, 'sbev_nchw_to_nhwc_b16')
+                continue
             if f.stride(2) == 1 and f[0].is_contiguous(memory_format=torch.channels_last):      # NHWC memory: zero relayout
                 code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}.get(f.dtype)
                 if code is None:

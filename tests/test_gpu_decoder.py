@@ -427,6 +427,40 @@ def test_profile_stride_brackets_every_nth_call_only():
         rt.profile_stride(0)
 
 
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_two_byte_ring_equals_the_dense_pyramid_of_the_same_frames(dtype):
+    """FrameFeatureCache(dtype=fp16 / bf16) (round 4): frames stay in their storage type (NCHW frames through the 2-byte relayout,
+    channels-last ones copied), and the decoder on the ring equals the decoder on the dense stack of the same frames -- and the fp32
+    decoder on the widened stack -- bit for bit, also after evictions wrapped the ring; other frame types are refused."""
+    from sparsebev_amd.cache import FrameFeatureCache
+    B, Q, T, L = 2, 36, 4, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    model = build(T, L, 31)
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=32)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    g = torch.Generator(device=DEV).manual_seed(34)
+    frames = [[torch.randn(B, 6, 256, h, w, generator=g, device=DEV).to(dtype) for h, w in sizes] for _ in range(T + 3)]
+    cache = FrameFeatureCache(T, n_slots=T + 1, dtype=dtype)
+    for i, fr in enumerate(frames):
+        if i % 2:                                                 # every other frame arrives channels-last
+            fr = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in fr]
+        cache.push(fr)
+        if i + 1 < T:
+            continue
+        assert all(b.dtype == dtype for b in cache.buffers)
+        newest_first = frames[i::-1][:T]
+        dense = [torch.cat([f[l] for f in newest_first], dim=1) for l in range(L)]
+        a = model(bbox, feat, dense, None, copy.deepcopy(metas))
+        r = model(bbox, feat, cache.pyramid(), None, copy.deepcopy(metas))
+        w = model(bbox, feat, [d.float() for d in dense], None, copy.deepcopy(metas))
+        assert torch.equal(a[0], r[0]) and torch.equal(a[1], r[1]), i
+        assert torch.equal(w[0], r[0]) and torch.equal(w[1], r[1]), i
+    with pytest.raises(RuntimeError):
+        cache.push([f.float() for f in frames[0]])
+    with pytest.raises(ValueError):
+        FrameFeatureCache(T, dtype=torch.float64)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 def test_ring_takes_channels_last_frames_through_the_widening_copy(dtype):
     """FrameFeatureCache.push with channels-last memory (what a channels_last conv stack emits, fp32 / fp16 / bf16): the frame is

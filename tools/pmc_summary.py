@@ -25,6 +25,9 @@ def short(name):
     m = re.search(r'adaptive_mixing_kernel<\d+, (true|false), (\d+)', name)
     if m:                      # the fused gather + mixing instantiations (L > 0) vs the plain mixing kernel
         return 'adaptive_mixing_kernel' if m.group(2) != '0' else 'adaptive_mixing_kernel_plain'
+    m = re.search(r'adaptive_mixing_kernelILi\d+ELb[01]ELi(\d+)E', name)      # (rocprofv3 leaves _Float16 instantiations mangled)
+    if m:
+        return 'adaptive_mixing_kernel' if m.group(1) != '0' else 'adaptive_mixing_kernel_plain'
     m = re.search(r'row_chain_kernel<(\d)(?:, \d)?>', name)
     if m:                      # the three row chains (csrc/row_chain.hip): 0 tail (+ next front), 1 layer-0 front, 2 attention chain
         return 'row_chain_kernel_' + {'0': 'tail', '1': 'front', '2': 'attention'}[m.group(1)]

@@ -290,8 +290,12 @@ def detector_standin(args, T, L, Q, B, ih, iw, sizes, device, transformer):
         head.transformer.decoder.decoder_layer.cls_branch[-1].bias.zero_()
     head = head.to(device).eval()
     metas = S.make_img_metas(B, T, ih, iw)
-    ring = FrameFeatureCache(T, n_slots=T)
     imgs = torch.rand(B * 6, 3, ih, iw, device=device) * 255
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        dts = {f.dtype for f in net(imgs)}
+    # the ring keeps the frames in the type the backbone emits (fp16 under autocast: taps are widened exactly inside the sampler --
+    # DESIGN 10.9); a mixed-type neck falls back to the fp32 ring (frames widened on entry)
+    ring = FrameFeatureCache(T, n_slots=T, dtype=dts.pop() if len(dts) == 1 and dts <= {torch.float16, torch.bfloat16} else torch.float32)
 
     def frame():
         with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
@@ -322,8 +326,9 @@ def detector_standin(args, T, L, Q, B, ih, iw, sizes, device, transformer):
     dtb = time.perf_counter() - t1
     return {'value': round(n * B / dt, 3), 'unit': 'samples/s', 'ms_per_step': round(1e3 * dt / n, 4),
             'backbone_ms': round(1e3 * dtb / n, 4), 'boxes_kept_last_step': int(sum(r[0].shape[0] for r in res)),
+            'ring_dtype': str(ring.dtype).replace('torch.', ''),
             'what': 'LABELLED STAND-IN, not the metric: stock torch.nn ResNet-50 + FPN (random init, fp16 autocast, MIOpen) on the 6 new '
-                    '%dx%d images per sample + frame ring + SparseBEVHead (this repo) + NMS-free decode, online mode, bs=%d; the reference '
+                    '%dx%d images per sample + frame ring (in the backbone\'s own storage type) + SparseBEVHead (this repo) + NMS-free decode, online mode, bs=%d; the reference '
                     'publishes 15.8 FPS for this pipeline on an RTX 3090 (README.md:28)' % (iw, ih, B)}
 
 

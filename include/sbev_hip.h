@@ -36,7 +36,8 @@ enum sbev_status {
     SBEV_OK = 0,
     SBEV_EINVAL = -1,  /* bad argument (the reference raises AT_ASSERTM -> RuntimeError: msmv_sampling.cpp:106-125) */
     SBEV_ELAUNCH = -2, /* hipLaunch / hipGetLastError failure (the reference only printf's: msmv_sampling_forward.cu:295-298) */
-    SBEV_ENODEV = -3   /* no gfx950 device visible */
+    SBEV_ENODEV = -3,  /* no gfx950 device visible */
+    SBEV_EFAULT = -4   /* an EARLIER decoder step's result is invalid (a pair-mode hand-off timed out: sbev_decoder_chain_pair_faults) */
 };
 
 enum sbev_dtype { SBEV_F32 = 0, SBEV_BF16 = 1, SBEV_F16 = 2 };   /* feature STORAGE types of the sampler (fp32 math throughout): bf16 and fp16 taps are widened exactly.
@@ -735,6 +736,15 @@ int sbev_decoder_row_chain(int enable);
  * the device; -1 on a HIP error. */
 int sbev_decoder_chain_pair(int enable);
 int64_t sbev_decoder_chain_pair_timeouts(void);
+/* The same event on the NORMAL path (round 5): a timed-out hand-off also bumps a sticky word in pinned host memory, read without
+ * synchronising anything.  While sbev_decoder_chain_pair_faults() > 0, sbev_decoder_forward (and sbev_graph_launch of a captured
+ * step) refuses with SBEV_EFAULT: the step that faulted -- the PREVIOUS one or an earlier one, its launches were asynchronous -- holds
+ * wrong rows and must be repeated.  The refusing call switches pair mode off (single-workgroup tail from here on: no hand-offs, no
+ * faults); the caller acknowledges with sbev_decoder_chain_pair_faults_ack() (returns the count) and re-runs.  A caller that
+ * synchronises on its own can ask sbev_decoder_chain_pair_faults() right after its synchronisation and learn about the CURRENT step.
+ * Pair mode is only used when the word could be installed (hipHostMalloc). */
+int64_t sbev_decoder_chain_pair_faults(void);
+int64_t sbev_decoder_chain_pair_faults_ack(void);
 /* Test hook for the poll bound: with 1, one member of the first pair of every pair-mode tail exits at once; its partner must time out
  * (sbev_decoder_chain_pair_timeouts grows, the launch ends after about a second per hand-off, only that pair's 8 rows are wrong).
  * Returns the previous setting.  Never set in production. */

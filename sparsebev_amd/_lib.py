@@ -160,6 +160,8 @@ SIGNATURES = {
     'sbev_decoder_row_chain': (ctypes.c_int, [ctypes.c_int]),
     'sbev_decoder_chain_pair': (ctypes.c_int, [ctypes.c_int]),
     'sbev_decoder_chain_pair_timeouts': (ctypes.c_int64, []),
+    'sbev_decoder_chain_pair_faults': (ctypes.c_int64, []),
+    'sbev_decoder_chain_pair_faults_ack': (ctypes.c_int64, []),
     'sbev_debug_chain_pair_drop': (ctypes.c_int, [ctypes.c_int]),
     'sbev_gemm_f32_workspace': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
     'sbev_gemm_f32': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int64,
@@ -236,7 +238,21 @@ def load():
     return lib
 
 
+class PairFaultError(SbevError):
+    """SBEV_EFAULT: an EARLIER decoder step lost a pair-mode hand-off (the GPU was shared or preempted for about a second) -- that
+    step's outputs are invalid.  By the time this is raised pair mode is off and the fault acknowledged: repeat the step(s) since
+    the last result you synchronised on and verified with ``runtime.check_pair_faults()``."""
+
+
+EFAULT = -4
+
+
 def check(status, what):
+    if status == EFAULT:
+        from . import runtime
+        msg = load().sbev_last_error().decode('utf-8', 'replace')
+        runtime._on_pair_fault()
+        raise PairFaultError('%s refused (%d): %s' % (what, status, msg))
     if status != 0:
         msg = load().sbev_last_error().decode('utf-8', 'replace')
         raise SbevError('%s failed (%d): %s' % (what, status, msg))

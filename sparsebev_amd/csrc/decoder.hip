@@ -207,6 +207,14 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const sbev_decoder_config& c = *cfg;
     SBEV_REQUIRE(w && feats_nhwc && query_bbox && query_feat && time_diff && lidar2img && cls_out && bbox_out && workspace,
                  "sbev_decoder_forward: null pointer");
+    if (const unsigned faults = sbev::chain_pair_faults_pending()) {
+        // an earlier step's pair tail lost a partner (the GPU was shared / preempted for ~1 s): that step's rows are wrong.  Sticky
+        // until acknowledged; pair mode goes off so that the repeated step cannot fault again.
+        sbev_decoder_chain_pair(0);
+        sbev::set_error("sbev_decoder_forward: %u pair-mode hand-off(s) of an EARLIER decoder step timed out -- that step's outputs are invalid; "
+                        "pair mode is now off: acknowledge with sbev_decoder_chain_pair_faults_ack() and repeat the step", faults);
+        return SBEV_EFAULT;
+    }
     const sbev::ProfCallScope prof_scope;     // with sbev_profile_stride(n): only every n-th call's launches are bracketed
     SBEV_REQUIRE((((uintptr_t)workspace) & 255) == 0, "sbev_decoder_forward: workspace must be 256-byte aligned");
     SBEV_REQUIRE(cfg->gemm_mode != SBEV_GEMM_BF16X3 || (w->pg_w2 && w->op_w2), "sbev_decoder_forward: gemm_mode bf16x3 needs pg_w2 / op_w2");
@@ -643,6 +651,12 @@ extern "C" int sbev_capture_end(sbev_stream_t stream, sbev_graph** out) {
 
 extern "C" int sbev_graph_launch(sbev_graph* g, sbev_stream_t stream) {
     SBEV_REQUIRE(g && g->exec, "sbev_graph_launch: null graph");
+    if (const unsigned faults = sbev::chain_pair_faults_pending()) {      // (see sbev_decoder_forward: sticky until acknowledged)
+        sbev_decoder_chain_pair(0);
+        sbev::set_error("sbev_graph_launch: %u pair-mode hand-off(s) of an EARLIER step timed out -- that step's outputs are invalid; pair mode "
+                        "is now off: acknowledge with sbev_decoder_chain_pair_faults_ack(), re-capture and repeat the step", faults);
+        return SBEV_EFAULT;
+    }
     return hip_ok(hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream)), "hipGraphLaunch");
 }
 

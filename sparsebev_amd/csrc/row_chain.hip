@@ -418,6 +418,11 @@ __device__ __forceinline__ void gather4_raw(float (&v)[4], const float* P, int K
 // block -> pair map puts both members on one XCD under round-robin dispatch (speed only).  The counters are zeroed by the attention
 // chain of the same layer, which always runs between two tails on the stream (no memset node).
 __device__ unsigned g_chain_pair_timeouts;
+// ... and a STICKY fault word in pinned, device-mapped HOST memory (pair_fault_host() below installs the pointer once per process): a
+// timed-out hand-off also bumps it with a system-scope atomic, so the host sees the fault WITHOUT synchronising the device -- at the next
+// sbev_decoder_forward / graph replay it is an error (SBEV_EFAULT), not eight silently wrong rows.  Read only on the timeout
+// path: no kernel argument, no register in the hot loop.
+__device__ unsigned* g_chain_pair_fault_host;
 constexpr unsigned PAIR_POLL_LIMIT = 1u << 20;       // x (s_sleep 2 + one memory round trip, ~1 us): about a second
 
 __device__ __forceinline__ void pair_store4(float* p, const float (&v)[4]) {
@@ -441,6 +446,8 @@ __device__ __forceinline__ void pair_wait(unsigned* word, unsigned arrivals) {
             __builtin_amdgcn_s_sleep(2);
             if (++n > PAIR_POLL_LIMIT) {
                 __hip_atomic_fetch_add(&g_chain_pair_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned* const host_word = g_chain_pair_fault_host;
+                if (host_word) __hip_atomic_fetch_add(host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -932,6 +939,33 @@ Offs offs(int rg) { return rg == 1 ? offs_of<1>() : rg == 2 ? offs_of<2>() : off
 // SBEV_CHAIN_PAIR16=1 enables it for A/B runs.)
 std::atomic<int> g_chain_pair{getenv("SBEV_NO_CHAIN_PAIR") ? 0 : 1};
 std::atomic<int> g_chain_pair_drop{0};
+// the sticky fault word (see g_chain_pair_fault_host): 64 bytes of pinned host memory mapped into the device, one per process (a process
+// drives one GPU: one process per GPU is the deployment model; with several devices the word is shared -- a fault on any of them stops
+// pair mode everywhere).  Installed before the first pair-mode launch on a device; nullptr when the allocation fails (the device-side
+// counter still works).
+std::atomic<unsigned> g_pair_fault_acked{0};
+volatile unsigned* pair_fault_host() {
+    static volatile unsigned* word = [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || !h) { (void)hipGetLastError(); return (volatile unsigned*)nullptr; }
+        *static_cast<volatile unsigned*>(h) = 0u;
+        return static_cast<volatile unsigned*>(h);
+    }();
+    return word;
+}
+bool pair_fault_install() {            // this device's g_chain_pair_fault_host -> the word; once per device
+    static std::atomic<int> done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (done[dev & 63].load(std::memory_order_acquire)) return true;
+    volatile unsigned* h = pair_fault_host();
+    if (!h) return false;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<unsigned*>(h), 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_pair_fault_host), &d, sizeof(d)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    done[dev & 63].store(1, std::memory_order_release);
+    return true;
+}
 int pair_blocks(long long rows, int rg) {
     const long long pairs = (rows + 4 * rg - 1) / (4 * rg);
     return (int)(16 * ((pairs + 7) / 8));
@@ -949,6 +983,7 @@ int device_cus() {
 }
 int pair_row_groups(long long rows) {
     if (g_chain_pair.load(std::memory_order_relaxed) == 0 || rows > 256 * 16) return 0;
+    if (!pair_fault_install()) return 0;        // no way to report a lost partner: the single-workgroup tail
     const int cus = device_cus();
     static const int max_rg = getenv("SBEV_CHAIN_PAIR16") ? 4 : 2;
     for (int rg = 2; rg <= max_rg; rg *= 2)
@@ -963,6 +998,12 @@ namespace sbev {
 // pair mode workspace: exchange rows (floats) and arrival counters (words) for `rows` rows, whatever the row block it picks
 long long chain_pair_floats(long long rows) { return 3 * (rows + 15) * DM; }
 long long chain_pair_sync_words(long long rows) { return (rows + 7) / 8; }
+
+// hand-offs that timed out and were not acknowledged yet (host memory: no device synchronisation)
+unsigned chain_pair_faults_pending() {
+    volatile unsigned* h = pair_fault_host();
+    return h ? *h - g_pair_fault_acked.load(std::memory_order_relaxed) : 0u;
+}
 
 bool row_chain_supported(const sbev_decoder_config& c) {
     return c.D == DM && c.ffn == FF && c.code_size == 10 && c.num_classes >= 1 && c.num_classes <= 64 &&
@@ -1195,6 +1236,17 @@ extern "C" int64_t sbev_decoder_chain_pair_timeouts(void) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_chain_pair_timeouts), sizeof(v)) != hipSuccess) return -1;
     return (int64_t)v;
+}
+
+// the sticky fault word: timed-out hand-offs since the last acknowledgement, read from pinned host memory (NO synchronisation; a fault
+// becomes visible once the faulting launch has run, ~1 s after its partner went missing)
+extern "C" int64_t sbev_decoder_chain_pair_faults(void) { return (int64_t)sbev::chain_pair_faults_pending(); }
+// acknowledge them (the caller has dealt with the invalid step): sbev_decoder_forward accepts calls again.  Returns how many there were.
+extern "C" int64_t sbev_decoder_chain_pair_faults_ack(void) {
+    volatile unsigned* h = pair_fault_host();
+    if (!h) return 0;
+    const unsigned now = *h;
+    return (int64_t)(now - g_pair_fault_acked.exchange(now));
 }
 
 extern "C" int64_t sbev_decoder_chain_pack_floats(const sbev_decoder_config* cfg) {

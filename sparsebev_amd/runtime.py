@@ -272,6 +272,8 @@ class DecoderRuntime:
     def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
         """pyramid: transformer.FeaturePyramid; ctx: transformer.DecoderContext.  Returns (cls, bbox) stacked over
         layers (not nan_to_num'ed)."""
+        if _STATE['chain_pair']:
+            check_pair_faults()             # an earlier step lost a pair hand-off: raise before anything is enqueued on top of it
         args, _keep, cls, box = self._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask)
         st = _lib.load().sbev_decoder_forward(*args, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(st, 'sbev_decoder_forward')
@@ -373,6 +375,8 @@ class StepGraphs:
         if not hasattr(mlvl_feats, 'levels') and not all(torch.is_tensor(f) and f.is_cuda for f in mlvl_feats):
             return None
         from . import transformer as TR
+        if _STATE['chain_pair']:
+            check_pair_faults()             # (before a capture or replay is built on an invalid step; one host-memory read)
         sig = rt._ensure_bound()
         fkey, ident, staged = self._feat_key(mlvl_feats)
         key = (tuple(query_bbox.shape), tuple(query_feat.shape), fkey, None if attn_mask is None else tuple(attn_mask.shape), sig,
@@ -566,6 +570,29 @@ def chain_pair(enable):
     prev = _lib.load().sbev_decoder_chain_pair(int(bool(enable)))
     _STATE['chain_pair'] = bool(enable)
     return bool(prev)
+
+
+def _on_pair_fault():
+    """SBEV_EFAULT came back (``_lib.check``): mirror what the library did (pair mode off -- captured pair-mode steps are keyed on
+    the switch and are not hit again) and acknowledge, so that the caller's repeated step runs on the single-workgroup tail."""
+    lib = _lib.load()
+    lib.sbev_decoder_chain_pair(0)
+    _STATE['chain_pair'] = False
+    lib.sbev_decoder_chain_pair_faults_ack()
+    import warnings
+    warnings.warn('sparsebev_amd: a pair-mode tail hand-off timed out (GPU shared / preempted?); pair mode is off for the rest of the process')
+
+
+def check_pair_faults():
+    """For callers that synchronise themselves: right AFTER ``torch.cuda.synchronize()`` (or an event / ``.item()`` on the step's
+    outputs) this tells whether the step just finished -- or any since the last check -- lost a pair hand-off; raises
+    ``_lib.PairFaultError`` (pair mode off, acknowledged) if so.  Costs one read of pinned host memory; never synchronises.  Without
+    it a fault surfaces at the NEXT decoder call instead (``sbev_decoder_forward`` / graph replay refuse with SBEV_EFAULT)."""
+    n = int(_lib.load().sbev_decoder_chain_pair_faults())
+    if n > 0:
+        _on_pair_fault()
+        raise _lib.PairFaultError('%d pair-mode hand-off(s) timed out since the last check: the step(s) since then hold invalid rows; '
+                                  'pair mode is off now, repeat them' % n)
 
 
 def chain_pair_timeouts():

@@ -158,7 +158,10 @@ def test_tail_pairs_under_uneven_load_and_graph_replay():
 def test_a_lost_pair_member_times_out_instead_of_hanging():
     """The poll bound: with the test hook one member of pair 0 leaves at once; its partner must give up after the bound (~1 s per
     hand-off), count a timeout and finish -- rows 8 .. of a ONE-layer run are untouched (rows are independent within the tail; the
-    next layer's attention would mix the broken rows in), and the next launch without the hook is exact again."""
+    next layer's attention would mix the broken rows in).  Round 5: the fault is OBSERVABLE on the normal path -- a sticky
+    word in pinned host memory; ``runtime.check_pair_faults()`` after the caller's own synchronisation raises for the step just
+    finished, and without that the NEXT decoder call refuses (SBEV_EFAULT -> PairFaultError) instead of computing on top of 8 wrong
+    rows; either way pair mode is off afterwards and the repeated step is right."""
     import time
     from sparsebev_amd import _lib
     feats, bbox, feat, metas, L = inputs(1, 100, 2, 'tiny', 91)
@@ -167,19 +170,76 @@ def test_a_lost_pair_member_times_out_instead_of_hanging():
     ref = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
     t0 = runtime.chain_pair_timeouts()
     lib = _lib.load()
-    assert lib.sbev_debug_chain_pair_drop(1) == 0
+    assert lib.sbev_decoder_chain_pair_faults() == 0
     try:
-        tic = time.time()
-        out = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
-        torch.cuda.synchronize()
-        took = time.time() - tic
+        for how in ('check after sync', 'next call refuses'):
+            assert runtime.chain_pair(True) in (True, False)
+            assert lib.sbev_debug_chain_pair_drop(1) == 0
+            try:
+                tic = time.time()
+                out = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+                torch.cuda.synchronize()
+                took = time.time() - tic
+            finally:
+                assert lib.sbev_debug_chain_pair_drop(0) == 1
+            assert took < 60.0
+            assert runtime.chain_pair_timeouts() > t0
+            assert lib.sbev_decoder_chain_pair_faults() > 0          # visible WITHOUT a device synchronisation of its own
+            assert torch.equal(out[0][:, :, 8:], ref[0][:, :, 8:]) and torch.equal(out[1][:, :, 8:], ref[1][:, :, 8:])
+            with pytest.raises(_lib.PairFaultError):
+                if how == 'check after sync':
+                    runtime.check_pair_faults()
+                else:
+                    model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+            assert lib.sbev_decoder_chain_pair_faults() == 0         # acknowledged ...
+            assert runtime.chain_pair(False) is False                # ... and pair mode went off with the fault
+            again = model(bbox, feat, list(feats), None, copy.deepcopy(metas))      # the repeated step: single-workgroup tail, right again
+            assert (again[0] - ref[0]).abs().max().item() < 2e-5 and (again[1] - ref[1]).abs().max().item() < 2e-5
+            t0 = runtime.chain_pair_timeouts()
     finally:
-        assert lib.sbev_debug_chain_pair_drop(0) == 1
-    assert took < 60.0
-    assert runtime.chain_pair_timeouts() > t0
-    assert torch.equal(out[0][:, :, 8:], ref[0][:, :, 8:]) and torch.equal(out[1][:, :, 8:], ref[1][:, :, 8:])
-    again = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
-    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+        runtime.chain_pair(True)
+    exact = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert torch.equal(exact[0], ref[0]) and torch.equal(exact[1], ref[1])
+
+
+def test_pair_fault_word_through_the_c_abi():
+    """sbev_decoder_forward itself refuses while a fault stands (pure-C callers have no Python runtime around them): SBEV_EFAULT and
+    a message, pair mode switched off by the refusing call, calls accepted again after sbev_decoder_chain_pair_faults_ack()."""
+    import ctypes
+    from sparsebev_amd import _lib
+    feats, bbox, feat, metas, L = inputs(1, 64, 2, 'tiny', 93)
+    model, _ = build(2, L, 94, 1)
+    model.decoder.static_graph = False
+    lib = _lib.load()
+    ref = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
+    rt = model.decoder._runtime
+    ctx = DecoderContext(copy.deepcopy(metas), 1, bbox.device)
+    pyr = FeaturePyramid(list(feats))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        assert lib.sbev_debug_chain_pair_drop(1) == 0
+        try:
+            args, keep, cls, box = rt._prepare(bbox, feat, pyr, ctx, None)
+            assert lib.sbev_decoder_forward(*args, stream) == 0          # the faulting step: accepted (nothing is known yet)
+            torch.cuda.synchronize()
+        finally:
+            lib.sbev_debug_chain_pair_drop(0)
+        n = lib.sbev_decoder_chain_pair_faults()
+        assert n > 0
+        args, keep, cls, box = rt._prepare(bbox, feat, pyr, ctx, None)
+        assert lib.sbev_decoder_forward(*args, stream) == _lib.EFAULT      # sticky: every call refuses ...
+        assert b'timed out' in lib.sbev_last_error()
+        assert lib.sbev_decoder_forward(*args, stream) == _lib.EFAULT
+        assert lib.sbev_decoder_chain_pair(1) == 0                        # ... and the first refusal switched pair mode off
+        assert lib.sbev_decoder_chain_pair_faults_ack() == n
+        assert lib.sbev_decoder_chain_pair_faults() == 0
+        assert lib.sbev_decoder_forward(*args, stream) == 0               # acknowledged: accepted again (pair mode back on by the line above)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(cls), ref[0]) and torch.equal(torch.nan_to_num(box), ref[1])
+        assert lib.sbev_decoder_chain_pair_faults() == 0
+    finally:
+        lib.sbev_decoder_chain_pair_faults_ack()
+        runtime.chain_pair(True)
 
 
 def test_row_chains_every_layer_from_the_same_inputs():

@@ -28,9 +28,12 @@ def short(name):
     m = re.search(r'adaptive_mixing_kernelILi\d+ELb[01]ELi(\d+)E', name)      # (rocprofv3 leaves _Float16 instantiations mangled)
     if m:
         return 'adaptive_mixing_kernel' if m.group(1) != '0' else 'adaptive_mixing_kernel_plain'
-    m = re.search(r'row_chain_kernel<(\d)(?:, \d)?>', name)
-    if m:                      # the three row chains (csrc/row_chain.hip): 0 tail (+ next front), 1 layer-0 front, 2 attention chain
-        return 'row_chain_kernel_' + {'0': 'tail', '1': 'front', '2': 'attention'}[m.group(1)]
+    # the three row chains (csrc/row_chain.hip): first template argument 0 tail (+ next front), 1 layer-0 front, 2 attention chain.  ANY
+    # number of further arguments (round 4's pair tail is row_chain_kernel<0, 2, true>: the two-argument pattern of round 3 dropped every
+    # chain from profiles/r4_pmc_*.json without a word), demangled or mangled
+    m = re.search(r'row_chain_kernel<(\d)\s*[,>]', name) or re.search(r'row_chain_kernelILi(\d)E', name)
+    if m:
+        return 'row_chain_kernel_' + {'0': 'tail', '1': 'front', '2': 'attention'}.get(m.group(1), m.group(1))
     for key in ('msmv_fwd_kernel', 'adaptive_mixing_kernel', 'transpose_tiles_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
                 'gemm_nt_f32_small_kernel', 'gemm_group_small_kernel', 'gemm_nt_f32_strip_kernel', 'gemm_nt_f32_regtile_kernel',
                 'sample_project_kernel', 'sampling_front_kernel', 'ffn_fused_kernel', 'branch_chain_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3',
@@ -47,9 +50,12 @@ def main():
     f, w = per_kernel(fetch, 'FETCH_SIZE'), per_kernel(write, 'WRITE_SIZE')
     hit, miss = (per_kernel(tcc, 'TCC_HIT_sum'), per_kernel(tcc, 'TCC_MISS_sum')) if tcc else ({}, {})
     res = {}
+    dropped = []
     for name in set(f) | set(w):
         s = short(name)
         if s is None:
+            if 'anonymous namespace' in name or '_GLOBAL__N_' in name:      # one of this library's kernels without a short name: say so
+                dropped.append(name.split('(')[0][:100])
             continue
         fk, n = f.get(name, (0.0, 0))
         wk, _ = w.get(name, (0.0, 0))
@@ -67,6 +73,8 @@ def main():
                        '--steps 4 --warmup 2 --no-cpu-baseline --no-alt --no-detector` (tools/profile_pmc.sh); KiB units; FETCH_SIZE x2 (gfx950 wide-read '
                        'under-count, validated on transpose_tiles_kernel whose true read bytes are known); FETCH/WRITE are fabric-side L2 requests, i.e. '
                        'HBM + Infinity-Cache traffic' % config, 'kernels': res}, open(out, 'w'), indent=1)
+    for name in sorted(set(dropped)):
+        print('pmc_summary: no short name for library kernel %s (not in the summary)' % name, file=sys.stderr)
     for k, v in sorted(res.items()):
         print('%-28s fetch(corr) %8.1f MB  write %8.1f MB  L2 hit %s' % (k, v['fetch_bytes_corrected_x2'] / 1e6, v['write_bytes'] / 1e6, v.get('l2_hit_ratio')))
 

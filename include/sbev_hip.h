@@ -357,6 +357,17 @@ int sbev_nchw_to_nhwc_b16_indirect(const void* const* table, int index, void* ou
 int sbev_copy_indirect(const void* const* table, int nseg, const int32_t* index, void* const* dst, const int64_t* nbytes,
                        sbev_stream_t stream);
 
+/* The decoder step's LAST launch (round 5): the stacked outputs cls [n_cls floats] / bbox [n_box floats] copied out of the runtime's
+ * buffers into the caller's, nan_to_num'ed on the way (NaN -> 0, +-Inf -> +-FLT_MAX, every other value bit for bit) -- both tensors
+ * in one launch.  Replaces: the two torch.nan_to_num launches of SparseBEVTransformer.forward (models/sparsebev_transformer.py:35-36)
+ * and, for a replayed step graph, the clones out of the graph's buffers.  _indirect: destinations = table[idx_cls] / table[idx_box]
+ * (device pointer table, see above), so that a captured step writes straight into tensors allocated per call.  Sources and
+ * destinations must not overlap. */
+int sbev_finish_outputs(const float* cls_src, const float* box_src, float* cls_dst, float* box_dst, int64_t n_cls, int64_t n_box,
+                        sbev_stream_t stream);
+int sbev_finish_outputs_indirect(const void* const* table, int idx_cls, int idx_box, const float* cls_src, const float* box_src,
+                                 int64_t n_cls, int64_t n_box, sbev_stream_t stream);
+
 
 /*
  * y = relu(LayerNorm(x[:, 0:3] @ w^T + b)): the first half of the position encoder

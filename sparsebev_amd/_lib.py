@@ -58,6 +58,8 @@ SIGNATURES = {
     'sbev_nchw_to_nhwc_b16': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_nchw_to_nhwc_b16_indirect': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_copy_indirect': (ctypes.c_int, [_vp, ctypes.c_int, _c_i32p, ctypes.POINTER(_vp), _c_i64p, _vp]),
+    'sbev_finish_outputs': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
+    'sbev_finish_outputs_indirect': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
     'sbev_linear3_ln_relu_f32': (ctypes.c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, ctypes.c_float, _vp,
                                                 ctypes.c_int64, ctypes.c_int, _vp]),
     'sbev_decoder_workspace_bytes': (ctypes.c_int64, [_vp]),

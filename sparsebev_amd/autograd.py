@@ -107,16 +107,33 @@ class Tap:
         self.deferred_ln = {}       # (id(gamma), id(beta)) -> [gamma, beta, relu, [(grad_y, x, row statistics), ...]]
         self.token = ParamTap.apply(self, *params) if self.ids else None
         self._empty = None
-        self._task = None           # the backward pass (autograd graph task) the recorded segments belong to
+        self._seen = {}             # id(backward node) -> (weak reference to it, graph task id of the execution that recorded)
 
     def fresh_pass(self):
-        """Called by every recording node: segments left behind by a backward pass that raised before ParamTap ran must not leak into
-        a retry of the same graph (retain_graph)."""
+        """Called by every recording node.  Segments left behind by a backward pass that RAISED before ParamTap ran must not leak into
+        a retry over the same graph (retain_graph) -- but a different graph-task id alone does not mean the earlier pass is dead: a
+        NESTED pass (``torch.utils.checkpoint(use_reentrant=True)`` around decoder layers, any Function that runs a backward inside
+        the outer one) has its own id while the outer pass is merely suspended, and its records belong to the same ParamTap (round 4
+        discarded on every id change: silently too-small parameter gradients under reentrant checkpointing -- ADVICE r4).  What does
+        identify a dead pass: a backward NODE that already contributed to the pending sums executes AGAIN under another task id while
+        ParamTap has not run in between -- a node runs once per pass, nested passes run other node objects (the recomputed graph's),
+        so this is a new pass over the same graph and the pending sums are an aborted pass's.  (Not covered: an aborted pass whose
+        every tapped node sat inside a reentrant checkpoint, retried -- the recomputed nodes are new objects; build a new forward.)"""
+        get_node = getattr(torch._C, '_current_autograd_node', None)
+        node = get_node() if get_node is not None else None
+        if node is None:
+            return
         task = torch._C._current_graph_task_id() if hasattr(torch._C, '_current_graph_task_id') else None
-        if task != self._task:
-            if self._task is not None:      # the previous pass never reached ParamTap (which resets _task): drop its partial sums
-                self.deferred, self.deferred_bias, self.deferred_ln, self.bufs = {}, {}, {}, {}
-            self._task = task
+        hit = self._seen.get(id(node))
+        if hit is not None and hit[0]() is node:
+            if hit[1] == task:
+                return                      # the same execution asking again (a node asks once per parameter)
+            # re-executed with its earlier contribution still pending: the earlier pass never reached ParamTap
+            self.deferred, self.deferred_bias, self.deferred_ln, self.bufs, self._seen = {}, {}, {}, {}, {}
+        try:
+            self._seen[id(node)] = (weakref.ref(node), task)
+        except TypeError:                   # (a node type without weak references: no dead-pass detection for it)
+            pass
 
     def has(self, pid):
         if self.token is None:
@@ -147,7 +164,7 @@ class ParamTap(torch.autograd.Function):
             bufs = tap.bufs
             return (None, *[bufs.pop(pid, None) for pid in ctx.pids])
         finally:                        # whatever happened: the next backward pass starts from empty lists
-            tap.deferred, tap.deferred_bias, tap.deferred_ln, tap._task = {}, {}, {}, None
+            tap.deferred, tap.deferred_bias, tap.deferred_ln, tap._seen = {}, {}, {}, {}
 
 
 def _group_bias_grads(tap):

@@ -281,6 +281,66 @@ extern "C" int sbev_copy_indirect(const void* const* table, int nseg, const int3
     return sbev::check_launch("sbev_copy_indirect");
 }
 
+// ---- the decoder step's last launch: stacked cls / bbox -> the caller's tensors, nan_to_num'ed ----------------------------------------
+// torch.nan_to_num(x) of SparseBEVTransformer.forward (models/sparsebev_transformer.py:35-36): NaN -> 0, +Inf -> FLT_MAX, -Inf -> -FLT_MAX,
+// everything else bit for bit.  Both outputs in ONE launch, out of place (it is also the copy out of a replayed graph's own buffers),
+// destinations either direct or table[idx] read on the device (a captured step writes into tensors allocated per call).
+namespace {
+struct FinishArgs {
+    const float* src[2];
+    float* dst[2];
+    const void* const* table;   // null: dst[] direct
+    int index[2];
+    long long n[2];
+    unsigned first_block1;      // output 1 owns blocks [first_block1, ...)
+};
+__device__ __forceinline__ float nan_to_num1(float v) {
+    const unsigned u = __float_as_uint(v), e = u & 0x7f800000u;
+    if (e != 0x7f800000u) return v;
+    if (u & 0x007fffffu) return 0.f;                                  // NaN
+    return __uint_as_float((u & 0x80000000u) | 0x7f7fffffu);          // +-Inf -> +-FLT_MAX
+}
+__global__ __launch_bounds__(256) void finish_outputs_kernel(const FinishArgs a) {
+    const int k = blockIdx.x >= a.first_block1 ? 1 : 0;
+    const float* __restrict__ src = a.src[k];
+    float* __restrict__ dst = a.table ? static_cast<float*>(const_cast<void*>(a.table[a.index[k]])) : a.dst[k];
+    const long long i = ((long long)(blockIdx.x - (k ? a.first_block1 : 0u)) * 256 + threadIdx.x) * 4;
+    if (i + 4 <= a.n[k] && ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0)) {
+        float4 v = *reinterpret_cast<const float4*>(src + i);
+        v.x = nan_to_num1(v.x); v.y = nan_to_num1(v.y); v.z = nan_to_num1(v.z); v.w = nan_to_num1(v.w);
+        *reinterpret_cast<float4*>(dst + i) = v;
+    } else {
+        for (long long j = i; j < a.n[k] && j < i + 4; ++j) dst[j] = nan_to_num1(src[j]);
+    }
+}
+int finish_outputs(const void* const* table, int idx_cls, int idx_box, const float* cls_src, const float* box_src, float* cls_dst,
+                   float* box_dst, int64_t n_cls, int64_t n_box, sbev_stream_t stream, const char* who) {
+    SBEV_REQUIRE(n_cls >= 0 && n_box >= 0 && n_cls + n_box <= (1LL << 40), "%s: bad sizes", who);
+    if (n_cls + n_box == 0) return SBEV_OK;
+    SBEV_REQUIRE((n_cls == 0 || cls_src) && (n_box == 0 || box_src), "%s: null source", who);
+    FinishArgs a{};
+    a.src[0] = cls_src; a.src[1] = box_src; a.dst[0] = cls_dst; a.dst[1] = box_dst;
+    a.table = table; a.index[0] = idx_cls; a.index[1] = idx_box; a.n[0] = n_cls; a.n[1] = n_box;
+    const long long b0 = (n_cls + 1023) / 1024, b1 = (n_box + 1023) / 1024;
+    SBEV_REQUIRE(b0 + b1 <= 0x7fffffffLL, "%s: too many elements for one launch", who);
+    a.first_block1 = (unsigned)b0;
+    hipLaunchKernelGGL(finish_outputs_kernel, dim3((unsigned)(b0 + b1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch(who);
+}
+}  // namespace
+
+extern "C" int sbev_finish_outputs(const float* cls_src, const float* box_src, float* cls_dst, float* box_dst, int64_t n_cls, int64_t n_box,
+                                   sbev_stream_t stream) {
+    SBEV_REQUIRE((n_cls == 0 || cls_dst) && (n_box == 0 || box_dst), "sbev_finish_outputs: null destination");
+    return finish_outputs(nullptr, 0, 0, cls_src, box_src, cls_dst, box_dst, n_cls, n_box, stream, "sbev_finish_outputs");
+}
+
+extern "C" int sbev_finish_outputs_indirect(const void* const* table, int idx_cls, int idx_box, const float* cls_src, const float* box_src,
+                                            int64_t n_cls, int64_t n_box, sbev_stream_t stream) {
+    SBEV_REQUIRE(table && (((uintptr_t)table) & 7) == 0 && idx_cls >= 0 && idx_box >= 0, "sbev_finish_outputs_indirect: null / unaligned table or negative index");
+    return finish_outputs(table, idx_cls, idx_box, cls_src, box_src, nullptr, nullptr, n_cls, n_box, stream, "sbev_finish_outputs_indirect");
+}
+
 extern "C" int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int channels, int hw,
                                      sbev_stream_t stream) {
     SBEV_REQUIRE(n_images >= 0 && channels >= 1 && hw >= 1, "sbev_nchw_to_nhwc_f32: bad sizes");

@@ -59,7 +59,7 @@ class DecoderRuntime:
         self._ws = None
         self._ws_key = None
         self._params = None        # cached parameter SLOTS (module._parameters dict, name); re-collected every 64 signature checks
-        self._graph_ws = {}        # workspace of the captured step graphs, shared by all graphs of one size (they replay on one stream)
+        self._graph_ws = {}        # (device, size, stream) -> [workspace of the captured step graphs of that size replayed on that stream, graphs using it]
         self._sig_calls = 0
         self.mode_eff = gemm_mode
         self.f16_headroom_log2 = 0.0
@@ -235,10 +235,17 @@ class DecoderRuntime:
         if need < 0:
             raise _lib.SbevError('sbev_decoder_workspace_bytes: ' + lib.sbev_last_error().decode())
         key = (str(dev), need)
-        if own_workspace:                   # captured graphs keep a workspace of their own (eager calls use the runtime's), ONE per
-            ws = self._graph_ws.get(key)    # size: graphs of a runtime replay on the caller's stream, one after the other
-            if ws is None:
-                ws = self._graph_ws[key] = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+        if own_workspace:                   # captured graphs keep a workspace of their own (eager calls use the runtime's): ONE per size
+            # AND per stream -- graphs replayed on one stream run one after the other and may share the pair counters / exchange rows /
+            # order buffer carved from it; two streams (multi-stream serving) would race on them.  Released with the last
+            # graph that uses it (StepGraphs._release_ws).
+            key = key + (torch.cuda.current_stream(dev).cuda_stream,)
+            slot = self._graph_ws.get(key)
+            if slot is None:
+                slot = self._graph_ws[key] = [torch.empty(need + 256, device=dev, dtype=torch.uint8), 0]
+            slot[1] += 1
+            ws = slot[0]
+            self._last_graph_ws_key = key
         else:
             if self._ws is None or self._ws_key != key:
                 self._ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
@@ -269,14 +276,21 @@ class DecoderRuntime:
         cfg.gemm_mode, cfg.overlap = self.mode_eff, int(self.overlap)
         return int(_lib.load().sbev_decoder_launches_per_layer(ctypes.byref(cfg), ctypes.byref(self._weights)))
 
-    def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
+    def forward(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None, finish=False):
         """pyramid: transformer.FeaturePyramid; ctx: transformer.DecoderContext.  Returns (cls, bbox) stacked over
-        layers (not nan_to_num'ed)."""
+        layers -- raw, or with ``finish`` nan_to_num'ed by one more launch of this library (sbev_finish_outputs: what
+        SparseBEVTransformer.forward applies, models/sparsebev_transformer.py:35-36)."""
         if _STATE['chain_pair']:
             check_pair_faults()             # an earlier step lost a pair hand-off: raise before anything is enqueued on top of it
         args, _keep, cls, box = self._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask)
-        st = _lib.load().sbev_decoder_forward(*args, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib = _lib.load()
+        st = lib.sbev_decoder_forward(*args, stream)
         _lib.check(st, 'sbev_decoder_forward')
+        if finish:
+            cls_o, box_o = torch.empty_like(cls), torch.empty_like(box)
+            _lib.check(lib.sbev_finish_outputs(_ptr(cls), _ptr(box), _ptr(cls_o), _ptr(box_o), cls.numel(), box.numel(), stream), 'sbev_finish_outputs')
+            return cls_o, box_o
         return cls, box
 
     def capture(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
@@ -315,32 +329,48 @@ class StepGraphs:
         ``MAX_WASTED`` address-keyed graphs stand captured but never replayed no further one is captured (the ring's own
         buffers are persistent by construction and exempt).
     A weight update, other switches, another layer count or box convention miss the cache.  At most ``MAX`` graphs are kept (least
-    recently used first out); all graphs of one workspace size share one workspace (DecoderRuntime._graph_ws).
+    recently used first out); the graphs of one workspace size replayed on one stream share one workspace (DecoderRuntime._graph_ws),
+    freed with the last of them.
     Replaces per-call Python + launch overhead of the reference's eager module chain (models/sparsebev_transformer.py:86-97)."""
 
     MAX = 8
     MAX_WASTED = 3
+    RETRY_EVERY = 64
 
     def __init__(self, runtime):
         self.rt = runtime
         self.entries = {}          # key -> dict(graph, ctx_buf, ...) or a _FirstSighting (seen once, not captured yet)
         self.replays = 0
         self.captures = 0
-        self.wasted = 0            # address-keyed graphs evicted or cleared without a single replay
+        self.wasted = 0            # address-keyed graphs evicted without a single replay (forgiven by a replay of one, or slowly by time)
+        self._refused = 0          # calls refused a capture because of them
         self._warned = False
 
     def clear(self):
         for e in self.entries.values():
             if isinstance(e, dict):
                 e['graph'].destroy()
+                self._release_ws(e)
         self.entries.clear()
+
+    def _release_ws(self, e):
+        """one graph less on its workspace; the last one frees it"""
+        slot = self.rt._graph_ws.get(e.get('ws_key'))
+        if slot is not None:
+            slot[1] -= 1
+            if slot[1] <= 0:
+                del self.rt._graph_ws[e['ws_key']]
 
     def _drop(self, key):
         e = self.entries.pop(key)
         if isinstance(e, dict):
-            if e['pinned'] and e['replays'] == 0:
+            # "captured and never replayed" only counts against the caller when the graph could still have been hit: an entry of a
+            # PREVIOUS weight signature (key[4]; every optimizer step makes one) was orphaned by the weight update, not by the caller
+            # bringing new buffers (ADVICE r4: evaluate-between-optimizer-steps loops switched replay off for good)
+            if e['pinned'] and e['replays'] == 0 and key[4] == self.rt._sig:
                 self.wasted += 1
             e['graph'].destroy()
+            self._release_ws(e)
 
     def _unproven(self):
         """address-keyed graphs (alive or already evicted) that were captured and never replayed afterwards"""
@@ -362,9 +392,11 @@ class StepGraphs:
             return ('nchw', tuple((tuple(f.shape), f.dtype) for f in feats)), [], True
         return ('list', tuple((f.data_ptr(), tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats)), list(feats), False
 
-    def run(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas):
+    def run(self, query_bbox, query_feat, mlvl_feats, attn_mask, img_metas, finish=False):
         """(cls, box) of the graph's own output buffers (the caller clones or post-processes out of place), or None when this
-        call has to take the eager path."""
+        call has to take the eager path.  ``finish``: the graph's last node (sbev_finish_outputs_indirect) writes the nan_to_num'ed
+        outputs into tensors allocated for THIS call, whose addresses travel in the pointer table -- nothing runs after the replay,
+        and what is returned belongs to the caller."""
         rt = self.rt
         if _STATE['profile'] or not (query_bbox.is_cuda and query_bbox.is_contiguous() and query_feat.is_contiguous()):
             return None                      # (bracketing launches with HIP events needs the eager enqueue)
@@ -381,11 +413,24 @@ class StepGraphs:
         fkey, ident, staged = self._feat_key(mlvl_feats)
         key = (tuple(query_bbox.shape), tuple(query_feat.shape), fkey, None if attn_mask is None else tuple(attn_mask.shape), sig,
                torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _STATE['order'], _lib.load().sbev_get_box_convention(),
-               rt.decoder.num_layers, tuple(rt.decoder.pc_range))
+               rt.decoder.num_layers, tuple(rt.decoder.pc_range),
+               torch.cuda.current_stream(query_bbox.device).cuda_stream,      # per stream: a graph's workspace belongs to the stream it replays on
+               bool(finish))
         e = self.entries.get(key, False)
         if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
             # first sighting (or an address whose tensor died and was recycled): eager this time, capture if it comes again
             if not staged and not hasattr(mlvl_feats, 'frame_slots') and self._unproven() >= self.MAX_WASTED:
+                # not for the life of the runtime: every RETRY_EVERY-th refused call forgives one never-replayed capture, so a caller
+                # that starts re-using its buffers later gets its graph after all (one probe capture per RETRY_EVERY calls otherwise)
+                self._refused += 1
+                if self._refused % self.RETRY_EVERY == 0:
+                    if self.wasted > 0:
+                        self.wasted -= 1
+                    else:
+                        stale = next((k for k, v in self.entries.items() if isinstance(v, dict) and v['pinned'] and v['replays'] == 0), None)
+                        if stale is not None:
+                            self.wasted -= 1          # (_drop counts it again: net zero)
+                            self._drop(stale)
                 if not self._warned:
                     import warnings
                     warnings.warn('sparsebev_amd: %d step graphs keyed on input addresses were captured and never replayed (the caller '
@@ -399,34 +444,46 @@ class StepGraphs:
             return None
         B = query_bbox.shape[0]
         packed, layout, ih, iw = TR.DecoderContext.pack(img_metas, B)
+        outs = None
+        if finish:                           # this call's own output tensors (the graph's last node writes them through the table)
+            nl, nc, cs = rt.decoder.num_layers, rt.decoder.decoder_layer.num_classes, rt.decoder.decoder_layer.code_size
+            Q = query_bbox.shape[1]
+            outs = (torch.empty(nl, B, Q, nc, device=query_bbox.device, dtype=torch.float32),
+                    torch.empty(nl, B, Q, cs, device=query_bbox.device, dtype=torch.float32))
         if isinstance(e, _FirstSighting):
-            e = self._capture(key, query_bbox, query_feat, mlvl_feats, attn_mask, B, packed, layout, ih, iw, staged)
+            e = self._capture(key, query_bbox, query_feat, mlvl_feats, attn_mask, B, packed, layout, ih, iw, staged, outs)
             if e is None:
                 return None
         else:
             if layout != e['layout'] or (ih, iw) != e['image']:
                 return None                  # other camera count / image size: not this graph's step
-            TR._upload(self._with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask), query_bbox.device, out=e['ctx_buf'])
+            TR._upload(self._with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask, outs), query_bbox.device, out=e['ctx_buf'])
         self.entries[key] = self.entries.pop(key)            # most recently used last
         e['graph'].replay()
         e['replays'] += 1
         self.replays += 1
-        return e['graph'].cls, e['graph'].box
+        if e['pinned'] and e['replays'] > 0:
+            self.wasted = 0                  # the caller DOES bring its buffers back: earlier never-replayed captures are forgiven
+        return outs if outs is not None else (e['graph'].cls, e['graph'].box)
 
     @staticmethod
-    def _with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask):
-        """packed per-sample constants + the pointer table of this call (int64 words viewed as fp32 pairs) in ONE upload."""
+    def _with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask, outs=None):
+        """packed per-sample constants + the pointer table of this call (int64 words viewed as fp32 pairs) in ONE upload.
+        Table: 0 query_bbox, 1 query_feat, 2 mask, [3 .. 3 + L) the NCHW levels (staged entries), then -- ``finish`` entries -- the
+        call's output tensors cls, bbox."""
         import numpy as np
         ptrs = [query_bbox.data_ptr(), query_feat.data_ptr(), attn_mask.data_ptr() if attn_mask is not None else 0]
         if e['staged']:
             ptrs += [f.data_ptr() for f in mlvl_feats]
+        if outs is not None:
+            ptrs += [outs[0].data_ptr(), outs[1].data_ptr()]
         full = np.empty(e['n_packed'] + 2 * len(ptrs), dtype=np.float32)
         full[:packed.size] = packed
         full[packed.size:e['n_packed']] = 0.0
         full[e['n_packed']:].view(np.int64)[:] = ptrs
         return full
 
-    def _capture(self, key, query_bbox, query_feat, mlvl_feats, attn_mask, B, packed, layout, ih, iw, staged):
+    def _capture(self, key, query_bbox, query_feat, mlvl_feats, attn_mask, B, packed, layout, ih, iw, staged, outs=None):
         import numpy as np
         from . import transformer as TR
         rt, lib = self.rt, _lib.load()
@@ -459,10 +516,11 @@ class StepGraphs:
         # (the online ring's buffers are persistent by construction)
         e = {'staged': staged, 'n_packed': n_packed, 'layout': layout, 'image': (ih, iw), 'replays': -1,
              'pinned': not staged and not hasattr(mlvl_feats, 'frame_slots')}
-        full = self._with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask)
+        full = self._with_table(packed, e, query_bbox, query_feat, mlvl_feats, attn_mask, outs)
         ctx = TR.DecoderContext.from_packed(full, layout, ih, iw, dev)     # the graph reads constants AND table from this tensor on every replay
         table = ctypes.c_void_p(ctx.buffer.data_ptr() + 4 * n_packed)
         args, keep, cls, box = rt._prepare(qb, qf, pyramid, ctx, mask, own_workspace=True)
+        e['ws_key'] = rt._last_graph_ws_key
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         sp = ctypes.c_void_p(side.cuda_stream)
@@ -478,9 +536,14 @@ class StepGraphs:
                 fn = lib.sbev_nchw_to_nhwc_f32_indirect if buf.dtype == torch.float32 else lib.sbev_nchw_to_nhwc_b16_indirect
                 ok = ok and fn(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
             ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
+            if outs is not None:
+                i_out = 3 + (len(mlvl_feats) if staged else 0)
+                ok = ok and lib.sbev_finish_outputs_indirect(table, i_out, i_out + 1, _ptr(cls), _ptr(box), cls.numel(), box.numel(), sp) == 0
         finally:
             handle = ctypes.c_void_p()
             st = lib.sbev_capture_end(sp, ctypes.byref(handle) if ok else None)
+        if not ok or st != 0:
+            self._release_ws(e)
         if not ok:
             raise _lib.SbevError('graph capture of the decoder step failed: ' + lib.sbev_last_error().decode())
         _lib.check(st, 'sbev_capture_end')
@@ -495,15 +558,20 @@ class StepGraphs:
 
 
 class _FirstSighting:
-    """An input combination seen once.  Address-keyed entries remember the tensor OBJECTS (weakly): the second sighting only counts
-    when the same live objects come back -- a recycled address of a freed tensor is a different input."""
+    """An input combination seen once.  Address-keyed entries remember WHAT MEMORY the tensors were (weakly): the second sighting only
+    counts when the same live storages come back at the same offsets / shapes / strides -- a recycled address of a freed tensor is a
+    different input, while a caller that re-creates its views over persistent channels-last buffers every call (``permute`` /
+    ``reshape`` per forward: new tensor OBJECTS, same storage) still matches (round 4 compared object identity and left that caller
+    eager for good, without a word -- ADVICE r4).  A storage's Python object lives exactly as long as some tensor uses it."""
 
     def __init__(self, tensors):
         import weakref
-        self.refs = [weakref.ref(t) for t in tensors]
+        self.refs = [(weakref.ref(t.untyped_storage()), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors]
 
     def same(self, tensors):
-        return len(tensors) == len(self.refs) and all(r() is t for r, t in zip(self.refs, tensors))
+        return len(tensors) == len(self.refs) and all(
+            r[0]() is not None and r[0]() is t.untyped_storage() and r[1:] == (t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype)
+            for r, t in zip(self.refs, tensors))
 
 
 class DecoderGraph:

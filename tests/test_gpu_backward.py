@@ -674,6 +674,42 @@ def test_tap_with_one_linear_at_two_row_counts_and_an_aborted_pass():
 
 
 @torch.enable_grad()
+@pytest.mark.parametrize('reentrant', [True, False])
+def test_tap_survives_nested_backward_passes_of_reentrant_checkpointing(reentrant):
+    """``torch.utils.checkpoint(use_reentrant=True)`` runs an INNER backward pass (its own graph-task id) inside the outer
+    one.  Round 4's Tap discarded every pending partial sum whenever the task id changed, so tapped nodes outside the checkpoints
+    lost their weight / bias / LayerNorm contributions -- parameter gradients silently too small.  The same shared Linear +
+    LayerNorm at two row counts, some calls inside checkpoints and some outside: gradients equal plain autograd's."""
+    from torch.utils.checkpoint import checkpoint
+    g = torch.Generator().manual_seed(78)
+    w = (torch.randn(256, 256, generator=g) / 16).to(DEV).requires_grad_(True)
+    b = torch.randn(256, generator=g).to(DEV).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True)
+    bet = (0.1 * torch.randn(256, generator=g)).to(DEV).requires_grad_(True)
+    xs = [torch.randn(m, 256, generator=g).to(DEV).requires_grad_(True) for m in (36, 20, 36, 36, 20, 36)]
+    inside = (False, True, False, True, True, False)
+
+    def ref_block(x):
+        return F.layer_norm(F.relu(F.linear(x, w, b)), (256,), gam, bet, 1e-5)
+    ref = sum((ref_block(x) * (i + 1)).pow(2).sum() for i, x in enumerate(xs))
+    want = torch.autograd.grad(ref, [w, b, gam, bet] + xs)
+
+    tap = AG.Tap([w, b, gam, bet])
+
+    def block(x):
+        return AG.layer_norm(AG.linear(x, w, b, relu=True, tap=tap), gam, bet, tap=tap)
+    ys = [checkpoint(block, x, use_reentrant=reentrant) if ck else block(x) for x, ck in zip(xs, inside)]
+    out = sum((y * (i + 1)).pow(2).sum() for i, y in enumerate(ys))
+    assert abs(out.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    for t in [w, b, gam, bet] + xs:
+        t.grad = None
+    out.backward()
+    for p, r, name in zip([w, b, gam, bet] + xs, want, ['weight', 'bias', 'gamma', 'beta'] + ['x%d' % i for i in range(len(xs))]):
+        assert p.grad is not None, name
+        assert (p.grad - r).abs().max() <= 2e-5 * r.abs().max().item(), (name, (p.grad - r).abs().max().item(), r.abs().max().item())
+
+
+@torch.enable_grad()
 def test_eval_mode_with_grad_is_differentiable_and_matches_the_inference_runtime():
     """Grad enabled + something requires grad -> the module is differentiable like the reference's (no silent detached
     outputs); its forward values equal the fused inference runtime's to rounding; under no_grad the runtime runs."""

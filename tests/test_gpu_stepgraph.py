@@ -257,6 +257,100 @@ def test_in_place_inputs_with_new_buffers_every_step_do_not_thrash():
     assert len(g.decoder._runtime._graph_ws) == 1             # one shared workspace, not one per graph
 
 
+def test_views_recreated_per_call_over_persistent_buffers_are_captured_and_thrash_is_forgiven():
+    """ADVICE r4 (three low items).  (1) A caller that rebuilds its channels-last VIEWS every call over persistent buffers (new tensor
+    objects, same storage, same offsets) is the same input: captured on the second call, replayed from the third on.  (2) The
+    no-thrash brake is not for life: a replay of an address-keyed graph forgives earlier never-replayed captures, and while the brake
+    holds every RETRY_EVERY-th refused call lets one probe capture through.  (3) Graphs are per stream and a workspace dies with its
+    last graph."""
+    feats, bbox, feat, metas, L = inputs(Q=49, T=2, seed=71)
+    g, e = build(2, L, 19), build(2, L, 19, graph=False)
+    base = [f.permute(0, 1, 3, 4, 2).contiguous() for f in feats]            # persistent NHWC buffers
+    for step in range(4):
+        views = [b.permute(0, 1, 4, 2, 3) for b in base]                     # new objects every call
+        got = g(bbox, feat, views, None, metas)
+        want = e(bbox, feat, views, None, metas)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), step
+    rt = g.decoder._runtime
+    sg = rt.step_graphs
+    assert sg.captures == 1 and sg.replays == 3
+    # (3) a second stream: its own graph and workspace; both freed by clear()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for step in range(3):
+            views = [b.permute(0, 1, 4, 2, 3) for b in base]
+            got2 = [t.clone() for t in g(bbox, feat, views, None, metas)]
+    side.synchronize()
+    assert torch.equal(got2[0], want[0]) and torch.equal(got2[1], want[1])
+    assert sg.captures == 2 and len(rt._graph_ws) == 2
+    sg.clear()
+    assert len(rt._graph_ws) == 0
+    # (2) thrash until the brake holds, then bring buffers back: forgiven within RETRY_EVERY calls
+    sg.RETRY_EVERY = 4
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for step in range(8):
+            nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+            g(bbox, feat, nhwc, None, metas)
+            g(bbox, feat, nhwc, None, metas)
+        assert sg._unproven() >= sg.MAX_WASTED
+        cap0, rep0 = sg.captures, sg.replays
+        keep = [b.clone() for b in base]                                      # buffers no graph has seen, re-used from now on
+        for step in range(40):
+            views = [b.permute(0, 1, 4, 2, 3) for b in keep]
+            got = g(bbox, feat, views, None, metas)
+    assert sg.captures > cap0 and sg.replays > rep0 + 8 and sg.wasted == 0
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_finish_outputs_is_nan_to_num_bit_for_bit_and_the_step_ends_in_it():
+    """Round 5: the step's last launch (sbev_finish_outputs / _indirect) replaces the two torch.nan_to_num launches of
+    SparseBEVTransformer.forward (models/sparsebev_transformer.py:35-36) and the clones out of a replayed graph's buffers: NaN -> 0,
+    +-Inf -> +-FLT_MAX, everything else (denormals, -0, FLT_MAX) bit for bit, any size and alignment; the module's outputs equal
+    nan_to_num of the decoder's raw outputs on the eager path, the captured path and replays with fresh tensors, and are the caller's
+    own (never a graph buffer)."""
+    import ctypes
+    from sparsebev_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n_cls, n_box, off in ((54000, 54000, 0), (1023, 7, 0), (1, 0, 0), (4097, 513, 1)):
+        a = torch.randn(n_cls + 2, generator=g).to('cuda')
+        b = torch.randn(n_box + 2, generator=g).to('cuda')
+        special = torch.tensor([float('nan'), float('inf'), float('-inf'), -0.0, 1e-42, -1e-42, 3.4028234e38, -3.4028234e38], device='cuda')
+        for t in (a, b):
+            k = min(len(special), max(t.numel() - 2, 0))
+            t[off:off + k] = special[:k]
+        a_s, b_s = a[off:off + n_cls], b[off:off + n_box]
+        oa, ob = torch.full_like(a, 7.0), torch.full_like(b, 7.0)
+        oa_s, ob_s = oa[off:off + n_cls], ob[off:off + n_box]
+        assert lib.sbev_finish_outputs(a_s.data_ptr(), b_s.data_ptr() if n_box else None, oa_s.data_ptr(), ob_s.data_ptr() if n_box else None,
+                                       n_cls, n_box, stream) == 0
+        assert torch.equal(oa_s.view(torch.int32), torch.nan_to_num(a_s).view(torch.int32))
+        assert torch.equal(ob_s.view(torch.int32), torch.nan_to_num(b_s).view(torch.int32))
+        assert (oa[off + n_cls:] == 7.0).all() and (ob[off + n_box:] == 7.0).all() and (oa[:off] == 7.0).all()      # nothing written outside
+    feats, bbox, feat, metas, L = inputs(Q=49, T=2, seed=81)
+    m, e = build(2, L, 21), build(2, L, 21, graph=False)
+    bad = bbox.clone()
+    bad[0, 3, 0] = float('nan')                                # one poisoned query: its rows come out as NaN / garbage before nan_to_num
+    seen = []
+    for step in range(4):
+        bq, fq = bad.clone(), feat.clone()                    # fresh tensors every step: one graph, replayed
+        got = m(bq, fq, [f.clone() for f in feats], None, metas)
+        raw = e.decoder(bq, fq, list(feats), None, metas)
+        want = (torch.nan_to_num(raw[0]), torch.nan_to_num(raw[1]))
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), step
+        eager = e(bq, fq, list(feats), None, metas)
+        assert torch.equal(eager[0], want[0]) and torch.equal(eager[1], want[1])
+        seen.append(got)
+    sg = m.decoder._runtime.step_graphs
+    assert sg.captures == 1 and sg.replays == 3
+    assert len({t[0].data_ptr() for t in seen}) == len(seen)          # every call's outputs are its own tensors ...
+    assert all(torch.equal(t[0], seen[0][0]) for t in seen)            # ... and a later replay does not touch an earlier call's
+
+
 def test_replaced_parameter_objects_rebind_at_once():
     """``load_state_dict(assign=True)`` / ``lin.weight = nn.Parameter(...)`` replace Parameter OBJECTS; the runtime's cached
     parameter slots look the current object up on every call, so packed weight images and graphs follow immediately."""

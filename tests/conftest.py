@@ -92,3 +92,30 @@ def _inference_mode_by_default():
     switch grad back on with ``torch.enable_grad()``."""
     with torch.no_grad():
         yield
+
+
+def free_running_bound(tag):
+    """Per-layer bound for a FREE-RUNNING 6-layer comparison against G7's recording, from fixture G13 (tests/golden/make_golden.py::
+    main_yardstick): 2 x the divergence the REFERENCE shows against itself on the same inputs -- the envelope of (its two samplers:
+    native grid_sample path vs MSMV_CUDA path on the CUDA kernel's semantics) and (query_feat nudged by one fp32 ulp).  An
+    implementation whose free-running drift stays inside it is as close to the reference as the reference is to itself.
+    Returns {'cls' | 'bbox' | 'feat': float64 array [layers]}, the yardstick itself under 'yard_*'."""
+    g = load_golden('g13_yardstick_' + tag)
+    out = {}
+    for what in ('cls', 'bbox', 'feat'):
+        yard = np.maximum(g['div_%s_kernel' % what].numpy(), g['div_%s_ulp' % what].numpy())
+        out['yard_' + what] = yard
+        out[what] = 2.0 * yard
+    return out
+
+
+def report_free_running(label, tag, got, ref, bound):
+    """max-abs divergence per layer of (cls, bbox[, feat]) against the reference recording, printed beside the G13 yardstick, asserted
+    against 2 x it.  got / ref: tuples of [layers, ...] tensors in the order cls, bbox[, feat]."""
+    names = ('cls', 'bbox', 'feat')[:len(got)]
+    for what, a, b in zip(names, got, ref):
+        d = np.array([(a[i].detach().cpu().double() - b[i].double()).abs().max().item() for i in range(b.shape[0])])
+        print('free-running %-12s %-8s %-4s divergence per layer %s | reference-vs-itself (G13) %s'
+              % (label, tag, what, ' '.join('%.1e' % v for v in d), ' '.join('%.1e' % v for v in bound['yard_' + what])))
+        bad = [(i, d[i], bound[what][i]) for i in range(len(d)) if not d[i] <= bound[what][i]]
+        assert not bad, '%s %s %s: layer divergence above 2 x the reference\'s own (layer, got, bound): %s' % (label, tag, what, bad)

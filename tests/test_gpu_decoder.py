@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, runtime_op_by_op
+from conftest import load_golden, runtime_op_by_op, free_running_bound, report_free_running
 from sparsebev_amd import synthetic as S
 from sparsebev_amd.transformer import SparseBEVTransformer, FeaturePyramid, DecoderContext
 
@@ -42,7 +42,9 @@ def test_g7_decoder_teacher_forced_and_free_running(tag):
     assert cls.shape == g['out_cls'].shape and box.shape == g['out_bbox'].shape
     assert (cls[0].cpu() - g['out_cls'][0]).abs().max() < TOL
     assert (box[0].cpu() - g['out_bbox'][0]).abs().max() < TOL
-    assert (cls.cpu() - g['out_cls']).abs().max() < 0.2           # rounding noise grows ~5x per random-init layer
+    # free-running drift, layer by layer, against the reference's OWN drift on these inputs (fixture G13: its two samplers against
+    # each other and a one-ulp nudge of query_feat; VERDICT r4 item 4 -- a bare 0.2 stood here): HIP-vs-reference <= 2 x that
+    report_free_running('hip', tag, (cls, box), (g['out_cls'], g['out_bbox']), free_running_bound(tag))
     assert 'time_diff' not in metas_in[0] and not torch.is_tensor(metas_in[0]['lidar2img'])   # inputs not mutated
     # the C++ runtime (one call, all layers) and the layer-by-layer Python path launch the same kernels
     cls_lw, box_lw = model(g['query_bbox'].to(DEV), g['query_feat'].to(DEV), list(feats), None, copy.deepcopy(metas), layerwise=True)

@@ -348,7 +348,7 @@ def main():
     ap.add_argument('--feat-dtype', default=None, choices=('fp32', 'fp16', 'bf16'),
                     help='feature STORAGE type (fp32 math throughout; default: the config\'s own -- fp32, bf16 for c5 / c6).  fp16 = what the reference\'s eval mode holds '
                          'before its out_fp32 cast (val.py:115): NCHW lists of it go through the 2-byte relayout inside the step unless --nhwc')
-    ap.add_argument('--query-order', type=int, default=None, choices=(0, 1),
+    ap.add_argument('--query-order', type=int, default=None, choices=(0, 1, 2),
                     help='fused gather + mixing items in the order of sbev_query_order (1) or in launch order (0); default: the library setting (SBEV_QUERY_ORDER). Results are bit-identical')
     ap.add_argument('--shuffle-queries', action='store_true', help='permute the query rows (a trained head does not keep the BEV raster order of its initialisation): robustness A/B for --query-order')
     ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
@@ -392,7 +392,7 @@ def main():
     bbox, qfeat = bbox.to(device), qfeat.to(device)
     metas = S.make_img_metas(B, T, ih, iw)
     if args.query_order is not None:
-        runtime.query_order(bool(args.query_order))
+        runtime.query_order(args.query_order)
 
     if args.online:
         from sparsebev_amd.cache import FrameFeatureCache
@@ -425,6 +425,7 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     elapsed = time.perf_counter() - t0
+    runtime.check_pair_faults()       # a timed step with a lost pair hand-off would be an invalid (and ~1 s slow) step: raise, never report it
     # host time to enqueue ONE step while the queue has room (the upload ring is 8 deep: issuing more than that many steps ahead
     # simply waits for the GPU, which is what the round-2 figure measured)
     t1 = time.perf_counter()

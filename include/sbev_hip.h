@@ -526,7 +526,8 @@ int sbev_decoder_fuse_sample_mix(int enable);
  * Measured (round 4, config 2): fabric reads of the launch 290 -> 232 MB, L2 hit 0.39 -> 0.47, duration unchanged (85.6 -> 87.7 us:
  * the launch is bound by each workgroup's chain of memory latencies, not by fabric bytes), plus 17 us for the sort -- so
  * sbev_decoder_forward keeps the launch order unless sbev_decoder_query_order(1) (env SBEV_QUERY_ORDER=1; returns the previous
- * setting): then every layer's input boxes are sorted in front of its self attention and the fused launch walks that order.
+ * setting): then every layer's input boxes are sorted in front of its self attention and the fused launch walks that order;
+ * sbev_decoder_query_order(2) (SBEV_QUERY_ORDER=2) sorts the step's INPUT boxes once and every layer walks that order.
  */
 int sbev_query_order_max(void);
 int sbev_query_order(const float* query_bbox, int64_t ld, const double* pc_range, int B, int Q, int32_t* order, sbev_stream_t stream);

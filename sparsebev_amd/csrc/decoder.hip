@@ -87,7 +87,7 @@ std::atomic<int> g_fuse_l5_f32{getenv("SBEV_NO_FUSE_L5F32") ? 0 : 1};
 // it) and NOT faster -- the launch is bound by a workgroup's chain of memory latencies at 4 workgroups per CU, not by fabric bytes
 //  -- and the sort is one more launch per layer: OFF by default, kept for A/B and for a chip whose HBM is
 // shared.  sbev_decoder_query_order(1) / SBEV_QUERY_ORDER=1 switches it on (bit-identical results).
-std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? (atoi(getenv("SBEV_QUERY_ORDER")) != 0) : 0};
+std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? (atoi(getenv("SBEV_QUERY_ORDER")) == 2 ? 2 : atoi(getenv("SBEV_QUERY_ORDER")) != 0) : 0};
 
 // the row-local op chains of a layer as three launches (row_chain.hip) when the caller supplied packed weights
 // (sbev_decoder_weights.chain_pack); sbev_decoder_row_chain(0) restores the op-by-op launches (A/B measurements)
@@ -179,7 +179,7 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
     // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
     // op by op: 17 with the fused gather + mixing
-    const bool ordered = chain && fused && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
+    const bool ordered = chain && fused && g_query_order.load(std::memory_order_relaxed) == 1 && c.Q <= sbev_query_order_max();      // (mode 2: one sort per STEP)
     return (chain ? 6 : 17) + (fused ? 0 : 1) + split + (ordered ? 1 : 0);
 }
 
@@ -313,7 +313,8 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
                                sample_mix_fusable(c);
             // launch order of this layer's gather items: sorted from the layer's input boxes (one workgroup per sample)
             const bool ordered = fused && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
-            if (ordered) TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, stream));
+            // (mode 2: sorted from the step's INPUT boxes only -- the refinements move a box by a fraction of its camera column)
+            if (ordered && (layer == 0 || g_query_order.load(std::memory_order_relaxed) == 1)) TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, stream));
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
@@ -540,7 +541,7 @@ extern "C" int sbev_decoder_fuse_sample_mix(int enable) {
 
 // returns the previous setting
 extern "C" int sbev_decoder_query_order(int enable) {
-    return g_query_order.exchange(enable ? 1 : 0, std::memory_order_relaxed);
+    return g_query_order.exchange(enable == 2 ? 2 : enable ? 1 : 0, std::memory_order_relaxed);      // 1: sorted every layer; 2: once per step (layer 0)
 }
 
 extern "C" int sbev_profile_sampler(int enable) {

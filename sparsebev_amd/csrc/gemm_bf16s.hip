@@ -46,21 +46,36 @@
 __device__ unsigned long long g_sbev_trace[2][512][8];
 #define SBEV_TRACE(G_, SLOT_)                                                                               \
     if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && (G_) < 512) g_sbev_trace[wave >> 2][G_][SLOT_] = __builtin_readcyclecounter();
-__device__ unsigned long long g_sbev_wgtime[1024][4];     // per workgroup: realtime (100 MHz) and shader clock at start / end
-#define SBEV_WGTIME(I_)                                                                                     \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                            \
-        g_sbev_wgtime[blockIdx.x][2 * (I_)] = __builtin_amdgcn_s_memrealtime();                             \
-        g_sbev_wgtime[blockIdx.x][2 * (I_) + 1] = __builtin_readcyclecounter();                             \
-    }
 extern "C" int sbev_debug_trace_read(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbev_trace), sizeof(g_sbev_trace));
 }
-extern "C" int sbev_debug_wgtime_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbev_wgtime), sizeof(g_sbev_wgtime));
-}
 #else
 #define SBEV_TRACE(G_, SLOT_)
-#define SBEV_WGTIME(I_)
+#endif
+// Per workgroup: wall clock (s_memrealtime, 100 MHz) and shader clock (s_memtime) at its first and last instruction -- two stamps per
+// workgroup, nothing inside the loops.  cycles / wall time = the clock the kernel actually RAN at (tools/gemm_clock.py writes
+// profiles/r5_gemm_clock.json from it; -DSBEV_EXP_WGTIME alone, or with the phase stamps of -DSBEV_EXP_TRACE).  One table per kernel
+// (KIND_: 0 tiled generator, 1 weight-stationary generator, 2 out-projection 256-row tiles, 3 out-projection 128-row tiles), the LAST
+// launch of each kind stays.  Never in the product build.
+#if defined(SBEV_EXP_TRACE) || defined(SBEV_EXP_WGTIME)
+__device__ unsigned long long g_sbev_wgtime[4][1024][4];
+#define SBEV_WGTIME(KIND_, I_)                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                            \
+        g_sbev_wgtime[KIND_][blockIdx.x][2 * (I_)] = __builtin_amdgcn_s_memrealtime();                      \
+        g_sbev_wgtime[KIND_][blockIdx.x][2 * (I_) + 1] = __builtin_readcyclecounter();                      \
+    }
+extern "C" int sbev_debug_wgtime_read(unsigned long long* out, int kind) {      // out: [1024][4]
+    if (kind < 0 || kind > 3) return -1;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sbev_wgtime), sizeof(g_sbev_wgtime[0]), sizeof(g_sbev_wgtime[0]) * (size_t)kind);
+}
+extern "C" int sbev_debug_wgtime_clear(void) {
+    static const unsigned long long zero[1024][4] = {};
+    for (int k = 0; k < 4; ++k)
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sbev_wgtime), zero, sizeof(zero), sizeof(zero) * (size_t)k) != hipSuccess) return -1;
+    return 0;
+}
+#else
+#define SBEV_WGTIME(KIND_, I_)
 #endif
 
 namespace {
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;                         // wr: row half = phase group (waves w, w + 4 share a SIMD)
-    SBEV_WGTIME(0)
+    SBEV_WGTIME(0, 0)
     const int M = a.M, nk = a.K / 16;
     const int lw = (int)xcd_contiguous(blockIdx.x, gridDim.x);
     const int rt = lw % a.ntm, ct0 = lw / a.ntm, cstep = (int)gridDim.x / a.ntm, nct = a.N / G_COLS;
@@ -645,7 +660,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
         }
         if (wr == 0) phase_barrier();
         if (pending) store_tile(cn0, ti);
-        SBEV_WGTIME(1)
+        SBEV_WGTIME(0, 1)
     };
     if (nfa == RF) run(std::integral_constant<int, RF>{});
     else if (nfa == RF - 1) run(std::integral_constant<int, RF - 1>{});
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
         0, (int)(unsigned)((long long)a.M * a.ldy * 4), 0x00020000);
     const unsigned ldyb = (unsigned)(a.ldy * 4);
     [[maybe_unused]] const int tid = (int)threadIdx.x;
-    SBEV_WGTIME(0)
+    SBEV_WGTIME(1, 0)
 
     // One barrier per fragment, all eight waves in the same phase.  (Tried, measured, not kept: the two waves of a SIMD half a fragment
     // apart -- the second group meeting the barrier in the MIDDLE of its fragment, so that one wave's boundary work lies beside its partner's
@@ -874,7 +889,7 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
             }
         }
     }
-    SBEV_WGTIME(1)
+    SBEV_WGTIME(1, 1)
 }
 
 // ==== out-projection-shaped split-K GEMM (N = 256) ================================================================================
@@ -914,7 +929,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, wc = wave & 3;  // K half of the chunk = phase group, 64-column quarter
-    SBEV_WGTIME(0)
+    SBEV_WGTIME(2, 0)
     const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int chunk = (int)(logical / (unsigned)a.nrt), rt = (int)(logical % (unsigned)a.nrt);
     const int M = a.M;
@@ -1101,7 +1116,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out3_kernel(const OutArgs a) {
                     }
             }
         }
-        SBEV_WGTIME(1)
+        SBEV_WGTIME(2, 1)
     };
     if (nfa == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
@@ -1137,7 +1152,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, wc = wave & 3;  // K half of the chunk = phase group, 64-column quarter
-    SBEV_WGTIME(0)
+    SBEV_WGTIME(3, 0)
     const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int chunk = (int)(logical / (unsigned)a.ntm), rt = (int)(logical % (unsigned)a.ntm);
     const int M = a.M;
@@ -1322,7 +1337,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
                     *reinterpret_cast<f32x4*>(out + (long long)row * 256) = *reinterpret_cast<const f32x4*>(img + r * FLD + lane * 4) * sc;
             }
         }
-        SBEV_WGTIME(1)
+        SBEV_WGTIME(3, 1)
     };
     if (nfa == 4) run(std::integral_constant<int, 4>{});
     else if (nfa == 3) run(std::integral_constant<int, 3>{});

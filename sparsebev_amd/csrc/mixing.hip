@@ -532,7 +532,11 @@ int launch_sample_mix(const SampleMixArgs& a, hipStream_t s) {
     size_t floats = Pin > 64 ? (size_t)POUT * (64 + 4) : (size_t)POUT * (Pin + 4) + (size_t)Pin * LDA;
     const size_t out_floats = (size_t)POUT * LDY;
     if (floats < out_floats) floats = out_floats;
-    const size_t bytes = (floats + 8) * sizeof(float);
+    size_t bytes = (floats + 8) * sizeof(float);
+#ifdef SBEV_EXP_MIX_PAD          // A/B (tools/exp/r5_run1.sh): unused LDS per workgroup = fewer workgroups per CU (34.8 KB: 4; + 10 KB: 3; + 25 KB: 2)
+    static const int exp_pad = getenv("SBEV_EXP_MIX_PAD") ? atoi(getenv("SBEV_EXP_MIX_PAD")) : 0;
+    bytes += (size_t)exp_pad;
+#endif
     auto k = adaptive_mixing_kernel<RT, true, L, FT, true>;
     if constexpr (RT <= 4) {
         if (a.Pin % 16 == 0 && a.s.P == 4) k = adaptive_mixing_kernel<RT, true, L, FT>;      // the tuned instantiation (4 points per frame, whole row tiles)

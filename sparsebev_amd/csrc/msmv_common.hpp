@@ -21,10 +21,15 @@ struct MsmvArgs {
     int slots[SBEV_MAX_FRAMES];
 };
 
+typedef float msmv_f2 __attribute__((ext_vector_type(2)));      // a channel pair: the operand type of the packed fmas in msmv_chunk.inc
+
 // lane i of every 16-lane row <- lane n of that row (v_mov_b32_dpp row_newbcast:n, gfx90a+; n is a constant after unrolling: the
 // switch folds).  All 64 lanes must be active.
+// bound_ctrl = true: every lane of a row_newbcast reads a valid lane (all 64 active), so `old` is never taken -- saying so lets the
+// compiler drop the `v_mov_b32 dst, 0` it otherwise emits in front of EVERY broadcast (32 per 4-level chunk, 11 % of the gather loop's
+// VALU instructions; round 5).  Same values bit for bit.
 template <int N>
-__device__ __forceinline__ int msmv_row_bcast_c(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false); }
+__device__ __forceinline__ int msmv_row_bcast_c(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, true); }
 __device__ __forceinline__ int msmv_row_bcast(int n, int v) {
     switch (n) {
         case 0: return msmv_row_bcast_c<0>(v);

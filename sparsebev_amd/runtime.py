@@ -603,15 +603,16 @@ class DecoderGraph:
 # process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
 import os as _os
 _STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0,
-          'order': int(_os.environ.get('SBEV_QUERY_ORDER', '0') or 0) != 0}
+          'order': (lambda v: 2 if v == 2 else int(v != 0))(int(_os.environ.get('SBEV_QUERY_ORDER', '0') or 0))}
 
 
 def query_order(enable):
     """The fused gather + mixing launch walks its items in sbev_query_order's order (one group and one arc of the camera ring per
     XCD: 20 % fewer fabric reads at config 2, not faster -- DESIGN.md section 10.8; off by default).  Bit-identical results either
     way.  Returns the previous setting."""
-    prev = bool(_lib.load().sbev_decoder_query_order(int(bool(enable))))
-    _STATE['order'] = bool(enable)
+    mode = 2 if enable == 2 and enable is not True else int(bool(enable))      # 2: sorted once per step (from the input boxes) instead of every layer
+    prev = int(_lib.load().sbev_decoder_query_order(mode))
+    _STATE['order'] = mode
     return prev
 
 

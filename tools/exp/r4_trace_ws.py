@@ -29,8 +29,8 @@ for grp in (0, 1):
         nxt = t[grp, g + 1, 0] if g + 1 < G else 0
         print('  i=%2d  to-sync %6d  wait %5d  barrier %5d  issue %5d  rest %6d   period %6d' % (g, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], (nxt - r[4]) if nxt else 0, (nxt - r[0]) if nxt else 0))
 buf2 = (ctypes.c_ulonglong * (1024 * 4))()
-raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p]
-assert raw.sbev_debug_wgtime_read(buf2) == 0
+raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p, ctypes.c_int]      # (round 5: one table per kernel kind, tools/gemm_clock.py)
+assert raw.sbev_debug_wgtime_read(buf2, 1) == 0
 wg = np.array(buf2, dtype=np.uint64).reshape(1024, 4).astype(np.int64)
 wg = wg[wg[:, 0] > 0]
 t0 = wg[:, 0].min()

@@ -38,8 +38,8 @@ for grp in (0, 1):
     print('  %d stages:' % G, tot, 'cycles ->', tot / G, 'per stage')
 
 buf2 = (ctypes.c_ulonglong * (1024 * 4))()
-raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p]
-assert raw.sbev_debug_wgtime_read(buf2) == 0
+raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p, ctypes.c_int]      # (round 5: one table per kernel kind, tools/gemm_clock.py)
+assert raw.sbev_debug_wgtime_read(buf2, 0) == 0
 w = np.array(buf2, dtype=np.uint64).reshape(1024, 4).astype(np.int64)
 w = w[w[:, 0] > 0]
 t0 = w[:, 0].min()

@@ -34,8 +34,8 @@ for grp in (0, 1):
         print('  s=%2d' % g, ' '.join('%6d' % v for v in d), '  total', nxt - r[0])
     print('  first stamp .. last stamp of 30 slabs:', t[grp, 29, 6] - t[grp, 0, 0], 'cycles')
 wt = (ctypes.c_ulonglong * (1024 * 4))()
-raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p]
-if raw.sbev_debug_wgtime_read(wt) == 0:
+raw.sbev_debug_wgtime_read.argtypes = [ctypes.c_void_p, ctypes.c_int]      # (round 5: one table per kernel kind, tools/gemm_clock.py)
+if raw.sbev_debug_wgtime_read(wt, 3 if mode == 'f16x3' else 2) == 0:
     a = np.array(wt, dtype=np.uint64).reshape(1024, 4).astype(np.int64)[:256]
     a = a[a[:, 2] > 0]
     if a[:, 2].max() > 0:

@@ -291,8 +291,10 @@ def test_views_recreated_per_call_over_persistent_buffers_are_captured_and_thras
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
+        hold = []                                                             # (kept alive: a freed buffer's address would come back and replay)
         for step in range(8):
             nhwc = [f.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3) for f in feats]
+            hold.append(nhwc)
             g(bbox, feat, nhwc, None, metas)
             g(bbox, feat, nhwc, None, metas)
         assert sg._unproven() >= sg.MAX_WASTED

@@ -3,7 +3,7 @@
 # gpurun) into profiles/ under the round's prefix.  usage: tools/collect_profiles.sh r3
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
-ROUND=${1:-r4}
+ROUND=${1:-r5}
 S=$R/gpurun_out/prof_$ROUND
 D=$R/profiles
 mkdir -p $D
@@ -16,6 +16,7 @@ cp $S/train.log $D/${ROUND}_train_step.log
 tail -1 $S/bench_line.json > $D/${ROUND}_bench_line.json
 for c in c1 c3 c4 c5 c6 c3_f32 c4_f32 c6_f32 nhwc online unfused fp16 fp16_nhwc c3_fp16 c4_fp16; do [ -s $S/bench_$c.json ] && cp $S/bench_$c.json $D/${ROUND}_bench_line_$c.json; done
 cp $S/${ROUND}_mfma_summary.json $D/ 2>/dev/null
+cp $S/${ROUND}_gemm_clock.json $S/${ROUND}_gemm_clock_under_pmc.json $D/ 2>/dev/null
 cp $S/${ROUND}_mfma_summary_bf16x6.json $D/ 2>/dev/null
 cp $S/${ROUND}_mfma_summary_f32.json $D/ 2>/dev/null
 for f in $R/gpurun_out/${ROUND}_pmc_*.json; do [ -f $f ] && cp $f $D/; done

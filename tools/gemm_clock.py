@@ -64,7 +64,17 @@ class Sysfs(threading.Thread):
         super().__init__(daemon=True)
         self.period, self.samples, self.stop_flag, self.marks = period, [], False, []
         self.files = {}
-        for hw in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+        # the box shows every GPU of the node in sysfs, this process owns ONE: pick the card whose PCI address is the HIP device's
+        self.bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            self.bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:      # noqa: BLE001
+            pass
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
+        mine = [hw for hw in cards if self.bdf and os.path.realpath(os.path.join(hw, '..', '..')).endswith(self.bdf)]
+        self.card_matched = bool(mine)
+        for hw in (mine or cards):
             for name, key in (('freq1_input', 'sclk_hz'), ('power1_average', 'power_uw'), ('power1_input', 'power_uw'), ('freq2_input', 'mclk_hz')):
                 p = os.path.join(hw, name)
                 if key not in self.files and os.path.exists(p):
@@ -94,7 +104,7 @@ class Sysfs(threading.Thread):
         self.marks.append((name, time.perf_counter()))
 
     def summary(self):
-        out = {'files': self.files, 'period_ms_actual': None, 'windows': {}}
+        out = {'files': self.files, 'hip_device_pci': self.bdf, 'card_matched_by_pci_address': self.card_matched, 'period_ms_actual': None, 'windows': {}}
         if len(self.samples) > 1:
             out['period_ms_actual'] = round(1e3 * (self.samples[-1]['t'] - self.samples[0]['t']) / (len(self.samples) - 1), 2)
         for (name, t0), (_, t1) in zip(self.marks[:-1], self.marks[1:]):
@@ -105,6 +115,9 @@ class Sysfs(threading.Thread):
                 if v:
                     w[unit] = {'min': round(min(v), 1), 'median': round(float(np.median(v)), 1), 'max': round(max(v), 1)}
             out['windows'][name] = w
+            if name in ('idle_before_c2', 'busy_steady_c2'):      # the samples themselves, ms since the window opened
+                out['series_' + name] = {'columns': ['t_ms', 'sclk_mhz', 'power_w'],
+                                         'rows': [[round(1e3 * (r['t'] - t0), 1), (r.get('sclk_hz') or 0) / 1e6, (r.get('power_uw') or 0) / 1e6] for r in rows]}
         return out
 
 
@@ -135,8 +148,10 @@ def decoder_step(config):
     return lambda: model(bbox, qfeat, list(feats), None, metas)
 
 
-def isolated(raw, M, gap_s, n=12):
-    """the two launches alone at the decoder's operand shapes for M rows: device idle for gap_s before each launch"""
+def isolated(raw, M, gap_s, n=12, zero=False):
+    """the two launches alone at the decoder's operand shapes for M rows: device idle for gap_s before each launch.
+    zero: all-zero operands -- the SAME instruction stream with (almost) no data toggling: if the clock is set by the power the data
+    path draws and not by the instruction mix, it rises (the guide's DVFS note: zero-filled inputs ran at 2.30 vs 1.90-1.95 GHz)"""
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)      # noqa: E731
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -153,6 +168,9 @@ def isolated(raw, M, gap_s, n=12):
     bo = torch.randn(K, device='cuda', generator=g)
     wof, wosc = dense.pack_f16s_frags(wo)
     xp = dense.f16s_pairs(xo, 9)
+    if zero:                   # the packed operand images themselves (the scales stay those of the random tensors: finite)
+        for t in (wf, xf, wof, xp, b, bo):
+            t.zero_()
     res = {}
     for name, kinds, call in (('generator', (1, 0), lambda: lib.sbev_linear_f16s_gen(p(xf), p(xsc), p(wf), p(wsc[1]), p(b), p(y), M, N, K, N, 0, 3, st)),
                               ('out_projection', (3, 2), lambda: dense.linear_splitk_f16s(xp, wof, wosc, bo, nprod=3, x_up_log2=9, x_is_pairs=True))):
@@ -199,11 +217,16 @@ def main():
         smp.mark('idle_before')
         time.sleep(1.0)
     for config in args.configs.split(','):
+        if smp:
+            smp.mark('setup_' + config)         # (model + feature generation, warm-up: not a measurement window)
         step = decoder_step(config)
         for _ in range(10):
             step()
         torch.cuda.synchronize()
         if smp:
+            time.sleep(0.5)
+            smp.mark('idle_before_' + config)
+            time.sleep(0.5)
             smp.mark('busy_steady_' + config)
         raw.sbev_debug_wgtime_clear()
         t0 = time.perf_counter()
@@ -214,6 +237,8 @@ def main():
             n += 20
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if smp:
+            smp.mark('after_' + config)
         rows = {KINDS[k]: read_kind(raw, k) for k in KINDS}
         out['steady'][config] = {'steps': n, 'ms_per_step_incl_syncs': round(1e3 * dt / n, 4), 'kernels': {k: v for k, v in rows.items() if v}}
         del step
@@ -225,6 +250,7 @@ def main():
         for config, M in (('c2', 900), ('c3', 3200)):
             if config in args.configs.split(','):
                 out['isolated'][config] = {'gap_ms_before_each_launch': 5.0, **isolated(raw, M, 0.005)}
+                out.setdefault('isolated_zero_operands', {})[config] = {'gap_ms_before_each_launch': 5.0, **isolated(raw, M, 0.005, zero=True)}
         smp.mark('idle_after')
         time.sleep(1.0)
         smp.mark('end')
@@ -234,11 +260,11 @@ def main():
         out['smi_snapshot_idle_after'] = smi_snapshot()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(out, open(args.out, 'w'), indent=1)
-    for cond in ('steady', 'isolated'):
-        for config, d in out[cond].items():
+    for cond in ('steady', 'isolated', 'isolated_zero_operands'):
+        for config, d in out.get(cond, {}).items():
             ks = d['kernels'] if cond == 'steady' else {v['kernel']: v for v in d.values() if isinstance(v, dict)}
             for k, v in ks.items():
-                print('%-9s %-3s %-56s %s GHz' % (cond, config, k[:56], v.get('shader_clock_ghz_median', v.get('shader_clock_ghz_median_of_launches'))))
+                print('%-22s %-3s %-56s %s GHz  span %s us' % (cond, config, k[:56], v.get('shader_clock_ghz_median', v.get('shader_clock_ghz_median_of_launches')), v.get('launch_span_us', v.get('launch_span_us_median'))))
     if 'sysfs' in out:
         for name, w in out['sysfs']['windows'].items():
             print('sysfs %-20s %s' % (name, {k: v for k, v in w.items() if k not in ('samples', 'seconds')}))

@@ -5,7 +5,7 @@
 # tools/profile_pmc.sh.  Everything lands in gpurun_out/prof_<round>/; copy what is to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${1:-r4}
+ROUND=${1:-r5}
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -15,10 +15,16 @@ Q="--no-cpu-baseline --no-alt --no-detector --no-live-pmc"
 # kernel stats of the same workload: the default mode of the two mixing GEMMs (f16x3), the exact f32-MFMA kernels, bf16x6
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python $R/bench.py $Q --steps 20 > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_f32 -o bench -- python $R/bench.py $Q --steps 20 --gemm f32 > $OUT/kt_f32.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt6 -o bench -- python $R/bench.py $Q --steps 20 --gemm bf16x6 > $OUT/kt6.log 2>&1
+# in-kernel shader clocks of the two mixing GEMMs + sysfs sclk / power samples (tools/gemm_clock.py; needs the -DSBEV_EXP_WGTIME variant library)
+CLK=$OUT/${ROUND}_gemm_clock.json
+if [ -f $R/sparsebev_amd/csrc/build/libsbev_expwgt.so ]; then
+  (cd $R && SBEV_LIB_PATH=$R/sparsebev_amd/csrc/build/libsbev_expwgt.so python tools/gemm_clock.py --out $CLK > $OUT/gemm_clock.log 2>&1; grep -E "GHz|sysfs" $OUT/gemm_clock.log | head -24)
+  SBEV_LIB_PATH=$R/sparsebev_amd/csrc/build/libsbev_expwgt.so rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/clk_pmc -o clk -- python $R/tools/gemm_clock.py --only steady --configs c2 --label "beneath rocprofv3 --pmc GRBM_GUI_ACTIVE" --out $OUT/${ROUND}_gemm_clock_under_pmc.json > $OUT/gemm_clock_pmc.log 2>&1
+  rm -rf $OUT/clk_pmc
+fi
 # MFMA-busy counter pass (its own run, --kernel-trace only beside it): default mode, then the exact kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 > $OUT/pmc_mfma.log 2>&1
-python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary.json | head -8
+python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary.json $CLK | head -8
 rm -f $(find $OUT/pmc_mfma -name "*counter_collection.csv")
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_f32 -o bench -- python $R/bench.py $Q --steps 5 --warmup 2 --gemm f32 > $OUT/pmc_mfma_f32.log 2>&1
 python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma_f32 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma_f32 -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary_f32.json | head -6

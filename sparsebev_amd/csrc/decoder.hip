@@ -195,6 +195,7 @@ extern "C" int sbev_decoder_mixed_up_log2(const sbev_decoder_config* cfg) {
 
 extern "C" int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg) {
     if (validate(cfg) != SBEV_OK) return -1;
+    sbev::chain_pair_prepare();            // (the one call every user makes before a forward or a capture)
     return (int64_t)carve(*cfg, nullptr).bytes;
 }
 

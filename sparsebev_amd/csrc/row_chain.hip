@@ -999,6 +999,13 @@ namespace sbev {
 long long chain_pair_floats(long long rows) { return 3 * (rows + 15) * DM; }
 long long chain_pair_sync_words(long long rows) { return (rows + 7) / 8; }
 
+// Install the fault word for the current device NOW (hipHostMalloc + hipMemcpyToSymbol: neither is legal under stream capture, and a
+// caller's first pair-mode launch may be a captured one): sbev_decoder_workspace_bytes calls this, which every caller runs before its
+// first forward / capture.  Quiet without a device.
+void chain_pair_prepare() {
+    if (g_chain_pair.load(std::memory_order_relaxed) != 0) (void)pair_fault_install();
+}
+
 // hand-offs that timed out and were not acknowledged yet (host memory: no device synchronisation)
 unsigned chain_pair_faults_pending() {
     volatile unsigned* h = pair_fault_host();

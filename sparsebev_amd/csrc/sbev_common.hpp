@@ -62,6 +62,7 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
                       float* qkvt, float eps, hipStream_t s, float* pair_x = nullptr, uint32_t* pair_sync = nullptr);
 long long chain_pair_floats(long long rows);         // pair mode of the tail: exchange rows / arrival counters for `rows` rows
 long long chain_pair_sync_words(long long rows);
+void chain_pair_prepare();                          // install the pair tail's host-mapped fault word for the current device (outside any capture)
 unsigned chain_pair_faults_pending();               // pair hand-offs that timed out and were not acknowledged (host word, no sync)
 
 // gemm.hip: pairs of independent small ops of a decoder layer's tail in ONE launch (see pair_kernel)

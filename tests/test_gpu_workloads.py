@@ -62,7 +62,7 @@ def oracle_per_sample(params, bbox, feat, feats_dev, metas, num_layers=1, forced
     from oracle import sparsebev_oracle as O
     cls, box, x = [], [], []
     for b in range(bbox.shape[0]):
-        fb = [f[b:b + 1].float().cpu().contiguous() for f in feats_dev]
+        fb = [f[b:b + 1].to(next(iter(params.values())).dtype).cpu().contiguous() for f in feats_dev]      # (fp32, or fp64 for the exact evaluation)
         fi = None if forced is None else [(qb[b:b + 1], qf[b:b + 1]) for qb, qf in forced]
         c, bb, xx = O.decoder(params, bbox[b:b + 1], feat[b:b + 1], fb, metas[b:b + 1], S.PC_RANGE, num_layers=num_layers,
                               num_points=P, sampler=sampler or O.msmv_sampling_kernel_semantics, forced_inputs=fi)
@@ -132,27 +132,33 @@ def test_c2_six_layers_teacher_forced_vs_oracle():
                     assert err < TOL, (i, mode, err)
     # the free-running 6-layer forward: finite, its first layer is the teacher-forced one, and its drift from the oracle's free run is
     # held against the drift the ARITHMETIC shows against itself at this very shape (the G13 yardstick, fixture-pinned at c1 / c2small,
-    # rebuilt here at full c2 from the pinned oracle: its two samplers against each other and a one-ulp nudge of query_feat; VERDICT
-    # r4 item 4): per layer <= 2 x that
+    # rebuilt here at full c2 from the pinned oracle: its two samplers against each other, one-ulp nudges of query_feat, and its fp32
+    # evaluation against its fp64 one): per layer <= 2 x that, as long as the yardstick itself is below saturation
     from oracle import sparsebev_oracle as O
     model.decoder.num_layers = 6
     cls6, box6 = model(bbox.to(DEV), feat.to(DEV), pyr, None, copy.deepcopy(metas))
     assert torch.isfinite(cls6).all() and torch.isfinite(box6).all()
     assert (cls6[0].cpu() - ref_cls[0]).abs().max() < TOL
-    nat = oracle_per_sample(params, bbox, feat, feats, metas, num_layers=6, sampler=O.msmv_sampling_gridsample)
-    nudged = feat.clone()
-    nudged.view(-1)[::2] = torch.nextafter(nudged.view(-1)[::2], torch.full_like(nudged.view(-1)[::2], float('inf')))
-    ulp = oracle_per_sample(params, bbox, nudged, feats, metas, num_layers=6)
+    runs = [oracle_per_sample(params, bbox, feat, feats, metas, num_layers=6, sampler=O.msmv_sampling_gridsample)]      # the other sampler
+    for off, way in ((0, 1.0), (1, -1.0)):                                                                                # one-ulp nudges
+        nudged = feat.clone()
+        nudged.view(-1)[off::2] = torch.nextafter(nudged.view(-1)[off::2], torch.full_like(nudged.view(-1)[off::2], way * float('inf')))
+        runs.append(oracle_per_sample(params, bbox, nudged, feats, metas, num_layers=6))
+    # ... and the same arithmetic evaluated in fp64: how far the fp32 evaluation itself sits from the exact one (the yardstick that moves
+    # EVERY op's rounding, as an independent implementation does -- the first two only move the sampler's / the input's)
+    p64 = {k: v.double() for k, v in params.items()}
+    runs.append(oracle_per_sample(p64, bbox.double(), feat.double(), [f.double() for f in feats], metas, num_layers=6))
 
     def div(a, b):
-        return np.array([(a[i].cpu().double() - b[i].double()).abs().max().item() for i in range(6)])
+        return np.array([(a[i].cpu().double() - b[i].cpu().double()).abs().max().item() for i in range(6)])
     for what, got, k in (('cls', cls6, 0), ('bbox', box6, 1)):
         ref = (ref_cls, ref_box)[k]
-        yard = np.maximum(div(ref, nat[k]), div(ref, ulp[k]))
+        yard = np.max(np.stack([div(ref, r[k]) for r in runs]), axis=0)
         d = div(got, ref)
         print('free-running hip c2 (full shape) %-4s divergence per layer %s | oracle-vs-itself %s'
               % (what, ' '.join('%.1e' % v for v in d), ' '.join('%.1e' % v for v in yard)))
-        assert (d <= 2.0 * np.maximum(yard, 2e-6)).all(), (what, d, yard)
+        live = yard < 0.05                 # beyond that two runs of the SAME arithmetic are decorrelated (O(1) apart): nothing left to compare
+        assert live[:2].all() and (d[live] <= 2.0 * np.maximum(yard[live], 2e-6)).all(), (what, d, yard)
 
 
 @pytest.mark.parametrize('name', ['c3', 'c4', 'c5', 'c6'])

@@ -347,6 +347,11 @@ int sbev_nchw_to_nhwc_f32(const float* in, float* out, int64_t n_images, int cha
  * launch, segment k = nbytes[k] bytes from table[index[k]] to dst[k] (index, dst, nbytes: host arrays). */
 int sbev_nchw_to_nhwc_f32_indirect(const void* const* table, int index, float* out, int64_t n_images, int channels, int hw,
                                    sbev_stream_t stream);
+/* All levels of one pyramid in ONE launch (round 5): level l = [n_images, channels, hw[l]] from table[index[l]] to out[l]; the coarse
+ * levels' few tiles run in the tail of the finest level's instead of in short launches of their own.  Needs hw[l] % 4 == 0, channels % 4
+ * == 0 and 16-byte aligned buffers (SBEV_EINVAL otherwise: launch the per-level form). */
+int sbev_nchw_to_nhwc_f32_multi_indirect(const void* const* table, int n_levels, const int32_t* index, float* const* out,
+                                         int64_t n_images, int channels, const int32_t* hw, sbev_stream_t stream);
 /* The same relayouts for 2-byte channels -- bf16 or fp16 feature STORAGE (enum sbev_dtype; bytes are moved, never interpreted): what
  * an fp16 backbone (the reference's eval mode, val.py:115, before the out_fp32 cast of models/sparsebev.py:46) or a bf16 neck emits
  * goes to the sampler's layout at half the traffic of the fp32 relayout.  128-channel x 64-pixel tiles; any sizes (channels % 8,

@@ -55,6 +55,7 @@ SIGNATURES = {
     'sbev_refine_bbox': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_nchw_to_nhwc_f32': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_nchw_to_nhwc_f32_indirect': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_nchw_to_nhwc_f32_multi_indirect': (ctypes.c_int, [_vp, ctypes.c_int, _c_i32p, ctypes.POINTER(_vp), ctypes.c_int64, ctypes.c_int, _c_i32p, _vp]),
     'sbev_nchw_to_nhwc_b16': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_nchw_to_nhwc_b16_indirect': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_copy_indirect': (ctypes.c_int, [_vp, ctypes.c_int, _c_i32p, ctypes.POINTER(_vp), _c_i64p, _vp]),

@@ -72,6 +72,59 @@ __global__ __launch_bounds__(256) void transpose_tiles_kernel(const TrArgs a) {
     }
 }
 
+// All levels of a pyramid in ONE launch (round 5): the per-level launches of a step (4 at r50, 5 at r101 / eva02) spend a launch boundary each
+// and the small levels cannot fill the chip (8 x 22 pixels x 48 images: one short round); here block b belongs to the level whose block range
+// holds it -- levels in the caller's order, finest first, so that the coarse levels' few blocks run in the tail of the big one.  Same tile
+// code (transpose_tiles_kernel<true>: every level S % 4 == 0, R % 4 == 0), sources from the pointer table.
+struct TrMultiArgs {
+    const void* const* table;
+    int index[SBEV_MAX_LEVELS];
+    float* out[SBEV_MAX_LEVELS];
+    int S[SBEV_MAX_LEVELS];
+    unsigned tiles_s[SBEV_MAX_LEVELS];           // ceil(S / TS)
+    unsigned first_block[SBEV_MAX_LEVELS + 1];   // level l owns blocks [first_block[l], first_block[l + 1])
+    int n_levels, R;
+    unsigned tiles_r;                            // ceil(R / TS)
+};
+__global__ __launch_bounds__(256) void transpose_tiles_multi_kernel(const TrMultiArgs a) {
+    __shared__ float tile[TS * TLD];
+    const int tid = threadIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int j = 1; j < SBEV_MAX_LEVELS; ++j)
+        if (j < a.n_levels && blockIdx.x >= a.first_block[j]) l = j;
+    unsigned rel = blockIdx.x - a.first_block[l];
+    const unsigned ts = a.tiles_s[l];
+    const unsigned per_img = ts * a.tiles_r;
+    const long long img = rel / per_img;
+    rel -= (unsigned)img * per_img;
+    const int r0 = (int)(rel / ts) * TS, s0 = (int)(rel % ts) * TS;
+    const int R = a.R, S = a.S[l];
+    const float* in = static_cast<const float*>(a.table[a.index[l]]) + img * R * S;
+    float* out = a.out[l] + img * R * S;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + (tid >> 4) + 16 * i, sx = s0 + (tid & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && sx < S) v = *reinterpret_cast<const float4*>(in + (long long)r * S + sx);
+        const int lr = (tid >> 4) + 16 * i, ls = (tid & 15) * 4;
+        tile[(ls + 0) * TLD + lr] = v.x;
+        tile[(ls + 1) * TLD + lr] = v.y;
+        tile[(ls + 2) * TLD + lr] = v.z;
+        tile[(ls + 3) * TLD + lr] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ls = (tid >> 4) + 16 * i, lr = (tid & 15) * 4;
+        const int sx = s0 + ls, r = r0 + lr;
+        if (sx < S && r < R) {
+            const float4 v = make_float4(tile[ls * TLD + lr], tile[ls * TLD + lr + 1], tile[ls * TLD + lr + 2], tile[ls * TLD + lr + 3]);
+            *reinterpret_cast<float4*>(out + (long long)sx * R + r) = v;
+        }
+    }
+}
+
 // ---- the same relayout for 2-byte elements (bf16 / fp16 STORAGE: pure byte movement) ------------------------------------------------
 // An fp16 backbone (the reference's eval mode, val.py:115) or a bf16 neck emits [N, R, S] maps of 2-byte channels.  A workgroup moves
 // 128 channels x 64 pixels: a thread reads 4 consecutive pixels (8 bytes) of TWO neighbouring channels, interleaves them into four
@@ -256,6 +309,31 @@ extern "C" int sbev_nchw_to_nhwc_f32_indirect(const void* const* table, int inde
     else
         hipLaunchKernelGGL(transpose_tiles_kernel<false>, grid, dim3(256), 0, s, a);
     return sbev::check_launch("sbev_nchw_to_nhwc_f32_indirect");
+}
+
+// every level of one pyramid in one launch (the levels share n_images and channels: [n_images, channels, hw[l]] each).  Returns
+// SBEV_EINVAL for shapes the vector tile code does not take (hw[l] % 4, channels % 4, 16-byte alignment): the caller then launches
+// sbev_nchw_to_nhwc_f32_indirect per level.
+extern "C" int sbev_nchw_to_nhwc_f32_multi_indirect(const void* const* table, int n_levels, const int32_t* index, float* const* out,
+                                                    int64_t n_images, int channels, const int32_t* hw, sbev_stream_t stream) {
+    SBEV_REQUIRE(n_levels >= 1 && n_levels <= SBEV_MAX_LEVELS && n_images >= 0 && channels >= 4 && channels % 4 == 0, "sbev_nchw_to_nhwc_f32_multi_indirect: bad sizes");
+    if (n_images == 0) return SBEV_OK;
+    SBEV_REQUIRE(table && index && out && hw && (((uintptr_t)table) & 7) == 0, "sbev_nchw_to_nhwc_f32_multi_indirect: null / unaligned pointer");
+    TrMultiArgs a{};
+    a.table = table; a.n_levels = n_levels; a.R = channels; a.tiles_r = (unsigned)((channels + TS - 1) / TS);
+    long long blocks = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        SBEV_REQUIRE(index[l] >= 0 && out[l] && hw[l] >= 4 && hw[l] % 4 == 0 && (((uintptr_t)out[l]) & 15) == 0,
+                     "sbev_nchw_to_nhwc_f32_multi_indirect: level %d (hw %% 4 == 0, 16-byte aligned destination)", l);
+        a.index[l] = index[l]; a.out[l] = out[l]; a.S[l] = hw[l];
+        a.tiles_s[l] = (unsigned)((hw[l] + TS - 1) / TS);
+        a.first_block[l] = (unsigned)blocks;
+        blocks += (long long)a.tiles_s[l] * a.tiles_r * n_images;
+        SBEV_REQUIRE(blocks <= 0x7fffffffLL, "sbev_nchw_to_nhwc_f32_multi_indirect: too many tiles for one launch");
+    }
+    a.first_block[n_levels] = (unsigned)blocks;
+    hipLaunchKernelGGL(transpose_tiles_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    return sbev::check_launch("sbev_nchw_to_nhwc_f32_multi_indirect");
 }
 
 extern "C" int sbev_copy_indirect(const void* const* table, int nseg, const int32_t* index, void* const* dst, const int64_t* nbytes,

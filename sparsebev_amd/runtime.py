@@ -415,7 +415,7 @@ class StepGraphs:
                torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _STATE['order'], _lib.load().sbev_get_box_convention(),
                rt.decoder.num_layers, tuple(rt.decoder.pc_range),
                torch.cuda.current_stream(query_bbox.device).cuda_stream,      # per stream: a graph's workspace belongs to the stream it replays on
-               bool(finish))
+               bool(finish), _STATE['relayout_multi'])
         e = self.entries.get(key, False)
         if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
             # first sighting (or an address whose tensor died and was recycled): eager this time, capture if it comes again
@@ -532,9 +532,18 @@ class StepGraphs:
         ok = True
         try:
             ok = lib.sbev_copy_indirect(table, len(segs), c_idx, c_dst, c_nb, sp) == 0
-            for idx, buf, n_img, ch, hw in relayout:
-                fn = lib.sbev_nchw_to_nhwc_f32_indirect if buf.dtype == torch.float32 else lib.sbev_nchw_to_nhwc_b16_indirect
-                ok = ok and fn(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
+            multi = (len(relayout) > 1 and all(r[1].dtype == torch.float32 and r[2] == relayout[0][2] and r[3] == relayout[0][3] and r[3] % 4 == 0
+                                               and r[4] % 4 == 0 for r in relayout) and len(relayout) <= MAX_LEVELS and _STATE['relayout_multi'])
+            if multi:                        # every fp32 level of the pyramid in ONE launch (the coarse levels ride in the finest one's tail)
+                n = len(relayout)
+                c_ix = (ctypes.c_int32 * n)(*[r[0] for r in relayout])
+                c_out = (ctypes.c_void_p * n)(*[r[1].data_ptr() for r in relayout])
+                c_hw = (ctypes.c_int32 * n)(*[r[4] for r in relayout])
+                ok = ok and lib.sbev_nchw_to_nhwc_f32_multi_indirect(table, n, c_ix, c_out, relayout[0][2], relayout[0][3], c_hw, sp) == 0
+            else:
+                for idx, buf, n_img, ch, hw in relayout:
+                    fn = lib.sbev_nchw_to_nhwc_f32_indirect if buf.dtype == torch.float32 else lib.sbev_nchw_to_nhwc_b16_indirect
+                    ok = ok and fn(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
             ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
             if outs is not None:
                 i_out = 3 + (len(mlvl_feats) if staged else 0)
@@ -603,6 +612,7 @@ class DecoderGraph:
 # process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
 import os as _os
 _STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0,
+          'relayout_multi': not _os.environ.get('SBEV_NO_RELAYOUT_MULTI'),      # staged fp32 NCHW pyramids: all levels in one launch (A/B switch)
           'order': (lambda v: 2 if v == 2 else int(v != 0))(int(_os.environ.get('SBEV_QUERY_ORDER', '0') or 0))}
 
 

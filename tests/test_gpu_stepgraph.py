@@ -353,6 +353,48 @@ def test_finish_outputs_is_nan_to_num_bit_for_bit_and_the_step_ends_in_it():
     assert all(torch.equal(t[0], seen[0][0]) for t in seen)            # ... and a later replay does not touch an earlier call's
 
 
+@pytest.mark.parametrize('pyr', ['tiny', 'tiny5'])
+def test_all_levels_relayouted_in_one_launch_equal_the_per_level_launches(pyr):
+    """Round 5: a staged fp32 NCHW pyramid goes through ONE relayout launch for all its levels (sbev_nchw_to_nhwc_f32_multi_indirect)
+    instead of one per level: the entry point against torch's permute on odd image counts / level sizes, and the captured decoder step
+    with the switch on and off (two graphs) bit for bit, fresh tensors every step."""
+    import ctypes
+    from sparsebev_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    n_img, ch = 7, 256
+    hws = [52 * 20, 28 * 12, 16 * 4, 8] if pyr == 'tiny' else [40 * 12, 36, 20 * 4, 12, 4]
+    srcs = [torch.randn(n_img, ch, hw, generator=g).to(DEV) for hw in hws]
+    outs = [torch.empty(n_img, hw, ch, device=DEV) for hw in hws]
+    table = torch.tensor([0, 0, 0] + [t.data_ptr() for t in srcs], dtype=torch.int64, device=DEV)
+    n = len(hws)
+    st = lib.sbev_nchw_to_nhwc_f32_multi_indirect(ctypes.c_void_p(table.data_ptr()), n, (ctypes.c_int32 * n)(*range(3, 3 + n)),
+                                                  (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n_img, ch, (ctypes.c_int32 * n)(*hws),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0, lib.sbev_last_error()
+    for src, out in zip(srcs, outs):
+        assert torch.equal(out, src.permute(0, 2, 1).contiguous())
+    assert lib.sbev_nchw_to_nhwc_f32_multi_indirect(ctypes.c_void_p(table.data_ptr()), n, (ctypes.c_int32 * n)(*range(3, 3 + n)),
+                                                    (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n_img, ch, (ctypes.c_int32 * n)(*[h + 2 for h in hws]),
+                                                    None) == -1          # hw % 4 != 0: the per-level form's job
+    # the decoder step on a pyramid whose every level takes the vector tile code (the real r50 maps: 64x176 ... 8x22; the tiny test
+    # pyramids end in a 1x3 level and keep the per-level launches)
+    feats, bbox, feat, metas, L = inputs(Q=49, T=1, pyr='r50_704x256', seed=91)
+    m, e = build(1, L, 23), build(1, L, 23, graph=False)
+    want = e(bbox, feat, list(feats), None, metas)
+    prev = runtime._STATE['relayout_multi']
+    try:
+        for on in (True, False):
+            runtime._STATE['relayout_multi'] = on
+            for step in range(3):
+                got = m(bbox.clone(), feat.clone(), [f.clone() for f in feats], None, metas)
+                assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (on, step)
+    finally:
+        runtime._STATE['relayout_multi'] = prev
+    sg = m.decoder._runtime.step_graphs
+    assert sg.captures == 2 and sg.replays == 4
+
+
 def test_replaced_parameter_objects_rebind_at_once():
     """``load_state_dict(assign=True)`` / ``lin.weight = nn.Parameter(...)`` replace Parameter OBJECTS; the runtime's cached
     parameter slots look the current object up on every call, so packed weight images and graphs follow immediately."""

@@ -6,6 +6,7 @@
  * Exit status 0 = parity within 1e-5 and errors reported as documented.
  */
 #include <hip/hip_runtime_api.h>
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -95,5 +96,35 @@ int main(void) {
                        d_loc, d_w, d_out, SBEV_OUT_REF, 1, 1, (sbev_stream_t)stream);
     if (rc >= 0) { fprintf(stderr, "P = 33 was not rejected\n"); return 1; }
     printf("P = 33 rejected: %d (%s)\n", rc, sbev_last_error());
+
+    /* round 5: the decoder step's last launch from C -- nan_to_num (models/sparsebev_transformer.py:35-36) of two buffers in one launch,
+       checked against the scalar rule; and the pair tail's fault word, which a C caller polls without synchronising anything */
+    {
+        enum { NA = 1027, NB = 38 };                              /* odd sizes: the scalar tail of the vector path */
+        float h_a[NA], h_b[NB], r_a[NA], r_b[NB];
+        const float specials[8] = {NAN, INFINITY, -INFINITY, -0.0f, 1e-42f, -1e-42f, FLT_MAX, -FLT_MAX};
+        for (int i = 0; i < NA; ++i) h_a[i] = i < 8 ? specials[i] : 4.f * frand() - 2.f;
+        for (int i = 0; i < NB; ++i) h_b[i] = i % 5 == 0 ? specials[(i / 5) % 8] : frand();
+        float *d_a, *d_b, *d_ao, *d_bo;
+        CHECK_HIP(hipMalloc((void**)&d_a, sizeof h_a)); CHECK_HIP(hipMalloc((void**)&d_b, sizeof h_b));
+        CHECK_HIP(hipMalloc((void**)&d_ao, sizeof h_a)); CHECK_HIP(hipMalloc((void**)&d_bo, sizeof h_b));
+        CHECK_HIP(hipMemcpy(d_a, h_a, sizeof h_a, hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_b, h_b, sizeof h_b, hipMemcpyHostToDevice));
+        rc = sbev_finish_outputs(d_a, d_b, d_ao, d_bo, NA, NB, (sbev_stream_t)stream);
+        if (rc != SBEV_OK) { fprintf(stderr, "sbev_finish_outputs: %d (%s)\n", rc, sbev_last_error()); return 1; }
+        CHECK_HIP(hipStreamSynchronize(stream));
+        CHECK_HIP(hipMemcpy(r_a, d_ao, sizeof h_a, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(r_b, d_bo, sizeof h_b, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < NA + NB; ++i) {
+            const float x = i < NA ? h_a[i] : h_b[i - NA], got = i < NA ? r_a[i] : r_b[i - NA];
+            const float want = isnan(x) ? 0.f : isinf(x) ? (x > 0 ? FLT_MAX : -FLT_MAX) : x;
+            bad += memcmp(&got, &want, sizeof got) != 0;          /* bit for bit: -0, denormals, FLT_MAX unchanged */
+        }
+        printf("sbev_finish_outputs from C: %d + %d values, %d differ from the scalar nan_to_num\n", NA, NB, bad);
+        if (bad) return 1;
+        if (sbev_decoder_chain_pair_faults() != 0 || sbev_decoder_chain_pair_faults_ack() != 0) { fprintf(stderr, "fault word not clean\n"); return 1; }
+        printf("pair fault word: clean\n");
+    }
     return 0;
 }

@@ -30,3 +30,4 @@ def test_sampler_called_from_c_matches_the_c_oracle():
     r = subprocess.run([_ensure_built()], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'max |hip - oracle|' in r.stdout and 'L = 6 rejected' in r.stdout and 'P = 33 rejected' in r.stdout
+    assert '0 differ from the scalar nan_to_num' in r.stdout and 'pair fault word: clean' in r.stdout          # round 5's entry points

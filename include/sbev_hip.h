@@ -793,6 +793,43 @@ int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_decoder_weig
                          void* workspace, int64_t workspace_bytes, sbev_stream_t stream);
 
 /*
+ * On-demand relayout (round 6).  The reference regroups EVERY pixel of every level on every call (models/sparsebev_transformer.py:73-85);
+ * the gather reads the 4 bilinear corners of each sample point per level (models/csrc/msmv_sampling/msmv_sampling_forward.cu:41-66,
+ * sparsebev_sampling.py:88-109) -- under half of the pyramid.  sbev_decoder_forward_lazy takes the reference's NCHW maps
+ * [B*T*N, 256, H_l, W_l] as SOURCES (direct pointers, or entries of a device pointer table read at launch time: the replayable form)
+ * and channels-last buffers of the same sizes as destinations (feats_nhwc; contents arbitrary): every layer's camera selection marks
+ * the 64-pixel x 64-channel units its points read, one launch behind it moves the marked units this step has not moved yet.  Outputs are
+ * bit-identical to sbev_nchw_to_nhwc_* followed by sbev_decoder_forward.  Dense pyramids of 4 groups x 64 channels
+ * (sbev_decoder_lazy_supported); fp32 / bf16 / fp16 storage; 16-byte aligned sources and destinations.  Every argument after `lazy` as in
+ * sbev_decoder_forward.
+ */
+typedef struct sbev_lazy_feats {
+    const void* const* table;              /* device array of source pointers, or NULL */
+    int32_t index[SBEV_MAX_LEVELS];        /* table != NULL: level l's NCHW source is table[index[l]] */
+    const void* src[SBEV_MAX_LEVELS];      /* table == NULL: level l's NCHW source */
+} sbev_lazy_feats;
+int sbev_decoder_lazy_supported(const sbev_decoder_config* cfg);
+int sbev_decoder_forward_lazy(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights, void* const* feats_nhwc,
+                              const sbev_lazy_feats* lazy, const float* query_bbox, const float* query_feat,
+                              const float* time_diff, const float* lidar2img, const float* vel_div,
+                              const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                              void* workspace, int64_t workspace_bytes, sbev_stream_t stream);
+/* The pieces, for callers that run the layers themselves: tiles of a pyramid (one 4-byte word of `need` and of `done` each; -1: shape not
+ * covered); the marking form of sbev_sample_and_project (hw: [L][2] = (H_l, W_l); byte g of a tile's `need` word := 1 when a point of
+ * group g reads one of its pixels); the move (first != 0: the step's first launch -- one workgroup per tile, `done` rebuilt from `need`;
+ * else only need & ~done; last != 0 additionally clears `need` for the next step).  A stale `need` only moves more units. */
+int64_t sbev_lazy_relayout_tiles(int n_levels, const int32_t* hw_pixels, int64_t n_images, int channels);
+int sbev_sample_and_project_touch(const float* query_bbox, const float* offset, int64_t ld_offset,
+                                  const float* scale_logits, int64_t ld_logits,
+                                  const float* time_diff, const float* lidar2img, const double* pc_range,
+                                  int B, int Q, int T, int N, int G, int P, int L,
+                                  float image_h, float image_w, float eps,
+                                  float* loc_bp, float* weights_bp, const int32_t* hw, uint32_t* need, sbev_stream_t stream);
+int sbev_nchw_to_nhwc_lazy(const void* const* table, const int32_t* index, const void* const* src, void* const* out, int n_levels,
+                           const int32_t* hw_pixels, int64_t n_images, int channels, int dtype, uint32_t* need, uint32_t* done, int first,
+                           int last, sbev_stream_t stream);
+
+/*
  * hipGraph capture of one decoder step: the launch sequence of sbev_decoder_forward is static per (config, pointer
  * set), so it can be recorded once on `stream` (explicit, non-default; nothing executes during the capture) and
  * replayed per sample.  The graph reads its inputs through the captured device pointers: refresh them in place.

@@ -67,6 +67,16 @@ SIGNATURES = {
     'sbev_decoder_launches_per_layer': (ctypes.c_int, [_vp, _vp]),
     'sbev_decoder_forward': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp, ctypes.c_int64, _vp]),
+    'sbev_decoder_forward_lazy': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                 _vp, ctypes.c_int64, _vp]),
+    'sbev_decoder_lazy_supported': (ctypes.c_int, [_vp]),
+    'sbev_lazy_relayout_tiles': (ctypes.c_int64, [ctypes.c_int, _c_i32p, ctypes.c_int64, ctypes.c_int]),
+    'sbev_sample_and_project_touch': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp,
+                                                     ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _c_i32p, _vp, _vp]),
+    'sbev_nchw_to_nhwc_lazy': (ctypes.c_int, [_vp, _c_i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _c_i32p, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_profile_sampler': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_stride': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_sampler_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),

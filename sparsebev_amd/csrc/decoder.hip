@@ -32,8 +32,17 @@ struct Buffers {
         *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc, *pair_x;
     uint32_t* pair_sync;
     int32_t* order;
+    uint32_t *touch_need, *touch_done;      // on-demand relayout (sbev_decoder_forward_lazy): one word per feature tile each, or null
     size_t bytes;
 };
+
+// tiles of the config's dense pyramid [B*T*N, D, H_l * W_l]; false: the lazy relayout does not take it (ring, odd sizes, D != 256)
+bool lazy_plan_of(const sbev_decoder_config& c, sbev::LazyPlan* p) {
+    if (c.n_slots > 0 || c.G != 4 || c.D != 256) return false;
+    int32_t s[SBEV_MAX_LEVELS];
+    for (int l = 0; l < c.L; ++l) s[l] = c.hw[l][0] * c.hw[l][1];
+    return sbev::lazy_plan(c.L, s, (long long)c.B * c.T * c.N, c.D, p);
+}
 
 int out_proj_splits(long long M, int N, int K) { return sbev_linear_splitk_plan(M, N, K); }
 
@@ -70,6 +79,11 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.pair_x = k.take((size_t)sbev::chain_pair_floats((long long)BQ));                   // tail chain in pair mode (row_chain.hip): exchange rows
     b.pair_sync = reinterpret_cast<uint32_t*>(k.take((size_t)sbev::chain_pair_sync_words((long long)BQ)));      // ... and arrival counters
     b.order = reinterpret_cast<int32_t*>(k.take(BQ));                                    // launch order of the gather items (sbev_query_order)
+    sbev::LazyPlan lp;
+    if (lazy_plan_of(c, &lp)) {                                                          // (45 KB at config 2, 1.4 MB at config 4)
+        b.touch_need = reinterpret_cast<uint32_t*>(k.take(lp.base[lp.n_levels]));
+        b.touch_done = reinterpret_cast<uint32_t*>(k.take(lp.base[lp.n_levels]));
+    }
     b.bytes = k.off;
     return b;
 }
@@ -199,11 +213,11 @@ extern "C" int64_t sbev_decoder_workspace_bytes(const sbev_decoder_config* cfg) 
     return (int64_t)carve(*cfg, nullptr).bytes;
 }
 
-extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_decoder_weights* w,
-                                    const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
-                                    const float* time_diff, const float* lidar2img, const float* vel_div,
-                                    const uint8_t* attn_mask, float* cls_out, float* bbox_out,
-                                    void* workspace, int64_t workspace_bytes, sbev_stream_t stream) {
+static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decoder_weights* w,
+                                const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
+                                const float* time_diff, const float* lidar2img, const float* vel_div,
+                                const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                                void* workspace, int64_t workspace_bytes, sbev_stream_t stream, const sbev_lazy_feats* lazy) {
     TRY(validate(cfg));
     const sbev_decoder_config& c = *cfg;
     SBEV_REQUIRE(w && feats_nhwc && query_bbox && query_feat && time_diff && lidar2img && cls_out && bbox_out && workspace,
@@ -235,6 +249,23 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     const int soN = c.G * c.P * (3 + c.L);
     const int splits = out_proj_splits(BQ, D, mixN);
     const float eps = 1e-5f;
+
+    // on-demand relayout (sbev_decoder_forward_lazy): feats_nhwc are DESTINATIONS; every layer's point selection marks the units its
+    // points read and one launch behind it moves the marked units that this step has not moved yet (csrc/layout.hip)
+    sbev::LazyPlan lplan{};
+    if (lazy) {
+        SBEV_REQUIRE(lazy_plan_of(c, &lplan) && b.touch_need, "sbev_decoder_forward_lazy: config not covered (dense pyramid, 4 groups of 64 channels)");
+        for (int l = 0; l < c.L; ++l)
+            SBEV_REQUIRE(feats_nhwc[l] && (((uintptr_t)feats_nhwc[l]) & 15) == 0 &&
+                         (lazy->table ? lazy->index[l] >= 0 : (lazy->src[l] && (((uintptr_t)lazy->src[l]) & 15) == 0 && lazy->src[l] != feats_nhwc[l])),
+                         "sbev_decoder_forward_lazy: level %d (16-byte aligned NCHW source and NHWC destination)", l);
+        SBEV_REQUIRE(!lazy->table || (((uintptr_t)lazy->table) & 7) == 0, "sbev_decoder_forward_lazy: unaligned pointer table");
+    }
+    auto lazy_move = [&](int layer) -> int {
+        if (!lazy) return SBEV_OK;
+        return sbev::launch_lazy_relayout(lplan, lazy->table, lazy->index, lazy->src, const_cast<void* const*>(feats_nhwc), c.feat_dtype == SBEV_F32 ? 4 : 2,
+                                          b.touch_need, b.touch_done, layer == 0, layer + 1 == c.num_layers, reinterpret_cast<hipStream_t>(stream));
+    };
 
     // feature pyramid descriptors: zero-copy NHWC, group g = channel slice [g*Cg, (g+1)*Cg)
     int32_t hw[2 * SBEV_MAX_LEVELS];
@@ -319,7 +350,9 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
-                                        nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr, b.pair_sync));
+                                        nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr, b.pair_sync,
+                                        lazy ? &lplan : nullptr, lazy ? b.touch_need : nullptr));
+            TRY(lazy_move(layer));
             if (nimg)
                 TRY(generator_bf16s(stream, true));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)
@@ -382,8 +415,10 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
             TRY(hip_ok(hipEventRecord(ev_pg, ax.stream), "hipEventRecord"));
         }
         // adaptive spatio-temporal sampling                                     (:170)
-        TRY(sbev_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
-                                    c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp, stream));
+        TRY(sbev::launch_sample_and_project(bbox, b.so, soN, b.so + c.G * c.P * 3, soN, time_diff, lidar2img, c.pc_range,
+                                            c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w, c.eps_homo, b.loc, b.wbp,
+                                            lazy ? &lplan : nullptr, lazy ? b.touch_need : nullptr, c.hw, s_main));
+        TRY(lazy_move(layer));
         // gather + adaptive mixing: ONE launch when the fused kernel covers the shape (the sampled features then never
         // touch HBM), else the sampler followed by the mixing kernel (same arithmetic, bit-identical results)
         // (round 2 kept two launches for 5 fp32 levels: 168 registers + spills, 272 vs 277 samples/s at config 4; the lean chunk code
@@ -486,6 +521,33 @@ extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_d
     }
     if (fork && ev_cls) TRY(hip_ok(hipStreamWaitEvent(s_main, ev_cls, 0), "hipStreamWaitEvent"));   // final join
     return SBEV_OK;
+}
+
+extern "C" int sbev_decoder_forward(const sbev_decoder_config* cfg, const sbev_decoder_weights* w,
+                                    const void* const* feats_nhwc, const float* query_bbox, const float* query_feat,
+                                    const float* time_diff, const float* lidar2img, const float* vel_div,
+                                    const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                                    void* workspace, int64_t workspace_bytes, sbev_stream_t stream) {
+    return decoder_forward_impl(cfg, w, feats_nhwc, query_bbox, query_feat, time_diff, lidar2img, vel_div, attn_mask, cls_out, bbox_out, workspace,
+                                workspace_bytes, stream, nullptr);
+}
+
+// The same step from the reference's NCHW feature maps WITHOUT a dense relayout: feats_nhwc[l] are channels-last buffers of the step's
+// own (any contents), `lazy` names the NCHW sources; only the 64-pixel x 64-channel units a sample point reads are moved, layer by
+// layer (models/sparsebev_transformer.py:73-85 regroups everything; sparsebev_sampling.py:88-109 reads under half of it).
+extern "C" int sbev_decoder_forward_lazy(const sbev_decoder_config* cfg, const sbev_decoder_weights* w, void* const* feats_nhwc,
+                                         const sbev_lazy_feats* lazy, const float* query_bbox, const float* query_feat,
+                                         const float* time_diff, const float* lidar2img, const float* vel_div,
+                                         const uint8_t* attn_mask, float* cls_out, float* bbox_out,
+                                         void* workspace, int64_t workspace_bytes, sbev_stream_t stream) {
+    SBEV_REQUIRE(lazy, "sbev_decoder_forward_lazy: null source descriptor");
+    return decoder_forward_impl(cfg, w, const_cast<const void* const*>(feats_nhwc), query_bbox, query_feat, time_diff, lidar2img, vel_div, attn_mask,
+                                cls_out, bbox_out, workspace, workspace_bytes, stream, lazy);
+}
+
+extern "C" int sbev_decoder_lazy_supported(const sbev_decoder_config* cfg) {
+    sbev::LazyPlan p;
+    return cfg && validate(cfg) == SBEV_OK && lazy_plan_of(*cfg, &p) ? 1 : 0;
 }
 
 // ---- kernel launch timing (HIP events on the launch stream), used by bench.py for the roofline figures --------

@@ -189,6 +189,295 @@ __global__ __launch_bounds__(256) void transpose_tiles16_kernel(const Tr16Args a
     }
 }
 
+// ---- on-demand ("lazy") relayout: only the units a sample point will read (round 6) -----------------------------------------------------
+// The reference regroups every pixel of every level on every call (models/sparsebev_transformer.py:73-85) and the dense kernels above
+// move 2 x the feature bytes per step -- 14 % of the step at config 2, 29 % at config 3, 41 % at config 4 -- although the gather reads
+// only the 4 bilinear corners of each sample point per level (msmv_sampling_forward.cu:41-66): under half of the pyramid
+// (tools/relayout_footprint.py: 46 % of the units after layer 0, 49 % after all six layers at config 2).  Here the kernel that selects a
+// point's camera (sample_point.hpp::touch_units, inside the attention row chain / sample_project_kernel) marks the units the point
+// reads -- unit = 64 consecutive pixels of one image of one level x the 64 channels of ONE group, a byte each, word = the tile's 4 groups
+// -- and these kernels move exactly the marked units that have not been moved in this step:
+//   layer 0  : lazy_tiles_kernel<first> -- one workgroup per TILE (the dense grid: the pyramid is ~half marked), done = need;
+//   layer >= 1: lazy_scan_kernel -- one thread per tile looks for need & ~done (a few hundred units at layer 1, a handful later), the
+//               workgroup moves what its 256 tiles found; the last layer's launch clears `need` for the next step.
+// Plain loads / stores only: `need` bytes are written by idempotent stores, `done` words by the one thread that owns the tile.  A stale or
+// uninitialised `need` (first step on a new workspace, an aborted step) only moves MORE units; `done` is rebuilt by every step's first launch.
+// Untouched units of the NHWC buffers keep whatever an earlier step left there: no tap ever reads them.
+struct LazyArgs {
+    const void* const* table;              // sources: table[index[l]] (replayable step) or src[l]
+    int index[SBEV_MAX_LEVELS];
+    const void* src[SBEV_MAX_LEVELS];      // [n_images, R, S_l]
+    void* out[SBEV_MAX_LEVELS];            // [n_images, S_l, R]
+    int S[SBEV_MAX_LEVELS];
+    unsigned tiles[SBEV_MAX_LEVELS];       // ceil(S_l / 64)
+    unsigned base[SBEV_MAX_LEVELS + 1];    // level l owns tiles [base[l], base[l + 1])
+    int n_levels, R;                       // R = 4 groups x 64 channels
+    unsigned* need;                        // [total tiles] 4 bytes each: group g of the tile is read by some sample point
+    unsigned* done;                        // [total tiles] 4 bytes each: moved in this step
+    int first, last;
+};
+
+constexpr int LAZY_SCAN = 32;
+__device__ __forceinline__ unsigned lazy_bytes_nonzero(unsigned w) {      // byte k != 0 -> bit k
+    return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
+}
+__device__ __forceinline__ unsigned lazy_bits_to_bytes(unsigned m) {      // bit k -> byte k = 1
+    return (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21);
+}
+
+// one unit: channels [64 g, 64 g + 64) x pixels [64 ts, 64 ts + 64) of image `img` of level l.  fp32: the dense tile code.
+__device__ __forceinline__ void lazy_move_unit(const LazyArgs& a, int l, long long img, int ts, int g, float* tile, const float*) {
+    const int tid = threadIdx.x;
+    const int R = a.R, S = a.S[l];
+    const int r0 = g * TS, s0 = ts * TS;
+    const float* in = static_cast<const float*>(a.table ? a.table[a.index[l]] : a.src[l]) + img * R * S;
+    float* out = static_cast<float*>(a.out[l]) + img * R * S;
+    if ((S & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + (tid >> 4) + 16 * i, sx = s0 + (tid & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sx < S) v = *reinterpret_cast<const float4*>(in + (long long)r * S + sx);
+            const int lr = (tid >> 4) + 16 * i, ls = (tid & 15) * 4;
+            tile[(ls + 0) * TLD + lr] = v.x;
+            tile[(ls + 1) * TLD + lr] = v.y;
+            tile[(ls + 2) * TLD + lr] = v.z;
+            tile[(ls + 3) * TLD + lr] = v.w;
+        }
+    } else {                                   // planes whose rows are not 16-byte aligned (e.g. a 10 x 25 level): scalar reads
+        for (int i = tid; i < TS * TS; i += 256) {
+            const int lr = i >> 6, ls = i & 63, sx = s0 + ls;
+            tile[ls * TLD + lr] = sx < S ? in[(long long)(r0 + lr) * S + sx] : 0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ls = (tid >> 4) + 16 * i, lr = (tid & 15) * 4;
+        const int sx = s0 + ls;
+        if (sx < S) {
+            const float4 v = make_float4(tile[ls * TLD + lr], tile[ls * TLD + lr + 1], tile[ls * TLD + lr + 2], tile[ls * TLD + lr + 3]);
+            *reinterpret_cast<float4*>(out + (long long)sx * R + r0 + lr) = v;
+        }
+    }
+    __syncthreads();
+}
+// 2-byte channels (bf16 / fp16 storage: bytes are moved, never interpreted): 32 channel PAIRS x 64 pixels, the pair interleave of
+// transpose_tiles16_kernel; 128-byte runs in, 128-byte runs out
+__device__ __forceinline__ void lazy_move_unit(const LazyArgs& a, int l, long long img, int ts, int g, float* tilef, const unsigned short*) {
+    unsigned* tile = reinterpret_cast<unsigned*>(tilef);          // tile[pixel][pair], row stride 33 words
+    constexpr int PLD = 33;
+    const int tid = threadIdx.x;
+    const int R = a.R, S = a.S[l];
+    const int r0 = g * 64, s0 = ts * 64;
+    const unsigned short* in = static_cast<const unsigned short*>(a.table ? a.table[a.index[l]] : a.src[l]) + img * R * S;
+    unsigned short* out = static_cast<unsigned short*>(a.out[l]) + img * R * S;
+    if ((S & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cp = (tid >> 4) + 16 * i, q = tid & 15;     // channel pair of the unit, pixel quad
+            const int r = r0 + 2 * cp, sx = s0 + 4 * q;
+            uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+            if (sx < S) {
+                lo = *reinterpret_cast<const uint2*>(in + (long long)r * S + sx);
+                hi = *reinterpret_cast<const uint2*>(in + (long long)(r + 1) * S + sx);
+            }
+            tile[(4 * q + 0) * PLD + cp] = __builtin_amdgcn_perm(hi.x, lo.x, 0x05040100u);
+            tile[(4 * q + 1) * PLD + cp] = __builtin_amdgcn_perm(hi.x, lo.x, 0x07060302u);
+            tile[(4 * q + 2) * PLD + cp] = __builtin_amdgcn_perm(hi.y, lo.y, 0x05040100u);
+            tile[(4 * q + 3) * PLD + cp] = __builtin_amdgcn_perm(hi.y, lo.y, 0x07060302u);
+        }
+    } else {
+        for (int i = tid; i < 32 * 64; i += 256) {
+            const int cp = i >> 6, ls = i & 63, sx = s0 + ls;
+            unsigned w = 0u;
+            if (sx < S) w = (unsigned)in[(long long)(r0 + 2 * cp) * S + sx] | ((unsigned)in[(long long)(r0 + 2 * cp + 1) * S + sx] << 16);
+            tile[ls * PLD + cp] = w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = (tid >> 3) + 32 * i, k = tid & 7;          // pixel of the unit, 16-byte piece (4 pairs = 8 channels)
+        const int sx = s0 + px;
+        if (sx < S) {
+            const unsigned* t = &tile[px * PLD + 4 * k];
+            *reinterpret_cast<uint4*>(out + (long long)sx * R + r0 + 8 * k) = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lazy_locate(const LazyArgs& a, unsigned t, int& l, long long& img, int& ts) {
+    l = 0;
+#pragma unroll
+    for (int j = 1; j < SBEV_MAX_LEVELS; ++j)
+        if (j < a.n_levels && t >= a.base[j]) l = j;
+    const unsigned rel = t - a.base[l];
+    const unsigned i = rel / a.tiles[l];
+    img = i;
+    ts = (int)(rel - i * a.tiles[l]);
+}
+
+// the step's FIRST lazy launch: one workgroup per tile, `done` is rebuilt from `need`
+template <typename ET>
+__global__ __launch_bounds__(256) void lazy_tiles_kernel(const LazyArgs a) {
+    __shared__ float tile[TS * TLD];
+    const unsigned t = blockIdx.x;
+    const unsigned pend = (unsigned)__builtin_amdgcn_readfirstlane((int)lazy_bytes_nonzero(a.need[t]));
+    if (threadIdx.x == 0) {
+        a.done[t] = lazy_bits_to_bytes(pend);
+        if (a.last) a.need[t] = 0u;
+    }
+    if (pend == 0u) return;
+    int l, ts;
+    long long img;
+    lazy_locate(a, t, l, img, ts);
+    for (int g = 0; g < 4; ++g)
+        if ((pend >> g) & 1u) lazy_move_unit(a, l, img, ts, g, tile, static_cast<const ET*>(nullptr));
+}
+
+// ---- one unit moved by ONE wave (the scan launches): no workgroup barrier, so the 4 waves of a workgroup move 4 units side by side and a
+// lane has all its loads of a pass in flight at once.  wt: the wave's own [64 pixels][33 words] of LDS.
+constexpr int WLD = 33;
+__device__ __forceinline__ void lazy_wave_sync() {          // LDS traffic of one wave executes in issue order; keep the compiler from reordering it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void lazy_move_unit_wave(const LazyArgs& a, int l, long long img, int ts, int g, float* wt, const float*) {
+    const int lane = threadIdx.x & 63;
+    const int R = a.R, S = a.S[l];
+    const int s0 = ts * TS;
+    const float* in = static_cast<const float*>(a.table ? a.table[a.index[l]] : a.src[l]) + img * R * S;
+    float* out = static_cast<float*>(a.out[l]) + img * R * S;
+    for (int half = 0; half < 2; ++half) {                  // 32 channels x 64 pixels per pass
+        const int r0 = g * TS + 32 * half;
+        if ((S & 3) == 0) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int lr = (lane >> 4) + 4 * i, sx = s0 + (lane & 15) * 4;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sx < S) v[i] = *reinterpret_cast<const float4*>(in + (long long)(r0 + lr) * S + sx);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int lr = (lane >> 4) + 4 * i, ls = (lane & 15) * 4;
+                wt[(ls + 0) * WLD + lr] = v[i].x;
+                wt[(ls + 1) * WLD + lr] = v[i].y;
+                wt[(ls + 2) * WLD + lr] = v[i].z;
+                wt[(ls + 3) * WLD + lr] = v[i].w;
+            }
+        } else {
+            for (int i = lane; i < 32 * TS; i += 64) {
+                const int lr = i >> 6, ls = i & 63, sx = s0 + ls;
+                wt[ls * WLD + lr] = sx < S ? in[(long long)(r0 + lr) * S + sx] : 0.f;
+            }
+        }
+        lazy_wave_sync();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ls = (lane >> 3) + 8 * i, lr = (lane & 7) * 4;
+            const int sx = s0 + ls;
+            if (sx < S) {
+                const float4 v = make_float4(wt[ls * WLD + lr], wt[ls * WLD + lr + 1], wt[ls * WLD + lr + 2], wt[ls * WLD + lr + 3]);
+                *reinterpret_cast<float4*>(out + (long long)sx * R + r0 + lr) = v;
+            }
+        }
+        lazy_wave_sync();
+    }
+}
+__device__ __forceinline__ void lazy_move_unit_wave(const LazyArgs& a, int l, long long img, int ts, int g, float* wtf, const unsigned short*) {
+    unsigned* wt = reinterpret_cast<unsigned*>(wtf);          // wt[pixel][channel pair]
+    const int lane = threadIdx.x & 63;
+    const int R = a.R, S = a.S[l];
+    const int r0 = g * 64, s0 = ts * 64;
+    const unsigned short* in = static_cast<const unsigned short*>(a.table ? a.table[a.index[l]] : a.src[l]) + img * R * S;
+    unsigned short* out = static_cast<unsigned short*>(a.out[l]) + img * R * S;
+    if ((S & 3) == 0) {
+        uint2 lo[8], hi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cp = (lane >> 4) + 4 * i, sx = s0 + 4 * (lane & 15);
+            lo[i] = make_uint2(0u, 0u); hi[i] = make_uint2(0u, 0u);
+            if (sx < S) {
+                lo[i] = *reinterpret_cast<const uint2*>(in + (long long)(r0 + 2 * cp) * S + sx);
+                hi[i] = *reinterpret_cast<const uint2*>(in + (long long)(r0 + 2 * cp + 1) * S + sx);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cp = (lane >> 4) + 4 * i, q = lane & 15;
+            wt[(4 * q + 0) * WLD + cp] = __builtin_amdgcn_perm(hi[i].x, lo[i].x, 0x05040100u);
+            wt[(4 * q + 1) * WLD + cp] = __builtin_amdgcn_perm(hi[i].x, lo[i].x, 0x07060302u);
+            wt[(4 * q + 2) * WLD + cp] = __builtin_amdgcn_perm(hi[i].y, lo[i].y, 0x05040100u);
+            wt[(4 * q + 3) * WLD + cp] = __builtin_amdgcn_perm(hi[i].y, lo[i].y, 0x07060302u);
+        }
+    } else {
+        for (int i = lane; i < 32 * 64; i += 64) {
+            const int cp = i >> 6, ls = i & 63, sx = s0 + ls;
+            unsigned w = 0u;
+            if (sx < S) w = (unsigned)in[(long long)(r0 + 2 * cp) * S + sx] | ((unsigned)in[(long long)(r0 + 2 * cp + 1) * S + sx] << 16);
+            wt[ls * WLD + cp] = w;
+        }
+    }
+    lazy_wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int px = (lane >> 3) + 8 * i, k = lane & 7;
+        const int sx = s0 + px;
+        if (sx < S) {
+            const unsigned* t = &wt[px * WLD + 4 * k];
+            *reinterpret_cast<uint4*>(out + (long long)sx * R + r0 + 8 * k) = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+    }
+    lazy_wave_sync();
+}
+
+// later launches of the step: a thread per tile finds what the layer's sample points marked and no earlier launch moved.  The units a
+// layer adds come in CLUSTERS of neighbouring tiles (boxes move a little: a band of new rows in one image, all 4 groups of a tile), and
+// every move is a chain of two memory round trips (~3 us), so (1) workgroup w looks at tiles w, w + n, w + 2 n, ... (n workgroups,
+// LAZY_SCAN tiles each): a run of consecutive new tiles lands on as many different workgroups; (2) a unit is moved by ONE wave
+// (lazy_move_unit_wave: no workgroup barrier), wave k takes entries k, k + 4, ... of the workgroup's list -- the 4 groups of a new tile
+// move side by side.  (First version: 64 consecutive tiles per workgroup, one unit at a time by the whole workgroup: 30 us per launch at
+// config 2 for ~600 units -- a few workgroups with a dozen serial moves each.)
+template <typename ET>
+__global__ __launch_bounds__(256) void lazy_scan_kernel(const LazyArgs a) {
+    __shared__ float wtile[4][TS * WLD];
+    __shared__ unsigned list[LAZY_SCAN * 4];
+    __shared__ unsigned n_list;
+    const int tid = threadIdx.x;
+    const unsigned total = a.base[a.n_levels];
+    const unsigned t = (unsigned)tid * gridDim.x + blockIdx.x;
+    if (tid == 0) n_list = 0u;
+    __syncthreads();
+    if (tid < LAZY_SCAN && t < total) {
+        const unsigned nw = a.need[t], dw = a.done[t];    // (both requests in flight together: the launch is a chain of round trips)
+        if (nw != 0u) {
+            const unsigned pend = lazy_bytes_nonzero(nw) & ~lazy_bytes_nonzero(dw);
+            if (pend) {
+                a.done[t] = dw | lazy_bits_to_bytes(pend);
+                const unsigned at = atomicAdd(&n_list, (unsigned)__builtin_popcount(pend));
+                unsigned k = 0;
+                for (int g = 0; g < 4; ++g)
+                    if ((pend >> g) & 1u) list[at + k++] = (unsigned)tid | ((unsigned)g << 8);
+            }
+            if (a.last) a.need[t] = 0u;
+        }
+    }
+    __syncthreads();
+    const unsigned n = n_list;
+    const int wave = tid >> 6;
+    for (unsigned i = (unsigned)wave; i < n; i += 4u) {
+        const unsigned e = list[i];
+        int l, ts;
+        long long img;
+        lazy_locate(a, (e & 255u) * gridDim.x + blockIdx.x, l, img, ts);
+        lazy_move_unit_wave(a, l, img, ts, (int)(e >> 8), wtile[wave], static_cast<const ET*>(nullptr));
+    }
+}
+
 __global__ __launch_bounds__(256) void linear3_ln_relu_kernel(const PosArgs a) { lin3_rows(a, blockIdx.x); }
 
 // contiguous copy with widening to fp32 (channels-last frames handed to the online ring: fp32 / fp16 / bf16 storage), 4 elements per thread
@@ -525,4 +814,68 @@ extern "C" int sbev_nchw_to_nhwc_b16_indirect(const void* const* table, int inde
                                               sbev_stream_t stream) {
     SBEV_REQUIRE(n_images == 0 || table, "sbev_nchw_to_nhwc_b16_indirect: null table");
     return nchw_to_nhwc_b16(nullptr, table, index, out, n_images, channels, hw, stream, "sbev_nchw_to_nhwc_b16_indirect");
+}
+
+// ---- on-demand relayout: host side ------------------------------------------------------------------------------------------------
+namespace sbev {
+// tiles of a pyramid [n_images, 256, hw[l]] per level; false when the lazy kernels do not take the shape
+bool lazy_plan(int n_levels, const int32_t* hw, long long n_images, int channels, LazyPlan* p) {
+    if (n_levels < 1 || n_levels > SBEV_MAX_LEVELS || channels != 256 || n_images < 1) return false;
+    long long tiles = 0;
+    p->n_levels = n_levels; p->n_images = n_images; p->R = channels;
+    for (int l = 0; l < n_levels; ++l) {
+        if (hw[l] < 1) return false;
+        p->S[l] = hw[l];
+        p->tiles[l] = (unsigned)((hw[l] + TS - 1) / TS);
+        p->base[l] = (unsigned)tiles;
+        tiles += (long long)p->tiles[l] * n_images;
+        if (tiles > 0x3fffffffLL) return false;
+    }
+    p->base[n_levels] = (unsigned)tiles;
+    return true;
+}
+
+int launch_lazy_relayout(const LazyPlan& p, const void* const* table, const int32_t* index, const void* const* src, void* const* out,
+                         int esize, uint32_t* need, uint32_t* done, bool first, bool last, hipStream_t s) {
+    LazyArgs a{};
+    a.table = table; a.n_levels = p.n_levels; a.R = p.R; a.need = need; a.done = done; a.first = first; a.last = last;
+    for (int l = 0; l < p.n_levels; ++l) {
+        a.index[l] = table ? index[l] : 0;
+        a.src[l] = table ? nullptr : src[l];
+        a.out[l] = out[l];
+        a.S[l] = p.S[l]; a.tiles[l] = p.tiles[l]; a.base[l] = p.base[l];
+    }
+    a.base[p.n_levels] = p.base[p.n_levels];
+    const unsigned total = p.base[p.n_levels];
+    if (first) {
+        if (esize == 4) hipLaunchKernelGGL(lazy_tiles_kernel<float>, dim3(total), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(lazy_tiles_kernel<unsigned short>, dim3(total), dim3(256), 0, s, a);
+    } else {
+        if (esize == 4) hipLaunchKernelGGL(lazy_scan_kernel<float>, dim3((total + LAZY_SCAN - 1) / LAZY_SCAN), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(lazy_scan_kernel<unsigned short>, dim3((total + LAZY_SCAN - 1) / LAZY_SCAN), dim3(256), 0, s, a);
+    }
+    return check_launch("lazy relayout");
+}
+}  // namespace sbev
+
+extern "C" int64_t sbev_lazy_relayout_tiles(int n_levels, const int32_t* hw, int64_t n_images, int channels) {
+    sbev::LazyPlan p;
+    if (!hw || !sbev::lazy_plan(n_levels, hw, n_images, channels, &p)) return -1;
+    return (int64_t)p.base[n_levels];
+}
+
+extern "C" int sbev_nchw_to_nhwc_lazy(const void* const* table, const int32_t* index, const void* const* src, void* const* out, int n_levels,
+                                      const int32_t* hw, int64_t n_images, int channels, int dtype, uint32_t* need, uint32_t* done, int first,
+                                      int last, sbev_stream_t stream) {
+    SBEV_REQUIRE(hw && out && need && done && (table ? index != nullptr : src != nullptr), "sbev_nchw_to_nhwc_lazy: null pointer");
+    SBEV_REQUIRE(dtype == SBEV_F32 || dtype == SBEV_BF16 || dtype == SBEV_F16, "sbev_nchw_to_nhwc_lazy: dtype %d", dtype);
+    SBEV_REQUIRE(!table || (((uintptr_t)table) & 7) == 0, "sbev_nchw_to_nhwc_lazy: unaligned pointer table");
+    sbev::LazyPlan p;
+    SBEV_REQUIRE(sbev::lazy_plan(n_levels, hw, n_images, channels, &p),
+                 "sbev_nchw_to_nhwc_lazy: needs 1..%d levels of 256 channels (got %d levels, %d channels)", SBEV_MAX_LEVELS, n_levels, channels);
+    for (int l = 0; l < n_levels; ++l)
+        SBEV_REQUIRE(out[l] && (((uintptr_t)out[l]) & 15) == 0 && (table ? index[l] >= 0 : (src[l] && (((uintptr_t)src[l]) & 15) == 0)),
+                     "sbev_nchw_to_nhwc_lazy: level %d (16-byte aligned source and destination)", l);
+    return sbev::launch_lazy_relayout(p, table, index, src, out, dtype == SBEV_F32 ? 4 : 2, need, done, first != 0, last != 0,
+                                      reinterpret_cast<hipStream_t>(stream));
 }

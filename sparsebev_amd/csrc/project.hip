@@ -216,24 +216,59 @@ extern "C" int sbev_sampling_front(const float* query_bbox, const float* offset,
     return sbev::check_launch("sbev_sampling_front");
 }
 
-extern "C" int sbev_sample_and_project(const float* query_bbox, const float* offset, int64_t ld_offset,
-                                       const float* scale_logits, int64_t ld_logits,
-                                       const float* time_diff, const float* lidar2img, const double* pc_range,
-                                       int B, int Q, int T, int N, int G, int P, int L,
-                                       float image_h, float image_w, float eps,
-                                       float* loc_bp, float* weights_bp, sbev_stream_t stream) {
+namespace sbev {
+int launch_sample_and_project(const float* query_bbox, const float* offset, int64_t ld_offset, const float* scale_logits, int64_t ld_logits,
+                              const float* time_diff, const float* lidar2img, const double* pc_range, int B, int Q, int T, int N, int G, int P,
+                              int L, float image_h, float image_w, float eps, float* loc_bp, float* weights_bp, const LazyPlan* touch,
+                              uint32_t* touch_need, const int32_t (*hw)[2], hipStream_t stream) {
     SBEV_REQUIRE(B >= 0 && Q >= 0 && T >= 1 && N >= 1 && G >= 1 && P >= 1, "sbev_sample_and_project: bad sizes");
     SBEV_REQUIRE(L >= 1 && L <= SBEV_MAX_LEVELS, "sbev_sample_and_project: L=%d not in 1..%d", L, SBEV_MAX_LEVELS);
     if (B == 0 || Q == 0) return SBEV_OK;
     SBEV_REQUIRE(query_bbox && offset && scale_logits && time_diff && lidar2img && pc_range && loc_bp && weights_bp,
                  "sbev_sample_and_project: null pointer");
     SBEV_REQUIRE(ld_offset >= (int64_t)G * P * 3 && ld_logits >= (int64_t)G * P * L, "sbev_sample_and_project: row strides smaller than the rows");
-    const FusedArgs a = sbev_ops::sample_point_args(query_bbox, time_diff, lidar2img, pc_range, B, Q, T, N, G, P, L, image_h, image_w,
-                                                    eps, loc_bp, weights_bp);
+    FusedArgs a = sbev_ops::sample_point_args(query_bbox, time_diff, lidar2img, pc_range, B, Q, T, N, G, P, L, image_h, image_w,
+                                              eps, loc_bp, weights_bp);
+    if (touch && touch_need) {
+        SBEV_REQUIRE(hw && touch->n_levels == L && G <= 4 && touch->n_images == (long long)B * T * N, "sbev_sample_and_project: touch map does not match the pyramid");
+        sbev_ops::sample_point_touch(a, *touch, hw, touch_need);
+    }
     const long long total = (long long)B * T * Q * G * P;
     const long long blocks = (total + 255) / 256;
     SBEV_REQUIRE(total <= 0x7fffffffLL, "sbev_sample_and_project: too many points");
-    hipLaunchKernelGGL(sample_project_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, offset,
+    hipLaunchKernelGGL(sample_project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, offset,
                        scale_logits, (long long)ld_offset, (long long)ld_logits);
     return sbev::check_launch("sbev_sample_and_project");
+}
+}  // namespace sbev
+
+extern "C" int sbev_sample_and_project(const float* query_bbox, const float* offset, int64_t ld_offset,
+                                       const float* scale_logits, int64_t ld_logits,
+                                       const float* time_diff, const float* lidar2img, const double* pc_range,
+                                       int B, int Q, int T, int N, int G, int P, int L,
+                                       float image_h, float image_w, float eps,
+                                       float* loc_bp, float* weights_bp, sbev_stream_t stream) {
+    return sbev::launch_sample_and_project(query_bbox, offset, ld_offset, scale_logits, ld_logits, time_diff, lidar2img, pc_range, B, Q, T, N, G, P, L,
+                                           image_h, image_w, eps, loc_bp, weights_bp, nullptr, nullptr, nullptr, reinterpret_cast<hipStream_t>(stream));
+}
+
+// the same launch, additionally marking the relayout units the selected points read (on-demand relayout, csrc/layout.hip): need = one
+// 4-byte word per tile of the pyramid [B*T*N, 256, hw_l] (sbev_lazy_relayout_tiles words), byte g of a tile's word is set to 1 when a
+// point of group g reads one of the tile's 64 pixels
+extern "C" int sbev_sample_and_project_touch(const float* query_bbox, const float* offset, int64_t ld_offset,
+                                             const float* scale_logits, int64_t ld_logits,
+                                             const float* time_diff, const float* lidar2img, const double* pc_range,
+                                             int B, int Q, int T, int N, int G, int P, int L,
+                                             float image_h, float image_w, float eps,
+                                             float* loc_bp, float* weights_bp, const int32_t* hw, uint32_t* need, sbev_stream_t stream) {
+    SBEV_REQUIRE(hw && need && L >= 1 && L <= SBEV_MAX_LEVELS, "sbev_sample_and_project_touch: null pointer / bad level count");
+    int32_t hw2[SBEV_MAX_LEVELS][2], s[SBEV_MAX_LEVELS];
+    for (int l = 0; l < L; ++l) {
+        hw2[l][0] = hw[2 * l]; hw2[l][1] = hw[2 * l + 1];
+        s[l] = hw[2 * l] * hw[2 * l + 1];
+    }
+    sbev::LazyPlan plan;
+    SBEV_REQUIRE(sbev::lazy_plan(L, s, (long long)B * T * N, 256, &plan), "sbev_sample_and_project_touch: pyramid not covered by the lazy relayout");
+    return sbev::launch_sample_and_project(query_bbox, offset, ld_offset, scale_logits, ld_logits, time_diff, lidar2img, pc_range, B, Q, T, N, G, P, L,
+                                           image_h, image_w, eps, loc_bp, weights_bp, &plan, need, hw2, reinterpret_cast<hipStream_t>(stream));
 }

@@ -1138,7 +1138,7 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
 // attention out-projection + residual + norm1 -> x1, sampling Linear -> sample points -> projection (loc, level weights)
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
                       const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
-                      hipStream_t s, uint16_t* x1_frag, const float* x1_scale, uint32_t* pair_sync) {
+                      hipStream_t s, uint16_t* x1_frag, const float* x1_scale, uint32_t* pair_sync, const LazyPlan* touch, uint32_t* touch_need) {
     const PackMap m = pack_map(c);
     ChainArgs a{};
     fill_common(a, c, eps);
@@ -1149,6 +1149,7 @@ int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& 
     a.x1_frag = x1_frag; a.x1_scale = x1_scale;
     a.proj = sbev_ops::sample_point_args(bbox, time_diff, lidar2img, c.pc_range, c.B, c.Q, c.T, c.N, c.G, c.P, c.L, c.image_h, c.image_w,
                                          c.eps_homo, loc_bp, w_bp);
+    if (touch && touch_need) sbev_ops::sample_point_touch(a.proj, *touch, c.hw, touch_need);      // on-demand relayout: mark what the points read
     const int rg = row_groups(a.M);
     const Offs o = offs(rg);
     a.units[0] = Unit{lin(w.chain_pack + m.attn_out, o.x2, LDX, c.D, c.D, pieces(rg, c.D / 64, c.D)), kNone, EPI_AOUT, 0};

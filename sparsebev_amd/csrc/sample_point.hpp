@@ -12,6 +12,17 @@
 
 namespace sbev_ops {
 
+// On-demand relayout (round 6, csrc/layout.hip "lazy relayout"): the thread that selects a point's camera also marks the relayout units
+// the gather will read for it -- per level the (up to) 4 bilinear corners under the sampler's own rule (msmv_chunk.inc phase 1 ==
+// msmv_sampling_forward.cu:41-66).  A unit = 64 consecutive pixels of one image of one level x the 64 channels of the point's group;
+// one BYTE per unit, set with a plain store (idempotent: no atomics, any number of writers), word = the 4 groups of a tile.
+struct TouchMap {
+    unsigned char* need;                   // null: off
+    int H[SBEV_MAX_LEVELS], W[SBEV_MAX_LEVELS];
+    unsigned tiles[SBEV_MAX_LEVELS];       // ceil(H * W / 64) per image
+    unsigned base[SBEV_MAX_LEVELS];        // first tile of level l (levels stacked, images inside a level)
+};
+
 struct SamplePointArgs {
     const float* bbox;      // [B,Q,10]
     const float* time_diff; // [B,T]
@@ -22,7 +33,34 @@ struct SamplePointArgs {
     int B, Q, T, N, G, P, L;
     float image_h, image_w, eps;
     float rot_sign;         // +1: 'v1.0.0' rotation (x cos - y sin, x sin + y cos); -1: 'v0.17.1' (models/utils.py:66-77)
+    TouchMap touch;
 };
+
+// the units (b, t, view, group g) reads at normalised image coordinates (u, v): exactly the corners msmv_chunk.inc loads
+__device__ __forceinline__ void touch_units(const SamplePointArgs& a, int b, int t, int g, float u, float v, float zview) {
+#pragma clang fp contract(off)
+    int view = (int)roundf(zview * (float)(a.N - 1));         // the sampler's own reading of loc.z
+    view = min(max(view, 0), a.N - 1);
+    const unsigned img = (unsigned)((b * a.T + t) * a.N + view);
+    for (int l = 0; l < a.L; ++l) {
+        const int H = a.touch.H[l], W = a.touch.W[l];
+        const float h_im = v * (float)(H - 1), w_im = u * (float)(W - 1);
+        if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;      // (NaN: nothing is read)
+        const int h0 = (int)fminf(fmaxf(floorf(h_im), -1.f), (float)H), w0 = (int)fminf(fmaxf(floorf(w_im), -1.f), (float)W);
+        unsigned char* row = a.touch.need + ((size_t)a.touch.base[l] + (size_t)img * a.touch.tiles[l]) * 4 + g;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+            const int hc = h0 + dh;
+            if (hc < 0 || hc > H - 1) continue;
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int wc = w0 + dw;
+                if (wc < 0 || wc > W - 1) continue;
+                row[(size_t)((unsigned)(hc * W + wc) >> 6) * 4] = 1;
+            }
+        }
+    }
+}
 
 inline SamplePointArgs sample_point_args(const float* bbox, const float* time_diff, const float* l2i, const double* pc_range, int B, int Q,
                                          int T, int N, int G, int P, int L, float image_h, float image_w, float eps, float* loc_bp,
@@ -37,6 +75,15 @@ inline SamplePointArgs sample_point_args(const float* bbox, const float* time_di
     a.image_h = image_h; a.image_w = image_w; a.eps = eps;
     a.rot_sign = sbev::box_convention() == SBEV_BOX_V0_17_1 ? -1.f : 1.f;
     return a;
+}
+
+// host: switch the marking on for a launch (plan: layout.hip::lazy_plan of the same pyramid; hw: the config's (H_l, W_l))
+inline void sample_point_touch(SamplePointArgs& a, const sbev::LazyPlan& plan, const int32_t (*hw)[2], uint32_t* need) {
+    a.touch.need = reinterpret_cast<unsigned char*>(need);
+    for (int l = 0; l < plan.n_levels; ++l) {
+        a.touch.H[l] = hw[l][0]; a.touch.W[l] = hw[l][1];
+        a.touch.tiles[l] = plan.tiles[l]; a.touch.base[l] = plan.base[l];
+    }
 }
 
 // (b, t, q, gp): bb = the query's box row, of = its 3 offsets of point gp, lg = its L level logits of point gp
@@ -74,7 +121,9 @@ __device__ __forceinline__ void sample_point(const SamplePointArgs& a, int b, in
     float* o = a.loc_bp + (((((long long)b * a.T + t) * a.G + g) * a.Q + q) * a.P + p) * 3;
     o[0] = su;
     o[1] = sv;
-    o[2] = __fdiv_rn((float)view, (float)(a.N - 1));
+    const float zv = __fdiv_rn((float)view, (float)(a.N - 1));
+    o[2] = zv;
+    if (a.touch.need) touch_units(a, b, t, g, su, sv, zv);
 
     // level softmax of (g, p): every frame's thread recomputes it (L expf) and writes ITS row t of group g's T weight
     // rows, instead of the t == 0 threads writing all T rows (their 56 workgroups were the kernel's tail)

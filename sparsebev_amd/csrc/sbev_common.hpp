@@ -49,6 +49,18 @@ int launch_splitk_slabs_bf16x3(const float* X, const uint16_t* W2, int64_t M, in
 int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
                               hipStream_t s, int x_up_log2 = 0, const float* nscale = nullptr, bool x_pairs = false, const float* xdev = nullptr);
 
+// layout.hip: on-demand relayout of the units the sample points mark (sample_point.hpp::TouchMap); need / done: one 4-byte word per tile
+struct LazyPlan {
+    int n_levels, R;
+    long long n_images;
+    int S[SBEV_MAX_LEVELS];
+    unsigned tiles[SBEV_MAX_LEVELS];
+    unsigned base[SBEV_MAX_LEVELS + 1];      // base[n_levels] = tiles of the pyramid
+};
+bool lazy_plan(int n_levels, const int32_t* hw, long long n_images, int channels, LazyPlan* p);
+int launch_lazy_relayout(const LazyPlan& p, const void* const* table, const int32_t* index, const void* const* src, void* const* out,
+                         int esize, uint32_t* need, uint32_t* done, bool first, bool last, hipStream_t s);
+
 // row_chain.hip: the row-local op chains of a decoder layer as single launches (weights pre-packed: sbev_decoder_chain_pack)
 bool row_chain_supported(const sbev_decoder_config& c);
 bool row_chain_pays(long long rows);
@@ -56,7 +68,13 @@ int launch_chain_front(const sbev_decoder_config& c, const sbev_decoder_weights&
                        float* qkvt, float eps, hipStream_t s);
 int launch_chain_attn(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* att, const float* x, float* x1,
                       const float* bbox, const float* time_diff, const float* lidar2img, float* loc_bp, float* w_bp, float eps,
-                      hipStream_t s, uint16_t* x1_frag = nullptr, const float* x1_scale = nullptr, uint32_t* pair_sync = nullptr);
+                      hipStream_t s, uint16_t* x1_frag = nullptr, const float* x1_scale = nullptr, uint32_t* pair_sync = nullptr,
+                      const LazyPlan* touch = nullptr, uint32_t* touch_need = nullptr);
+// project.hip: sbev_sample_and_project that also marks the relayout units its points read (touch != null)
+int launch_sample_and_project(const float* query_bbox, const float* offset, int64_t ld_offset, const float* scale_logits, int64_t ld_logits,
+                              const float* time_diff, const float* lidar2img, const double* pc_range, int B, int Q, int T, int N, int G, int P,
+                              int L, float image_h, float image_w, float eps, float* loc_bp, float* weights_bp, const LazyPlan* touch,
+                              uint32_t* touch_need, const int32_t (*hw)[2], hipStream_t stream);
 int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& w, const float* slabs, int splits, const float* x1,
                       const float* bbox, const float* vel_div, float* x3, float* cls_out, float* box_out, int with_front, float* x,
                       float* qkvt, float eps, hipStream_t s, float* pair_x = nullptr, uint32_t* pair_sync = nullptr);

@@ -36,6 +36,11 @@ class DecoderWeights(ctypes.Structure):
     _fields_ = [(n, _f) for n in _WEIGHT_FIELDS]
 
 
+class LazyFeats(ctypes.Structure):
+    """sbev_lazy_feats: the NCHW sources of the on-demand relayout (a device pointer table + indices, or direct pointers)"""
+    _fields_ = [('table', _f), ('index', ctypes.c_int32 * MAX_LEVELS), ('src', _f * MAX_LEVELS)]
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -242,13 +247,13 @@ class DecoderRuntime:
             key = key + (torch.cuda.current_stream(dev).cuda_stream,)
             slot = self._graph_ws.get(key)
             if slot is None:
-                slot = self._graph_ws[key] = [torch.empty(need + 256, device=dev, dtype=torch.uint8), 0]
+                slot = self._graph_ws[key] = [torch.zeros(need + 256, device=dev, dtype=torch.uint8), 0]      # (zeroed once: the on-demand relayout's flag words start clean)
             slot[1] += 1
             ws = slot[0]
             self._last_graph_ws_key = key
         else:
             if self._ws is None or self._ws_key != key:
-                self._ws = torch.empty(need + 256, device=dev, dtype=torch.uint8)
+                self._ws = torch.zeros(need + 256, device=dev, dtype=torch.uint8)
                 self._ws_key = key
             ws = self._ws
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
@@ -292,6 +297,28 @@ class DecoderRuntime:
             _lib.check(lib.sbev_finish_outputs(_ptr(cls), _ptr(box), _ptr(cls_o), _ptr(box_o), cls.numel(), box.numel(), stream), 'sbev_finish_outputs')
             return cls_o, box_o
         return cls, box
+
+    def forward_lazy(self, query_bbox, query_feat, mlvl_feats, ctx, attn_mask=None, buffers=None):
+        """The eager step on the reference's NCHW feature list ``[B, T*6, 256, H_l, W_l]`` WITHOUT a dense relayout
+        (sbev_decoder_forward_lazy): channels-last buffers (``buffers``, or new uninitialised ones) receive only the units the sample
+        points read.  Bit-identical to ``forward`` on ``FeaturePyramid(mlvl_feats)``.  Returns (cls, box, pyramid-of-buffers)."""
+        from . import transformer as TR
+        if _STATE['chain_pair']:
+            check_pair_faults()
+        pyramid = buffers if buffers is not None else TR.FeaturePyramid.empty_like_nchw(mlvl_feats)
+        args, _keep, cls, box = self._prepare(query_bbox, query_feat, pyramid, ctx, attn_mask)
+        lib = _lib.load()
+        if not lib.sbev_decoder_lazy_supported(args[0]):
+            raise _lib.SbevError('sbev_decoder_forward_lazy does not cover this pyramid (4 groups x 64 channels; no frame ring)')
+        lz = LazyFeats()
+        for l, f in enumerate(mlvl_feats):
+            if not (f.is_cuda and f.is_contiguous() and f.data_ptr() % 16 == 0 and f.dtype == pyramid.levels[l].dtype):
+                raise RuntimeError('forward_lazy needs contiguous, 16-byte aligned device NCHW levels of the buffers\' dtype')
+            lz.src[l] = f.data_ptr()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = lib.sbev_decoder_forward_lazy(args[0], args[1], args[2], ctypes.byref(lz), *args[3:], stream)
+        _lib.check(st, 'sbev_decoder_forward_lazy')
+        return cls, box, pyramid
 
     def capture(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):
         """Record one decoder step into a hipGraph (sbev_decoder_capture) and return a DecoderGraph.  The graph reads
@@ -415,7 +442,7 @@ class StepGraphs:
                torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _STATE['order'], _lib.load().sbev_get_box_convention(),
                rt.decoder.num_layers, tuple(rt.decoder.pc_range),
                torch.cuda.current_stream(query_bbox.device).cuda_stream,      # per stream: a graph's workspace belongs to the stream it replays on
-               bool(finish), _STATE['relayout_multi'])
+               bool(finish), _STATE['relayout_multi'], _STATE['lazy'])
         e = self.entries.get(key, False)
         if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
             # first sighting (or an address whose tensor died and was recycled): eager this time, capture if it comes again
@@ -532,7 +559,9 @@ class StepGraphs:
         ok = True
         try:
             ok = lib.sbev_copy_indirect(table, len(segs), c_idx, c_dst, c_nb, sp) == 0
-            multi = (len(relayout) > 1 and all(r[1].dtype == torch.float32 and r[2] == relayout[0][2] and r[3] == relayout[0][3] and r[3] % 4 == 0
+            # on-demand relayout: no dense pass at all -- every layer moves the units its sample points marked (sbev_decoder_forward_lazy)
+            lazy = bool(relayout) and staged and len(relayout) == len(mlvl_feats) and _STATE['lazy'] and bool(lib.sbev_decoder_lazy_supported(args[0]))
+            multi = (not lazy and len(relayout) > 1 and all(r[1].dtype == torch.float32 and r[2] == relayout[0][2] and r[3] == relayout[0][3] and r[3] % 4 == 0
                                                and r[4] % 4 == 0 for r in relayout) and len(relayout) <= MAX_LEVELS and _STATE['relayout_multi'])
             if multi:                        # every fp32 level of the pyramid in ONE launch (the coarse levels ride in the finest one's tail)
                 n = len(relayout)
@@ -540,11 +569,18 @@ class StepGraphs:
                 c_out = (ctypes.c_void_p * n)(*[r[1].data_ptr() for r in relayout])
                 c_hw = (ctypes.c_int32 * n)(*[r[4] for r in relayout])
                 ok = ok and lib.sbev_nchw_to_nhwc_f32_multi_indirect(table, n, c_ix, c_out, relayout[0][2], relayout[0][3], c_hw, sp) == 0
-            else:
+            elif not lazy:
                 for idx, buf, n_img, ch, hw in relayout:
                     fn = lib.sbev_nchw_to_nhwc_f32_indirect if buf.dtype == torch.float32 else lib.sbev_nchw_to_nhwc_b16_indirect
                     ok = ok and fn(table, idx, _ptr(buf), n_img, ch, hw, sp) == 0
-            ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
+            if lazy:
+                lz = LazyFeats()
+                lz.table = table
+                for l, r in enumerate(relayout):
+                    lz.index[l] = r[0]
+                ok = ok and lib.sbev_decoder_forward_lazy(args[0], args[1], args[2], ctypes.byref(lz), *args[3:], sp) == 0
+            else:
+                ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
             if outs is not None:
                 i_out = 3 + (len(mlvl_feats) if staged else 0)
                 ok = ok and lib.sbev_finish_outputs_indirect(table, i_out, i_out + 1, _ptr(cls), _ptr(box), cls.numel(), box.numel(), sp) == 0
@@ -612,8 +648,17 @@ class DecoderGraph:
 # process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
 import os as _os
 _STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0,
+          'lazy': not _os.environ.get('SBEV_NO_SPARSE_RELAYOUT'),      # staged NCHW pyramids: on-demand relayout of the units the sample points read
           'relayout_multi': not _os.environ.get('SBEV_NO_RELAYOUT_MULTI'),      # staged fp32 NCHW pyramids: all levels in one launch (A/B switch)
           'order': (lambda v: 2 if v == 2 else int(v != 0))(int(_os.environ.get('SBEV_QUERY_ORDER', '0') or 0))}
+
+
+def lazy_relayout(enable):
+    """Replayable steps on NCHW feature lists move only the feature units the sample points read (on-demand relayout, default on;
+    ``SBEV_NO_SPARSE_RELAYOUT=1`` starts with the dense relayout).  Bit-identical results either way.  Returns the previous setting."""
+    prev = _STATE['lazy']
+    _STATE['lazy'] = bool(enable)
+    return prev
 
 
 def query_order(enable):

@@ -323,6 +323,18 @@ class FeaturePyramid:
                 self.copied += 1
             self.levels.append(nhwc.reshape(self.B * TN, f.shape[3], f.shape[4], self.GC))
 
+    @classmethod
+    def empty_like_nchw(cls, mlvl_feats):
+        """Uninitialised channels-last buffers for the on-demand relayout (runtime.DecoderRuntime.forward_lazy): the step writes only
+        the units its sample points read."""
+        self = cls.__new__(cls)
+        f0 = mlvl_feats[0]
+        self.B, TN, self.GC = f0.shape[0], f0.shape[1], f0.shape[2]
+        self.T = TN // N_VIEWS
+        self.copied = 0
+        self.levels = [torch.empty(self.B * TN, f.shape[3], f.shape[4], self.GC, device=f.device, dtype=f.dtype) for f in mlvl_feats]
+        return self
+
     def sample(self, loc, w_bp, T, G):
         return ops.msmv_sampling_nhwc(self.levels, self.B, T, G, loc, w_bp, out_layout=ops.OUT_MIX)
 

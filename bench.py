@@ -352,6 +352,8 @@ def main():
                     help='fused gather + mixing items in the order of sbev_query_order (1) or in launch order (0); default: the library setting (SBEV_QUERY_ORDER). Results are bit-identical')
     ap.add_argument('--shuffle-queries', action='store_true', help='permute the query rows (a trained head does not keep the BEV raster order of its initialisation): robustness A/B for --query-order')
     ap.add_argument('--overlap', type=int, default=0, help='0 = single stream (default); 1 = generator GEMM + classification branch on a second stream; 2 = classification branch only')
+    ap.add_argument('--dense-relayout', action='store_true', help='A/B: relayout the WHOLE NCHW pyramid every step (rounds 1-5) instead of only the feature units the '
+                                                                   'sample points read (on-demand relayout, csrc/layout.hip; bit-identical outputs)')
     ap.add_argument('--gemm', default=DEFAULT_GEMM, choices=sorted(runtime.GEMM_MODES),
                     help='the two big mixing GEMMs: f16x3 = fp32-class scaled fp16 hi + lo split, 3 products (default); f32 = exact f32-input MFMA; '
                          'bf16x6 = hi + mid + lo bf16 images, 6 products; f16x4 = 4 fp16 products; bf16x3s / bf16x3 = 3 bf16 products (2^-16 class)')
@@ -360,7 +362,10 @@ def main():
     for flag, val in (('--feat-dtype', args.feat_dtype), ('--query-order', args.query_order)):
         if val is not None:
             CHILD_ARGS.extend([flag, str(val)])
-    for flag, on in (('--nhwc', args.nhwc), ('--online', args.online), ('--shuffle-queries', args.shuffle_queries)):
+    if args.dense_relayout or os.environ.get('SBEV_NO_SPARSE_RELAYOUT'):
+        args.dense_relayout = True
+        runtime.lazy_relayout(False)
+    for flag, on in (('--nhwc', args.nhwc), ('--online', args.online), ('--shuffle-queries', args.shuffle_queries), ('--dense-relayout', args.dense_relayout)):
         if on:
             CHILD_ARGS.append(flag)
     torch.set_grad_enabled(False)     # inference benchmark, like the reference's timing.py / val.py (with grad enabled the
@@ -570,11 +575,12 @@ def main():
             'dtype': ('f32' if fdtype == torch.float32 else ('bf16' if fdtype == torch.bfloat16 else 'fp16') + '-storage/f32-math') + ('' if args.gemm == 'f32' else ' (the two mixing GEMMs: %s = %s)' % (args.gemm, GEMM_WHAT[args.gemm])),
             'data': 'synthetic',
             'config': {'workload': '%s: %s, %d queries, T=%d, bs=%d per GPU, 6 decoder layers, random-init weights, '
-                                   '%s feature input%s' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step)'),
+                                   '%s feature input%s' % (args.config, pyr, Q, T, B, 'online ring: 1 new NCHW frame relayouted per step, T-1 cached' if args.online else ('NHWC zero-copy' if args.nhwc else 'NCHW (reference layout, relayout inside the step%s)' % (': dense' if args.dense_relayout else ': on demand -- only the feature units the sample points read')),
                                                            '' if own_dtype else ', %s feature storage' % args.feat_dtype),
                        'global_batch': B * world, 'parallelism': 'sample-sharded x%d' % world,
                        'launches_per_layer': launches_per_layer, 'step_graph': graph_info,
                        'query_order': bool(runtime._STATE['order']), 'shuffled_queries': bool(args.shuffle_queries),
+                       'relayout': None if (args.nhwc or args.online) else ('dense' if args.dense_relayout else 'on-demand'),
                        'checksum': checksum_sum},
             # per-rank spread (weak scaling: every rank runs the same per-GPU batch): slowest / fastest rank's own rate
             'per_rank_samples_per_s': {'min': round(args.steps * B / elapsed_max, 3), 'max': round(args.steps * B / elapsed_min, 3)},

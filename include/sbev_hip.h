@@ -762,6 +762,22 @@ int64_t sbev_decoder_chain_pair_timeouts(void);
  * Pair mode is only used when the word could be installed (hipHostMalloc). */
 int64_t sbev_decoder_chain_pair_faults(void);
 int64_t sbev_decoder_chain_pair_faults_ack(void);
+/* In-launch fold of the out-projection's split-K slabs (round 6; fp16 GEMM modes, row chains on, every workgroup of the out-projection
+ * resident at once: <= ~1000 rows on 256 CUs).  The S chunk-workgroups of a row tile write their slab through, meet at a counter in the
+ * decoder workspace (zeroed by the layer's attention chain, like the pair counters) and each sums ceil(rows / S) rows of the tile over all
+ * slabs in slab order -- bit-identical to the tail's own sum -- so the tail reads ONE row block instead of S (32 x 8 rows x 1 KB per
+ * workgroup, twice per pair: 59 MB per layer at 900 rows).  Polls are bounded like the pair hand-off's; a row tile that never completes
+ * raises the same fault word (sbev_decoder_chain_pair_faults) and counts in sbev_decoder_chain_pair_timeouts.  Follows the pair switch
+ * (sbev_decoder_chain_pair(0) turns both off); sbev_decoder_out_fold(0 / 1) switches it alone (returns the previous setting).  DEFAULT 0:
+ * measured at config 2 the fold costs the out-projection 12.6 us and saves the tail 4 -- an A/B switch, not the
+ * product path; SBEV_OUT_FOLD=1 in the environment starts with 1.  sbev_debug_out_fold_drop: test hook, never set in production. */
+int sbev_decoder_out_fold(int enable);
+int sbev_debug_out_fold_drop(int enable);
+/* Per-device setup that is illegal under stream capture (hipHostMalloc + hipMemcpyToSymbol of the fault word above): call once per device
+ * before the first capture that may contain a decoder step -- the ctypes binding does when it loads the library.  Without it
+ * sbev_decoder_workspace_bytes attempts the same; an attempt that fails (e.g. made inside a torch.cuda.graph capture) is retried by later
+ * calls, with one message on stderr / sbev_last_error(), and pair mode stays off meanwhile.  The word is shared by all devices of a process. */
+int sbev_init(void);
 /* Test hook for the poll bound: with 1, one member of the first pair of every pair-mode tail exits at once; its partner must time out
  * (sbev_decoder_chain_pair_timeouts grows, the launch ends after about a second per hand-off, only that pair's 8 rows are wrong).
  * Returns the previous setting.  Never set in production. */

@@ -77,6 +77,9 @@ SIGNATURES = {
                                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _c_i32p, _vp, _vp]),
     'sbev_nchw_to_nhwc_lazy': (ctypes.c_int, [_vp, _c_i32p, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _c_i32p, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    'sbev_init': (ctypes.c_int, []),
+    'sbev_decoder_out_fold': (ctypes.c_int, [ctypes.c_int]),
+    'sbev_debug_out_fold_drop': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_sampler': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_stride': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_sampler_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
@@ -248,6 +251,8 @@ def load():
     if lib.sbev_abi_version() != 1:
         raise ImportError('sparsebev_amd: libsbev_hip.so ABI %d != 1 (stale build?)' % lib.sbev_abi_version())
     _lib = lib
+    if torch.cuda.is_available():
+        lib.sbev_init()          # per-device setup that must not run inside somebody's stream capture (pair-mode fault word); retried lazily on failure
     return lib
 
 

@@ -29,7 +29,7 @@ struct Carver {
 
 struct Buffers {
     float *t0, *t1, *x, *x1, *x2, *x3, *qkvt, *att, *so, *wbp, *loc, *sampled, *params, *mixed, *slabs,
-        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc, *pair_x;
+        *h, *c0, *c1, *r0, *r1, *reg, *bbox, *x1s, *xsc, *pair_x, *folded;
     uint32_t* pair_sync;
     int32_t* order;
     uint32_t *touch_need, *touch_done;      // on-demand relayout (sbev_decoder_forward_lazy): one word per feature tile each, or null
@@ -79,6 +79,7 @@ Buffers carve(const sbev_decoder_config& c, void* ws) {
     b.pair_x = k.take((size_t)sbev::chain_pair_floats((long long)BQ));                   // tail chain in pair mode (row_chain.hip): exchange rows
     b.pair_sync = reinterpret_cast<uint32_t*>(k.take((size_t)sbev::chain_pair_sync_words((long long)BQ)));      // ... and arrival counters
     b.order = reinterpret_cast<int32_t*>(k.take(BQ));                                    // launch order of the gather items (sbev_query_order)
+    b.folded = k.take(BQ * D);                                                           // the out-projection's slabs folded inside its launch (gemm_bf16s.hip)
     sbev::LazyPlan lp;
     if (lazy_plan_of(c, &lp)) {                                                          // (45 KB at config 2, 1.4 MB at config 4)
         b.touch_need = reinterpret_cast<uint32_t*>(k.take(lp.base[lp.n_levels]));
@@ -329,6 +330,8 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
         return sbev_adaptive_mixing_f32(b.sampled, b.params, b.mixed, BQ, c.G, Pin, Cg, c.out_points, eps, st);
     };
 
+    // read ONCE per call (a toggle 0 -> 2 between two layers' loads walked an unsorted b.order)
+    const int query_order_mode = g_query_order.load(std::memory_order_relaxed);
     const float* bbox = query_bbox;
     const float* feat = query_feat;
     bool pe0_done = false;             // the previous layer's tail already ran this layer's first position-encoder stage
@@ -344,9 +347,9 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
             const bool fused = g_fuse_sample_mix.load(std::memory_order_relaxed) != 0 &&
                                sample_mix_fusable(c);
             // launch order of this layer's gather items: sorted from the layer's input boxes (one workgroup per sample)
-            const bool ordered = fused && g_query_order.load(std::memory_order_relaxed) != 0 && c.Q <= sbev_query_order_max();
+            const bool ordered = fused && query_order_mode != 0 && c.Q <= sbev_query_order_max();
             // (mode 2: sorted from the step's INPUT boxes only -- the refinements move a box by a fraction of its camera column)
-            if (ordered && (layer == 0 || g_query_order.load(std::memory_order_relaxed) == 1)) TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, stream));
+            if (ordered && (layer == 0 || query_order_mode == 1)) TRY(sbev_query_order(bbox, c.code_size, c.pc_range, c.B, c.Q, b.order, stream));
             TRY(sbev_sasa_f32(b.qkvt, c.attn_in_rows, bbox, c.pc_range, attn_mask, b.att, c.B, c.Q, c.H, D / c.H, stream));
             // (fp16 GEMM modes: the chain also leaves x1 as the generator's fragment operand -- no pack launch)
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
@@ -371,13 +374,17 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
                 TRY(mix_plain(stream));
             }
             int used = 0;
+            // fp16 modes: the S slabs are folded inside the out-projection launch where all its workgroups are resident at once (<= ~1000
+            // rows on 256 CUs) and the fault word is there to report a row tile that never completed; the tail then reads ONE row block
+            const bool fold = nimg >= 4 && sbev::chain_pair_enabled() && sbev::out_fold_ok(BQ, mixN) && sbev::chain_fault_word_ready();
             if (nimg)
-                TRY(sbev::launch_splitk_slabs_bf16s(b.mixed, w->op_wp, BQ, mixN, mixN, nimg, b.slabs, &used, s_main, mixed_up, w->op_nscale, nimg >= 4));
+                TRY(sbev::launch_splitk_slabs_bf16s(b.mixed, w->op_wp, BQ, mixN, mixN, nimg, b.slabs, &used, s_main, mixed_up, w->op_nscale, nimg >= 4, nullptr,
+                                                    fold ? b.pair_sync + sbev::chain_fold_sync_offset(BQ) : nullptr, fold ? b.folded : nullptr));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(sbev::launch_splitk_slabs_bf16x3(b.mixed, w->op_w2, BQ, D, mixN, mixN, splits, b.slabs, &used, s_main));
             else
                 TRY(sbev::launch_splitk_slabs(b.mixed, w->op_w, BQ, D, mixN, mixN, mixN, splits, b.slabs, &used, s_main));
-            TRY(sbev::launch_chain_tail(c, *w, b.slabs, used, b.x1, bbox, c.T > 1 ? vel_div : nullptr, b.x3, cls_l, box_l,
+            TRY(sbev::launch_chain_tail(c, *w, (fold && used == 1) ? b.folded : b.slabs, used, b.x1, bbox, c.T > 1 ? vel_div : nullptr, b.x3, cls_l, box_l,
                                         layer + 1 < c.num_layers, b.x, b.qkvt, eps, s_main, b.pair_x, b.pair_sync));
             bbox = box_l;
             continue;

@@ -1138,7 +1138,19 @@ struct Out4Args {
     long long ldx;
     int ntm, base, rem, S;       // row tiles: the first `rem` have base + 1 fragments of 32 rows, the others `base`; K chunks
     const float* nscale;         // [256] 2^-ew[n] 2^-ex
+    // in-launch fold of the S slabs (round 6): the S chunk-workgroups of a row tile are co-resident (one round of workgroups: host-checked),
+    // meet at fold_sync[row tile] and each sums a share of the tile's rows over all slabs, in slab order, into `folded` [M, 256]
+    unsigned* fold_sync;         // null: off (the consumer sums the slabs)
+    float* folded;
+    int debug_drop;              // test hook (sbev_debug_out_fold_drop): chunk 1 of row tile 0 never arrives -- its tile must time out, not hang
 };
+
+// a chunk-workgroup whose row tile never became complete within the poll bound (the device was shared: not every workgroup of the launch
+// was resident): counted here and in the host-mapped word the decoder's fault gate reads (csrc/row_chain.hip installs both pointers)
+__device__ unsigned g_fold_timeouts;
+__device__ unsigned* g_fold_fault_host;
+constexpr unsigned FOLD_POLL_LIMIT = 1u << 20;
+constexpr int FOLD_CPOL = 17;    // sc0 | sc1: write-through stores, loads served past this XCD's L2 (MI355X guide, inter-workgroup visibility)
 
 template <int MODE>
 __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) {
@@ -1328,13 +1340,68 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
                     }
         }
         __syncthreads();
-        {
+        if (a.fold_sync == nullptr) {
             const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + lane * 4);          // a lane owns 4 fixed columns: exact powers of two
             float* out = a.P + (long long)chunk * M * 256 + lane * 4;
             for (int r = wave; r < NFA * 32; r += 8) {
                 const int row = m0 + r;
                 if (row < M SBEV_EXP_STORE_COND)
                     *reinterpret_cast<f32x4*>(out + (long long)row * 256) = *reinterpret_cast<const f32x4*>(img + r * FLD + lane * 4) * sc;
+            }
+        } else {
+            // ---- the same slab, written through; then the row tile's S workgroups meet and fold ------------------------------------
+            // The consumer (the tail row chain) summed the S slabs of its rows itself: 32 slabs x 8 rows = 256 KB per workgroup, read by
+            // BOTH members of a pair -- 59 MB through the fabric in the first 10 us of a 48-us launch.  Here every chunk-workgroup sums
+            // ceil(rows / S) rows of its tile over all S slabs (slab order 0 .. S - 1 from +0: the consumer's own order, bit for bit)
+            // and the consumer reads ONE row block.
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + lane * 4);
+            const __amdgpu_buffer_rsrc_t slab_rs = __builtin_amdgcn_make_buffer_rsrc(a.P, 0, 0x7fffffff, 0x00020000);
+            const unsigned row_b = 1024u, slab_b = (unsigned)M * 1024u;                   // bytes (S * M * 1 KiB < 2^31: host-checked)
+            for (int r = wave; r < NFA * 32; r += 8) {
+                const int row = m0 + r;
+                if (row < M) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(img + r * FLD + lane * 4) * sc;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab_rs, (int)((unsigned)chunk * slab_b + (unsigned)row * row_b + (unsigned)lane * 16u), 0, FOLD_CPOL);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its slab rows have left
+            __syncthreads();
+            if (a.debug_drop && rt == 0 && chunk == 1) return;
+            if (tid == 0) {
+                unsigned* const word = a.fold_sync + rt;
+                __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned n = 0;
+                while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.S) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++n > FOLD_POLL_LIMIT) {
+                        __hip_atomic_fetch_add(&g_fold_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned* const host_word = g_fold_fault_host;
+                        if (host_word) __hip_atomic_fetch_add(host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const int rp = (NFA * 32 + a.S - 1) / a.S;                // rows of the tile per chunk-workgroup (4 at 128 rows x 32 chunks)
+            for (int j = wave; j < rp; j += 8) {
+                const int r = chunk * rp + j, row = m0 + r;
+                if (r >= NFA * 32 || row >= M) continue;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                const unsigned base_b = (unsigned)row * row_b + (unsigned)lane * 16u;
+                for (int z0 = 0; z0 < a.S; z0 += 32) {
+                    f32x4 q[32];
+#pragma unroll
+                    for (int z = 0; z < 32; ++z) {
+                        const int zz = z0 + z < a.S ? z0 + z : a.S - 1;
+                        q[z] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slab_rs, (int)((unsigned)zz * slab_b + base_b), 0, FOLD_CPOL));
+                    }
+#pragma unroll
+                    for (int z = 0; z < 32; ++z) {
+                        const float m = z0 + z < a.S ? 1.f : 0.f;
+                        t[0] += q[z][0] * m; t[1] += q[z][1] * m; t[2] += q[z][2] * m; t[3] += q[z][3] * m;
+                    }
+                }
+                *reinterpret_cast<f32x4*>(a.folded + (long long)row * 256 + lane * 4) = t;
             }
         }
         SBEV_WGTIME(3, 1)
@@ -1582,15 +1649,44 @@ extern "C" int sbev_linear_bf16s_out_plan(int64_t M, int N, int K) {      // sla
 
 namespace sbev {
 // the GEMM half: *used partial slabs [used, M, 256] (to be summed by sbev_splitk_reduce_f32 or the row-chain tail)
+// the out-projection's in-launch fold is possible for this shape on the current device: pre-split operand plan whose workgroups all fit
+// the device at once (one workgroup per CU: 144 KiB of LDS), slabs addressable through one buffer resource
+// OFF by default: measured at config 2 (profiles/r6_out_fold_ab.txt) the fold costs the out-projection +12.6 us (56.2 -> 68.8: write-through
+// drain, the arrival round trip, 29.5 MB of slab reads past the L2) and saves the tail 4 us (51 -> 47) -- 512 vs 535 samples/s.  Kept as an
+// A/B switch (SBEV_OUT_FOLD=1 / sbev_decoder_out_fold(1)), bit-identical either way.
+std::atomic<int> g_out_fold{getenv("SBEV_OUT_FOLD") ? 1 : 0};
+std::atomic<int> g_out_fold_drop{0};
+int out_fold_drop(int enable) { return g_out_fold_drop.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
+bool out_fold_ok(long long M, int K) {
+    if (g_out_fold.load(std::memory_order_relaxed) == 0 || M < 1 || M > 4096) return false;
+    const Out4Plan pl = out4_plan(M, K);
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return pl.S > 1 && (long long)pl.ntm * pl.S <= cus && pl.ntm <= 64 && (long long)pl.S * M * 1024 < 0x7fffffffLL;
+}
+// the fold's fault words (see g_fold_fault_host): `host_word_dev` = device address of the decoder's host-mapped fault word
+bool out_fold_install(void* host_word_dev) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fold_fault_host), &host_word_dev, sizeof(host_word_dev)) == hipSuccess;
+}
+int out_fold_switch(int enable) { return g_out_fold.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
+long long out_fold_timeouts() {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fold_timeouts), sizeof(v)) != hipSuccess) return -1;
+    return (long long)v;
+}
+
 int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
-                              hipStream_t s, int x_up_log2, const float* nscale, bool x_pairs, const float* xdev) {
+                              hipStream_t s, int x_up_log2, const float* nscale, bool x_pairs, const float* xdev, unsigned* fold_sync,
+                              float* folded) {
     SBEV_REQUIRE(nimg < 4 || nscale, "sbev_linear_splitk_f16s: null scale pointer");
     SBEV_REQUIRE(!xdev || (nimg >= 4 && !x_pairs), "sbev_linear_splitk_f16s: a device-side X scale needs an fp16 mode and fp32 X");
     if (x_pairs) {                              // fp16 modes with the pre-split operand: 128-row tiles
         SBEV_REQUIRE(nimg >= 4, "sbev_linear_splitk_f16s: pre-split X needs an fp16 mode");
         const Out4Plan pl = out4_plan(M, K);
-        *used = pl.S;
-        Out4Args a4{reinterpret_cast<const unsigned*>(X), Wp, slabs, (int)M, K, (long long)ldx, pl.ntm, pl.base, pl.rem, pl.S, nscale};
+        const bool fold = fold_sync && folded && out_fold_ok(M, K);      // (the caller asked AND the shape / device allow it: else S slabs as before)
+        *used = fold ? 1 : pl.S;                                        // folded: the consumer reads `folded` as ONE slab
+        Out4Args a4{reinterpret_cast<const unsigned*>(X), Wp, slabs, (int)M, K, (long long)ldx, pl.ntm, pl.base, pl.rem, pl.S, nscale,
+                    fold ? fold_sync : nullptr, fold ? folded : nullptr, g_out_fold_drop.load(std::memory_order_relaxed)};
         const long long wgs4 = (long long)pl.ntm * pl.S;
         SBEV_REQUIRE(wgs4 <= 0x7fffffffLL, "sbev_linear_splitk_f16s: too many workgroups");
         constexpr int LDS4 = 144 * 1024;        // 48 KiB of X stages + 8 waves x 12 KiB of W ring (the 128 KiB fold buffer reuses them)
@@ -1714,3 +1810,8 @@ extern "C" int sbev_f16s_out_scale(const float* wdown, int x_up_log2, float* nsc
     hipLaunchKernelGGL(out_scale_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), wdown, ldexpf(1.f, -x_up_log2), nscale, N);
     return sbev::check_launch("sbev_f16s_out_scale");
 }
+
+// the out-projection's in-launch slab fold inside sbev_decoder_forward (default 0: measured slower, see g_out_fold; SBEV_OUT_FOLD=1 starts with 1); returns the previous setting
+extern "C" int sbev_decoder_out_fold(int enable) { return sbev::out_fold_switch(enable); }
+// test hook for the fold's poll bound (never set in production): one chunk-workgroup of row tile 0 leaves without arriving
+extern "C" int sbev_debug_out_fold_drop(int enable) { return sbev::out_fold_drop(enable); }

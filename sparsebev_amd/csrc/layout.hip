@@ -217,7 +217,7 @@ struct LazyArgs {
     int first, last;
 };
 
-constexpr int LAZY_SCAN = 32;
+constexpr int LAZY_SCAN = 16;
 __device__ __forceinline__ unsigned lazy_bytes_nonzero(unsigned w) {      // byte k != 0 -> bit k
     return ((w & 0xffu) ? 1u : 0u) | ((w & 0xff00u) ? 2u : 0u) | ((w & 0xff0000u) ? 4u : 0u) | ((w & 0xff000000u) ? 8u : 0u);
 }
@@ -351,23 +351,30 @@ __device__ __forceinline__ void lazy_move_unit_wave(const LazyArgs& a, int l, lo
     const int s0 = ts * TS;
     const float* in = static_cast<const float*>(a.table ? a.table[a.index[l]] : a.src[l]) + img * R * S;
     float* out = static_cast<float*>(a.out[l]) + img * R * S;
-    for (int half = 0; half < 2; ++half) {                  // 32 channels x 64 pixels per pass
-        const int r0 = g * TS + 32 * half;
-        if ((S & 3) == 0) {
-            float4 v[8];
+    const int rg = g * TS;
+    const bool vec = (S & 3) == 0;
+    float4 v[2][8];                                         // both 32-channel halves requested up front: one exposed round trip per unit
+    if (vec) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int lr = (lane >> 4) + 4 * i, sx = s0 + (lane & 15) * 4;
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (sx < S) v[i] = *reinterpret_cast<const float4*>(in + (long long)(r0 + lr) * S + sx);
+                const int lr = 32 * half + (lane >> 4) + 4 * i, sx = s0 + (lane & 15) * 4;
+                v[half][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sx < S) v[half][i] = *reinterpret_cast<const float4*>(in + (long long)(rg + lr) * S + sx);
             }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                  // 32 channels x 64 pixels per pass through the wave's LDS tile
+        const int r0 = rg + 32 * half;
+        if (vec) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int lr = (lane >> 4) + 4 * i, ls = (lane & 15) * 4;
-                wt[(ls + 0) * WLD + lr] = v[i].x;
-                wt[(ls + 1) * WLD + lr] = v[i].y;
-                wt[(ls + 2) * WLD + lr] = v[i].z;
-                wt[(ls + 3) * WLD + lr] = v[i].w;
+                wt[(ls + 0) * WLD + lr] = v[half][i].x;
+                wt[(ls + 1) * WLD + lr] = v[half][i].y;
+                wt[(ls + 2) * WLD + lr] = v[half][i].z;
+                wt[(ls + 3) * WLD + lr] = v[half][i].w;
             }
         } else {
             for (int i = lane; i < 32 * TS; i += 64) {
@@ -381,8 +388,8 @@ __device__ __forceinline__ void lazy_move_unit_wave(const LazyArgs& a, int l, lo
             const int ls = (lane >> 3) + 8 * i, lr = (lane & 7) * 4;
             const int sx = s0 + ls;
             if (sx < S) {
-                const float4 v = make_float4(wt[ls * WLD + lr], wt[ls * WLD + lr + 1], wt[ls * WLD + lr + 2], wt[ls * WLD + lr + 3]);
-                *reinterpret_cast<float4*>(out + (long long)sx * R + r0 + lr) = v;
+                const float4 o = make_float4(wt[ls * WLD + lr], wt[ls * WLD + lr + 1], wt[ls * WLD + lr + 2], wt[ls * WLD + lr + 3]);
+                *reinterpret_cast<float4*>(out + (long long)sx * R + r0 + lr) = o;
             }
         }
         lazy_wave_sync();

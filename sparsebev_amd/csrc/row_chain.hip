@@ -21,6 +21,7 @@
 // Results equal the op-by-op launches to fp32 round-off (other summation order), not bit for bit; DESIGN.md section 4.
 #include "sbev_common.hpp"
 #include "sample_point.hpp"
+#include <mutex>
 #include <atomic>
 #include <cstdlib>
 
@@ -944,14 +945,31 @@ std::atomic<int> g_chain_pair_drop{0};
 // pair mode everywhere).  Installed before the first pair-mode launch on a device; nullptr when the allocation fails (the device-side
 // counter still works).
 std::atomic<unsigned> g_pair_fault_acked{0};
+std::atomic<int> g_pair_fault_warned{0};
 volatile unsigned* pair_fault_host() {
-    static volatile unsigned* word = [] {
-        void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || !h) { (void)hipGetLastError(); return (volatile unsigned*)nullptr; }
-        *static_cast<volatile unsigned*>(h) = 0u;
-        return static_cast<volatile unsigned*>(h);
-    }();
-    return word;
+    // NOT a function-local static initialised by the first call: that call may run where hipHostMalloc is illegal (a caller's stream
+    // capture around its first decoder call) and the failure would be cached for the life of the process -- a failed
+    // attempt is retried by the next call; sbev_init() (called when the Python binding loads the library) makes the first attempt early
+    static std::atomic<volatile unsigned*> word{nullptr};
+    static std::mutex mu;
+    volatile unsigned* w = word.load(std::memory_order_acquire);
+    if (w) return w;
+    std::lock_guard<std::mutex> lk(mu);
+    w = word.load(std::memory_order_acquire);
+    if (w) return w;
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || !h) {
+        const hipError_t e = hipGetLastError();
+        if (g_pair_fault_warned.exchange(1) == 0) {
+            sbev::set_error("pair-mode fault word: hipHostMalloc failed (%s) -- pair mode stays off until a later call succeeds (stream capture active? call sbev_init() first)",
+                            hipGetErrorString(e));
+            fprintf(stderr, "sparsebev_amd: %s\n", sbev_last_error());
+        }
+        return nullptr;
+    }
+    *static_cast<volatile unsigned*>(h) = 0u;
+    word.store(static_cast<volatile unsigned*>(h), std::memory_order_release);
+    return static_cast<volatile unsigned*>(h);
 }
 bool pair_fault_install() {            // this device's g_chain_pair_fault_host -> the word; once per device
     static std::atomic<int> done[64];
@@ -963,6 +981,7 @@ bool pair_fault_install() {            // this device's g_chain_pair_fault_host 
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, const_cast<unsigned*>(h), 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_pair_fault_host), &d, sizeof(d)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (!sbev::out_fold_install(d)) { (void)hipGetLastError(); return false; }      // (the out-projection's in-launch fold reports into the same word)
     done[dev & 63].store(1, std::memory_order_release);
     return true;
 }
@@ -997,7 +1016,11 @@ namespace sbev {
 
 // pair mode workspace: exchange rows (floats) and arrival counters (words) for `rows` rows, whatever the row block it picks
 long long chain_pair_floats(long long rows) { return 3 * (rows + 15) * DM; }
-long long chain_pair_sync_words(long long rows) { return (rows + 7) / 8; }
+// (+ 64 words behind the pair counters: the out-projection's fold counters, one per row tile -- zeroed by the same attention-chain loop)
+long long chain_pair_sync_words(long long rows) { return (rows + 7) / 8 + 64; }
+long long chain_fold_sync_offset(long long rows) { return (rows + 7) / 8; }
+bool chain_fault_word_ready() { return pair_fault_install(); }
+bool chain_pair_enabled() { return g_chain_pair.load(std::memory_order_relaxed) != 0; }
 
 // Install the fault word for the current device NOW (hipHostMalloc + hipMemcpyToSymbol: neither is legal under stream capture, and a
 // caller's first pair-mode launch may be a captured one): sbev_decoder_workspace_bytes calls this, which every caller runs before its
@@ -1243,12 +1266,25 @@ extern "C" int sbev_debug_chain_pair_drop(int enable) { return g_chain_pair_drop
 extern "C" int64_t sbev_decoder_chain_pair_timeouts(void) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_chain_pair_timeouts), sizeof(v)) != hipSuccess) return -1;
-    return (int64_t)v;
+    const long long f = sbev::out_fold_timeouts();          // (+ row tiles of the out-projection's in-launch fold that never completed)
+    if (f < 0) return -1;
+    return (int64_t)v + f;
 }
 
 // the sticky fault word: timed-out hand-offs since the last acknowledgement, read from pinned host memory (NO synchronisation; a fault
 // becomes visible once the faulting launch has run, ~1 s after its partner went missing)
 extern "C" int64_t sbev_decoder_chain_pair_faults(void) { return (int64_t)sbev::chain_pair_faults_pending(); }
+// One-time per-device setup that must not happen inside a caller's stream capture: the pair tail's host-mapped fault word (hipHostMalloc +
+// hipMemcpyToSymbol).  The Python binding calls it when it loads the library on a GPU box; C callers call it once per device before their
+// first capture (sbev_decoder_workspace_bytes still does the same lazily, and a failed attempt is retried by later calls).
+extern "C" int sbev_init(void) {
+    if (g_chain_pair.load(std::memory_order_relaxed) == 0) return SBEV_OK;
+    if (!pair_fault_install()) {
+        sbev::set_error("sbev_init: could not install the pair-mode fault word on the current device (pair mode stays off until a later attempt succeeds)");
+        return SBEV_ELAUNCH;
+    }
+    return SBEV_OK;
+}
 // acknowledge them (the caller has dealt with the invalid step): sbev_decoder_forward accepts calls again.  Returns how many there were.
 extern "C" int64_t sbev_decoder_chain_pair_faults_ack(void) {
     volatile unsigned* h = pair_fault_host();

@@ -48,16 +48,15 @@ __device__ __forceinline__ void touch_units(const SamplePointArgs& a, int b, int
         if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;      // (NaN: nothing is read)
         const int h0 = (int)fminf(fmaxf(floorf(h_im), -1.f), (float)H), w0 = (int)fminf(fmaxf(floorf(w_im), -1.f), (float)W);
         unsigned char* row = a.touch.need + ((size_t)a.touch.base[l] + (size_t)img * a.touch.tiles[l]) * 4 + g;
+        // the two corners of a row share a tile unless they straddle a 64-pixel boundary: one store for both then
+        const int wa = max(w0, 0), wb = min(w0 + 1, W - 1);           // (w0 in [-1, W - 1] here: at least one corner column is inside)
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
             const int hc = h0 + dh;
             if (hc < 0 || hc > H - 1) continue;
-#pragma unroll
-            for (int dw = 0; dw < 2; ++dw) {
-                const int wc = w0 + dw;
-                if (wc < 0 || wc > W - 1) continue;
-                row[(size_t)((unsigned)(hc * W + wc) >> 6) * 4] = 1;
-            }
+            const unsigned ta = (unsigned)(hc * W + wa) >> 6, tb = (unsigned)(hc * W + wb) >> 6;
+            row[(size_t)ta * 4] = 1;
+            if (tb != ta) row[(size_t)tb * 4] = 1;
         }
     }
 }

@@ -46,8 +46,17 @@ int launch_splitk_slabs_bf16x3(const float* X, const uint16_t* W2, int64_t M, in
                                float* workspace, int* used, hipStream_t s);
 
 // gemm_bf16s.hip: the GEMM half of sbev_linear_splitk_bf16s (*used partial slabs [used, M, 256], not reduced)
+// fold_sync + folded (pre-split fp16 operand only): the S chunk-workgroups of a row tile fold their slabs INSIDE the launch into
+// `folded` [M, 256] and *used = 1 -- taken only where out_fold_ok(M, K) (every workgroup of the launch resident at once); fold_sync: one
+// zeroed word per row tile (<= 64).  A row tile that never completes within the poll bound raises the decoder's fault word.
 int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int K, int64_t ldx, int nimg, float* slabs, int* used,
-                              hipStream_t s, int x_up_log2 = 0, const float* nscale = nullptr, bool x_pairs = false, const float* xdev = nullptr);
+                              hipStream_t s, int x_up_log2 = 0, const float* nscale = nullptr, bool x_pairs = false, const float* xdev = nullptr,
+                              unsigned* fold_sync = nullptr, float* folded = nullptr);
+bool out_fold_ok(long long M, int K);
+bool out_fold_install(void* host_word_dev);
+long long out_fold_timeouts();
+int out_fold_switch(int enable);
+int out_fold_drop(int enable);
 
 // layout.hip: on-demand relayout of the units the sample points mark (sample_point.hpp::TouchMap); need / done: one 4-byte word per tile
 struct LazyPlan {
@@ -80,6 +89,9 @@ int launch_chain_tail(const sbev_decoder_config& c, const sbev_decoder_weights& 
                       float* qkvt, float eps, hipStream_t s, float* pair_x = nullptr, uint32_t* pair_sync = nullptr);
 long long chain_pair_floats(long long rows);         // pair mode of the tail: exchange rows / arrival counters for `rows` rows
 long long chain_pair_sync_words(long long rows);
+long long chain_fold_sync_offset(long long rows);    // the out-projection's fold counters inside the same zeroed block (64 words)
+bool chain_pair_enabled();                           // sbev_decoder_chain_pair's current setting (the in-launch hand-offs' master switch)
+bool chain_fault_word_ready();                       // the host-mapped fault word is installed on the current device (never under capture: sbev_init)
 void chain_pair_prepare();                          // install the pair tail's host-mapped fault word for the current device (outside any capture)
 unsigned chain_pair_faults_pending();               // pair hand-offs that timed out and were not acknowledged (host word, no sync)
 

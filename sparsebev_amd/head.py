@@ -111,6 +111,11 @@ class NMSFreeCoder:
         boxes, scores, labels, count = nms_free_decode(cls, box, self.num_classes, self.max_num, self.score_threshold,
                                                        self.post_center_range, bottom_center)
         counts = count.tolist()             # the one device -> host sync (the reference's boolean indexing syncs per sample)
+        # ... and therefore the place where a lost pair hand-off of THIS step's decoder (csrc/row_chain.hip pair tail) can be reported for
+        # this step instead of the next one: one read of pinned host memory; raises PairFaultError, pair mode off, acknowledged
+        from . import runtime
+        if runtime._STATE['chain_pair']:
+            runtime.check_pair_faults()
         return [{'bboxes': boxes[i, :n], 'scores': scores[i, :n], 'labels': labels[i, :n].long()} for i, n in enumerate(counts)]
 
     def decode_single(self, cls_scores, bbox_preds):

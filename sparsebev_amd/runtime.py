@@ -399,9 +399,14 @@ class StepGraphs:
             e['graph'].destroy()
             self._release_ws(e)
 
+    def _never_replayed(self):
+        """keys of the live address-keyed graphs of the CURRENT weight signature that were captured and never replayed (an entry of an older
+        signature was orphaned by the weight update, not by the caller bringing new buffers: ADVICE r5)"""
+        return [k for k, e in self.entries.items() if isinstance(e, dict) and e['pinned'] and e['replays'] == 0 and k[4] == self.rt._sig]
+
     def _unproven(self):
         """address-keyed graphs (alive or already evicted) that were captured and never replayed afterwards"""
-        return self.wasted + sum(1 for e in self.entries.values() if isinstance(e, dict) and e['pinned'] and e['replays'] == 0)
+        return max(self.wasted, 0) + len(self._never_replayed())
 
     @staticmethod
     def _relayout_ok(f):
@@ -442,7 +447,7 @@ class StepGraphs:
                torch.cuda.current_device(), _STATE['row_chain'], _STATE['chain_pair'], _STATE['fuse'], _STATE['order'], _lib.load().sbev_get_box_convention(),
                rt.decoder.num_layers, tuple(rt.decoder.pc_range),
                torch.cuda.current_stream(query_bbox.device).cuda_stream,      # per stream: a graph's workspace belongs to the stream it replays on
-               bool(finish), _STATE['relayout_multi'], _STATE['lazy'])
+               bool(finish), _STATE['relayout_multi'], _STATE['lazy'], _STATE['out_fold'])
         e = self.entries.get(key, False)
         if e is False or (isinstance(e, _FirstSighting) and not e.same(ident)):
             # first sighting (or an address whose tensor died and was recycled): eager this time, capture if it comes again
@@ -454,10 +459,10 @@ class StepGraphs:
                     if self.wasted > 0:
                         self.wasted -= 1
                     else:
-                        stale = next((k for k, v in self.entries.items() if isinstance(v, dict) and v['pinned'] and v['replays'] == 0), None)
+                        stale = next(iter(self._never_replayed()), None)
                         if stale is not None:
-                            self.wasted -= 1          # (_drop counts it again: net zero)
-                            self._drop(stale)
+                            self._drop(stale)         # (counts it as wasted ...)
+                            self.wasted = max(self.wasted - 1, 0)      # ... which this probe forgives: net zero, never negative
                 if not self._warned:
                     import warnings
                     warnings.warn('sparsebev_amd: %d step graphs keyed on input addresses were captured and never replayed (the caller '
@@ -548,15 +553,20 @@ class StepGraphs:
         table = ctypes.c_void_p(ctx.buffer.data_ptr() + 4 * n_packed)
         args, keep, cls, box = rt._prepare(qb, qf, pyramid, ctx, mask, own_workspace=True)
         e['ws_key'] = rt._last_graph_ws_key
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        sp = ctypes.c_void_p(side.cuda_stream)
-        segs = [(0, qb), (1, qf)] + ([(2, mask)] if mask is not None else [])
-        c_idx = (ctypes.c_int32 * len(segs))(*[i for i, _ in segs])
-        c_dst = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for _, t in segs])
-        c_nb = (ctypes.c_int64 * len(segs))(*[t.numel() * t.element_size() for _, t in segs])
-        _lib.check(lib.sbev_capture_begin(sp), 'sbev_capture_begin')
+        try:                                 # (anything that raises before the capture proper must give the workspace reference back: ADVICE r5)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            sp = ctypes.c_void_p(side.cuda_stream)
+            segs = [(0, qb), (1, qf)] + ([(2, mask)] if mask is not None else [])
+            c_idx = (ctypes.c_int32 * len(segs))(*[i for i, _ in segs])
+            c_dst = (ctypes.c_void_p * len(segs))(*[t.data_ptr() for _, t in segs])
+            c_nb = (ctypes.c_int64 * len(segs))(*[t.numel() * t.element_size() for _, t in segs])
+            _lib.check(lib.sbev_capture_begin(sp), 'sbev_capture_begin')
+        except BaseException:
+            self._release_ws(e)
+            raise
         ok = True
+        st_fwd = 0
         try:
             ok = lib.sbev_copy_indirect(table, len(segs), c_idx, c_dst, c_nb, sp) == 0
             # on-demand relayout: no dense pass at all -- every layer moves the units its sample points marked (sbev_decoder_forward_lazy)
@@ -578,9 +588,10 @@ class StepGraphs:
                 lz.table = table
                 for l, r in enumerate(relayout):
                     lz.index[l] = r[0]
-                ok = ok and lib.sbev_decoder_forward_lazy(args[0], args[1], args[2], ctypes.byref(lz), *args[3:], sp) == 0
+                st_fwd = lib.sbev_decoder_forward_lazy(args[0], args[1], args[2], ctypes.byref(lz), *args[3:], sp) if ok else 0
             else:
-                ok = ok and lib.sbev_decoder_forward(*args, sp) == 0
+                st_fwd = lib.sbev_decoder_forward(*args, sp) if ok else 0
+            ok = ok and st_fwd == 0
             if outs is not None:
                 i_out = 3 + (len(mlvl_feats) if staged else 0)
                 ok = ok and lib.sbev_finish_outputs_indirect(table, i_out, i_out + 1, _ptr(cls), _ptr(box), cls.numel(), box.numel(), sp) == 0
@@ -589,6 +600,8 @@ class StepGraphs:
             st = lib.sbev_capture_end(sp, ctypes.byref(handle) if ok else None)
         if not ok or st != 0:
             self._release_ws(e)
+        if st_fwd == _lib.EFAULT:            # an EARLIER step lost a pair hand-off: the caller sees PairFaultError (pair mode off, acknowledged), as on the eager path
+            _lib.check(st_fwd, 'sbev_decoder_forward (capture)')
         if not ok:
             raise _lib.SbevError('graph capture of the decoder step failed: ' + lib.sbev_last_error().decode())
         _lib.check(st, 'sbev_capture_end')
@@ -648,9 +661,20 @@ class DecoderGraph:
 # process-wide switches mirrored here so that a captured step is only replayed under the settings it was recorded with
 import os as _os
 _STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PAIR'), 'fuse': True, 'profile': 0,
+          'out_fold': bool(_os.environ.get('SBEV_OUT_FOLD')),          # A/B (off: measured slower): the out-projection folds its split-K slabs inside its launch
           'lazy': not _os.environ.get('SBEV_NO_SPARSE_RELAYOUT'),      # staged NCHW pyramids: on-demand relayout of the units the sample points read
           'relayout_multi': not _os.environ.get('SBEV_NO_RELAYOUT_MULTI'),      # staged fp32 NCHW pyramids: all levels in one launch (A/B switch)
           'order': (lambda v: 2 if v == 2 else int(v != 0))(int(_os.environ.get('SBEV_QUERY_ORDER', '0') or 0))}
+
+
+def out_fold(enable):
+    """The out-projection GEMM folds its split-K slabs inside its launch (the chunk-workgroups of a row tile meet at a counter; fp16 GEMM
+    modes, row chains, <= ~1000 rows; follows ``chain_pair``) so that the tail chain reads one row block instead of 32 slabs.  Bit-identical
+    results either way.  OFF by default -- at config 2 it costs the out-projection 12.6 us and saves the tail 4 (DESIGN.md section 12.2);
+    ``SBEV_OUT_FOLD=1`` starts with it on.  Returns the previous setting."""
+    prev = bool(_lib.load().sbev_decoder_out_fold(int(bool(enable))))
+    _STATE['out_fold'] = bool(enable)
+    return prev
 
 
 def lazy_relayout(enable):

@@ -202,6 +202,92 @@ def test_a_lost_pair_member_times_out_instead_of_hanging():
     assert torch.equal(exact[0], ref[0]) and torch.equal(exact[1], ref[1])
 
 
+@pytest.mark.parametrize('B,Q,T,pyr,layers', [(1, 4, 2, 'tiny', 1), (1, 100, 2, 'tiny', 2), (1, 900, 8, 'tiny', 6), (2, 441, 2, 'tiny', 2),
+                                              (1, 1024, 2, 'tiny', 2), (1, 1089, 2, 'tiny', 2)])
+def test_out_projection_fold_inside_the_launch_is_bit_identical(B, Q, T, pyr, layers):
+    """Round 6: the out-projection's chunk-workgroups fold their split-K slabs inside the launch (gemm_bf16s.hip, out4 kernel: write-through
+    slabs, one counter per row tile, ceil(rows / S) rows per chunk-workgroup summed in slab order) and the tail reads one row block.  Same
+    summation order as the tail's own: outputs equal bit for bit with the fold off, eager and replayed, run to run; no poll ran out.
+    1089 rows: more workgroups than CUs -- the fold is not taken (bit-identical trivially)."""
+    feats, bbox, feat, metas, L = inputs(B, Q, T, pyr, 171)
+    model, _ = build(T, L, 172, layers)
+    t0 = runtime.chain_pair_timeouts()
+    b = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
+    prev = runtime.out_fold(True)              # (an A/B switch, off by default: measured slower at config 2 -- DESIGN.md section 12.2)
+    try:
+        a = [[t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))] for _ in range(4)]      # eager, capture, replays
+    finally:
+        runtime.out_fold(prev)
+    for x in a:
+        assert torch.equal(x[0], b[0]) and torch.equal(x[1], b[1])
+    assert runtime.chain_pair_timeouts() == t0
+
+
+def test_fold_under_load_and_graph_replay():
+    """200 replays of the captured 6-layer step at config 2's row count beside a second stream's traffic: every output word equal to the first
+    replay (a stale slab, a lost arrival or a counter that was not re-zeroed would show as a difference or a timeout)."""
+    feats, bbox, feat, metas, L = inputs(1, 900, 8, 'tiny', 181)
+    model, _ = build(8, L, 182, 6)
+    t0 = runtime.chain_pair_timeouts()
+    ref = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
+    prev = runtime.out_fold(True)
+    try:
+        side = torch.cuda.Stream()
+        junk = torch.randn(64 << 20, device=DEV)
+        for i in range(200):
+            if i % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk2 = junk * 1.0001 + 1.0
+            out = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), i
+        torch.cuda.synchronize()
+        del junk2
+    finally:
+        runtime.out_fold(prev)
+    assert model.decoder._runtime.step_graphs.replays >= 150
+    assert runtime.chain_pair_timeouts() == t0
+
+
+def test_a_lost_fold_member_times_out_and_raises_the_fault_word():
+    """The fold's poll bound: with the test hook chunk 1 of row tile 0 never arrives; the other chunk-workgroups of that tile give up after
+    the bound, count a timeout and raise the host-mapped fault word (rows of tile 0 are wrong: the step is invalid); the next call
+    refuses (PairFaultError), the in-launch hand-offs go off, the repeated step is right."""
+    import time
+    from sparsebev_amd import _lib
+    feats, bbox, feat, metas, L = inputs(1, 289, 2, 'tiny', 191)
+    model, _ = build(2, L, 192, 1)
+    model.decoder.static_graph = False
+    ref = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
+    lib = _lib.load()
+    t0 = runtime.chain_pair_timeouts()
+    assert lib.sbev_decoder_chain_pair_faults() == 0
+    prev_fold = runtime.out_fold(True)
+    try:
+        assert lib.sbev_debug_out_fold_drop(1) == 0
+        try:
+            tic = time.time()
+            out = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+            torch.cuda.synchronize()
+            took = time.time() - tic
+        finally:
+            assert lib.sbev_debug_out_fold_drop(0) == 1
+        assert took < 120.0
+        assert runtime.chain_pair_timeouts() > t0
+        assert lib.sbev_decoder_chain_pair_faults() > 0
+        with pytest.raises(_lib.PairFaultError):
+            model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+        assert lib.sbev_decoder_chain_pair_faults() == 0
+        again = model(bbox, feat, list(feats), None, copy.deepcopy(metas))          # hand-offs off: slabs summed by the single-workgroup tail
+        assert (again[0] - ref[0]).abs().max().item() < 2e-5 and (again[1] - ref[1]).abs().max().item() < 2e-5
+    finally:
+        lib.sbev_debug_out_fold_drop(0)
+        lib.sbev_decoder_chain_pair_faults_ack()
+        runtime.chain_pair(True)
+        runtime.out_fold(prev_fold)
+    exact = model(bbox, feat, list(feats), None, copy.deepcopy(metas))
+    assert torch.equal(exact[0], ref[0]) and torch.equal(exact[1], ref[1])
+
+
 def test_pair_fault_word_through_the_c_abi():
     """sbev_decoder_forward itself refuses while a fault stands (pure-C callers have no Python runtime around them): SBEV_EFAULT and
     a message, pair mode switched off by the refusing call, calls accepted again after sbev_decoder_chain_pair_faults_ack()."""

@@ -115,6 +115,10 @@ def test_decoder_runtime_ordered_equals_launch_order(T, L, pyr, P, B, Q, gemm):
             r = m.decoder._runtime
             assert r.launches_per_layer(B, Q) == 7
             assert r.step_graphs.replays >= 1
+            # mode 2 (untested): ONE sort per step, from the step's input boxes; every layer walks that order -- eager, captured, replayed
+            rt.query_order(2)
+            assert rt._STATE['order'] == 2 and r.launches_per_layer(B, Q) == 6
+            outs += [[t.clone() for t in m(bbox, feat, list(feats), None, copy.deepcopy(metas))] for _ in range(4)]
             rt.query_order(False)
             assert r.launches_per_layer(B, Q) == 6
             c = [t.clone() for t in m(bbox, feat, list(feats), None, copy.deepcopy(metas))]

@@ -19,4 +19,11 @@ def test_pmc_summary_names_every_row_chain_instantiation():
     assert P.short(ns + 'adaptive_mixing_kernel<2, true, 4, float, false>(x)') == 'adaptive_mixing_kernel'
     assert P.short(ns + 'adaptive_mixing_kernel<2, true, 0, float, false>(x)') == 'adaptive_mixing_kernel_plain'
     assert P.short(ns + 'sasa_kernel<false>(x)') == 'sasa_kernel'
+    # round 5's two new kernels dropped out of profiles/r5_pmc_*.json ('transpose_tiles_kernel' is not a substring of
+    # 'transpose_tiles_multi_kernel'); round 6's on-demand relayout kernels
+    assert P.short('(anonymous namespace)::transpose_tiles_multi_kernel((anonymous namespace)::TrMultiArgs)') == 'transpose_tiles_multi_kernel'
+    assert P.short(ns + 'transpose_tiles_kernel<true>((anonymous namespace)::TrArgs)') == 'transpose_tiles_kernel'
+    assert P.short('(anonymous namespace)::finish_outputs_kernel((anonymous namespace)::FinishArgs)') == 'finish_outputs_kernel'
+    assert P.short(ns + 'lazy_tiles_kernel<float>((anonymous namespace)::LazyArgs)') == 'lazy_tiles_kernel'
+    assert P.short(ns + 'lazy_scan_kernel<unsigned short>((anonymous namespace)::LazyArgs)') == 'lazy_scan_kernel'
     assert P.short('void at::native::vectorized_elementwise_kernel<4>(x)') is None

@@ -34,7 +34,8 @@ def short(name):
     m = re.search(r'row_chain_kernel<(\d)\s*[,>]', name) or re.search(r'row_chain_kernelILi(\d)E', name)
     if m:
         return 'row_chain_kernel_' + {'0': 'tail', '1': 'front', '2': 'attention'}.get(m.group(1), m.group(1))
-    for key in ('msmv_fwd_kernel', 'adaptive_mixing_kernel', 'transpose_tiles_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
+    for key in ('msmv_fwd_kernel', 'adaptive_mixing_kernel', 'transpose_tiles_multi_kernel', 'transpose_tiles_kernel', 'transpose_tiles16_kernel',
+                'lazy_tiles_kernel', 'lazy_scan_kernel', 'finish_outputs_kernel', 'copy_indirect_kernel', 'query_order_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
                 'gemm_nt_f32_small_kernel', 'gemm_group_small_kernel', 'gemm_nt_f32_strip_kernel', 'gemm_nt_f32_regtile_kernel',
                 'sample_project_kernel', 'sampling_front_kernel', 'ffn_fused_kernel', 'branch_chain_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3',
                 'gemm_f16s_gen_ws_kernel', 'gemm_bf16s_gen3_kernel', 'gemm_bf16s_out3_kernel', 'gemm_bf16s_out4_kernel', 'pack_frags_kernel'):

@@ -44,6 +44,7 @@ GEMM_WHAT = {
     'bf16x3': '3 x bf16 split products, f32 accumulate (sbev_linear_bf16x3, round-2 kernels)'}
 GEMM_PRODUCTS = {'f16x3': 3, 'f16x4': 4, 'bf16x6': 6, 'bf16x3s': 3, 'bf16x3': 3}
 DEFAULT_GEMM = os.environ.get('SBEV_GEMM_MODE') or 'f16x3'
+OUT8_MIN_ROWS = int(os.environ.get('SBEV_OUT8_MIN_ROWS', '1024')) or (1 << 30)      # rows from which the out-projection runs on 256-row tiles (csrc/gemm_bf16s.hip)
 
 
 def pmc_profile(config, kernel='msmv_fwd_kernel'):
@@ -648,14 +649,14 @@ def main():
                  'frac': round(npr * fl / (us * 1e-6) / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4), 'image_products': npr,
                  'fp32_equiv_tflops': round(fl / (us * 1e-6) / 1e12, 1), 'launches': len(ms), 'avg_us': round(us, 2), 'algorithmic_flop_per_launch': fl}
                 for name, fl, us, ms in (('%s (mixing parameter generator, %s)' % ('gemm_f16s_gen_ws_kernel' if GEMM_PRODUCTS[args.gemm] in (3, 4) and args.gemm != 'bf16x3' else 'gemm_bf16s_gen3_kernel', args.gemm), fl_g, g_us, gemm_ms[0]),
-                                         ('gemm_bf16s_out%s_kernel (mixing out-projection, split-K, %s)' % ('4' if args.gemm.startswith('f16') else '3', args.gemm), fl_o, o_us, gemm_ms[1]))]
+                                         ('gemm_bf16s_out%s_kernel (mixing out-projection, split-K, %s)' % (('8' if B * Q >= OUT8_MIN_ROWS else '4') if args.gemm.startswith('f16') else '3', args.gemm), fl_o, o_us, gemm_ms[1]))]
             # the fp32-class emulation may be the default once generator + out-projection <= 2 x 60 us at config 2
             out['gemm_gate'] = {'generator_us': round(g_us, 2), 'out_proj_us': round(o_us, 2), 'sum_us': round(g_us + o_us, 2),
                                 'measured': 'HIP events around the two launches of 10 eager steps right after the timed region (an upper bound: the records '
                                             'include the launch gap)', 'config': args.config}
             gk = (kt or {}).get('gemm_f16s_gen_ws_kernel', (kt or {}).get('gemm_bf16s_gen3_kernel'))
             if gk:
-                ok = kt.get('gemm_bf16s_out4_kernel', kt.get('gemm_bf16s_out3_kernel'))
+                ok = kt.get('gemm_bf16s_out8_kernel', kt.get('gemm_bf16s_out4_kernel', kt.get('gemm_bf16s_out3_kernel')))
                 out['gemm_gate'].update({'generator_us_rocprof': gk, 'out_proj_us_rocprof': ok,
                                          'sum_us_rocprof': round(gk + ok, 2) if ok else None,
                                          'rocprof': 'rocprofv3 --kernel-trace --stats of 23 steps of this command re-run now on this box: AverageNs of the two kernels'})

@@ -772,6 +772,10 @@ int64_t sbev_decoder_chain_pair_faults_ack(void);
  * measured at config 2 the fold costs the out-projection 12.6 us and saves the tail 4 -- an A/B switch, not the
  * product path; SBEV_OUT_FOLD=1 in the environment starts with 1.  sbev_debug_out_fold_drop: test hook, never set in production. */
 int sbev_decoder_out_fold(int enable);
+/* Rows from which the fp16-mode out-projection with the pre-split operand (the decoder's path) runs on 256-row tiles
+ * (gemm_bf16s_out8_kernel: two row halves as phase groups sharing one W ring -- a third less operand delivery per product than the 128-row
+ * kernel; default 1024: the batch configs and the 1600-query config; env SBEV_OUT8_MIN_ROWS; 0 = never, other values are raised to 1024).  Returns the previous threshold. */
+int sbev_linear_out8_min_rows(int rows);
 int sbev_debug_out_fold_drop(int enable);
 /* Per-device setup that is illegal under stream capture (hipHostMalloc + hipMemcpyToSymbol of the fault word above): call once per device
  * before the first capture that may contain a decoder step -- the ctypes binding does when it loads the library.  Without it

@@ -79,6 +79,7 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     'sbev_init': (ctypes.c_int, []),
     'sbev_decoder_out_fold': (ctypes.c_int, [ctypes.c_int]),
+    'sbev_linear_out8_min_rows': (ctypes.c_int, [ctypes.c_int]),
     'sbev_debug_out_fold_drop': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_sampler': (ctypes.c_int, [ctypes.c_int]),
     'sbev_profile_stride': (ctypes.c_int, [ctypes.c_int]),

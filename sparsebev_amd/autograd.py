@@ -419,6 +419,76 @@ def linear(x, w, b, relu=False, residual=None, tap=None):
     return Linear.apply(x, w, b, relu, residual)
 
 
+class LinearPair(torch.autograd.Function):
+    """Two INDEPENDENT Linears in one launch each way (round 6): (ya, yb) = (act_a(xa Wa^T + ba), act_b(xb Wb^T + bb)) through
+    dense.linear_group (gemm_group_small_kernel: the grouped launch the inference runtime uses for the two branch heads), and in backward
+    both grad_x products as one grouped launch of Linears with W^T.  The decoder layer's classification and regression branches are two
+    such chains side by side (models/sparsebev_transformer.py:174-183): 18 small-tile launches per layer and step were 6.4 % of the
+    captured training step at 6.3 us each for ~1 us of arithmetic.  Same arithmetic per output tile as two Linear nodes; weight / bias
+    gradients go through the same Tap deferral."""
+
+    @staticmethod
+    def forward(ctx, xa, wa, ba, relu_a, xb, wb, bb, relu_b, tap=None, token=None):
+        ya, yb = dense.linear_group([(xa, wa, ba, relu_a), (xb, wb, bb, relu_b)])
+        ctx.relu = (bool(relu_a), bool(relu_b))
+        ctx.save_for_backward(xa, wa, ya if relu_a else None, xb, wb, yb if relu_b else None)
+        ctx.has_b = (ba is not None, bb is not None)
+        ctx.tap, ctx.w_id, ctx.b_id = tap, (id(wa), id(wb)), (id(ba), id(bb))
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, gya, gyb):
+        xa, wa, ya, xb, wb, yb = ctx.saved_tensors
+        tap = ctx.tap
+        if tap is not None:
+            tap.fresh_pass()
+        xs, ws, ys, gys = (xa, xb), (wa, wb), (ya, yb), (gya, gyb)
+        need_x = (ctx.needs_input_grad[0], ctx.needs_input_grad[4])
+        need_w = (ctx.needs_input_grad[1], ctx.needs_input_grad[5])
+        need_b = (ctx.needs_input_grad[2], ctx.needs_input_grad[6])
+        gz, gw, db, x2s = [None, None], [None, None], [None, None], [None, None]
+        for i in range(2):
+            N, K = ws[i].shape
+            if gys[i] is None:
+                continue
+            gy2 = _c(gys[i]).reshape(-1, N)
+            x2s[i] = _c(xs[i]).reshape(-1, K)
+            w_tapped = need_w[i] and tap is not None and tap.has(ctx.w_id[i])
+            want_db = ctx.has_b[i] and need_b[i]
+            recorded = tap.deferred_bias.get(ctx.b_id[i]) if tap is not None else None
+            y2 = ys[i].reshape(-1, N) if ctx.relu[i] else None
+            if (w_tapped and want_db and tap.has(ctx.b_id[i]) and gy2.shape[0] * N <= _BIAS_DEFER_MAX and gy2.is_contiguous()
+                    and (not recorded or recorded[0].shape == gy2.shape)):
+                gz[i] = _bias_relu_bwd(gy2, y2, False)[0] if ctx.relu[i] else gy2
+                tap.deferred_bias.setdefault(ctx.b_id[i], []).append(gz[i])
+            else:
+                gz[i], db[i] = _bias_relu_bwd(gy2, y2, want_db, tap, ctx.b_id[i])
+            if w_tapped:
+                _tap_gemm(tap, ctx.w_id[i], gz[i], True, N, x2s[i], True, K, N, K, gz[i].shape[0])
+            elif need_w[i]:
+                gw[i] = gemm(gz[i], True, N, x2s[i], True, K, N, K, gz[i].shape[0])
+        # grad_x = grad_y . W of both members: one grouped launch when both are small-tile shapes (N, K multiples of 4), else one by one
+        gx = [None, None]
+        both = all(need_x[i] and gz[i] is not None and ws[i].shape[0] % 4 == 0 and ws[i].shape[1] % 4 == 0 for i in range(2)) \
+            and ws[0].shape[0] == ws[1].shape[0]
+        if both:
+            gx = dense.linear_group([(gz[0], _transposed(ws[0]), None, False), (gz[1], _transposed(ws[1]), None, False)])
+        else:
+            for i in range(2):
+                if need_x[i] and gz[i] is not None:
+                    gx[i] = _linear_grads(gz[i], x2s[i], _c(ws[i]), True, False)[0]
+        gxa = gx[0].reshape(xa.shape) if gx[0] is not None else None
+        gxb = gx[1].reshape(xb.shape) if gx[1] is not None else None
+        return (gxa, gw[0], db[0], None, gxb, gw[1], db[1], None, None,
+                tap.token_grad() if (tap is not None and tap.token is not None) else None)
+
+
+def linear_pair(xa, wa, ba, relu_a, xb, wb, bb, relu_b, tap=None):
+    if tap is not None and tap.token is not None:
+        return LinearPair.apply(xa, wa, ba, relu_a, xb, wb, bb, relu_b, tap, tap.token)
+    return LinearPair.apply(xa, wa, ba, relu_a, xb, wb, bb, relu_b)
+
+
 class LayerNorm(torch.autograd.Function):
     """relu?(LayerNorm(x)) (+ add_after): forward = dense.layer_norm, backward = sbev_layer_norm_bwd."""
 

@@ -1412,6 +1412,175 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
     else run(std::integral_constant<int, 1>{});
 }
 
+// ---- out-projection, 256-row tiles (fp16 modes, pre-split X; round 6: from 1024 rows -- the batch shapes and the 1600-query config) -------------------------------------
+// At 3200 / 3600 rows the 128-row kernel above reaches 0.28 / 0.31 of the matrix peak while the generator reaches 0.46 on the same rows:
+// every 128-row tile streams its K chunk of ALL 256 W rows through the L2 -> LDS path -- 25 tiles x 33.5 MB of W + 420 MB of X per launch at
+// 3200 rows -- and that delivery adds to the matrix time instead of hiding under it.  Here a workgroup owns up to
+// 256 rows x 256 columns x one K chunk: the two phase groups are the two ROW halves (not the two K halves), each with its own X stage ring,
+// and they SHARE one W ring per 64-column quarter -- the group-0 wave of a quarter requests a k-step's W fragments (LDS-DMA, two steps
+// ahead), waits for them in its own FETCH phase, and the group-1 wave reads the same slot one phase later, behind the barrier in between.
+// Per 16-k step a workgroup takes 16 KB of X + 16 KB of W for twice the MFMAs the 128-row kernel gets out of 8 + 16 KB: a third less
+// operand delivery per product, no fold of K halves.  Same products, same accumulation order over k as the 128-row kernel WITHOUT its
+// K-half split -- results differ from it by fp32 summation order (a chunk's two halves are added k-ascending here), not in class.
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16s_out8_kernel(const Out4Args a) {
+    typedef Fmt<MODE> PR;
+    static_assert(PR::F16 && PR::NIMG == 2, "pre-split fp16 operands");
+    constexpr int NIMG = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int IMG = 128 * 32;               // bytes of one image of one group's stage: 128 rows x 16 k
+    constexpr int HSTAGE = NIMG * IMG;
+    constexpr int NST = 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = wave >> 2, wc = wave & 3;    // row half of the tile = phase group, 64-column quarter
+    const unsigned logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int chunk = (int)(logical / (unsigned)a.ntm), rt = (int)(logical % (unsigned)a.ntm);
+    const int M = a.M;
+    const int f0 = rt * a.base + (rt < a.rem ? rt : a.rem);
+    const int nf = a.base + (rt < a.rem ? 1 : 0);                // row fragments of this tile: 2 .. 8
+    const int nfa0 = (nf + 1) / 2, nfa1 = nf / 2;                // ... of row half 0 / 1
+    const int nfa = rh == 0 ? nfa0 : nfa1;
+    const int m0 = f0 * 32, mh = m0 + (rh == 0 ? 0 : nfa0 * 32);
+    const int KS = a.K / 16;
+    const int c0 = (int)((long long)KS * chunk / a.S), c1 = (int)((long long)KS * (chunk + 1) / a.S);
+    const int n_all = c1 - c0;                  // both groups walk every k-step of the chunk
+
+    const int th = tid & 255;
+    const int srow = th >> 1, skq = th & 1;     // staging: thread -> (row of its half, 8-k half of the step)
+    int grow = mh + srow;
+    grow = grow < M ? grow : M - 1;
+    const unsigned* xp = a.Xp + (long long)grow * a.ldx + skq * 8;
+    const unsigned wofs = (unsigned)(srow * 32 + skq * 16);
+    unsigned char* hst = lds + rh * (NST * HSTAGE);              // this group's X stage ring
+    const int last = c1 - 1;
+    auto loadx = [&](int i, u32x4& v0, u32x4& v1) {              // k-step i (clamped: a dummy past the end)
+        int sl = c0 + i;
+        sl = sl < last ? sl : last;
+        const unsigned* p = xp + (long long)sl * 16;
+        v0 = *reinterpret_cast<const u32x4*>(p);
+        v1 = *reinterpret_cast<const u32x4*>(p + 4);
+    };
+    auto stagex = [&](int i, const u32x4 p, const u32x4 q) {     // k-step i -> ring slot i % 3: de-interleave hi | lo
+        unsigned char* st = hst + (i % NST) * HSTAGE + wofs;
+        *reinterpret_cast<u32x4*>(st) = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x05040100u), __builtin_amdgcn_perm(p.w, p.z, 0x05040100u),
+                                                __builtin_amdgcn_perm(q.y, q.x, 0x05040100u), __builtin_amdgcn_perm(q.w, q.z, 0x05040100u)};
+        *reinterpret_cast<u32x4*>(st + IMG) = (u32x4){__builtin_amdgcn_perm(p.y, p.x, 0x07060302u), __builtin_amdgcn_perm(p.w, p.z, 0x07060302u),
+                                                      __builtin_amdgcn_perm(q.y, q.x, 0x07060302u), __builtin_amdgcn_perm(q.w, q.z, 0x07060302u)};
+    };
+    // W: ONE 3-slot ring per column quarter, filled by the quarter's group-0 wave, read by both of its waves
+    constexpr int WSLOT = 2 * NIMG * 1024;               // one step of one quarter: 2 column fragments x 2 images
+    constexpr int WRING0 = 2 * NST * HSTAGE;             // behind the two groups' X stages
+    const unsigned wring = (unsigned)(WRING0 + wc * (NST * WSLOT));
+    const unsigned char* wg0 = reinterpret_cast<const unsigned char*>(a.Wp) + (long long)(2 * wc) * KS * (NIMG * 1024);
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue_w = [&](int i) {                          // (group 0 only) k-step i (clamped) -> ring slot i % 3
+        int sl = c0 + i;
+        sl = sl < last ? sl : last;
+        const unsigned dst = wring + (unsigned)((i % NST) * WSLOT);
+        glds16_images<NIMG>(wg0 + (long long)sl * (NIMG * 1024), voff, dst);
+        glds16_images<NIMG>(wg0 + ((long long)KS + sl) * (NIMG * 1024), voff, dst + NIMG * 1024);
+    };
+    auto readw = [&](int i, bf16x8 (&w)[2][NIMG]) {
+        const unsigned char* src = lds + wring + (i % NST) * WSLOT + voff;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int img = 0; img < NIMG; ++img) w[fb][img] = *reinterpret_cast<const bf16x8*>(src + (fb * NIMG + img) * 1024);
+    };
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned fo = (unsigned)l31 * 32u + (unsigned)lh * 16u;
+
+    auto run = [&](auto nfa_c) {
+        constexpr int NFA = decltype(nfa_c)::value;
+        f32x16 acc[NFA][2];
+#pragma unroll
+        for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[fa][fb][e] = 0.f;
+        u32x4 xa0, xa1, xb0, xb1;
+        bf16x8 wa[2][NIMG], xf[NFA][NIMG];
+        loadx(0, xa0, xa1);
+        loadx(1, xb0, xb1);
+        if (rh == 0) { issue_w(0); issue_w(1); }
+        stagex(0, xa0, xa1);
+        loadx(2, xa0, xa1);
+        stagex(1, xb0, xb1);
+        loadx(3, xb0, xb1);
+        wait_vmcnt_imm<0>();
+        __syncthreads();
+        if (rh == 1) phase_barrier();                         // the second row half runs one phase behind
+#define SBEV_O8_STEP(S_, X0, X1)                                                                    \
+        {                                                                                                   \
+            {   /* FETCH */                                                                                 \
+                /* group 0: W of this step (its own request of two steps ago) has landed once at most the 8 younger requests are */ \
+                /* outstanding (X of step + 2, W of step + 1, X of step + 3); group 1 reads the slot one phase -- one barrier -- later */ \
+                wait_vmcnt_imm<8>();                                                                        \
+                readw((S_), wa);                                                                            \
+                const unsigned char* A = hst + ((S_) % NST) * HSTAGE + fo;                                  \
+                _Pragma("unroll") for (int img = 0; img < NIMG; ++img)                                      \
+                    _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                      \
+                        xf[fa][img] = *reinterpret_cast<const bf16x8*>(A + img * IMG + fa * 1024);          \
+                stagex((S_) + 2, X0, X1);                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                if (rh == 0) issue_w((S_) + 2);                                                             \
+                loadx((S_) + 4, X0, X1);                                                                    \
+                /* the slot read above is overwritten by group 0's request of the NEXT phase: the reads must have returned by the barrier */ \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
+            }                                                                                               \
+            phase_barrier();                                                                                \
+            _Pragma("unroll") for (int p = 0; p < PR::N; ++p)                                               \
+                _Pragma("unroll") for (int fa = 0; fa < NFA; ++fa)                                          \
+                    _Pragma("unroll") for (int fb = 0; fb < 2; ++fb)                                        \
+                        acc[fa][fb] = SBEV_MFMA(wa[fb][PR::ib(p)], xf[fa][PR::ia(p)], acc[fa][fb]);         \
+            phase_barrier();                                                                                \
+        }
+        int sl = 0;
+        for (; sl + 1 < n_all; sl += 2) {
+            SBEV_O8_STEP(sl, xa0, xa1)
+            SBEV_O8_STEP(sl + 1, xb0, xb1)
+        }
+        if (sl < n_all) SBEV_O8_STEP(sl, xa0, xa1)
+#undef SBEV_O8_STEP
+        if (rh == 0) phase_barrier();
+        // the chunk's slab: one row half at a time through an [m][n] image in LDS (a lane holds one output ROW m and 4-column pieces), all 8
+        // waves then read whole rows back and store 1 KiB per instruction
+        wait_vmcnt_imm<0>();                                   // the last (dummy, clamped) W requests still write LDS this image reuses
+        __syncthreads();
+        constexpr int FLD = 256 + 4;
+        float* img = reinterpret_cast<float*>(lds);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.nscale + lane * 4);
+        float* out = a.P + (long long)chunk * M * 256 + lane * 4;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (rh == pass) {
+#pragma unroll
+                for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(img + (fa * 32 + l31) * FLD + wc * 64 + fb * 32 + 8 * g + 4 * lh) =
+                                (f32x4){acc[fa][fb][4 * g], acc[fa][fb][4 * g + 1], acc[fa][fb][4 * g + 2], acc[fa][fb][4 * g + 3]};
+            }
+            __syncthreads();
+            const int prow0 = m0 + (pass == 0 ? 0 : nfa0 * 32), prows = (pass == 0 ? nfa0 : nfa1) * 32;
+            for (int r = wave; r < prows; r += 8) {
+                const int row = prow0 + r;
+                if (row < M SBEV_EXP_STORE_COND)
+                    *reinterpret_cast<f32x4*>(out + (long long)row * 256) = *reinterpret_cast<const f32x4*>(img + r * FLD + lane * 4) * sc;
+            }
+            __syncthreads();
+        }
+    };
+    if (nfa == 4) run(std::integral_constant<int, 4>{});
+    else if (nfa == 3) run(std::integral_constant<int, 3>{});
+    else if (nfa == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
+}
+
 template <typename Kern>
 int reserve_lds(Kern k, int bytes, const char* what) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1455,6 +1624,35 @@ Out4Plan out4_plan(long long M, int K) {
         if (eff > best_eff + 1e-9) { best_eff = eff; p.S = s; }
     }
     return p;
+}
+
+// the 256-row kernel's plan: row tiles of <= 8 fragments (balanced, >= 2), K chunks of >= 8 k-steps, ONE round of workgroups (more chunks
+// would only add slabs for the consumer to sum)
+// (measured, samples/s with / without: 3200 rows 1289 / 1189, 3600 rows 506 / 481, 1600 rows 194.6 / 187.2; 900 rows 536.6 / 538.8 -- the
+// kernel itself is 4 us faster there too, but 4 row tiles x 64 chunks leave the tail 64 slabs to sum instead of 32: from 1024 rows)
+constexpr int OUT8_HARD_MIN = 1024;       // (workspaces are sized for the 256-row plan from here on, whatever the switch says later)
+int out8_clamp(int rows) { return rows <= 0 ? 0 : (rows < OUT8_HARD_MIN ? OUT8_HARD_MIN : rows); }
+std::atomic<int> g_out8_min_rows{out8_clamp(getenv("SBEV_OUT8_MIN_ROWS") ? atoi(getenv("SBEV_OUT8_MIN_ROWS")) : OUT8_HARD_MIN)};
+Out4Plan out8_plan(long long M, int K) {
+    const int nfrag = (int)((M + 31) / 32);
+    Out4Plan p{};
+    p.ntm = (nfrag + 7) / 8;
+    p.base = nfrag / p.ntm;
+    p.rem = nfrag % p.ntm;
+    const int max_s = K / 16 / 8 < 1 ? 1 : K / 16 / 8;
+    p.S = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 64 && s <= max_s && (long long)p.ntm * s <= 256; ++s) {
+        const double eff = (double)p.ntm * s / 256.0;
+        if (eff > best_eff + 1e-9) { best_eff = eff; p.S = s; }
+    }
+    return p;
+}
+bool out8_takes(long long M, int K) {
+    const int mr = g_out8_min_rows.load(std::memory_order_relaxed);
+    if (mr <= 0 || M < mr) return false;
+    const Out4Plan p = out8_plan(M, K);
+    return p.base >= 2 && p.ntm <= 256;
 }
 
 }  // namespace
@@ -1643,8 +1841,8 @@ extern "C" int sbev_linear_bf16s_out_ok(int64_t M, int N, int K) {
 
 extern "C" int sbev_linear_bf16s_out_plan(int64_t M, int N, int K) {      // slabs to provide: the larger of the two kernels' plans
     if (!sbev_linear_bf16s_out_ok(M, N, K)) return 0;
-    const int a = out_chunks(M, K), b = out4_plan(M, K).S;
-    return a > b ? a : b;
+    const int a = out_chunks(M, K), b = out4_plan(M, K).S, c = M >= OUT8_HARD_MIN ? out8_plan(M, K).S : 0;      // (whichever kernel a call picks)
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 namespace sbev {
@@ -1668,6 +1866,7 @@ bool out_fold_ok(long long M, int K) {
 bool out_fold_install(void* host_word_dev) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fold_fault_host), &host_word_dev, sizeof(host_word_dev)) == hipSuccess;
 }
+int out8_min_rows(int rows) { return g_out8_min_rows.exchange(out8_clamp(rows), std::memory_order_relaxed); }
 int out_fold_switch(int enable) { return g_out_fold.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
 long long out_fold_timeouts() {
     unsigned v = 0;
@@ -1682,8 +1881,9 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
     SBEV_REQUIRE(!xdev || (nimg >= 4 && !x_pairs), "sbev_linear_splitk_f16s: a device-side X scale needs an fp16 mode and fp32 X");
     if (x_pairs) {                              // fp16 modes with the pre-split operand: 128-row tiles
         SBEV_REQUIRE(nimg >= 4, "sbev_linear_splitk_f16s: pre-split X needs an fp16 mode");
-        const Out4Plan pl = out4_plan(M, K);
-        const bool fold = fold_sync && folded && out_fold_ok(M, K);      // (the caller asked AND the shape / device allow it: else S slabs as before)
+        const bool big = out8_takes(M, K);                               // batch shapes: 256-row tiles (a third less operand delivery)
+        const Out4Plan pl = big ? out8_plan(M, K) : out4_plan(M, K);
+        const bool fold = !big && fold_sync && folded && out_fold_ok(M, K);      // (the caller asked AND the shape / device allow it: else S slabs as before)
         *used = fold ? 1 : pl.S;                                        // folded: the consumer reads `folded` as ONE slab
         Out4Args a4{reinterpret_cast<const unsigned*>(X), Wp, slabs, (int)M, K, (long long)ldx, pl.ntm, pl.base, pl.rem, pl.S, nscale,
                     fold ? fold_sync : nullptr, fold ? folded : nullptr, g_out_fold_drop.load(std::memory_order_relaxed)};
@@ -1700,7 +1900,11 @@ int launch_splitk_slabs_bf16s(const float* X, const uint16_t* Wp, int64_t M, int
             hipLaunchKernelGGL(KERN, dim3((unsigned)wgs4), dim3(512), LDS4, s, a4);              \
             if (prof) profile_end(s, f0, f1, 2);                                                 \
         }
-        if (nimg == 4) SBEV_LAUNCH_OUT4(gemm_bf16s_out4_kernel<2>) else SBEV_LAUNCH_OUT4(gemm_bf16s_out4_kernel<3>)
+        if (big) {
+            if (nimg == 4) SBEV_LAUNCH_OUT4(gemm_bf16s_out8_kernel<2>) else SBEV_LAUNCH_OUT4(gemm_bf16s_out8_kernel<3>)
+        } else {
+            if (nimg == 4) SBEV_LAUNCH_OUT4(gemm_bf16s_out4_kernel<2>) else SBEV_LAUNCH_OUT4(gemm_bf16s_out4_kernel<3>)
+        }
 #undef SBEV_LAUNCH_OUT4
         return check_launch("sbev_linear_splitk_f16s (gemm, 128-row tiles)");
     }
@@ -1815,3 +2019,7 @@ extern "C" int sbev_f16s_out_scale(const float* wdown, int x_up_log2, float* nsc
 extern "C" int sbev_decoder_out_fold(int enable) { return sbev::out_fold_switch(enable); }
 // test hook for the fold's poll bound (never set in production): one chunk-workgroup of row tile 0 leaves without arriving
 extern "C" int sbev_debug_out_fold_drop(int enable) { return sbev::out_fold_drop(enable); }
+
+// rows from which the pre-split out-projection runs on 256-row tiles (gemm_bf16s_out8_kernel; default 1024, SBEV_OUT8_MIN_ROWS in the
+// environment; 0 = never, anything else is raised to 1024): returns the previous threshold.  A/B switch; results differ by fp32 summation order only.
+extern "C" int sbev_linear_out8_min_rows(int rows) { return sbev::out8_min_rows(rows); }

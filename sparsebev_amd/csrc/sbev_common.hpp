@@ -56,6 +56,7 @@ bool out_fold_ok(long long M, int K);
 bool out_fold_install(void* host_word_dev);
 long long out_fold_timeouts();
 int out_fold_switch(int enable);
+int out8_min_rows(int rows);
 int out_fold_drop(int enable);
 
 // layout.hip: on-demand relayout of the units the sample points mark (sample_point.hpp::TouchMap); need / done: one 4-byte word per tile

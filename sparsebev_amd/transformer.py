@@ -252,12 +252,21 @@ class SparseBEVTransformerDecoderLayer(_Base):
         else:
             x = AG.layer_norm(AG.linear(h, f1.weight, f1.bias, residual=x, tap=tap), self.norm3.weight, self.norm3.bias, tap=tap)
         cb, rb = self.cls_branch, self.reg_branch
-        c = AG.layer_norm(AG.linear(x, cb[0].weight, cb[0].bias, tap=tap), cb[1].weight, cb[1].bias, relu=True, tap=tap)
-        c = AG.layer_norm(AG.linear(c, cb[3].weight, cb[3].bias, tap=tap), cb[4].weight, cb[4].bias, relu=True, tap=tap)
-        cls_score = AG.linear(c, cb[6].weight, cb[6].bias, tap=tap)
-        r = AG.linear(x, rb[0].weight, rb[0].bias, relu=True, tap=tap)
-        r = AG.linear(r, rb[2].weight, rb[2].bias, relu=True, tap=tap)
-        reg = AG.linear(r, rb[4].weight, rb[4].bias, tap=tap)
+        if os.environ.get('SBEV_NO_TRAIN_PAIRS') == '1':       # A/B: one launch per Linear (rounds 2-5)
+            c = AG.layer_norm(AG.linear(x, cb[0].weight, cb[0].bias, tap=tap), cb[1].weight, cb[1].bias, relu=True, tap=tap)
+            c = AG.layer_norm(AG.linear(c, cb[3].weight, cb[3].bias, tap=tap), cb[4].weight, cb[4].bias, relu=True, tap=tap)
+            cls_score = AG.linear(c, cb[6].weight, cb[6].bias, tap=tap)
+            r = AG.linear(x, rb[0].weight, rb[0].bias, relu=True, tap=tap)
+            r = AG.linear(r, rb[2].weight, rb[2].bias, relu=True, tap=tap)
+            reg = AG.linear(r, rb[4].weight, rb[4].bias, tap=tap)
+        else:
+            # the two branch heads level by level, each level ONE grouped launch forward and one for the two grad_x products backward
+            # (AG.LinearPair; the inference runtime groups the same way: csrc/decoder.hip `grouped`)
+            c, r = AG.linear_pair(x, cb[0].weight, cb[0].bias, False, x, rb[0].weight, rb[0].bias, True, tap=tap)
+            c = AG.layer_norm(c, cb[1].weight, cb[1].bias, relu=True, tap=tap)
+            c, r = AG.linear_pair(c, cb[3].weight, cb[3].bias, False, r, rb[2].weight, rb[2].bias, True, tap=tap)
+            c = AG.layer_norm(c, cb[4].weight, cb[4].bias, relu=True, tap=tap)
+            cls_score, reg = AG.linear_pair(c, cb[6].weight, cb[6].bias, False, r, rb[4].weight, rb[4].bias, False, tap=tap)
         bbox_pred = AG.RefineBbox.apply(query_bbox, reg, ctx.vel_div)
         return x, cls_score, bbox_pred
 
@@ -385,7 +394,17 @@ class _PinnedUpload:
         else:
             slot[1].synchronize()
         slot[0].copy_(t)
-        out = slot[0].to(device, non_blocking=True) if out is None else out.copy_(slot[0], non_blocking=True)
+        if out is not None and t.dtype == torch.float32 and os.environ.get('SBEV_UPLOAD_DMA') != '1':
+            # refresh of a replayed step's constants: a KERNEL reads the page-locked slot over the bus (sbev_copy_widen_f32 on the device-visible
+            # host pointer) instead of an SDMA copy -- the copy engine's start-up left ~8 us of idle stream between two replayed steps
+            # (kernel trace, round 6), a 4-us kernel does not
+            from . import _lib
+            import ctypes
+            st = _lib.load().sbev_copy_widen_f32(ctypes.c_void_p(slot[0].data_ptr()), 0, ctypes.c_void_p(out.data_ptr()), t.numel(),
+                                                 ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+            _lib.check(st, 'sbev_copy_widen_f32')
+        else:
+            out = slot[0].to(device, non_blocking=True) if out is None else out.copy_(slot[0], non_blocking=True)
         slot[1].record(torch.cuda.current_stream(device))
         return out
 

@@ -398,9 +398,12 @@ def test_weight_stationary_generator_equals_the_tiled_kernel(M, N, relu, use_bia
 
 
 @pytest.mark.parametrize('pairs', [False, True])
-@pytest.mark.parametrize('M,K', [(1, 256), (33, 512), (64, 1024), (65, 2048), (97, 4096), (100, 32768), (129, 2048), (3200, 4096), (7, 32768 + 32)])
+@pytest.mark.parametrize('M,K', [(1, 256), (33, 512), (64, 1024), (65, 2048), (97, 4096), (100, 32768), (129, 2048), (3200, 4096), (7, 32768 + 32),
+                                 (1024, 2048), (1056, 32768), (2049, 4096), (2300, 8192 + 32), (3600, 32768)])
 def test_out_projection_f16_ragged(M, K, pairs):
-    """1 .. 4 row fragments per tile, odd k-step counts per chunk (the two wave quartets of a workgroup get unequal halves)."""
+    """1 .. 4 row fragments per tile, odd k-step counts per chunk (the two wave quartets of a workgroup get unequal halves).  From 1024 rows
+    the pre-split path runs on 256-row tiles (round 6, gemm_bf16s_out8_kernel): 7 / 8 fragments per tile split 4 + 3 / 4 + 4 over the two row
+    halves, last tile partly outside the matrix."""
     N = 256
     x, w, b = _rand((M, K), M + K), _rand((N, K), K, K ** -0.5), _rand((N,), 13)
     wf, wsc = dense.pack_f16s_frags(w)
@@ -408,6 +411,36 @@ def test_out_projection_f16_ragged(M, K, pairs):
     y = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=3, x_up_log2=11, x_is_pairs=pairs)
     ref = x.double() @ w.double().t() + b.double()
     assert (y.double() - ref).abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize('M,K', [(3200, 32768), (3600, 32768), (2112, 4096)])
+def test_out_projection_256_row_tiles_against_the_128_row_kernel(M, K):
+    """Round 6: the batch shapes' out-projection on 256-row tiles (two row halves as phase groups sharing one W ring) -- same products as
+    the 128-row kernel, k-ascending inside a chunk instead of two K halves: equal to it to fp32 summation round-off, not narrower against
+    fp64, bit-stable run to run; sbev_linear_out8_min_rows switches."""
+    from sparsebev_amd import _lib
+    lib = _lib.load()
+    N = 256
+    x, w, b = _rand((M, K), M + K + 3), _rand((N, K), K + 5, K ** -0.5), _rand((N,), 17)
+    wf, wsc = dense.pack_f16s_frags(w)
+    xin = dense.f16s_pairs(x, 11)
+    prev = lib.sbev_linear_out8_min_rows(1024)
+    try:
+        y8 = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=3, x_up_log2=11, x_is_pairs=True)
+        assert torch.equal(y8, dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=3, x_up_log2=11, x_is_pairs=True))
+        lib.sbev_linear_out8_min_rows(0)
+        y4 = dense.linear_splitk_f16s(xin, wf, wsc, b, nprod=3, x_up_log2=11, x_is_pairs=True)
+    finally:
+        lib.sbev_linear_out8_min_rows(prev)
+    ref = x.double() @ w.double().t() + b.double()
+    e8, r8 = _errs(y8, ref)
+    e4, r4 = _errs(y4, ref)
+    ef, rf = _errs(dense.linear(x, w, b), ref)             # the exact f32-input MFMA kernels: the fp32-class yardstick of every split mode
+    print('out-projection M=%d K=%d  256-row tiles max/rms %.3e %.3e   128-row tiles %.3e %.3e   exact f32 MFMA %.3e %.3e' % (M, K, e8, r8, e4, r4, ef, rf))
+    assert not torch.equal(y8, y4) or K < 8192           # (another summation order: a different kernel really ran)
+    # fewer, longer k-chains than the 128-row plan (19 chunks of 108 k-steps against 51 x 2 halves of 20 at 3200 rows): more fp32
+    # accumulation round-off than it, still not more than the exact kernels'
+    assert (y8 - y4).abs().max().item() < 6e-6 and e8 <= 1.05 * ef + 1e-30 and r8 <= 1.05 * rf + 1e-30
 
 
 @pytest.mark.parametrize('M,K,mag', [(900, 32768, 1.0), (900, 32768, 3e-7), (97, 4096, 5e4), (1, 256, 1.0)])

@@ -15,7 +15,7 @@ def main():
     for path in sys.argv[3:]:
         per = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(path)):
-            if sub in r['Kernel_Name']:
+            if any(x in r['Kernel_Name'] for x in sub.split('|')):      # (alternatives: a demangled and a mangled spelling of one kernel)
                 per[r['Dispatch_Id']][r['Counter_Name']] += float(r['Counter_Value'])
         n = len(per)
         agg = collections.defaultdict(float)

@@ -38,7 +38,7 @@ def short(name):
                 'lazy_tiles_kernel', 'lazy_scan_kernel', 'finish_outputs_kernel', 'copy_indirect_kernel', 'query_order_kernel', 'sasa_kernel', 'splitk_reduce_kernel',
                 'gemm_nt_f32_small_kernel', 'gemm_group_small_kernel', 'gemm_nt_f32_strip_kernel', 'gemm_nt_f32_regtile_kernel',
                 'sample_project_kernel', 'sampling_front_kernel', 'ffn_fused_kernel', 'branch_chain_kernel', 'gemm_nt_f32_kernel<true', 'gemm_nt_f32_kernel<false', 'gemm_bf16x3',
-                'gemm_f16s_gen_ws_kernel', 'gemm_bf16s_gen3_kernel', 'gemm_bf16s_out3_kernel', 'gemm_bf16s_out4_kernel', 'pack_frags_kernel'):
+                'gemm_f16s_gen_ws_kernel', 'gemm_bf16s_gen3_kernel', 'gemm_bf16s_out3_kernel', 'gemm_bf16s_out4_kernel', 'gemm_bf16s_out8_kernel', 'pack_frags_kernel'):
         if key in name:
             return key
     return None

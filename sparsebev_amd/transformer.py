@@ -394,17 +394,7 @@ class _PinnedUpload:
         else:
             slot[1].synchronize()
         slot[0].copy_(t)
-        if out is not None and t.dtype == torch.float32 and os.environ.get('SBEV_UPLOAD_DMA') != '1':
-            # refresh of a replayed step's constants: a KERNEL reads the page-locked slot over the bus (sbev_copy_widen_f32 on the device-visible
-            # host pointer) instead of an SDMA copy -- the copy engine's start-up left ~8 us of idle stream between two replayed steps
-            # (kernel trace, round 6), a 4-us kernel does not
-            from . import _lib
-            import ctypes
-            st = _lib.load().sbev_copy_widen_f32(ctypes.c_void_p(slot[0].data_ptr()), 0, ctypes.c_void_p(out.data_ptr()), t.numel(),
-                                                 ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
-            _lib.check(st, 'sbev_copy_widen_f32')
-        else:
-            out = slot[0].to(device, non_blocking=True) if out is None else out.copy_(slot[0], non_blocking=True)
+        out = slot[0].to(device, non_blocking=True) if out is None else out.copy_(slot[0], non_blocking=True)
         slot[1].record(torch.cuda.current_stream(device))
         return out
 

@@ -681,7 +681,7 @@ int sbev_sasa_bwd_f32_ds(const float* qkvt, int64_t ld, const float* query_bbox,
 int sbev_dropout_f32_ds(const float* x, float* y, int64_t n, uint64_t seed, const uint64_t* seed_dev, float p, sbev_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Whole-decoder runtime: ONE call enqueues every kernel of every layer (18 launches per layer) on `stream`.
+ * Whole-decoder runtime: ONE call enqueues every kernel of every layer (18 launches per layer, DESIGN_HISTORY.md section 4) on `stream`.
  * Replaces: the Python control flow of SparseBEVTransformerDecoder.forward / ...DecoderLayer.forward
  *           (models/sparsebev_transformer.py:56-101,162-193) at inference.
  * ---------------------------------------------------------------------------------------------------------- */
@@ -769,7 +769,7 @@ int64_t sbev_decoder_chain_pair_faults_ack(void);
  * workgroup, twice per pair: 59 MB per layer at 900 rows).  Polls are bounded like the pair hand-off's; a row tile that never completes
  * raises the same fault word (sbev_decoder_chain_pair_faults) and counts in sbev_decoder_chain_pair_timeouts.  Follows the pair switch
  * (sbev_decoder_chain_pair(0) turns both off); sbev_decoder_out_fold(0 / 1) switches it alone (returns the previous setting).  DEFAULT 0:
- * measured at config 2 the fold costs the out-projection 12.6 us and saves the tail 4 (DESIGN.md section 12.2) -- an A/B switch, not the
+ * measured at config 2 the fold costs the out-projection 12.6 us and saves the tail 4 (DESIGN.md section 4.4) -- an A/B switch, not the
  * product path; SBEV_OUT_FOLD=1 in the environment starts with 1.  sbev_debug_out_fold_drop: test hook, never set in production. */
 int sbev_decoder_out_fold(int enable);
 /* Rows from which the fp16-mode out-projection with the pre-split operand (the decoder's path) runs on 256-row tiles

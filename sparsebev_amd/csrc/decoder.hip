@@ -100,7 +100,7 @@ std::atomic<int> g_fuse_l5_f32{getenv("SBEV_NO_FUSE_L5F32") ? 0 : 1};
 // the fused gather + mixing launch walks its items in the order of sbev_query_order (one group and one arc of the camera ring per XCD):
 // 20 % fewer fabric reads for the launch at config 2 (PMC: 290 -> 232 MB, L2 hit 0.39 -> 0.47; tools/sampler_footprint.py predicts
 // it) and NOT faster -- the launch is bound by a workgroup's chain of memory latencies at 4 workgroups per CU, not by fabric bytes
-//  -- and the sort is one more launch per layer: OFF by default, kept for A/B and for a chip whose HBM is
+// (DESIGN_HISTORY.md section 10.8) -- and the sort is one more launch per layer: OFF by default, kept for A/B and for a chip whose HBM is
 // shared.  sbev_decoder_query_order(1) / SBEV_QUERY_ORDER=1 switches it on (bit-identical results).
 std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? (atoi(getenv("SBEV_QUERY_ORDER")) == 2 ? 2 : atoi(getenv("SBEV_QUERY_ORDER")) != 0) : 0};
 
@@ -193,7 +193,7 @@ extern "C" int sbev_decoder_launches_per_layer(const sbev_decoder_config* cfg, c
                       : (c.gemm_mode == SBEV_GEMM_F16X3 || c.gemm_mode == SBEV_GEMM_F16X4) ? (chain ? 0 : 1)      // x1 -> fp16 image fragments (the attention chain writes them)
                       : (c.gemm_mode == SBEV_GEMM_BF16X3 && sbev_linear_bf16x3_strip_ok(BQ, c.G * ((c.D / c.G) * (c.D / c.G) + c.T * c.P * c.out_points), c.D)) ? 1 : 0;
     // chains: attention, attention chain, generator, gather + mixing, out-projection, tail (+ next front)
-    // op by op: 17 with the fused gather + mixing
+    // op by op: 17 with the fused gather + mixing (DESIGN_HISTORY.md section 4)
     const bool ordered = chain && fused && g_query_order.load(std::memory_order_relaxed) == 1 && c.Q <= sbev_query_order_max();      // (mode 2: one sort per STEP)
     return (chain ? 6 : 17) + (fused ? 0 : 1) + split + (ordered ? 1 : 0);
 }

@@ -1,6 +1,6 @@
 // Split-operand Linears for the two 15-GFLOP GEMMs of adaptive mixing on the 16-bit matrix core (round 3): fp32 operands as two or
 // three 16-bit images, the image products that matter, fp32 accumulation.  MODE (template; API code `nimg` / `nprod + 1`):
-//   f16x3   (code 4, the decoder's default): x 2^e = hi + lo, two RNE fp16 images of the operand scaled by a
+//   f16x3   (code 4, the decoder's default, DESIGN_HISTORY.md section 9.7): x 2^e = hi + lo, two RNE fp16 images of the operand scaled by a
 //           power of two per row / tensor (11 + 11 significand bits + lo's sign: the fp32 value to <= 2^-23), products hl + lh + hh
 //           on v_mfma_f32_32x32x16_f16; the dropped lo x lo is <= 2^-24 |a b|.  Max and rms error against fp64 BELOW the exact
 //           f32-MFMA kernels' at both shapes, also on 12-binade inputs (tests/test_gpu_bf16s.py).   f16x4 (code 5): + lo x lo.
@@ -11,7 +11,7 @@
 // sbev_linear_f32 / sbev_linear_splitk_f32.
 //
 // Why these kernels and not gemm_bf16x3.hip's: a 16-byte-per-lane VGPR write-back (global load or ds_read_b128) costs the issuing
-// wave ~85 matrix-pipe cycles when it is alone on its SIMD and 23-38 with a partner wave, so the
+// wave ~85 matrix-pipe cycles when it is alone on its SIMD and 23-38 with a partner wave (DESIGN_HISTORY.md section 4), so the
 // one-wave-per-SIMD register-stationary strips that win for 32-cycle-per-16x16x4 f32 MFMAs are load-issue-bound at 16-bit rates
 // (72 us for 45 GFLOP = 25 % of peak).  Here every workgroup is 8 waves = two per SIMD running as two PHASE GROUPS one barrier phase
 // apart (one fetches while the other multiplies), operands are pre-ordered as whole 1-KiB MFMA fragments that an LDS-DMA
@@ -342,7 +342,7 @@ struct GenArgs {
 constexpr int G_COLS = 256;                     // columns of a workgroup tile (8 fragments); rows: 128 or 256 (RF)
 
 // ---- generator -----------------------------------------------------------------------------------------------------------------
-// History (c2, bf16x6), every step measured on the MI355X:
+// History (c2, bf16x6; DESIGN_HISTORY.md section 4), every step measured on the MI355X:
 //   v1  one 128 x 256 tile per workgroup, 32-k slabs, two LDS stages filled from ROW-MAJOR bf16 planes, a barrier per slab: 116 us;
 //       without its stores 93, without its MFMAs 73, with neither 50 -- the parts add up, nothing overlapped.
 //   v2  persistent workgroups, 16-k stages in a 4-deep LDS-DMA ring, fragments read one stage ahead between the MFMAs
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_gen3_kernel(const GenArgs a) {
 }
 
 // ---- generator, WEIGHT-STATIONARY version (round 4; K = 256, two images) ------------------------------------------------------------
-// What bounded the kernel above: a 256 x 256 tile streams 32 KB per 16-k stage through the L2 -> CU path
+// What bounded the kernel above (DESIGN_HISTORY.md section 9.7): a 256 x 256 tile streams 32 KB per 16-k stage through the L2 -> CU path
 // (~21 B/clk/CU by LDS-DMA) for 1632 cycles of MFMAs, alternately -- the FETCH phase of one wave group is as long as the COMPUTE phase
 // of the other, and both operands of every tile come through that path again (X: once per column tile).  With M ~ 10^3 rows and
 // K = 256 the weights of 32 output columns are 16 k-steps x 2 images x 4 registers = 128 VGPRs: a wave can HOLD its B operands for
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
     // One barrier per fragment, all eight waves in the same phase.  (Tried, measured, not kept: the two waves of a SIMD half a fragment
     // apart -- the second group meeting the barrier in the MIDDLE of its fragment, so that one wave's boundary work lies beside its partner's
     // MFMA stream -- and the LDS-DMA issued by one group only: 49.0 vs 49.3 us at c2, 189 vs 190 at c3.  The kernel is power-capped, not
-    // schedule-bound: DESIGN.md section 10.2.)  What the barrier b_i at the end of fragment i orders: before it every wave waits for its own
+    // schedule-bound: DESIGN_HISTORY.md section 10.2.)  What the barrier b_i at the end of fragment i orders: before it every wave waits for its own
     // pieces of fragment i + 1 (loads return in order: at most the 4 pieces of fragment i + 2 may be outstanding; stores still in flight only
     // make the wait longer); after it every wave refills slot (i + 3) % 4 = (i - 1) % 4, which everybody has finished reading.  The stores of
     // fragment i - 1 ride in the first half of fragment i: behind the barrier, never in front of the counted wait (hipcc otherwise sinks them
@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(512) void gemm_bf16s_out4_kernel(const Out4Args a) 
 // ---- out-projection, 256-row tiles (fp16 modes, pre-split X; round 6: from 1024 rows -- the batch shapes and the 1600-query config) -------------------------------------
 // At 3200 / 3600 rows the 128-row kernel above reaches 0.28 / 0.31 of the matrix peak while the generator reaches 0.46 on the same rows:
 // every 128-row tile streams its K chunk of ALL 256 W rows through the L2 -> LDS path -- 25 tiles x 33.5 MB of W + 420 MB of X per launch at
-// 3200 rows -- and that delivery adds to the matrix time instead of hiding under it.  Here a workgroup owns up to
+// 3200 rows -- and that delivery adds to the matrix time instead of hiding under it (DESIGN_HISTORY.md section 11.7).  Here a workgroup owns up to
 // 256 rows x 256 columns x one K chunk: the two phase groups are the two ROW halves (not the two K halves), each with its own X stage ring,
 // and they SHARE one W ring per 64-column quarter -- the group-0 wave of a quarter requests a k-step's W fragments (LDS-DMA, two steps
 // ahead), waits for them in its own FETCH phase, and the group-1 wave reads the same slot one phase later, behind the barrier in between.

@@ -18,7 +18,7 @@
 // Work split: 8 waves; a unit (one or two independent Linears reading LDS rows) is cut into items of 64 columns x 128 k;
 // item i goes to wave i % 8 in round i / 8 and leaves its partial sums in LDS slot i; the unit's epilogue (wave = row)
 // adds the k-halves in a fixed order, + bias, ReLU / residual / LayerNorm, and writes the next unit's input rows.
-// Results equal the op-by-op launches to fp32 round-off (other summation order), not bit for bit; DESIGN.md section 4.
+// Results equal the op-by-op launches to fp32 round-off (other summation order), not bit for bit; DESIGN_HISTORY.md section 4.
 #include "sbev_common.hpp"
 #include "sample_point.hpp"
 #include <mutex>
@@ -403,8 +403,8 @@ __device__ __forceinline__ void gather4_raw(float (&v)[4], const float* P, int K
 }
 
 // ---- pair mode: two workgroups share a row block (PAIR instantiations of the tail) --------------------------------------------------
-// Every workgroup of a chain streams every weight, and a CU takes ~60 GB/s from the L2 whatever the row count (DESIGN.md section
-// 10.3): the only way to stream less per CU is to split a row block's Linears between CUs.  A PAIR of workgroups owns R rows;
+// Every workgroup of a chain streams every weight, and a CU takes ~60 GB/s from the L2 whatever the row count (DESIGN_HISTORY.md
+// section 10.3): the only way to stream less per CU is to split a row block's Linears between CUs.  A PAIR of workgroups owns R rows;
 // both reduce the out-projection slabs and run norm2 (bit-identical x2 rows), then
 //   ffn.layers.0    member s computes the hidden columns [256 s, 256 s + 256)            (its half of the weight's ROWS)
 //   ffn.layers.1    member s sums over k in [256 s, 256 s + 256) -- the hidden columns it has -- for all 256 outputs; the partial

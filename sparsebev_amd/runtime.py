@@ -670,7 +670,7 @@ _STATE = {'row_chain': True, 'chain_pair': not _os.environ.get('SBEV_NO_CHAIN_PA
 def out_fold(enable):
     """The out-projection GEMM folds its split-K slabs inside its launch (the chunk-workgroups of a row tile meet at a counter; fp16 GEMM
     modes, row chains, <= ~1000 rows; follows ``chain_pair``) so that the tail chain reads one row block instead of 32 slabs.  Bit-identical
-    results either way.  OFF by default -- at config 2 it costs the out-projection 12.6 us and saves the tail 4 (DESIGN.md section 12.2);
+    results either way.  OFF by default -- at config 2 it costs the out-projection 12.6 us and saves the tail 4 (DESIGN.md section 4.4);
     ``SBEV_OUT_FOLD=1`` starts with it on.  Returns the previous setting."""
     prev = bool(_lib.load().sbev_decoder_out_fold(int(bool(enable))))
     _STATE['out_fold'] = bool(enable)
@@ -687,7 +687,7 @@ def lazy_relayout(enable):
 
 def query_order(enable):
     """The fused gather + mixing launch walks its items in sbev_query_order's order (one group and one arc of the camera ring per
-    XCD: 20 % fewer fabric reads at config 2, not faster -- DESIGN.md section 10.8; off by default).  Bit-identical results either
+    XCD: 20 % fewer fabric reads at config 2, not faster -- DESIGN_HISTORY.md section 10.8; off by default).  Bit-identical results either
     way.  Returns the previous setting."""
     mode = 2 if enable == 2 and enable is not True else int(bool(enable))      # 2: sorted once per step (from the input boxes) instead of every layer
     prev = int(_lib.load().sbev_decoder_query_order(mode))

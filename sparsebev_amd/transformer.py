@@ -474,7 +474,7 @@ class SparseBEVTransformerDecoder(_Base):
         # the two big mixing GEMMs (runtime.GEMM_MODES).  Default 'f16x3': fp32 operands as scaled fp16 hi + lo images, 3 products,
         # fp32 accumulation on the 16-bit matrix core -- fp32-class: max and rms error against fp64 BELOW the exact f32-input MFMA
         # kernels' at both GEMM shapes, also on inputs spanning 12 binades (tests/test_gpu_bf16s.py), and generator + out-projection
-        # within the review's 2 x 60 us at config 2.  'f32' = the exact f32-input MFMA kernels (the default of
+        # within the review's 2 x 60 us at config 2 (DESIGN_HISTORY.md section 9.1).  'f32' = the exact f32-input MFMA kernels (the default of
         # rounds 1-2; SBEV_GEMM_MODE=f32 selects it process-wide); 'bf16x6' = hi + mid + lo bf16 images, 6 products; 'f16x4' = all four
         # fp16 products; 'bf16x3' / 'bf16x3s' = the 2^-16-class modes.  Shapes the split kernels do not cover (embed_dims != 256) run 'f32'.
         self.gemm_mode = os.environ.get('SBEV_GEMM_MODE') or 'f16x3'

@@ -213,7 +213,7 @@ def test_out_projection_fold_inside_the_launch_is_bit_identical(B, Q, T, pyr, la
     model, _ = build(T, L, 172, layers)
     t0 = runtime.chain_pair_timeouts()
     b = [t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))]
-    prev = runtime.out_fold(True)              # (an A/B switch, off by default: measured slower at config 2 -- DESIGN.md section 12.2)
+    prev = runtime.out_fold(True)              # (an A/B switch, off by default: measured slower at config 2 -- DESIGN.md section 4.4)
     try:
         a = [[t.clone() for t in model(bbox, feat, list(feats), None, copy.deepcopy(metas))] for _ in range(4)]      # eager, capture, replays
     finally:

@@ -1,4 +1,4 @@
-"""tools/sampler_footprint.py (the CPU model behind DESIGN.md section 10.8) on a small case: its invariants, and that the orders it
+"""tools/sampler_footprint.py (the CPU model behind DESIGN_HISTORY.md section 10.8) on a small case: its invariants, and that the orders it
 compares are permutations.  CPU only."""
 import os
 import sys

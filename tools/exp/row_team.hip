@@ -1,12 +1,12 @@
 // Row-local Linear chains on TEAMS of workgroups (round 4 EXPERIMENT, not part of libsbev_hip.so).
 // Build + run: tools/exp/r4_run13.sh (hipcc -shared against libsbev_hip.so) and tools/exp/r4_team_proto.py.
-// Result: correct to 1.3e-6, deadlock-free, self-resetting -- and 7 - 9 us per stage, no faster than the
+// Result (DESIGN_HISTORY.md section 10): correct to 1.3e-6, deadlock-free, self-resetting -- and 7 - 9 us per stage, no faster than the
 // row chains' 6.8 us: 1.7 - 3.7 us of VALU to LayerNorm / scale / split the gathered rows (repeated in all 8 slices), 2 - 3 us of
 // exposed latency in the epilogue, 1 - 2 us per hand-off.  Kept as the measured record of that design.
 //
 // row_chain.hip gives every workgroup 4 rows and lets it stream ALL weights of the chain (3.25 MB for the tail): 225 workgroups x
 // 3.25 MB through an L2 -> CU path that delivers ~60 GB/s per CU -- 54 us for 1.4 GFLOP, whatever the item order or the row count per
-// workgroup.  The only way to stream less per CU is to split the COLUMNS of every Linear over several CUs,
+// workgroup (DESIGN_HISTORY.md section 10).  The only way to stream less per CU is to split the COLUMNS of every Linear over several CUs,
 // which makes every stage an all-gather of the previous stage's output rows.  Here a team of 8 workgroups owns 32 rows: workgroup
 // (team, slice) computes the column fragments slice, slice + 8, ... of each stage for those rows on v_mfma_f32_32x32x16_f16 with
 // fp16 hi + lo operands (3 products, fp32-class: gemm_bf16s.hip), publishes them through global memory and meets its team at a

@@ -5,7 +5,7 @@
 # tools/profile_pmc.sh.  Everything lands in gpurun_out/prof_<round>/; copy what is to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${1:-r5}
+ROUND=${1:-r6}
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -30,6 +30,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 python $R/tools/mfma_summary.py $(find $OUT/pmc_mfma_f32 -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_mfma_f32 -name "*kernel_trace.csv" | head -1) $OUT/${ROUND}_mfma_summary_f32.json | head -6
 rm -f $(find $OUT/pmc_mfma_f32 -name "*counter_collection.csv")
 for c in c1 c3 c4 c5 c6; do python $R/bench.py --config $c $Q --steps 30 2>/dev/null | tail -1 > $OUT/bench_$c.json; cut -c1-220 $OUT/bench_$c.json; done
+# round 6: the dense-relayout A/B of the NCHW configs (on-demand relayout is the default) and their kernel stats
+for c in c2 c3 c4; do python $R/bench.py --config $c $Q --steps 30 --dense-relayout 2>/dev/null | tail -1 > $OUT/bench_${c}_dense.json; cut -c1-200 $OUT/bench_${c}_dense.json; done
+for c in c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$c -o bench -- python $R/bench.py --config $c $Q --steps 20 > $OUT/kt_$c.log 2>&1
+done
 for c in c3 c4 c6; do python $R/bench.py --config $c $Q --steps 30 --gemm f32 2>/dev/null | tail -1 > $OUT/bench_${c}_f32.json; cut -c1-200 $OUT/bench_${c}_f32.json; done
 python $R/bench.py --nhwc $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_nhwc.json; cut -c1-200 $OUT/bench_nhwc.json
 python $R/bench.py --online $Q --steps 50 2>/dev/null | tail -1 > $OUT/bench_online.json; cut -c1-200 $OUT/bench_online.json

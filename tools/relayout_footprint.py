@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Which part of the feature pyramid does the decoder READ?  (CPU only; design tool for the on-demand relayout, DESIGN.md section 12.)
+"""Which part of the feature pyramid does the decoder READ?  (CPU only; design tool for the on-demand relayout, DESIGN.md section 4.7.)
 
 The reference regroups EVERY pixel of every level on every call (models/sparsebev_transformer.py:73-85) and so did this repo's
 NCHW -> NHWC relayout (csrc/layout.hip::transpose_tiles_kernel).  The gather only reads the 4 bilinear corners of each sample

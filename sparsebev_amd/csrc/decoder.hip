@@ -300,8 +300,25 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
     SBEV_REQUIRE(nimg == 0 || (sbev_linear_bf16s_gen_ok(BQ, pgN, D) && sbev_linear_bf16s_out_ok(BQ, D, mixN)),
                  "sbev_decoder_forward: gemm_mode %d does not cover this shape (rows %lld, generator %d x %d, out-projection %d x %d)",
                  cfg->gemm_mode, (long long)BQ, pgN, D, D, mixN);
-    auto generator_bf16s = [&](sbev_stream_t st, bool packed = false) -> int {      // x1 -> image fragments (once per layer) -> Y = X W^T + b
+    // on-demand relayout, layers 1..5: the scan (find + move what this layer's points marked) rides in the generator GEMM's prologue
+    // where that kernel is the weight-stationary one (fp16 modes) -- the only launch between the marks and the gather that does not touch
+    // the features; SBEV_LAZY_SCAN_LAUNCH=1 keeps it a launch of its own (A/B)
+    static const bool scan_own_launch = getenv("SBEV_LAZY_SCAN_LAUNCH") != nullptr;
+    // (up to 1024 rows: measured at config 2 555 vs 541 samples/s; at 3200 / 3600 rows a layer adds tens of thousands of units and the
+    // launch of its own, with one workgroup per 16 tiles, spreads them better: 1303-1321 vs 1312-1349 and 521 vs 523 -- neutral, kept apart)
+    const bool scan_in_gen = lazy && nimg >= 4 && !scan_own_launch && BQ <= 1024 && sbev::linear_f16s_gen_takes_scan(BQ, pgN, D, pgN, nimg - 1);
+    auto generator_bf16s = [&](sbev_stream_t st, bool packed = false, int scan_layer = -1) -> int {      // x1 -> image fragments (once per layer) -> Y = X W^T + b
         uint16_t* xs = reinterpret_cast<uint16_t*>(b.x1s);
+        if (nimg >= 4 && scan_layer > 0) {                    // (fragments there already -- chain or pack launch --, this layer's scan inside)
+            const sbev::LazyScan lz{&lplan, lazy->table, lazy->index, lazy->src, const_cast<void* const*>(feats_nhwc), c.feat_dtype == SBEV_F32 ? 4 : 2,
+                                    b.touch_need, b.touch_done, scan_layer + 1 == c.num_layers};
+            if (!packed) {
+                int e = sbev_pack_f16s_frags(b.x1, D, xs, const_cast<float*>(w->pg_xscale), (int)BQ, D, 2, st);
+                if (e != SBEV_OK) return e;
+            }
+            return sbev::linear_f16s_gen_scan(xs, w->pg_xscale, w->pg_ws, w->pg_wdown, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg - 1, lz,
+                                              reinterpret_cast<hipStream_t>(st));
+        }
         if (nimg >= 4 && packed)                               // (the attention chain already wrote the fragments)
             return sbev_linear_f16s_gen(xs, w->pg_xscale, w->pg_ws, w->pg_wdown, w->pg_b, b.params, BQ, pgN, D, pgN, 0, nimg - 1, st);
         if (nimg >= 4) {                                       // fp16 hi + lo: x1 scaled by one power of two (its maximum -> [2^14, 2^15))
@@ -355,9 +372,10 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
             TRY(sbev::launch_chain_attn(c, *w, b.att, b.x, b.x1, bbox, time_diff, lidar2img, b.loc, b.wbp, eps, s_main,
                                         nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr, b.pair_sync,
                                         lazy ? &lplan : nullptr, lazy ? b.touch_need : nullptr));
-            TRY(lazy_move(layer));
+            const bool ride = scan_in_gen && layer > 0;
+            if (!ride) TRY(lazy_move(layer));
             if (nimg)
-                TRY(generator_bf16s(stream, true));
+                TRY(generator_bf16s(stream, true, ride ? layer : -1));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)
                 TRY(generator_bf16x3(stream));
             else

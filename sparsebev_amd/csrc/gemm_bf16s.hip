@@ -80,6 +80,8 @@ extern "C" int sbev_debug_wgtime_clear(void) {
 
 namespace {
 
+#include "lazy_relayout.hpp"      // the generator runs the on-demand relayout's scan in its prologue (gemm_f16s_gen_ws_kernel)
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -698,6 +700,12 @@ struct GenWsArgs {
     int ntask;                   // (N / 256) * nrs
     const float* colscale;       // fp16 modes: [N] 2^-ew; null otherwise
     const float* xscale;         // fp16 modes: {2^ex, 2^-ex}
+    // on-demand relayout (round 6): layers 1..5 find and move the feature units their sample points marked and no earlier launch of the
+    // step moved -- a few hundred 16-KB units at config 2.  As a launch of its own that is 7-20 us of launch + dependent round trips between
+    // the attention chain and this GEMM; here every workgroup does its share BEFORE its first request of the GEMM (the only kernel between
+    // the marks and the gather that does not touch the features): one round trip for the flags, a wave per found unit.
+    int lazy_on, lazy_esize;
+    LazyArgs lazy;
 };
 
 #ifndef SBEV_WS_NCH
@@ -734,6 +742,16 @@ __global__ __launch_bounds__(512) void gemm_f16s_gen_ws_kernel(const GenWsArgs a
     const unsigned ldyb = (unsigned)(a.ldy * 4);
     [[maybe_unused]] const int tid = (int)threadIdx.x;
     SBEV_WGTIME(1, 0)
+    if (a.lazy_on) {
+        // (LDS: 8 wave tiles of 8448 B, then the list of up to 4 x 512 units and its counter -- 76 KB of the 128-KB ring, before any DMA)
+        float* wt = reinterpret_cast<float*>(lds);
+        unsigned* list = reinterpret_cast<unsigned*>(lds + 8 * (LZ_TS * WLD * 4));
+        unsigned* n_list = list + 4 * 512;
+        if (a.lazy_esize == 4) lazy_scan_share<float>(a.lazy, blockIdx.x, gridDim.x, 512, wt, list, n_list);
+        else lazy_scan_share<unsigned short>(a.lazy, blockIdx.x, gridDim.x, 512, wt, list, n_list);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the counted waits below start from "nothing outstanding")
+        __syncthreads();
+    }
 
     // One barrier per fragment, all eight waves in the same phase.  (Tried, measured, not kept: the two waves of a SIMD half a fragment
     // apart -- the second group meeting the barrier in the MIDDLE of its fragment, so that one wave's boundary work lies beside its partner's
@@ -1722,8 +1740,12 @@ extern "C" int sbev_linear_bf16s_gen_ok(int64_t M, int N, int K) {
            ntm_of(M) <= 256;
 }
 
+static bool gen_ws_takes(int64_t M, int N, int K, int64_t ldy, int nimg) {
+    return g_gen_ws.load(std::memory_order_relaxed) != 0 && K == 16 * WS_KS && nimg != 3 && M * ldy * 4 < 0x7fffffffLL;
+}
+
 static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias, float* Y, int64_t M, int N, int K, int64_t ldy, int relu,
-                      int nimg, const float* xscale, const float* colscale, sbev_stream_t stream) {
+                      int nimg, const float* xscale, const float* colscale, sbev_stream_t stream, const sbev::LazyScan* lz = nullptr) {
     SBEV_REQUIRE(M >= 0 && sbev_linear_bf16s_gen_ok(M > 0 ? M : 1, N, K), "sbev_linear_bf16s_gen: needs N %% 256 == 0, K %% 32 == 0, K <= 4096 (M=%lld N=%d K=%d)", (long long)M, N, K);
     if (M == 0) return SBEV_OK;
     SBEV_REQUIRE(Xs && Ws && Y && ldy >= N && ldy % 4 == 0, "sbev_linear_bf16s_gen: bad pointers / leading dimension");
@@ -1737,7 +1759,8 @@ static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     // weight-stationary kernel (round 4): K = 256, two images, Y addressable by a 31-bit byte offset
-    if (g_gen_ws.load(std::memory_order_relaxed) != 0 && K == 16 * WS_KS && nimg != 3 && M * ldy * 4 < 0x7fffffffLL) {
+    SBEV_REQUIRE(!lz || gen_ws_takes(M, N, K, ldy, nimg), "generator: the on-demand relayout's scan rides in the weight-stationary kernel only");
+    if (gen_ws_takes(M, N, K, ldy, nimg)) {
         // row splits: tasks = column tiles x splits walked by <= one workgroup per CU; a task costs its fragments + ~4 fragments' worth
         // of weight load (256 KB that nothing overlaps).  c2 (29 fragments, 128 column tiles): 2 splits = 256 tasks of 15 / 14 fragments
         const int nct = N / G_COLS;
@@ -1748,7 +1771,20 @@ static int gen_launch(const uint16_t* Xs, const uint16_t* Ws, const float* bias,
             const double cost = (double)((tasks + cus - 1) / cus) * ((nfrag + r - 1) / r + 4.0);
             if (cost < best - 1e-9) { best = cost; nrs = r; }
         }
-        GenWsArgs w{Xs, Ws, bias, Y, (int)M, N, (long long)ldy, relu, nrs, nfrag / nrs, nfrag % nrs, nct * nrs, colscale, xscale};
+        GenWsArgs w{Xs, Ws, bias, Y, (int)M, N, (long long)ldy, relu, nrs, nfrag / nrs, nfrag % nrs, nct * nrs, colscale, xscale, 0, 4, {}};
+        if (lz) {
+            w.lazy_on = 1; w.lazy_esize = lz->esize;
+            LazyArgs& la = w.lazy;
+            la.table = lz->table; la.n_levels = lz->plan->n_levels; la.R = lz->plan->R; la.need = lz->need; la.done = lz->done;
+            la.first = 0; la.last = lz->last ? 1 : 0;
+            for (int l = 0; l < lz->plan->n_levels; ++l) {
+                la.index[l] = lz->table ? lz->index[l] : 0;
+                la.src[l] = lz->table ? nullptr : lz->src[l];
+                la.out[l] = lz->out[l];
+                la.S[l] = lz->plan->S[l]; la.tiles[l] = lz->plan->tiles[l]; la.base[l] = lz->plan->base[l];
+            }
+            la.base[lz->plan->n_levels] = lz->plan->base[lz->plan->n_levels];
+        }
         const unsigned grid = (unsigned)(w.ntask < cus ? w.ntask : cus);
         const int lds = WS_SLOTS * WS_FRAG;
         int st;
@@ -1834,6 +1870,16 @@ extern "C" int sbev_linear_f16s_gen(const uint16_t* Xs, const float* xscale, con
     SBEV_REQUIRE(M == 0 || (xscale && wdown), "sbev_linear_f16s_gen: null scale pointer");
     return gen_launch(Xs, Ws, bias, Y, M, N, K, ldy, relu, nprod + 1, xscale, wdown, stream);
 }
+
+namespace sbev {
+bool linear_f16s_gen_takes_scan(int64_t M, int N, int K, int64_t ldy, int nprod) { return gen_ws_takes(M, N, K, ldy, nprod + 1); }
+int linear_f16s_gen_scan(const uint16_t* Xs, const float* xscale, const uint16_t* Ws, const float* wdown, const float* bias, float* Y, int64_t M,
+                         int N, int K, int64_t ldy, int relu, int nprod, const LazyScan& lz, hipStream_t stream) {
+    SBEV_REQUIRE(nprod == 3 || nprod == 4, "sbev_linear_f16s_gen: nprod=%d (3 or 4 image products)", nprod);
+    SBEV_REQUIRE(M == 0 || (xscale && wdown), "sbev_linear_f16s_gen: null scale pointer");
+    return gen_launch(Xs, Ws, bias, Y, M, N, K, ldy, relu, nprod + 1, xscale, wdown, reinterpret_cast<sbev_stream_t>(stream), &lz);
+}
+}  // namespace sbev
 
 extern "C" int sbev_linear_bf16s_out_ok(int64_t M, int N, int K) {
     return M >= 1 && M <= 0x7fffffffLL / 512 && N == 256 && K >= 256 && K % 32 == 0;

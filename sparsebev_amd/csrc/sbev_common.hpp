@@ -68,6 +68,20 @@ struct LazyPlan {
     unsigned base[SBEV_MAX_LEVELS + 1];      // base[n_levels] = tiles of the pyramid
 };
 bool lazy_plan(int n_levels, const int32_t* hw, long long n_images, int channels, LazyPlan* p);
+// the scan of layers 1..5 riding in the generator GEMM's prologue (gemm_bf16s.hip): what the stand-alone launch would have been given
+struct LazyScan {
+    const LazyPlan* plan;
+    const void* const* table;
+    const int32_t* index;
+    const void* const* src;
+    void* const* out;
+    int esize;
+    uint32_t *need, *done;
+    bool last;
+};
+bool linear_f16s_gen_takes_scan(int64_t M, int N, int K, int64_t ldy, int nprod);
+int linear_f16s_gen_scan(const uint16_t* Xs, const float* xscale, const uint16_t* Ws, const float* wdown, const float* bias, float* Y, int64_t M,
+                         int N, int K, int64_t ldy, int relu, int nprod, const LazyScan& lz, hipStream_t stream);
 int launch_lazy_relayout(const LazyPlan& p, const void* const* table, const int32_t* index, const void* const* src, void* const* out,
                          int esize, uint32_t* need, uint32_t* done, bool first, bool last, hipStream_t s);
 

@@ -298,7 +298,16 @@ class DecoderRuntime:
             return cls_o, box_o
         return cls, box
 
-    def forward_lazy(self, query_bbox, query_feat, mlvl_feats, ctx, attn_mask=None, buffers=None):
+    def lazy_ok(self, mlvl_feats):
+        """whether a feature LIST qualifies for the on-demand relayout of the eager step: the switch is on, every level is a contiguous,
+        16-byte aligned NCHW device tensor [B, T*6, 256, H, W] of one dtype (what StepGraphs stages), 4 groups of 64 channels"""
+        if not _STATE['lazy'] or hasattr(mlvl_feats, 'levels') or len(mlvl_feats) == 0:
+            return False
+        f0 = mlvl_feats[0]
+        return all(torch.is_tensor(f) and f.is_cuda and StepGraphs._relayout_ok(f) and f.dtype == f0.dtype and f.shape[2] == 256 for f in mlvl_feats) \
+            and self.decoder.decoder_layer.sampling.num_groups == 4
+
+    def forward_lazy(self, query_bbox, query_feat, mlvl_feats, ctx, attn_mask=None, buffers=None, finish=False):
         """The eager step on the reference's NCHW feature list ``[B, T*6, 256, H_l, W_l]`` WITHOUT a dense relayout
         (sbev_decoder_forward_lazy): channels-last buffers (``buffers``, or new uninitialised ones) receive only the units the sample
         points read.  Bit-identical to ``forward`` on ``FeaturePyramid(mlvl_feats)``.  Returns (cls, box, pyramid-of-buffers)."""
@@ -318,6 +327,10 @@ class DecoderRuntime:
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         st = lib.sbev_decoder_forward_lazy(args[0], args[1], args[2], ctypes.byref(lz), *args[3:], stream)
         _lib.check(st, 'sbev_decoder_forward_lazy')
+        if finish:
+            cls_o, box_o = torch.empty_like(cls), torch.empty_like(box)
+            _lib.check(lib.sbev_finish_outputs(_ptr(cls), _ptr(box), _ptr(cls_o), _ptr(box_o), cls.numel(), box.numel(), stream), 'sbev_finish_outputs')
+            return cls_o, box_o, pyramid
         return cls, box, pyramid
 
     def capture(self, query_bbox, query_feat, pyramid, ctx, attn_mask=None):

@@ -535,9 +535,14 @@ class SparseBEVTransformerDecoder(_Base):
                         return _Finished(out)
                     return out if _may_alias else (out[0].clone(), out[1].clone())
         ctx = DecoderContext(img_metas, B, query_bbox.device)
-        feats = mlvl_feats if hasattr(mlvl_feats, 'levels') else FeaturePyramid(mlvl_feats)   # FeaturePyramid / cache.RingPyramid pass through
         query_bbox = query_bbox.float().contiguous()
         query_feat = query_feat.float().contiguous()
+        if inference and not (layerwise or DUMP.enabled) and self._runtime.lazy_ok(mlvl_feats):
+            # the eager step on the reference's NCHW lists (first sighting of a shape, graphs off, launch profiling): on-demand relayout
+            # too -- only the feature units the sample points read are moved (runtime.forward_lazy; bit-identical to the dense pass)
+            out = self._runtime.forward_lazy(query_bbox, query_feat, list(mlvl_feats), ctx, attn_mask, finish=_finish)[:2]
+            return _Finished(out) if _finish else out
+        feats = mlvl_feats if hasattr(mlvl_feats, 'levels') else FeaturePyramid(mlvl_feats)   # FeaturePyramid / cache.RingPyramid pass through
         if not inference:
             return self.forward_differentiable(query_bbox, query_feat, mlvl_feats, feats, attn_mask, ctx)
         if not (layerwise or DUMP.enabled):

@@ -228,8 +228,12 @@ def test_replayed_lazy_step_follows_fresh_tensors_and_equals_the_dense_step():
             for m in m2:
                 m['lidar2img'] = [x * (1.0 + 0.01 * step) for x in m['lidar2img']]
             got = g(bbox, feat, list(feats), None, m2)
+            runtime.lazy_relayout(False)            # (the eager step takes the on-demand path too: the reference here is the DENSE eager step)
             want = e(bbox, feat, list(feats), None, m2)
+            runtime.lazy_relayout(True)
+            eager_lazy = e(bbox, feat, list(feats), None, m2)
             assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), 'step %d' % step
+            assert torch.equal(eager_lazy[0], want[0]) and torch.equal(eager_lazy[1], want[1]), 'eager lazy step %d' % step
         sg = g.decoder._runtime.step_graphs
         assert sg.captures == 1 and sg.replays == 4
         nodes_lazy = next(v for v in sg.entries.values() if isinstance(v, dict))['graph'].num_nodes
@@ -240,7 +244,9 @@ def test_replayed_lazy_step_follows_fresh_tensors_and_equals_the_dense_step():
         assert sg.captures == 2
         nodes_dense = [v for v in sg.entries.values() if isinstance(v, dict)][-1]['graph'].num_nodes
         print('graph nodes: lazy %d, dense %d' % (nodes_lazy, nodes_dense))
-        assert nodes_lazy == nodes_dense - 1 + 3            # one relayout launch less, one move launch per layer more
+        # one dense relayout launch less, one move launch more for layer 0; the scans of layers 1 .. 2 ride in the generator GEMM's prologue
+        # (fp16 GEMM modes, <= 1024 rows: csrc/decoder.hip `scan_in_gen`)
+        assert nodes_lazy == nodes_dense - 1 + 1
     finally:
         runtime.lazy_relayout(prev)
 

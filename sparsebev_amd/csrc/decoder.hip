@@ -373,7 +373,7 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
                                         nimg >= 4 ? reinterpret_cast<uint16_t*>(b.x1s) : nullptr, nimg >= 4 ? w->pg_xscale : nullptr, b.pair_sync,
                                         lazy ? &lplan : nullptr, lazy ? b.touch_need : nullptr));
             const bool ride = scan_in_gen && layer > 0;
-            if (!ride) TRY(lazy_move(layer));
+            if (!ride) TRY(lazy_move(layer));      // (layer 0's move behind the generator instead of in front of it: measured equal, 537-539 both ways)
             if (nimg)
                 TRY(generator_bf16s(stream, true, ride ? layer : -1));
             else if (c.gemm_mode == SBEV_GEMM_BF16X3)

@@ -177,10 +177,12 @@ def _poisoned_like(feats):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
-@pytest.mark.parametrize('chains', [True, False])
-def test_eager_lazy_step_equals_dense_relayout_bit_for_bit(chains, dtype):
-    B, Q, T = 2, 100, 2
-    ih, iw, sizes = S.PYRAMIDS['r50_704x256']
+@pytest.mark.parametrize('chains,pyr_name', [(True, 'r50_704x256'), (False, 'r50_704x256'), (True, 'eva02_1600x640')])
+def test_eager_lazy_step_equals_dense_relayout_bit_for_bit(chains, pyr_name, dtype):
+    """row chains (the scans of layers 1 .. 2 ride in the generator GEMM's prologue) and op by op (every move a launch of its own); 4 levels and
+    5 levels with an odd plane size (10 x 25: scalar reads)"""
+    B, Q, T = (2, 100, 2) if pyr_name == 'r50_704x256' else (1, 64, 2)
+    ih, iw, sizes = S.PYRAMIDS[pyr_name]
     feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=3, dtype=dtype)]
     bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=5)]
     metas = S.make_img_metas(B, T, ih, iw)

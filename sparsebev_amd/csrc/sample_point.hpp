@@ -55,13 +55,9 @@ __device__ __forceinline__ void touch_units(const SamplePointArgs& a, int b, int
             const int hc = h0 + dh;
             if (hc < 0 || hc > H - 1) continue;
             const unsigned ta = (unsigned)(hc * W + wa) >> 6, tb = (unsigned)(hc * W + wb) >> 6;
-#ifdef SBEV_EXP_TOUCH_RBW      // A/B: read before write (most units are marked already: L1 hits instead of L2 write transactions)
-            if (row[(size_t)ta * 4] == 0) row[(size_t)ta * 4] = 1;
-            if (tb != ta && row[(size_t)tb * 4] == 0) row[(size_t)tb * 4] = 1;
-#else
+            // (plain idempotent stores; read-before-write -- most units are marked already -- measured slower: attention chain 22.6 vs 21.0 us)
             row[(size_t)ta * 4] = 1;
             if (tb != ta) row[(size_t)tb * 4] = 1;
-#endif
         }
     }
 }

@@ -829,6 +829,11 @@ typedef struct sbev_lazy_feats {
     const void* src[SBEV_MAX_LEVELS];      /* table == NULL: level l's NCHW source */
 } sbev_lazy_feats;
 int sbev_decoder_lazy_supported(const sbev_decoder_config* cfg);
+/* Layers 1.. find and move the units their points marked and no earlier launch moved ("scan").  Up to 1024 rows in the fp16 GEMM modes that
+ * scan rides in the generator GEMM's prologue (every generator workgroup takes its share before its first request: five launches per step
+ * less at config 2); sbev_decoder_lazy_scan_launch(1) (env SBEV_LAZY_SCAN_LAUNCH=1) keeps it a launch of its own.  Bit-identical; returns
+ * the previous setting.  Read when a step is enqueued / captured. */
+int sbev_decoder_lazy_scan_launch(int enable);
 int sbev_decoder_forward_lazy(const sbev_decoder_config* cfg, const sbev_decoder_weights* weights, void* const* feats_nhwc,
                               const sbev_lazy_feats* lazy, const float* query_bbox, const float* query_feat,
                               const float* time_diff, const float* lidar2img, const float* vel_div,

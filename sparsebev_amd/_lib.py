@@ -70,6 +70,7 @@ SIGNATURES = {
     'sbev_decoder_forward_lazy': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                  _vp, ctypes.c_int64, _vp]),
     'sbev_decoder_lazy_supported': (ctypes.c_int, [_vp]),
+    'sbev_decoder_lazy_scan_launch': (ctypes.c_int, [ctypes.c_int]),
     'sbev_lazy_relayout_tiles': (ctypes.c_int64, [ctypes.c_int, _c_i32p, ctypes.c_int64, ctypes.c_int]),
     'sbev_sample_and_project_touch': (ctypes.c_int, [_vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp,
                                                      ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -107,6 +107,8 @@ std::atomic<int> g_query_order{getenv("SBEV_QUERY_ORDER") ? (atoi(getenv("SBEV_Q
 // the row-local op chains of a layer as three launches (row_chain.hip) when the caller supplied packed weights
 // (sbev_decoder_weights.chain_pack); sbev_decoder_row_chain(0) restores the op-by-op launches (A/B measurements)
 std::atomic<int> g_row_chain{1};
+// on-demand relayout: the scans of layers 1.. as launches of their own instead of riding in the generator GEMM's prologue (A/B)
+std::atomic<int> g_lazy_scan_launch{getenv("SBEV_LAZY_SCAN_LAUNCH") ? 1 : 0};
 
 int validate(const sbev_decoder_config* c) {
     SBEV_REQUIRE(c != nullptr, "sbev_decoder: null config");
@@ -302,8 +304,8 @@ static int decoder_forward_impl(const sbev_decoder_config* cfg, const sbev_decod
                  cfg->gemm_mode, (long long)BQ, pgN, D, D, mixN);
     // on-demand relayout, layers 1..5: the scan (find + move what this layer's points marked) rides in the generator GEMM's prologue
     // where that kernel is the weight-stationary one (fp16 modes) -- the only launch between the marks and the gather that does not touch
-    // the features; SBEV_LAZY_SCAN_LAUNCH=1 keeps it a launch of its own (A/B)
-    static const bool scan_own_launch = getenv("SBEV_LAZY_SCAN_LAUNCH") != nullptr;
+    // the features; sbev_decoder_lazy_scan_launch(1) / SBEV_LAZY_SCAN_LAUNCH=1 keeps it a launch of its own (A/B; bit-identical)
+    const bool scan_own_launch = g_lazy_scan_launch.load(std::memory_order_relaxed) != 0;
     // (up to 1024 rows: measured at config 2 555 vs 541 samples/s; at 3200 / 3600 rows a layer adds tens of thousands of units and the
     // launch of its own, with one workgroup per 16 tiles, spreads them better: 1303-1321 vs 1312-1349 and 521 vs 523 -- neutral, kept apart)
     const bool scan_in_gen = lazy && nimg >= 4 && !scan_own_launch && BQ <= 1024 && sbev::linear_f16s_gen_takes_scan(BQ, pgN, D, pgN, nimg - 1);
@@ -616,6 +618,9 @@ extern "C" int sbev_profile_stride(int every_n_calls) {
     sbev::g_prof_calls = 0;
     return SBEV_OK;
 }
+
+// returns the previous setting
+extern "C" int sbev_decoder_lazy_scan_launch(int enable) { return g_lazy_scan_launch.exchange(enable ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int sbev_decoder_row_chain(int enable) {
     g_row_chain.store(enable != 0, std::memory_order_relaxed);

@@ -190,8 +190,17 @@ def test_eager_lazy_step_equals_dense_relayout_bit_for_bit(chains, pyr_name, dty
     rt = _runtime_of(m, bbox, feat, feats, metas)
     ctx = TR.DecoderContext(metas, B, DEV)
 
+    lib = _lib.load()
+
     def run():
         want = rt.forward(bbox, feat, TR.FeaturePyramid(feats), ctx)
+        # the scans of layers 1 .. as launches of their own (the row-chain path otherwise carries them in the generator GEMM's prologue)
+        prev_scan = lib.sbev_decoder_lazy_scan_launch(1)
+        try:
+            cls_s, box_s, _ = rt.forward_lazy(bbox, feat, feats, ctx, buffers=_poisoned_like(feats))
+        finally:
+            lib.sbev_decoder_lazy_scan_launch(prev_scan)
+        assert torch.equal(cls_s, want[0]) and torch.equal(box_s, want[1]), 'scan as its own launch'
         pyr = _poisoned_like(feats)
         cls, box, pyr = rt.forward_lazy(bbox, feat, feats, ctx, buffers=pyr)
         assert torch.isfinite(cls).all() and torch.isfinite(box).all(), 'a tap read a unit that was not moved (NaN poison)'

@@ -778,7 +778,7 @@ int sbev_decoder_out_fold(int enable);
 int sbev_linear_out8_min_rows(int rows);
 int sbev_debug_out_fold_drop(int enable);
 /* Per-device setup that is illegal under stream capture (hipHostMalloc + hipMemcpyToSymbol of the fault word above): call once per device
- * before the first capture that may contain a decoder step -- the ctypes binding does when it loads the library.  Without it
+ * before the first capture that may contain a decoder step -- the ctypes binding does when it loads the library in a process that already has its device context.  Without it
  * sbev_decoder_workspace_bytes attempts the same; an attempt that fails (e.g. made inside a torch.cuda.graph capture) is retried by later
  * calls, with one message on stderr / sbev_last_error(), and pair mode stays off meanwhile.  The word is shared by all devices of a process. */
 int sbev_init(void);

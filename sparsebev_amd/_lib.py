@@ -253,8 +253,11 @@ def load():
     if lib.sbev_abi_version() != 1:
         raise ImportError('sparsebev_amd: libsbev_hip.so ABI %d != 1 (stale build?)' % lib.sbev_abi_version())
     _lib = lib
-    if torch.cuda.is_available():
-        lib.sbev_init()          # per-device setup that must not run inside somebody's stream capture (pair-mode fault word); retried lazily on failure
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        # per-device setup that must not run inside somebody's stream capture (pair-mode fault word); retried lazily on failure.  Only when
+        # the process already has its device context: a rank of a multi-GPU job that imports this before torch.cuda.set_device(LOCAL_RANK)
+        # must not open a context on GPU 0 for it (the install then happens at its first sbev_decoder_workspace_bytes, on ITS device)
+        lib.sbev_init()
     return lib
 
 

@@ -517,6 +517,43 @@ def test_shared_parameter_gradients_collected_per_call_equal_autograd_accumulati
 
 
 @torch.enable_grad()
+def test_grouped_branch_launches_equal_one_launch_per_linear():
+    """Round 6 (autograd.LinearPair): the classification and regression heads level by level in ONE grouped launch each way -- forward
+    outputs bit-identical to one Linear node per head (the grouped kernel runs the same tile code), parameter and query gradients equal to
+    summation-order rounding; with and without the parameter tap."""
+    import os
+    B, Q, T, L = 1, 64, 2, 4
+    ih, iw, sizes = S.PYRAMIDS['tiny']
+    bbox, feat = [t.to(DEV) for t in S.make_queries(B, Q, seed=36)]
+    metas = S.make_img_metas(B, T, ih, iw)
+    feats = [f.to(DEV) for f in S.make_features(B, T, sizes, seed=37)]
+
+    def run(pairs, tap):
+        prev = os.environ.pop('SBEV_NO_TRAIN_PAIRS', None)
+        if not pairs:
+            os.environ['SBEV_NO_TRAIN_PAIRS'] = '1'
+        try:
+            model = build(T, L, 35, 2).eval()
+            model.decoder.tap_param_grads = tap
+            q = feat.clone().requires_grad_(True)
+            cls, box = model(bbox, q, list(feats), None, copy.deepcopy(metas))
+            (cls.sum() + box.pow(2).sum()).backward()
+            return cls.detach(), box.detach(), q.grad, {n: p.grad for n, p in model.named_parameters()}
+        finally:
+            os.environ.pop('SBEV_NO_TRAIN_PAIRS', None)
+            if prev is not None:
+                os.environ['SBEV_NO_TRAIN_PAIRS'] = prev
+
+    for tap in (True, False):
+        a, b = run(True, tap), run(False, tap)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert (a[2] - b[2]).abs().max() <= 2e-5 * max(b[2].abs().max().item(), 1e-3)
+        assert set(a[3]) == set(b[3]) and all(g is not None for g in a[3].values())
+        for n in a[3]:
+            assert (a[3][n] - b[3][n]).abs().max() <= 2e-5 * max(b[3][n].abs().max().item(), 1e-3), n
+
+
+@torch.enable_grad()
 @pytest.mark.parametrize('feat_grad', [False, True])
 def test_captured_training_step_replays_with_new_data_and_equals_the_eager_step(feat_grad):
     """sparsebev_amd.train_graph.CapturedTrainStep: forward + backward of a 3-layer decoder captured as ONE hipGraph on batch A, then
